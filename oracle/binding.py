@@ -1,0 +1,192 @@
+"""ctypes binding of the CPU oracle (oracle/tetra_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.  PARITY UNPINNED
+(see tetra_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtetra_oracle.so")
+
+MAX_TAPS = 129
+PHASES = 128
+ITAPS = 8
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("symbolrate", C.c_double), ("samplerate", C.c_double),
+        ("rrc_tap_count", C.c_int), ("rrc_beta", C.c_double),
+        ("agc_rate", C.c_double), ("costas_bandwidth", C.c_double),
+        ("fll_bandwidth", C.c_double), ("omega_gain", C.c_double),
+        ("mu_gain", C.c_double), ("omega_rel_limit", C.c_double),
+    ]
+
+
+class State(C.Structure):
+    _fields_ = [
+        ("agc_gain", C.c_float),
+        ("fll_phase", C.c_float), ("fll_freq", C.c_float),
+        ("hist", C.c_float * (2 * (MAX_TAPS - 1))),
+        ("mu", C.c_float), ("omega", C.c_float),
+        ("offset", C.c_int32),
+        ("ybuf", C.c_float * (2 * (ITAPS - 1))),
+        ("costas_phase", C.c_float), ("costas_freq", C.c_float),
+        ("ph2", C.c_float),
+        ("prev", C.c_uint8),
+    ]
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("cfg", Cfg),
+        ("ntaps", C.c_int),
+        ("rrc", C.c_float * MAX_TAPS),
+        ("be_a", C.c_float * MAX_TAPS),
+        ("be_b", C.c_float * MAX_TAPS),
+        ("bank", (C.c_float * ITAPS) * PHASES),
+        ("agc_rate", C.c_float), ("agc_set_point", C.c_float), ("agc_max_gain", C.c_float),
+        ("fll_alpha", C.c_float), ("fll_beta", C.c_float),
+        ("fll_min_freq", C.c_float), ("fll_max_freq", C.c_float),
+        ("tr_alpha", C.c_float), ("tr_beta", C.c_float),
+        ("tr_min_freq", C.c_float), ("tr_max_freq", C.c_float), ("tr_omega", C.c_float),
+        ("costas_alpha", C.c_float), ("costas_beta", C.c_float),
+        ("costas_min_freq", C.c_float), ("costas_max_freq", C.c_float),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc if the .so is missing or older than its sources."""
+    srcs = [os.path.join(_HERE, f) for f in ("tetra_oracle.c", "tetra_oracle.h", "Makefile")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "libtetra_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.tetra_oracle_default_cfg.argtypes = [C.POINTER(Cfg)]
+        L.tetra_oracle_default_cfg.restype = None
+        L.tetra_oracle_design.argtypes = [C.POINTER(Cfg), C.POINTER(Tables)]
+        L.tetra_oracle_design.restype = C.c_int
+        L.tetra_oracle_reset.argtypes = [C.POINTER(Tables), C.POINTER(State)]
+        L.tetra_oracle_reset.restype = None
+        L.tetra_oracle_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.tetra_oracle_sincosf.restype = None
+        vp = C.c_void_p
+        L.tetra_oracle_process.argtypes = [C.POINTER(Tables), C.POINTER(State), C.c_int, vp, vp, vp, vp, vp, vp]
+        L.tetra_oracle_process.restype = C.c_int
+        L.tetra_oracle_process_batch.argtypes = [C.POINTER(Tables), C.POINTER(State), C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
+        L.tetra_oracle_process_batch.restype = C.c_int
+        L.tetra_oracle_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def default_cfg():
+    cfg = Cfg()
+    lib().tetra_oracle_default_cfg(C.byref(cfg))
+    return cfg
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """One channel of the reference chain: PI4DQPSK -> DQPSKSymbolExtractor -> BitUnpacker."""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg if cfg is not None else default_cfg()
+        self.tab = Tables()
+        rc = lib().tetra_oracle_design(C.byref(self.cfg), C.byref(self.tab))
+        if rc != 0:
+            raise ValueError("tetra_oracle_design failed: %d" % rc)
+        self.st = State()
+        self.reset()
+
+    def reset(self):
+        lib().tetra_oracle_reset(C.byref(self.tab), C.byref(self.st))
+
+    # tables as numpy (copies)
+    @property
+    def ntaps(self):
+        return int(self.tab.ntaps)
+
+    def rrc_taps(self):
+        return np.ctypeslib.as_array(self.tab.rrc)[: self.ntaps].copy()
+
+    def bandedge_taps(self):
+        a = np.ctypeslib.as_array(self.tab.be_a)[: self.ntaps].copy()
+        b = np.ctypeslib.as_array(self.tab.be_b)[: self.ntaps].copy()
+        return a, b
+
+    def interp_bank(self):
+        return np.ctypeslib.as_array(self.tab.bank).copy()
+
+    def process(self, iq, stages=False):
+        """iq: complex64[count].  Returns dict(sym, dibits, bits[, x, y])."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        n = iq.shape[0]
+        cap = n // 2 + n // 16 + 8
+        sym = np.zeros(cap, np.complex64)
+        dib = np.zeros(cap, np.uint8)
+        bits = np.zeros(2 * cap, np.uint8)
+        x = np.zeros(n, np.complex64) if stages else None
+        y = np.zeros(n, np.complex64) if stages else None
+        S = lib().tetra_oracle_process(C.byref(self.tab), C.byref(self.st), n, _ptr(iq), _ptr(x), _ptr(y),
+                                       _ptr(sym), _ptr(dib), _ptr(bits))
+        out = dict(sym=sym[:S], dibits=dib[:S], bits=bits[: 2 * S])
+        if stages:
+            out["x"] = x
+            out["y"] = y
+        return out
+
+
+def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None):
+    """iq: complex64[C][N] channel-major.  Returns (bits[C][stride] u8, n_bits[C] i32, sym or None, states)."""
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    Cn, N = iq.shape
+    cfg = cfg if cfg is not None else default_cfg()
+    tab = Tables()
+    rc = lib().tetra_oracle_design(C.byref(cfg), C.byref(tab))
+    if rc != 0:
+        raise ValueError("tetra_oracle_design failed: %d" % rc)
+    if states is None:
+        states = (State * Cn)()
+        for c in range(Cn):
+            lib().tetra_oracle_reset(C.byref(tab), C.byref(states[c]))
+    stride = bits_stride(N)
+    bits = np.zeros((Cn, stride), np.uint8)
+    nb = np.zeros(Cn, np.int32)
+    sym = np.zeros((Cn, stride // 2), np.complex64) if want_sym else None
+    rc = lib().tetra_oracle_process_batch(C.byref(tab), states, Cn, N, chunk, threads, _ptr(iq), _ptr(bits),
+                                          stride, _ptr(nb), _ptr(sym))
+    if rc != 0:
+        raise RuntimeError("oracle batch overflow: %d" % rc)
+    return bits, nb, sym, states
+
+
+def bits_stride(n_samples):
+    """Output row stride used by the tests: >= ceil(N/1.96)+2 bits, multiple of 16."""
+    s = int(n_samples / 1.9) + 16
+    return (s + 15) // 16 * 16
+
+
+def max_threads():
+    return int(lib().tetra_oracle_max_threads())

@@ -1,0 +1,452 @@
+/*
+ * tetra_oracle.c -- CPU restatement of the reference demodulator chain.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see tetra_oracle.h for both notes
+ * and for the arithmetic contract this file defines.
+ *
+ * All file:line citations are relative to the reference repository
+ * cropinghigh/sdrpp-tetra-demodulator.  "SDR++ core" marks semantics of the
+ * un-vendored AlexandreRouma/SDRPlusPlus core/src/dsp headers (unpinned, master;
+ * SURVEY.md Appendix A) that the reference calls into.
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp -shared -fPIC (see Makefile).
+ */
+#include "tetra_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* SDR++ core dsp/types.h: FL_M_PI */
+#define FL_M_PI 3.1415926535f
+#define DB_M_PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------------- */
+/* Run-time phasor: fixed-polynomial sin/cos (replaces the libm cosf/sinf of    */
+/* SDR++ core math::phasor, called at fll.cpp:137, pi4dqpsk_costas.cpp:7,16).   */
+/* Three-term Cody-Waite reduction by pi/2 + Cephes single-precision minimax    */
+/* polynomials on [-pi/4, pi/4].                                                */
+/* ------------------------------------------------------------------------- */
+void tetra_oracle_sincosf(float x, float* s, float* c) {
+    float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    int q = ((int)k) & 3;
+    float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = ps * z;
+    float sr = fmaf(ps, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = pc * z;
+    float cr = fmaf(pc, z, fmaf(-0.5f, z, 1.0f));
+    float so, co;
+    switch (q) {
+    case 0:  so = sr;  co = cr;  break;
+    case 1:  so = cr;  co = -sr; break;
+    case 2:  so = -sr; co = -cr; break;
+    default: so = -cr; co = sr;  break;
+    }
+    *s = so;
+    *c = co;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Tap / coefficient design (host, once).                                       */
+/* ------------------------------------------------------------------------- */
+
+/* SDR++ core dsp/math/sinc.h: unnormalised sinc in double. */
+static double sdr_sinc(double x) { return (x == 0.0) ? 1.0 : (sin(x) / x); }
+
+/* SDR++ core PhaseControlLoop<float>::criticallyDamped;
+ * called from FLL::init fll.cpp:23-24 and loop::PLL::init (pi4dqpsk.cpp:21). */
+static void critically_damped(float bandwidth, float* alpha, float* beta) {
+    float damp = (float)(sqrt(2.0) / 2.0);
+    float denom = (float)(1.0 + 2.0 * (double)damp * (double)bandwidth + (double)(bandwidth * bandwidth));
+    *alpha = (4 * damp * bandwidth) / denom;
+    *beta = (4 * bandwidth * bandwidth) / denom;
+}
+
+/* SDR++ core taps::rootRaisedCosine<float>(count, beta, symbolrate, samplerate);
+ * called at pi4dqpsk.cpp:18. */
+static void design_rrc(int count, double beta, double symbolrate, double samplerate, float* taps) {
+    double Ts = samplerate / symbolrate;
+    double limit = Ts / (4.0 * beta);
+    for (int i = 0; i < count; i++) {
+        double t = (double)i - (double)count / 2.0 + 0.5;
+        double v;
+        if (t == 0.0) {
+            v = (1.0 + beta * (4.0 / DB_M_PI - 1.0)) / Ts;
+        } else if (t == limit || t == -limit) {
+            v = ((1.0 + 2.0 / DB_M_PI) * sin(DB_M_PI / (4.0 * beta)) +
+                 (1.0 - 2.0 / DB_M_PI) * cos(DB_M_PI / (4.0 * beta))) * beta / (Ts * sqrt(2.0));
+        } else {
+            double a = 4.0 * beta * t / Ts;
+            v = ((sin((1.0 - beta) * DB_M_PI * t / Ts) + cos((1.0 + beta) * DB_M_PI * t / Ts) * a) /
+                 ((1.0 - a * a) * DB_M_PI * t / Ts)) / Ts;
+        }
+        taps[i] = (float)v;
+    }
+}
+
+/* FLL::createBandedgeFilters, fll.cpp:61-95.  Stores the conjugate tap pair as
+ * a[] (common real part) and b[] (imaginary part of the LOWER filter; the upper
+ * filter's is -b), already in the reversed FIR order of fll.cpp:92-93. */
+static void design_bandedge(int filt_size, float filt_a, double symbolrate, double samplerate,
+                            float* a, float* b) {
+    float sps = (float)(samplerate / symbolrate);                 /* fll.cpp:62 */
+    const int M = (int)(filt_size / sps);                         /* fll.cpp:64 */
+    float power = 0;
+    float bb[TETRA_ORACLE_MAX_TAPS];
+    for (int i = 0; i < filt_size; i++) {                         /* fll.cpp:69-75 */
+        float k = -M + i * 2.0f / sps;
+        float tap = (float)(sdr_sinc(filt_a * k - 0.5f) + sdr_sinc(filt_a * k + 0.5f));
+        power += tap;
+        bb[i] = tap;
+    }
+    int N = (int)((filt_size - 1.0f) / 2.0f);                     /* fll.cpp:83 */
+    for (int i = 0; i < filt_size; i++) {                         /* fll.cpp:84-94 */
+        float tap = bb[i] / power;
+        float k = (-N + (int)i) / (2.0f * sps);
+        float arg = -2.0f * FL_M_PI * (1.0f + filt_a) * k;        /* lower: phasor(-2pi(1+a)k) */
+        float re = cosf(arg) * tap;                               /* math::phasor = {cosf, sinf} */
+        float im = sinf(arg) * tap;
+        a[filt_size - i - 1] = re;
+        b[filt_size - i - 1] = im;   /* upper filter: phasor(+...) = conj -> (re, -im) */
+    }
+}
+
+/* COMPLEX_FD::generateInterpTaps complex_fd.cpp:153-158 =
+ * windowedSinc<float>(P*T, hzToRads(0.5/P,1), nuttall, P) + buildPolyphaseBank(P)
+ * (SDR++ core). */
+static double win_nuttall(double n, double N) {
+    static const double coefs[4] = { 0.355768, 0.487396, 0.144232, 0.012604 };
+    double win = 0.0, sign = 1.0;
+    for (int i = 0; i < 4; i++) {
+        win += sign * coefs[i] * cos((double)i * 2.0 * DB_M_PI * n / N);
+        sign = -sign;
+    }
+    return win;
+}
+
+static void design_interp_bank(float bank[TETRA_ORACLE_INTERP_PHASES][TETRA_ORACLE_INTERP_TAPS]) {
+    const int P = TETRA_ORACLE_INTERP_PHASES, T = TETRA_ORACLE_INTERP_TAPS;
+    const int count = P * T;
+    double bw = 0.5 / (double)P;
+    double omega = 2.0 * DB_M_PI * bw / 1.0;            /* math::hzToRads(bw, 1.0) */
+    double half = (double)count / 2.0;
+    double corr = (double)P * omega / DB_M_PI;          /* norm * omega / pi */
+    for (int i = 0; i < count; i++) {
+        double t = (double)i - half + 0.5;
+        float tap = (float)(sdr_sinc(t * omega) * win_nuttall(t - half, (double)count) * corr);
+        bank[(P - 1) - (i % P)][i / P] = tap;           /* buildPolyphaseBank */
+    }
+}
+
+void tetra_oracle_default_cfg(tetra_oracle_cfg_t* cfg) {
+    /* src/main.cpp:35-44 and the gain computation of src/main.cpp:78-82 (float arithmetic
+     * with the double literal 2.0 in the denominator, as written there). */
+    float bw = 0.00628f, damp = 0.707f;
+    float denom = (float)(1.0f + 2.0 * damp * bw + bw * bw);
+    float mu = (4.0f * damp * bw) / denom;
+    float om = (4.0f * bw * bw) / denom;
+    cfg->symbolrate = 18000;
+    cfg->samplerate = 36000;
+    cfg->rrc_tap_count = 65;
+    cfg->rrc_beta = 0.35f;
+    cfg->agc_rate = 0.02f;
+    cfg->costas_bandwidth = 0.01f;
+    cfg->fll_bandwidth = 0.006f;
+    cfg->omega_gain = om;
+    cfg->mu_gain = mu;
+    cfg->omega_rel_limit = 0.02f;
+}
+
+int tetra_oracle_design(const tetra_oracle_cfg_t* cfg, tetra_oracle_tables_t* tab) {
+    if (!cfg || !tab) return -1;
+    if (cfg->rrc_tap_count < 2 || cfg->rrc_tap_count > TETRA_ORACLE_MAX_TAPS) return -2;
+    if (!(cfg->symbolrate > 0) || !(cfg->samplerate > 0)) return -3;
+    memset(tab, 0, sizeof(*tab));
+    tab->cfg = *cfg;
+    tab->ntaps = cfg->rrc_tap_count;
+
+    /* PI4DQPSK::init pi4dqpsk.cpp:17: FLL::init(NULL, fllBandwidth, (int)sym, (int)samp, taps,
+     * (float)beta, 0, -pi/2, +pi/2); rates pass through int parameters (fll.h:33). */
+    int sym_i = (int)cfg->symbolrate, samp_i = (int)cfg->samplerate;
+    design_bandedge(tab->ntaps, (float)cfg->rrc_beta, (double)sym_i, (double)samp_i, tab->be_a, tab->be_b);
+    float a_unused;
+    critically_damped((float)cfg->fll_bandwidth, &a_unused, &tab->fll_beta);
+    tab->fll_alpha = 0.0f;                                     /* fll.cpp:25 */
+    tab->fll_min_freq = (float)(double)(-FL_M_PI / 2.0f);      /* pi4dqpsk.cpp:17 */
+    tab->fll_max_freq = (float)(double)(FL_M_PI / 2.0f);
+
+    design_rrc(tab->ntaps, cfg->rrc_beta, cfg->symbolrate, cfg->samplerate, tab->rrc); /* pi4dqpsk.cpp:18 */
+
+    tab->agc_set_point = (float)1.0;                           /* pi4dqpsk.cpp:20 */
+    tab->agc_max_gain = (float)10e6;
+    tab->agc_rate = (float)cfg->agc_rate;
+
+    critically_damped((float)cfg->costas_bandwidth, &tab->costas_alpha, &tab->costas_beta); /* pi4dqpsk.cpp:21 */
+    tab->costas_min_freq = (float)(double)(-FL_M_PI / 10.0f);
+    tab->costas_max_freq = (float)(double)(FL_M_PI / 10.0f);
+
+    /* COMPLEX_FD::init complex_fd.cpp:12-28, called at pi4dqpsk.cpp:22 */
+    double omega = cfg->samplerate / cfg->symbolrate;
+    tab->tr_alpha = (float)cfg->mu_gain;
+    tab->tr_beta = (float)cfg->omega_gain;
+    tab->tr_omega = (float)omega;
+    tab->tr_min_freq = (float)(omega * (1.0 - cfg->omega_rel_limit));
+    tab->tr_max_freq = (float)(omega * (1.0 + cfg->omega_rel_limit));
+    design_interp_bank(tab->bank);
+    return 0;
+}
+
+void tetra_oracle_reset(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st) {
+    memset(st, 0, sizeof(*st));
+    st->agc_gain = 1.0f;            /* FastAGC initGain (SDR++ core) */
+    st->fll_phase = 0.0f;           /* fll.cpp:26 */
+    st->fll_freq = 0.0f;
+    st->mu = 0.0f;                  /* complex_fd.cpp:22 */
+    st->omega = tab->tr_omega;
+    st->offset = 0;
+    st->costas_phase = 0.0f;
+    st->costas_freq = 0.0f;
+    st->ph2 = 0.0f;
+    st->prev = 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Run-time chain.                                                              */
+/* ------------------------------------------------------------------------- */
+
+/* SDR++ core complex_t::fastAmplitude */
+static inline float fast_amplitude(float re, float im) {
+    float r = fabsf(re), i = fabsf(im);
+    return (r > i) ? (r + 0.4f * i) : (i + 0.4f * r);
+}
+
+int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st,
+                         int count, const float* iq,
+                         float* x_out, float* y_out, float* sym_out,
+                         uint8_t* dibits, uint8_t* bits) {
+    const int nt = tab->ntaps;
+    const int H = nt - 1;
+    if (count <= 0) return 0;
+
+    /* delay line + new samples, split re/im: w[0..H-1] = history, w[H+i] = x_i */
+    float* wr = (float*)malloc(sizeof(float) * (size_t)(H + count) * 2);
+    float* wi = wr + (H + count);
+    float* yr = (float*)malloc(sizeof(float) * (size_t)(7 + count) * 2);
+    float* yi = yr + (7 + count);
+    for (int k = 0; k < H; k++) { wr[k] = st->hist[2 * k]; wi[k] = st->hist[2 * k + 1]; }
+
+    /* --- FastAGC::process (SDR++ core; pi4dqpsk.cpp:134) fused sample-wise with
+     * --- FLL::process fll.cpp:135-149 (no feedback between the stages). */
+    float g = st->agc_gain;
+    float ph = st->fll_phase, fr = st->fll_freq;
+    const float pmax = FL_M_PI, pmin = -FL_M_PI, pdelta = pmax - pmin;
+    for (int i = 0; i < count; i++) {
+        /* AGC */
+        float ar = iq[2 * i] * g, ai = iq[2 * i + 1] * g;
+        float amp = sqrtf(ar * ar + ai * ai);
+        g += (tab->agc_set_point - amp) * tab->agc_rate;
+        if (g > tab->agc_max_gain) g = tab->agc_max_gain;
+        /* FLL: x = in * phasor(-phase)  fll.cpp:137-138 */
+        float s, c;
+        tetra_oracle_sincosf(-ph, &s, &c);
+        float xr = ar * c - ai * s;
+        float xi = ai * c + ar * s;
+        wr[H + i] = xr;
+        wi[H + i] = xi;
+        /* two band-edge FIRs over the same delay line, fll.cpp:141-142 */
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
+        const float* pr = wr + i;
+        const float* pi = wi + i;
+        for (int k = 0; k < nt; k++) {
+            s1 = fmaf(pr[k], tab->be_a[k], s1);
+            s2 = fmaf(pi[k], tab->be_b[k], s2);
+            s3 = fmaf(pr[k], tab->be_b[k], s3);
+            s4 = fmaf(pi[k], tab->be_a[k], s4);
+        }
+        float lre = s1 - s2, lim = s4 + s3;     /* x * (a + jb) */
+        float hre = s1 + s2, him = s4 - s3;     /* x * (a - jb) */
+        float err = fast_amplitude(hre, him) - fast_amplitude(lre, lim); /* fll.cpp:143 */
+        /* pcl.advance(err) fll.cpp:145 (PhaseControlLoop<float>, alpha forced 0) */
+        fr += tab->fll_beta * err;
+        if (fr > tab->fll_max_freq) fr = tab->fll_max_freq;
+        else if (fr < tab->fll_min_freq) fr = tab->fll_min_freq;
+        ph += fr + tab->fll_alpha * err;
+        while (ph > pmax) ph -= pdelta;
+        while (ph < pmin) ph += pdelta;
+    }
+    st->agc_gain = g;
+    st->fll_phase = ph;
+    st->fll_freq = fr;
+    if (x_out) for (int i = 0; i < count; i++) { x_out[2 * i] = wr[H + i]; x_out[2 * i + 1] = wi[H + i]; }
+
+    /* --- FIR<complex_t,float>::process (SDR++ core; pi4dqpsk.cpp:136): RRC --- */
+    for (int k = 0; k < 7; k++) { yr[k] = st->ybuf[2 * k]; yi[k] = st->ybuf[2 * k + 1]; }
+    for (int i = 0; i < count; i++) {
+        float ar = 0.0f, ai = 0.0f;
+        const float* pr = wr + i;
+        const float* pi = wi + i;
+        for (int k = 0; k < nt; k++) {
+            ar = fmaf(pr[k], tab->rrc[k], ar);
+            ai = fmaf(pi[k], tab->rrc[k], ai);
+        }
+        yr[7 + i] = ar;
+        yi[7 + i] = ai;
+    }
+    if (y_out) for (int i = 0; i < count; i++) { y_out[2 * i] = yr[7 + i]; y_out[2 * i + 1] = yi[7 + i]; }
+    /* FIR delay line update (memmove in SDR++ core FIR::process) */
+    for (int k = 0; k < H; k++) { st->hist[2 * k] = wr[count + k]; st->hist[2 * k + 1] = wi[count + k]; }
+
+    /* --- COMPLEX_FD::process complex_fd.cpp:89-151, PI4DQPSK_COSTAS::process
+     * --- pi4dqpsk_costas.cpp:5-21, DQPSKSymbolExtractor::process dqpsk_sym_extr.cpp:4-55
+     * --- (decisions only; the sync statistic is not on the bit path),
+     * --- BitUnpacker::process bit_unpacker.cpp:4-10; fused symbol-wise. */
+    float mu = st->mu, om = st->omega;
+    int offset = st->offset;
+    float cph = st->costas_phase, cfr = st->costas_freq, ph2 = st->ph2;
+    uint8_t prev = st->prev;
+    int S = 0;
+    while (offset < count) {
+        /* complex_fd.cpp:101-103 */
+        int phase = (int)floorf(mu * (float)TETRA_ORACLE_INTERP_PHASES);
+        if (phase < 0) phase = 0;
+        if (phase > TETRA_ORACLE_INTERP_PHASES - 1) phase = TETRA_ORACLE_INTERP_PHASES - 1;
+        const float* br = yr + offset;
+        const float* bi = yi + offset;
+        const float* tp = tab->bank[phase];
+        float vr = 0.0f, vi = 0.0f;
+        for (int k = 0; k < 8; k++) { vr = fmaf(br[k], tp[k], vr); vi = fmaf(bi[k], tp[k], vi); }
+        /* derivative, complex_fd.cpp:107-123 (_outSps == 1: every output is a symbol) */
+        float dr, di;
+        if (phase == 0) {
+            const float* t1 = tab->bank[phase + 1];
+            float fr1 = 0.0f, fi1 = 0.0f;
+            for (int k = 0; k < 8; k++) { fr1 = fmaf(br[k], t1[k], fr1); fi1 = fmaf(bi[k], t1[k], fi1); }
+            dr = fr1 - vr; di = fi1 - vi;
+        } else if (phase == TETRA_ORACLE_INTERP_PHASES - 1) {
+            const float* t0 = tab->bank[phase - 1];
+            float fr0 = 0.0f, fi0 = 0.0f;
+            for (int k = 0; k < 8; k++) { fr0 = fmaf(br[k], t0[k], fr0); fi0 = fmaf(bi[k], t0[k], fi0); }
+            dr = vr - fr0; di = vi - fi0;
+        } else {
+            const float* t1 = tab->bank[phase + 1];
+            const float* t0 = tab->bank[phase - 1];
+            float fr1 = 0.0f, fi1 = 0.0f, fr0 = 0.0f, fi0 = 0.0f;
+            for (int k = 0; k < 8; k++) {
+                fr1 = fmaf(br[k], t1[k], fr1); fi1 = fmaf(bi[k], t1[k], fi1);
+                fr0 = fmaf(br[k], t0[k], fr0); fi0 = fmaf(bi[k], t0[k], fi0);
+            }
+            dr = (fr1 - fr0) * 0.5f; di = (fi1 - fi0) * 0.5f;
+        }
+        /* complex_fd.cpp:126, 136-137 */
+        float terr = ((vr > 0 ? 1.0f : -1.0f) * dr) + ((vi > 0 ? 1.0f : -1.0f) * di);
+        if (terr > 1.0f) terr = 1.0f;
+        if (terr < -1.0f) terr = -1.0f;
+        /* pcl.advance (PhaseControlLoop<float,false>) complex_fd.cpp:140-143 */
+        om += tab->tr_beta * terr;
+        if (om > tab->tr_max_freq) om = tab->tr_max_freq;
+        else if (om < tab->tr_min_freq) om = tab->tr_min_freq;
+        mu += om + tab->tr_alpha * terr;
+        float delta = floorf(mu);
+        offset += (int)delta;
+        mu -= delta;
+
+        /* Costas, pi4dqpsk_costas.cpp:7-19 */
+        float s, c;
+        tetra_oracle_sincosf(-cph, &s, &c);
+        float xr = vr * c - vi * s;
+        float xi = vi * c + vr * s;
+        ph2 += -FL_M_PI / 4.0f;
+        if (ph2 >= 2 * FL_M_PI) ph2 -= 2 * FL_M_PI;
+        else if (ph2 <= -2 * FL_M_PI) ph2 += 2 * FL_M_PI;
+        tetra_oracle_sincosf(ph2, &s, &c);
+        float zr = xr * c - xi * s;
+        float zi = xi * c + xr * s;
+        /* errorFunction pi4dqpsk_costas.cpp:23-28 (math::step: x>0 ? 1 : -1) */
+        float cerr = ((zr > 0 ? 1.0f : -1.0f) * zi) - ((zi > 0 ? 1.0f : -1.0f) * zr);
+        if (cerr < -1.0f) cerr = -1.0f;
+        if (cerr > 1.0f) cerr = 1.0f;
+        cfr += tab->costas_beta * cerr;
+        if (cfr > tab->costas_max_freq) cfr = tab->costas_max_freq;
+        else if (cfr < tab->costas_min_freq) cfr = tab->costas_min_freq;
+        cph += cfr + tab->costas_alpha * cerr;
+        while (cph > pmax) cph -= pdelta;
+        while (cph < pmin) cph += pdelta;
+        if (sym_out) { sym_out[2 * S] = zr; sym_out[2 * S + 1] = zi; }
+
+        /* slicer + differential decoder, dqpsk_sym_extr.cpp:6-7, 32-52 */
+        int a = zi < 0, b = zr < 0;
+        uint8_t sym = (uint8_t)((a << 1) | (a != b));
+        uint8_t pd = (uint8_t)((sym - prev + 4) % 4);
+        static const uint8_t remap[4] = { 0, 1, 3, 2 };
+        uint8_t d = remap[pd];
+        prev = sym;
+        if (dibits) dibits[S] = d;
+        /* bit_unpacker.cpp:6-7 */
+        if (bits) { bits[2 * S] = (uint8_t)((d & 2) >> 1); bits[2 * S + 1] = (uint8_t)(d & 1); }
+        S++;
+    }
+    offset -= count;                                            /* complex_fd.cpp:145 */
+    for (int k = 0; k < 7; k++) { st->ybuf[2 * k] = yr[count + k]; st->ybuf[2 * k + 1] = yi[count + k]; } /* :148 */
+    st->mu = mu; st->omega = om; st->offset = offset;
+    st->costas_phase = cph; st->costas_freq = cfr; st->ph2 = ph2; st->prev = prev;
+
+    free(wr);
+    free(yr);
+    return S;
+}
+
+int tetra_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int tetra_oracle_process_batch(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* states,
+                               int n_channels, int n_samples, int chunk, int threads,
+                               const float* iq, uint8_t* bits, int bits_stride,
+                               int32_t* n_bits, float* sym) {
+    if (chunk <= 0 || chunk > n_samples) chunk = n_samples;
+    int rc = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int c = 0; c < n_channels; c++) {
+        const float* in = iq + (size_t)c * (size_t)n_samples * 2;
+        uint8_t* bo = bits + (size_t)c * (size_t)bits_stride;
+        float* so = sym ? sym + (size_t)c * (size_t)(bits_stride / 2) * 2 : NULL;
+        int nb = 0;
+        int maxs = chunk / 2 + chunk / 16 + 8;
+        uint8_t* tb = (uint8_t*)malloc((size_t)maxs * 2);
+        float* ts = (float*)malloc(sizeof(float) * (size_t)maxs * 2);
+        for (int pos = 0; pos < n_samples; pos += chunk) {
+            int cnt = (n_samples - pos < chunk) ? (n_samples - pos) : chunk;
+            int S = tetra_oracle_process(tab, &states[c], cnt, in + (size_t)pos * 2, NULL, NULL, ts, NULL, tb);
+            if (nb + 2 * S > bits_stride) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+                rc = -1;
+                break;
+            }
+            memcpy(bo + nb, tb, (size_t)2 * S);
+            if (so) memcpy(so + nb, ts, sizeof(float) * (size_t)2 * S);
+            nb += 2 * S;
+        }
+        n_bits[c] = nb;
+        free(tb);
+        free(ts);
+    }
+    return rc;
+}

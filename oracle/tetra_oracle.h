@@ -1,0 +1,135 @@
+/*
+ * tetra_oracle.h -- CPU restatement of the reference's pi/4-DQPSK demodulator chain.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (include/, the
+ * sdrpp-tetra-demodulator_amd/ package, the C-ABI library) may include, link or
+ * call anything in oracle/.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (cropinghigh/sdrpp-tetra-demodulator) ships no
+ * tests, golden vectors or fixtures for this path, and its src/dsp sources cannot
+ * be compiled in this image without writing stand-ins for the absent SDR++ core
+ * headers and VOLK (forbidden), so this restatement is NOT checked against
+ * reference outputs.  It follows the reference source line by line (citations on
+ * every function) plus the SDR++-core semantics listed in SURVEY.md Appendix A,
+ * and is validated functionally: known-answer tests recover the transmitted bits
+ * (ETSI bit<->phase map of src/decoder/src/phy/tetra_burst.c:99-117) with the
+ * constant lag the reference chain has.
+ *
+ * Arithmetic contract (this is what the HIP kernels must reproduce bit for bit):
+ *   - everything is IEEE-754 binary32, round-to-nearest-even, no contraction
+ *     (compile with -ffp-contract=off), subnormals kept;
+ *   - every dot product (FLL band-edge FIRs, RRC FIR, 8-tap interpolator rows) is
+ *     one fmaf chain per real sum, accumulator starting at +0.0f, taps applied in
+ *     ascending tap index (oldest sample first) -- the order of a scalar
+ *     `for k: acc += hist[k]*tap[k]` loop (VOLK's own order is SIMD-ISA dependent,
+ *     so reference floats are not bit-reproducible across machines anyway);
+ *   - the two 65-tap complex band-edge FIRs of the FLL are evaluated through the
+ *     four real sums S1=sum xr*a, S2=sum xi*b, S3=sum xr*b, S4=sum xi*a of the
+ *     conjugate tap pair tL=a+jb, tH=a-jb (src/dsp/fll.cpp:89-93 builds exactly
+ *     conjugate taps);
+ *   - all loop arithmetic (AGC, phase-control loops, error functions, complex
+ *     multiplies) is plain non-fused mul/add in the order the reference source
+ *     writes it;
+ *   - cosf/sinf of the run-time loop phases go through tetra_oracle_sincosf()
+ *     below (a fixed polynomial, <= ~1.5 ulp), because host libm and GPU ocml
+ *     differ in the last ulp; init-time tap design uses the host libm like the
+ *     reference does;
+ *   - sqrtf is the correctly rounded IEEE square root.
+ */
+#ifndef TETRA_ORACLE_H
+#define TETRA_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TETRA_ORACLE_MAX_TAPS 129   /* rrc tap count limit of the restatement */
+#define TETRA_ORACLE_INTERP_PHASES 128
+#define TETRA_ORACLE_INTERP_TAPS 8
+
+/* The ten parameters of PI4DQPSK::init (src/dsp/pi4dqpsk.h:36). */
+typedef struct {
+    double symbolrate;       /* 18000   src/main.cpp:84 */
+    double samplerate;       /* 36000   src/main.cpp:35 */
+    int    rrc_tap_count;    /* 65      src/main.cpp:40 */
+    double rrc_beta;         /* 0.35    src/main.cpp:41 */
+    double agc_rate;         /* 0.02    src/main.cpp:42 */
+    double costas_bandwidth; /* 0.01    src/main.cpp:43 */
+    double fll_bandwidth;    /* 0.006   src/main.cpp:44 */
+    double omega_gain;       /* src/main.cpp:82 recov_omega */
+    double mu_gain;          /* src/main.cpp:81 recov_mu */
+    double omega_rel_limit;  /* 0.02    src/main.cpp:39 */
+} tetra_oracle_cfg_t;
+
+/* Per-channel loop state, in the reference's own terms. */
+typedef struct {
+    float agc_gain;                 /* FastAGC _gain */
+    float fll_phase, fll_freq;      /* FLL pcl.phase / pcl.freq (fll.h:58) */
+    float hist[2 * (TETRA_ORACLE_MAX_TAPS - 1)]; /* last taps-1 FLL outputs (re,im): FIR delay lines */
+    float mu, omega;                /* COMPLEX_FD pcl.phase / pcl.freq (complex_fd.h:57) */
+    int32_t offset;                 /* COMPLEX_FD offset (complex_fd.h:72) */
+    float ybuf[2 * (TETRA_ORACLE_INTERP_TAPS - 1)]; /* COMPLEX_FD delay buffer */
+    float costas_phase, costas_freq;/* PLL pcl */
+    float ph2;                      /* pi4dqpsk_costas.h:32 */
+    uint8_t prev;                   /* dqpsk_sym_extr.h:42 */
+} tetra_oracle_state_t;
+
+/* Derived constants + tables, shared by all channels. */
+typedef struct {
+    tetra_oracle_cfg_t cfg;
+    int   ntaps;                              /* rrc_tap_count */
+    float rrc[TETRA_ORACLE_MAX_TAPS];         /* taps::rootRaisedCosine */
+    float be_a[TETRA_ORACLE_MAX_TAPS];        /* band-edge tap real part (tL.re == tH.re) */
+    float be_b[TETRA_ORACLE_MAX_TAPS];        /* band-edge tap imag part of tL (tH.im = -b) */
+    float bank[TETRA_ORACLE_INTERP_PHASES][TETRA_ORACLE_INTERP_TAPS];
+    float agc_rate, agc_set_point, agc_max_gain;
+    float fll_alpha, fll_beta, fll_min_freq, fll_max_freq;
+    float tr_alpha /*mu gain*/, tr_beta /*omega gain*/, tr_min_freq, tr_max_freq, tr_omega;
+    float costas_alpha, costas_beta, costas_min_freq, costas_max_freq;
+} tetra_oracle_tables_t;
+
+void tetra_oracle_default_cfg(tetra_oracle_cfg_t* cfg);
+/* 0 on success, <0 on bad parameters. */
+int  tetra_oracle_design(const tetra_oracle_cfg_t* cfg, tetra_oracle_tables_t* tab);
+void tetra_oracle_reset(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st);
+
+void tetra_oracle_sincosf(float x, float* s, float* c);
+
+/*
+ * One PI4DQPSK::process + DQPSKSymbolExtractor::process + BitUnpacker::process
+ * call on one channel.  iq = count interleaved (re,im) samples.
+ * Optional outputs (NULL to skip):
+ *   x_out   [2*count]  FLL output (input of the RRC filter)
+ *   y_out   [2*count]  RRC output (input of timing recovery)
+ *   sym_out [2*S]      Costas output = PI4DQPSK::process output
+ *   dibits  [S]        DQPSKSymbolExtractor output
+ *   bits    [2*S]      BitUnpacker output (what tetra_burst_sync_in eats)
+ * Output capacity needed: S <= count/1.9 + 2.  Returns S (symbols produced).
+ */
+int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st,
+                         int count, const float* iq,
+                         float* x_out, float* y_out, float* sym_out,
+                         uint8_t* dibits, uint8_t* bits);
+
+/*
+ * Batched driver used for the CPU baseline and for big parity tests: C channels,
+ * channel-major iq[C][n_samples] (interleaved re,im), processed in `chunk`-sample
+ * process() calls (chunk<=0: one call), channels split over `threads` OpenMP
+ * threads (<=0: all).  bits[C][bits_stride], n_bits[C]; sym (optional)
+ * [C][bits_stride/2] complex.  states[C] carried in/out (must be initialised).
+ * Returns 0, or <0 if an output row would overflow.
+ */
+int tetra_oracle_process_batch(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* states,
+                               int n_channels, int n_samples, int chunk, int threads,
+                               const float* iq, uint8_t* bits, int bits_stride,
+                               int32_t* n_bits, float* sym);
+
+int tetra_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
