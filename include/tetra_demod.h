@@ -1,0 +1,180 @@
+/*
+ * tetra_demod.h -- C ABI of the MI355X-native batched TETRA pi/4-DQPSK demodulator.
+ *
+ * This is the drop-in boundary for ONE path of cropinghigh/sdrpp-tetra-demodulator: the
+ * src/dsp chain AGC -> FLL -> RRC -> timing recovery -> Costas -> symbol slicer ->
+ * differential decoder -> bit unpacker.  A handle owns C independent channels; each channel
+ * is exactly one reference chain
+ *     dsp::demod::PI4DQPSK        (src/dsp/pi4dqpsk.h:27-81, process() src/dsp/pi4dqpsk.cpp:132-140)
+ *  -> dsp::DQPSKSymbolExtractor   (src/dsp/dqpsk_sym_extr.h:19-46, process() src/dsp/dqpsk_sym_extr.cpp:4-55)
+ *  -> dsp::BitUnpacker            (src/dsp/bit_unpacker.h:16-34, process() src/dsp/bit_unpacker.cpp:4-10)
+ * wired as in src/main.cpp:84,90-91.  The single-channel dsp::block wrapper of
+ * sdrpp-tetra-demodulator_amd/host/ is C = 1.
+ *
+ * Conventions: extern "C", plain pointers and sizes, int status (0 = ok, < 0 = error), no
+ * exceptions, no global state.  A handle is driven by one thread at a time (the reference runs
+ * one worker thread per block and takes ctrlMtx + tempStop() around setters,
+ * src/dsp/pi4dqpsk.cpp:32-42).  All work runs on the GPU; there is no CPU fallback and every
+ * entry point fails with TETRA_ERR_NO_DEVICE / TETRA_ERR_HIP when no usable HIP device exists.
+ */
+#ifndef TETRA_DEMOD_H
+#define TETRA_DEMOD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TETRA_DEMOD_ABI_VERSION 1
+
+enum {
+    TETRA_OK = 0,
+    TETRA_ERR_ARG = -1,         /* NULL / out-of-range argument */
+    TETRA_ERR_UNSUPPORTED = -2, /* parameter outside what the kernels implement (e.g. > 80 RRC taps) */
+    TETRA_ERR_NO_DEVICE = -3,   /* no HIP device / bad ordinal */
+    TETRA_ERR_HIP = -4,         /* a HIP runtime call failed (see tetra_demod_last_hip_error) */
+    TETRA_ERR_NOMEM = -5,
+    TETRA_ERR_SIZE = -6,        /* n_samples > max_samples, or an output stride too small */
+    TETRA_ERR_ALIGN = -7        /* output pointer / stride not 8-byte aligned */
+};
+
+/* Input sample layout of process(): element (channel c, sample n) of the complex64 stream. */
+enum {
+    TETRA_LAYOUT_CHANNEL_MAJOR = 0, /* iq[c][n]: each channel contiguous = the reference's complex_t in[count] per channel */
+    TETRA_LAYOUT_TIME_MAJOR = 1     /* iq[n][c]: one frame per sample instant (what a polyphase channeliser emits) */
+};
+
+/*
+ * Configuration = channel count + the ten arguments of PI4DQPSK::init (src/dsp/pi4dqpsk.h:36),
+ * with the reference plugin's values (src/main.cpp:35-44,78-84) as defaults.
+ */
+typedef struct tetra_demod_config {
+    int32_t n_channels;      /* C >= 1 */
+    int32_t max_samples;     /* largest n_samples of one process() call (reference: count <= STREAM_BUFFER_SIZE = 1e6) */
+    int32_t layout;          /* TETRA_LAYOUT_* */
+    int32_t device;          /* HIP device ordinal; -1 = current device */
+    double symbolrate;       /* 18000 */
+    double samplerate;       /* 36000 */
+    int32_t rrc_tap_count;   /* 65; 2..80 supported */
+    int32_t reserved0;
+    double rrc_beta;         /* 0.35 */
+    double agc_rate;         /* 0.02 */
+    double costas_bandwidth; /* 0.01 */
+    double fll_bandwidth;    /* 0.006 */
+    double omega_gain;       /* timing loop beta, src/main.cpp:82 */
+    double mu_gain;          /* timing loop alpha, src/main.cpp:81 */
+    double omega_rel_limit;  /* 0.02 */
+    /* Optional caller-supplied tables (NULL = design them like the reference does).  In an SDR++
+     * build the host may pass SDR++'s own tap generators' output here. */
+    const float* rrc_taps;        /* [rrc_tap_count]                 taps::rootRaisedCosine, pi4dqpsk.cpp:18 */
+    const float* bandedge_taps;   /* [2][rrc_tap_count]: re, im of the LOWER band-edge filter, fll.cpp:61-95 */
+    const float* interp_bank;     /* [128][8]                        complex_fd.cpp:153-158 */
+} tetra_demod_config_t;
+
+/* Per-channel loop state in the reference's own terms (checkpoint / tests). */
+typedef struct tetra_demod_channel_state {
+    float agc_gain;                  /* FastAGC gain */
+    float fll_phase, fll_freq;       /* FLL pcl (src/dsp/fll.h:58) */
+    float mu, omega;                 /* COMPLEX_FD pcl.phase / pcl.freq (src/dsp/complex_fd.h:57) */
+    int32_t offset;                  /* COMPLEX_FD offset (src/dsp/complex_fd.h:72) */
+    float costas_phase, costas_freq; /* PLL pcl of PI4DQPSK_COSTAS */
+    float ph2;                       /* src/dsp/pi4dqpsk_costas.h:32 */
+    int32_t prev;                    /* DQPSKSymbolExtractor prev (src/dsp/dqpsk_sym_extr.h:42) */
+    float hist[2 * 80];              /* last 80 FLL outputs (re,im), newest last: FIR delay lines (only the last taps-1 matter) */
+    float ybuf[2 * 7];               /* COMPLEX_FD delay buffer: last 7 RRC outputs */
+} tetra_demod_channel_state_t;
+
+/* IDs for tetra_demod_set_param: the setters of PI4DQPSK (src/dsp/pi4dqpsk.h:52-63). */
+enum {
+    TETRA_PARAM_SYMBOLRATE = 0,       /* setSymbolrate      pi4dqpsk.cpp:32-42  (also resets timing recovery, complex_fd.cpp:30-41) */
+    TETRA_PARAM_SAMPLERATE = 1,       /* setSamplerate      pi4dqpsk.cpp:44-54 */
+    TETRA_PARAM_RRC_TAP_COUNT = 2,    /* setRRCTapCount     pi4dqpsk.cpp:68-70 */
+    TETRA_PARAM_RRC_BETA = 3,         /* setRRCParams beta  pi4dqpsk.cpp:56-66 (double; the reference's setRRCBeta(int) truncation quirk is NOT reproduced) */
+    TETRA_PARAM_AGC_RATE = 4,         /* setAGCRate         pi4dqpsk.cpp:76-80 */
+    TETRA_PARAM_COSTAS_BANDWIDTH = 5, /* setCostasBandwidth pi4dqpsk.cpp:82-86 */
+    TETRA_PARAM_FLL_BANDWIDTH = 6,    /* setFllBandwidth    pi4dqpsk.cpp:88-92 */
+    TETRA_PARAM_OMEGA_GAIN = 7,       /* setOmegaGain       pi4dqpsk.cpp:102-106 */
+    TETRA_PARAM_MU_GAIN = 8,          /* setMuGain          pi4dqpsk.cpp:108-112 */
+    TETRA_PARAM_OMEGA_REL_LIMIT = 9   /* setOmegaRelLimit   pi4dqpsk.cpp:114-118 */
+};
+
+typedef struct tetra_demod tetra_demod_t;
+
+/* Fill cfg with the reference plugin's parameters (src/main.cpp:35-44,78-84), C = 1. */
+int tetra_demod_default_config(tetra_demod_config_t* cfg);
+
+/* Number of HIP devices visible (0 if none); the per-GPU channel ranges of a multi-GPU host are
+ * one handle per device (cfg.device). */
+int tetra_demod_device_count(void);
+
+/* Replaces PI4DQPSK::init + DQPSKSymbolExtractor::init + BitUnpacker::init (src/main.cpp:84,90-91)
+ * for C channels: designs the taps, allocates device state. */
+int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out);
+int tetra_demod_destroy(tetra_demod_t* h);
+
+/* Smallest bits_stride accepted for n_samples: n/0.95 + 16 rounded up to a multiple of 16
+ * (bits = 2 x symbols, symbols <= n/omega_min + 1 with omega_min = 2(1 - omega_rel_limit)). */
+int tetra_demod_bits_stride(int n_samples);
+
+/*
+ * Replaces one PI4DQPSK::process + DQPSKSymbolExtractor::process + BitUnpacker::process call per
+ * channel (src/dsp/pi4dqpsk.cpp:132-140, dqpsk_sym_extr.cpp:4-55, bit_unpacker.cpp:4-10).
+ *   iq      n_channels x n_samples complex64 (interleaved re,im) in cfg.layout
+ *   bits    [n_channels][bits_stride] uint8, one bit per byte, MSB of each dibit first -- the stream
+ *           tetra_burst_sync_in() consumes (src/decoder/src/phy/tetra_burst_sync.c:54)
+ *   n_bits  [n_channels] int32: bits written per channel this call (2 x symbols; varies per channel
+ *           because the timing loop's omega floats within +-omega_rel_limit)
+ *   sym     optional [n_channels][bits_stride/2] complex64: PI4DQPSK::process output (constellation
+ *           points after the Costas loop), NULL to skip
+ * Loop state is carried across calls; the result is independent of how a stream is cut into calls.
+ * _device: all pointers are device pointers on the handle's GPU, work is enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream) and the call returns without synchronising.
+ * Host variant: pointers are host memory; copies in, runs, copies out, synchronises.
+ */
+int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_samples, uint8_t* d_bits,
+                               int bits_stride, int32_t* d_n_bits, float* d_sym, void* hip_stream);
+int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
+                        int32_t* n_bits, float* sym);
+
+/* PI4DQPSK::reset (src/dsp/pi4dqpsk.cpp:120-130) + slicer state; channel = -1 resets all. */
+int tetra_demod_reset(tetra_demod_t* h, int channel);
+
+/* The twelve PI4DQPSK setters collapse to one call (IDs above).  Like the reference, changing a
+ * rate or the RRC design re-designs the taps and keeps loop state; TETRA_PARAM_SYMBOLRATE /
+ * _SAMPLERATE additionally reset the timing loop (COMPLEX_FD::setOmega, complex_fd.cpp:30-41). */
+int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value);
+
+int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out);
+int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in);
+
+/* Copies of the designed tables (any pointer may be NULL): rrc[taps], be_re[taps], be_im[taps]
+ * (lower band-edge filter), bank[128*8]; *taps receives the tap count. */
+int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank);
+
+/* Debug/verification tap: RRC output (timing-recovery input) of the last process call,
+ * y[n_channels][n_samples] complex64 channel-major, copied to host memory. */
+int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples);
+
+/* GPU time of the two kernels of the most recent process call, from HIP events recorded on the
+ * call's stream (synchronises on them).  k1 = AGC+FLL+RRC, k2 = timing+Costas+slicer. */
+int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms);
+/* Same for the n (1..64) most recent kernel-launching process calls, oldest first: k1_ms[n], k2_ms[n]
+ * (either may be NULL).  The events are recorded on each call's own stream, so a benchmark can read the
+ * per-launch kernel durations of its timed region after the region ends, without synchronising inside it. */
+int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* k1_ms, float* k2_ms);
+
+/* Device self-test of the primitives the bit-exact contract rests on: in[0..63] -> sqrt, in[64..127] ->
+ * sin/cos; out[0..63] = row_shr:1 DPP of lane ids (old = 100+lane), out[64..127] = row_shl:1 (old = 200+lane),
+ * out[128..191] = sqrt, out[192..255] = sin, out[256..319] = cos.  Used by the GPU tests. */
+int tetra_demod_debug_selftest(tetra_demod_t* h, const float* in128, float* out320);
+
+const char* tetra_demod_strerror(int status);
+/* hipError_t of the last failing HIP call on this handle (0 if none). */
+int tetra_demod_last_hip_error(tetra_demod_t* h);
+int tetra_demod_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETRA_DEMOD_H */

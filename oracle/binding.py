@@ -183,8 +183,8 @@ def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None)
 
 
 def bits_stride(n_samples):
-    """Output row stride used by the tests: >= ceil(N/1.96)+2 bits, multiple of 16."""
-    s = int(n_samples / 1.9) + 16
+    """Output row stride used by the tests: >= 2*(N/1.94+1) bits, multiple of 16."""
+    s = int(n_samples / 0.95) + 16
     return (s + 15) // 16 * 16
 
 

@@ -1,0 +1,259 @@
+"""ctypes binding of the C ABI (include/tetra_demod.h) -> libtetra_demod_hip.so.
+
+Mirrors the reference's block interface for this path: one `Demodulator` = C copies of
+PI4DQPSK -> DQPSKSymbolExtractor -> BitUnpacker (src/dsp/pi4dqpsk.h:27-81,
+src/dsp/dqpsk_sym_extr.h:19-46, src/dsp/bit_unpacker.h:16-34) with init / process / reset /
+setters.  There is no CPU fallback: if the HIP library is missing or no GPU is usable, every
+call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+LAYOUT_CHANNEL_MAJOR = 0
+LAYOUT_TIME_MAJOR = 1
+
+PARAMS = dict(symbolrate=0, samplerate=1, rrc_tap_count=2, rrc_beta=3, agc_rate=4, costas_bandwidth=5,
+              fll_bandwidth=6, omega_gain=7, mu_gain=8, omega_rel_limit=9)
+
+EXPORTS = [
+    "tetra_demod_default_config", "tetra_demod_device_count", "tetra_demod_create", "tetra_demod_destroy",
+    "tetra_demod_bits_stride", "tetra_demod_process_device", "tetra_demod_process", "tetra_demod_reset",
+    "tetra_demod_set_param", "tetra_demod_get_state", "tetra_demod_set_state", "tetra_demod_get_tables",
+    "tetra_demod_debug_read_rrc_out", "tetra_demod_last_kernel_ms", "tetra_demod_strerror",
+    "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_channels", C.c_int32), ("max_samples", C.c_int32), ("layout", C.c_int32), ("device", C.c_int32),
+        ("symbolrate", C.c_double), ("samplerate", C.c_double),
+        ("rrc_tap_count", C.c_int32), ("reserved0", C.c_int32),
+        ("rrc_beta", C.c_double), ("agc_rate", C.c_double), ("costas_bandwidth", C.c_double),
+        ("fll_bandwidth", C.c_double), ("omega_gain", C.c_double), ("mu_gain", C.c_double),
+        ("omega_rel_limit", C.c_double),
+        ("rrc_taps", C.c_void_p), ("bandedge_taps", C.c_void_p), ("interp_bank", C.c_void_p),
+    ]
+
+
+class ChannelState(C.Structure):
+    _fields_ = [
+        ("agc_gain", C.c_float), ("fll_phase", C.c_float), ("fll_freq", C.c_float),
+        ("mu", C.c_float), ("omega", C.c_float), ("offset", C.c_int32),
+        ("costas_phase", C.c_float), ("costas_freq", C.c_float), ("ph2", C.c_float), ("prev", C.c_int32),
+        ("hist", C.c_float * 160), ("ybuf", C.c_float * 14),
+    ]
+
+
+class TetraDemodError(RuntimeError):
+    def __init__(self, status, what, hip=0):
+        self.status = status
+        self.hip = hip
+        msg = "%s failed: %d (%s)" % (what, status, _strerror(status))
+        if hip:
+            msg += " [hipError %d]" % hip
+        super().__init__(msg)
+
+
+_lib = None
+
+
+def load_library(rebuild_if_stale=True):
+    """Load libtetra_demod_hip.so (building it with hipcc when missing/stale).  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if rebuild_if_stale and _build.is_stale():
+        path = _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError("HIP library %s is missing; run __graft_entry__.build() (no CPU fallback exists)" % path)
+    L = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int
+    L.tetra_demod_default_config.argtypes = [C.POINTER(Config)]
+    L.tetra_demod_device_count.argtypes = []
+    L.tetra_demod_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.tetra_demod_destroy.argtypes = [vp]
+    L.tetra_demod_bits_stride.argtypes = [i32]
+    L.tetra_demod_process_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.tetra_demod_process.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.tetra_demod_reset.argtypes = [vp, i32]
+    L.tetra_demod_set_param.argtypes = [vp, i32, C.c_double]
+    L.tetra_demod_get_state.argtypes = [vp, i32, C.POINTER(ChannelState)]
+    L.tetra_demod_set_state.argtypes = [vp, i32, C.POINTER(ChannelState)]
+    L.tetra_demod_get_tables.argtypes = [vp, C.POINTER(i32), vp, vp, vp, vp]
+    L.tetra_demod_debug_read_rrc_out.argtypes = [vp, vp, i32]
+    L.tetra_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.tetra_demod_strerror.argtypes = [i32]
+    L.tetra_demod_strerror.restype = C.c_char_p
+    L.tetra_demod_last_hip_error.argtypes = [vp]
+    L.tetra_demod_abi_version.argtypes = []
+    L.tetra_demod_debug_selftest.argtypes = [vp, vp, vp]
+    L.tetra_demod_kernel_ms_history.argtypes = [vp, i32, vp, vp]
+    for name in EXPORTS:
+        if name != "tetra_demod_strerror":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def _strerror(status):
+    try:
+        return load_library(False).tetra_demod_strerror(status).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def default_config():
+    cfg = Config()
+    rc = load_library().tetra_demod_default_config(C.byref(cfg))
+    if rc:
+        raise TetraDemodError(rc, "tetra_demod_default_config")
+    return cfg
+
+
+def device_count():
+    return int(load_library().tetra_demod_device_count())
+
+
+def bits_stride(n_samples):
+    return int(load_library().tetra_demod_bits_stride(int(n_samples)))
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Demodulator:
+    """C batched reference chains on one GPU."""
+
+    def __init__(self, n_channels=1, max_samples=65536, layout=LAYOUT_CHANNEL_MAJOR, device=-1,
+                 rrc_taps=None, bandedge_taps=None, interp_bank=None, **params):
+        self._lib = load_library()
+        cfg = default_config()
+        cfg.n_channels = n_channels
+        cfg.max_samples = max_samples
+        cfg.layout = layout
+        cfg.device = device
+        for k, v in params.items():
+            if k not in PARAMS:
+                raise TypeError("unknown parameter %r" % k)
+            setattr(cfg, k, v)
+        keep = []
+        for name, arr in (("rrc_taps", rrc_taps), ("bandedge_taps", bandedge_taps), ("interp_bank", interp_bank)):
+            if arr is not None:
+                a = np.ascontiguousarray(arr, dtype=np.float32)
+                keep.append(a)
+                setattr(cfg, name, a.ctypes.data)
+        self.cfg = cfg
+        self.n_channels = n_channels
+        self.max_samples = max_samples
+        self.layout = layout
+        h = C.c_void_p()
+        rc = self._lib.tetra_demod_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise TetraDemodError(rc, "tetra_demod_create")
+        self._h = h
+
+    def _check(self, rc, what):
+        if rc:
+            raise TetraDemodError(rc, what, self._lib.tetra_demod_last_hip_error(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tetra_demod_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- PI4DQPSK::process + DQPSKSymbolExtractor::process + BitUnpacker::process --------------------
+    def process(self, iq, want_sym=False):
+        """Host path.  iq complex64 [C][N] (channel-major) or [N][C] (time-major handle).
+        Returns (bits u8 [C][stride], n_bits i32 [C], sym complex64 [C][stride/2] or None)."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        if iq.ndim == 1:
+            iq = iq[None, :] if self.layout == LAYOUT_CHANNEL_MAJOR else iq[:, None]
+        n = iq.shape[1] if self.layout == LAYOUT_CHANNEL_MAJOR else iq.shape[0]
+        cdim = iq.shape[0] if self.layout == LAYOUT_CHANNEL_MAJOR else iq.shape[1]
+        if cdim != self.n_channels:
+            raise ValueError("expected %d channels, got %d" % (self.n_channels, cdim))
+        stride = bits_stride(n)
+        bits = np.zeros((self.n_channels, stride), np.uint8)
+        nb = np.zeros(self.n_channels, np.int32)
+        sym = np.zeros((self.n_channels, stride // 2), np.complex64) if want_sym else None
+        rc = self._lib.tetra_demod_process(self._h, _np_ptr(iq), n, _np_ptr(bits), stride, _np_ptr(nb), _np_ptr(sym))
+        self._check(rc, "tetra_demod_process")
+        return bits, nb, sym
+
+    def process_device(self, d_iq, n_samples, d_bits, bits_stride_, d_n_bits, d_sym=None, stream=None):
+        """Device path: arguments are objects with .data_ptr() (torch tensors on this GPU) or ints."""
+        def p(x):
+            if x is None:
+                return None
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        s = None
+        if stream is not None:
+            s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+        rc = self._lib.tetra_demod_process_device(self._h, p(d_iq), int(n_samples), p(d_bits), int(bits_stride_),
+                                                  p(d_n_bits), p(d_sym), s)
+        self._check(rc, "tetra_demod_process_device")
+
+    # --- PI4DQPSK::reset and the setters -----------------------------------------------------------
+    def reset(self, channel=-1):
+        self._check(self._lib.tetra_demod_reset(self._h, channel), "tetra_demod_reset")
+
+    def set_param(self, name, value):
+        self._check(self._lib.tetra_demod_set_param(self._h, PARAMS[name], float(value)), "tetra_demod_set_param")
+
+    def get_state(self, channel):
+        st = ChannelState()
+        self._check(self._lib.tetra_demod_get_state(self._h, channel, C.byref(st)), "tetra_demod_get_state")
+        return st
+
+    def set_state(self, channel, st):
+        self._check(self._lib.tetra_demod_set_state(self._h, channel, C.byref(st)), "tetra_demod_set_state")
+
+    def tables(self):
+        nt = C.c_int(0)
+        self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), None, None, None, None), "tetra_demod_get_tables")
+        n = nt.value
+        rrc = np.zeros(n, np.float32)
+        re = np.zeros(n, np.float32)
+        im = np.zeros(n, np.float32)
+        bank = np.zeros((128, 8), np.float32)
+        self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), _np_ptr(rrc), _np_ptr(re), _np_ptr(im),
+                                                     _np_ptr(bank)), "tetra_demod_get_tables")
+        return dict(rrc=rrc, be_re=re, be_im=im, bank=bank)
+
+    def read_rrc_out(self, n_samples):
+        y = np.zeros((self.n_channels, n_samples), np.complex64)
+        self._check(self._lib.tetra_demod_debug_read_rrc_out(self._h, _np_ptr(y), n_samples),
+                    "tetra_demod_debug_read_rrc_out")
+        return y
+
+    def selftest(self, in128):
+        a = np.ascontiguousarray(in128, np.float32)
+        assert a.shape == (128,)
+        out = np.zeros(320, np.float32)
+        self._check(self._lib.tetra_demod_debug_selftest(self._h, _np_ptr(a), _np_ptr(out)), "tetra_demod_debug_selftest")
+        return out.reshape(5, 64)
+
+    def kernel_ms_history(self, n):
+        k1 = np.zeros(n, np.float32)
+        k2 = np.zeros(n, np.float32)
+        self._check(self._lib.tetra_demod_kernel_ms_history(self._h, n, _np_ptr(k1), _np_ptr(k2)),
+                    "tetra_demod_kernel_ms_history")
+        return k1, k2
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._lib.tetra_demod_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "tetra_demod_last_kernel_ms")
+        return a.value, b.value

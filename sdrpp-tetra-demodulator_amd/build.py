@@ -1,0 +1,38 @@
+"""Builds libtetra_demod_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtetra_demod_hip.so")
+SOURCES = ["tetra_demod.hip"]
+DEPS = ["tetra_demod.hip", "demod_core.hpp", "design.hpp", os.path.join("..", "..", "include", "tetra_demod.h")]
+
+# -ffp-contract=off + correctly rounded sqrt: the arithmetic contract shared with the oracle.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"]
+
+
+def hipcc_path():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
+    return p
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    """Compile the library if missing or older than its sources.  Returns the .so path."""
+    if force or is_stale():
+        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB

@@ -1,0 +1,398 @@
+// demod_core.hpp -- per-lane arithmetic of the batched TETRA pi/4-DQPSK demodulator kernels.
+//
+// One source, two targets:
+//   * device (hipcc, gfx950): V = float, one value per lane, cross-lane moves are DPP
+//     row shifts inside a 16-lane row;
+//   * host emulation (-DTETRA_HOST_EMUL, g++): V = Row16, a 16-lane row stepped in lockstep, with
+//     the DPP moves emulated.  tests/ use it to check the systolic schedule against the CPU
+//     oracle without a GPU.  It is NOT a fallback: the library has no CPU path.
+//
+// Arithmetic contract (must stay bit-identical to oracle/tetra_oracle.c, which restates the
+// reference): binary32, no contraction (-ffp-contract=off), explicit fma only inside dot-product
+// chains and inside sincos, loop arithmetic as separate mul/add, correctly rounded sqrt.
+//
+// Reference citations (cropinghigh/sdrpp-tetra-demodulator):
+//   AGC      SDR++ core loop::FastAGC::process, called at src/dsp/pi4dqpsk.cpp:134
+//   FLL      src/dsp/fll.cpp:135-149
+//   RRC      SDR++ core filter::FIR<complex_t,float>::process, called at src/dsp/pi4dqpsk.cpp:136
+//   timing   src/dsp/complex_fd.cpp:89-151
+//   Costas   src/dsp/pi4dqpsk_costas.cpp:5-28
+//   slicer   src/dsp/dqpsk_sym_extr.cpp:6-7,32-52 ; unpacker src/dsp/bit_unpacker.cpp:4-10
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TD_FN __device__ __forceinline__
+#define TD_MFN __device__ __forceinline__
+#define TD_DEVICE 1
+#else
+#include <math.h>
+#define TD_FN static inline __attribute__((always_inline))
+#define TD_MFN inline __attribute__((always_inline))
+#define TD_DEVICE 0
+#endif
+
+namespace tdm {
+
+constexpr float kFlPi = 3.1415926535f;       // SDR++ core FL_M_PI
+constexpr int kLanes = 16;                    // lanes per channel row (one DPP row)
+constexpr int kTapsPerLane = 5;               // taps applied per lane visit
+constexpr int kPadTaps = kLanes * kTapsPerLane;  // 80: max FIR length of the systolic array
+constexpr int kHist = kPadTaps;               // stored delay-line samples per channel
+constexpr int kInterpPhases = 128;
+constexpr int kInterpTaps = 8;
+
+// ---------------------------------------------------------------------------------------------
+// float backend (device lanes, and host scalar code)
+// ---------------------------------------------------------------------------------------------
+TD_FN float v_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+TD_FN float v_sqrt(float a) { return __builtin_sqrtf(a); }
+TD_FN float v_rint(float a) { return __builtin_rintf(a); }
+TD_FN float v_floor(float a) { return __builtin_floorf(a); }
+TD_FN float v_abs(float a) { return __builtin_fabsf(a); }
+TD_FN float v_sel(bool m, float a, float b) { return m ? a : b; }
+TD_FN int v_sel(bool m, int a, int b) { return m ? a : b; }
+TD_FN int v_ftoi(float a) { return (int)a; }
+TD_FN bool v_ieq(int a, int b) { return a == b; }
+TD_FN int v_iand(int a, int b) { return a & b; }
+
+template <class V> struct vtraits;
+template <> struct vtraits<float> { using M = bool; using I = int; };
+
+#if TD_DEVICE
+typedef float pk2 __attribute__((ext_vector_type(2)));
+// Pair<float> on the device is a 64-bit register pair so that pk_fma lowers to v_pk_fma_f32.
+template <class V> struct Pair;
+template <> struct Pair<float> {
+    pk2 v;
+    TD_MFN Pair() {}
+    TD_MFN Pair(float x, float y) { v.x = x; v.y = y; }
+    TD_MFN float x() const { return v.x; }
+    TD_MFN float y() const { return v.y; }
+};
+TD_FN Pair<float> pk_fma(Pair<float> a, Pair<float> b, Pair<float> c) {
+    Pair<float> r;
+    r.v = __builtin_elementwise_fma(a.v, b.v, c.v);
+    return r;
+}
+// DPP row moves (gfx9 DPP controls): row_shr:1 = 0x111 (lane l <- lane l-1), row_shl:1 = 0x101
+// (lane l <- lane l+1).  With bound_ctrl off, lanes whose source is outside the 16-lane row keep `old`.
+TD_FN float row_shr1(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x111, 0xf, 0xf, false));
+}
+TD_FN float row_shl1(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x101, 0xf, 0xf, false));
+}
+#else
+template <class V> struct Pair {
+    V vx, vy;
+    Pair() {}
+    Pair(V x, V y) : vx(x), vy(y) {}
+    V x() const { return vx; }
+    V y() const { return vy; }
+};
+template <class V> TD_FN Pair<V> pk_fma(Pair<V> a, Pair<V> b, Pair<V> c) {
+    return Pair<V>(v_fma(a.x(), b.x(), c.x()), v_fma(a.y(), b.y(), c.y()));
+}
+#endif
+
+#if defined(TETRA_HOST_EMUL)
+// ---------------------------------------------------------------------------------------------
+// Row16 backend: a 16-lane row in lockstep (host emulation of one DPP row).
+// ---------------------------------------------------------------------------------------------
+struct Row16m { bool l[16]; };
+struct Row16i { int l[16]; };
+struct Row16 {
+    float l[16];
+    Row16() {}
+    Row16(float s) { for (int i = 0; i < 16; i++) l[i] = s; }
+};
+#define TD_R16_BIN(op) \
+    TD_FN Row16 operator op(Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] op b.l[i]; return r; } \
+    TD_FN Row16 operator op(Row16 a, float b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] op b; return r; } \
+    TD_FN Row16 operator op(float a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = a op b.l[i]; return r; }
+TD_R16_BIN(+) TD_R16_BIN(-) TD_R16_BIN(*)
+#undef TD_R16_BIN
+#define TD_R16_CMP(op) \
+    TD_FN Row16m operator op(Row16 a, Row16 b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] op b.l[i]; return r; } \
+    TD_FN Row16m operator op(Row16 a, float b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] op b; return r; }
+TD_R16_CMP(>) TD_R16_CMP(<) TD_R16_CMP(>=) TD_R16_CMP(<=)
+#undef TD_R16_CMP
+TD_FN Row16 operator-(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = -a.l[i]; return r; }
+TD_FN Row16 v_fma(Row16 a, Row16 b, Row16 c) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fmaf(a.l[i], b.l[i], c.l[i]); return r; }
+TD_FN Row16 v_sqrt(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = sqrtf(a.l[i]); return r; }
+TD_FN Row16 v_rint(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = rintf(a.l[i]); return r; }
+TD_FN Row16 v_abs(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fabsf(a.l[i]); return r; }
+TD_FN Row16 v_sel(Row16m m, Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = m.l[i] ? a.l[i] : b.l[i]; return r; }
+TD_FN Row16i v_ftoi(Row16 a) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = (int)a.l[i]; return r; }
+TD_FN Row16m v_ieq(Row16i a, int b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] == b; return r; }
+TD_FN Row16i v_iand(Row16i a, int b) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] & b; return r; }
+template <> struct vtraits<Row16> { using M = Row16m; using I = Row16i; };
+TD_FN Row16 row_shr1(Row16 old, Row16 src) { Row16 r; r.l[0] = old.l[0]; for (int i = 1; i < 16; i++) r.l[i] = src.l[i - 1]; return r; }
+TD_FN Row16 row_shl1(Row16 old, Row16 src) { Row16 r; r.l[15] = old.l[15]; for (int i = 0; i < 15; i++) r.l[i] = src.l[i + 1]; return r; }
+#endif  // TETRA_HOST_EMUL
+
+template <class V> TD_FN Pair<V> row_shr1(Pair<V> old, Pair<V> src) {
+    return Pair<V>(row_shr1(old.x(), src.x()), row_shr1(old.y(), src.y()));
+}
+template <class V> TD_FN Pair<V> row_shl1(Pair<V> old, Pair<V> src) {
+    return Pair<V>(row_shl1(old.x(), src.x()), row_shl1(old.y(), src.y()));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same polynomial as
+// tetra_oracle_sincosf).  Valid for |x| up to a few hundred.
+// ---------------------------------------------------------------------------------------------
+template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
+    V k = v_rint(x * 0.636619772367581343f);
+    V nk = -k;
+    V r = v_fma(nk, V(1.5703125f), x);
+    r = v_fma(nk, V(4.837512969970703125e-4f), r);
+    r = v_fma(nk, V(7.54978995489188216e-8f), r);
+    typename vtraits<V>::I q = v_iand(v_ftoi(k), 3);
+    V z = r * r;
+    V ps = v_fma(V(-1.9515295891e-4f), z, V(8.3321608736e-3f));
+    ps = v_fma(ps, z, V(-1.6666654611e-1f));
+    ps = ps * z;
+    V sr = v_fma(ps, r, r);
+    V pc = v_fma(V(2.443315711809948e-5f), z, V(-1.388731625493765e-3f));
+    pc = v_fma(pc, z, V(4.166664568298827e-2f));
+    pc = pc * z;
+    V cr = v_fma(pc, z, v_fma(V(-0.5f), z, V(1.0f)));
+    typename vtraits<V>::M q0 = v_ieq(q, 0), q1 = v_ieq(q, 1), q2 = v_ieq(q, 2);
+    s = v_sel(q0, sr, v_sel(q1, cr, v_sel(q2, -sr, -cr)));
+    c = v_sel(q0, cr, v_sel(q1, -sr, v_sel(q2, -cr, sr)));
+}
+
+// SDR++ core complex_t::fastAmplitude
+template <class V> TD_FN V fast_amp(V re, V im) {
+    V r = v_abs(re), i = v_abs(im);
+    return v_sel(r > i, r + 0.4f * i, i + 0.4f * r);
+}
+
+// SDR++ core PhaseControlLoop<float, CLAMP>::advance.  The reference wraps with while loops; one
+// conditional step each way is identical as long as |freq + alpha*err| < 2*pi, which the frequency
+// limits of pi4dqpsk.cpp:17,21 guarantee (|freq| <= pi/2, |alpha*err| < 1).
+template <class V, bool CLAMP> TD_FN void pcl_advance(V err, V& phase, V& freq, float alpha, float beta,
+                                                      float minf, float maxf) {
+    freq = freq + beta * err;
+    freq = v_sel(freq > maxf, V(maxf), v_sel(freq < minf, V(minf), freq));
+    phase = phase + (freq + alpha * err);
+    if (CLAMP) {
+        const float pmax = kFlPi, pmin = -kFlPi, pdelta = pmax - pmin;
+        phase = v_sel(phase > pmax, phase - pdelta, phase);
+        phase = v_sel(phase < pmin, phase + pdelta, phase);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1 row program: AGC -> FLL -> RRC for one channel on a 16-lane row.
+//
+// The three 65-tap FIRs (two conjugate band-edge filters evaluated as four real sums, one RRC) run
+// as ONE systolic array along the row.  Taps are zero-padded at the old end to 80 = 16 lanes x 5;
+// padded tap kp lives in lane 15 - kp/5, slot kp%5, so lane 0 owns the five newest taps.  The
+// derotated sample x_i is produced in lane 0 and travels outward one lane per step (row_shr:1);
+// partial sums are created in lane 15 and travel inward one lane per four steps (row_shl:1),
+// receiving their taps in ascending tap order -- bit-identical to a direct-form fmaf chain
+// `for k: acc = fmaf(hist[k], tap[k], acc)` -- and complete in lane 0 in the very step that
+// produces x_i, where the FLL error needs them.  Only the newest tap sits on the per-sample
+// critical path.  Lanes 1..15 execute the scalar loop code on don't-care data.
+// ---------------------------------------------------------------------------------------------
+struct K1Consts {
+    float agc_set_point, agc_rate, agc_max_gain;
+    float fll_alpha, fll_beta, fll_min_freq, fll_max_freq;
+};
+
+template <class V> struct K1Row {
+    typedef Pair<V> P;
+    // per-lane tap blocks: t13[j] = (a, b), t24[j] = (b, a) of band-edge tap, th[j] = (h, h) of RRC tap
+    P t13[kTapsPerLane], t24[kTapsPerLane], th[kTapsPerLane];
+    // resident partial sums (4 per lane per sum group): (S1,S3), (S2,S4), (y.re, y.im)
+    P r13[4], r24[4], ry[4];
+    P xs;          // x pipeline register: lane l holds x_{i-l}
+    V g, ph, fr;   // AGC gain, FLL phase, FLL freq (meaningful in lane 0)
+
+    TD_MFN void clear_pipeline() {
+        for (int q = 0; q < 4; q++) { r13[q] = P(V(0.0f), V(0.0f)); r24[q] = P(V(0.0f), V(0.0f)); ry[q] = P(V(0.0f), V(0.0f)); }
+        xs = P(V(0.0f), V(0.0f));
+    }
+
+    // One sample step.  PH = step index mod 4 (selects which resident register is oldest).
+    // REPLAY: `in` is a stored delay-line sample x (no AGC/FLL, loop state untouched).
+    // Returns the completed RRC output y_i (valid in lane 0; don't-care when REPLAY).
+    template <int PH, bool REPLAY> TD_MFN P step(const K1Consts& k, P in) {
+        P x;
+        if (REPLAY) {
+            x = in;
+        } else {
+            // FastAGC::process
+            V ar = in.x() * g, ai = in.y() * g;
+            V amp = v_sqrt(ar * ar + ai * ai);
+            g = g + (k.agc_set_point - amp) * k.agc_rate;
+            g = v_sel(g > k.agc_max_gain, V(k.agc_max_gain), g);
+            // fll.cpp:137-138  x = in * phasor(-phase)
+            V s, c;
+            sincos_t<V>(-ph, s, c);
+            x = P(ar * c - ai * s, ai * c + ar * s);
+        }
+        xs = row_shr1(x, xs);
+        P xr2(xs.x(), xs.x()), xi2(xs.y(), xs.y());
+        // newest tap of this lane's block on the oldest resident sums
+        P c13 = pk_fma(xr2, t13[4], r13[PH]);
+        P c24 = pk_fma(xi2, t24[4], r24[PH]);
+        P cy = pk_fma(xs, th[4], ry[PH]);
+        // hop one lane inward; lane 15 starts fresh sums at +0
+        const P zero(V(0.0f), V(0.0f));
+        P h13 = row_shl1(zero, c13), h24 = row_shl1(zero, c24), hy = row_shl1(zero, cy);
+        r13[PH] = pk_fma(xr2, t13[0], h13);
+        r24[PH] = pk_fma(xi2, t24[0], h24);
+        ry[PH] = pk_fma(xs, th[0], hy);
+        r13[(PH + 1) & 3] = pk_fma(xr2, t13[3], r13[(PH + 1) & 3]);
+        r24[(PH + 1) & 3] = pk_fma(xi2, t24[3], r24[(PH + 1) & 3]);
+        ry[(PH + 1) & 3] = pk_fma(xs, th[3], ry[(PH + 1) & 3]);
+        r13[(PH + 2) & 3] = pk_fma(xr2, t13[2], r13[(PH + 2) & 3]);
+        r24[(PH + 2) & 3] = pk_fma(xi2, t24[2], r24[(PH + 2) & 3]);
+        ry[(PH + 2) & 3] = pk_fma(xs, th[2], ry[(PH + 2) & 3]);
+        r13[(PH + 3) & 3] = pk_fma(xr2, t13[1], r13[(PH + 3) & 3]);
+        r24[(PH + 3) & 3] = pk_fma(xi2, t24[1], r24[(PH + 3) & 3]);
+        ry[(PH + 3) & 3] = pk_fma(xs, th[1], ry[(PH + 3) & 3]);
+        if (!REPLAY) {
+            // fll.cpp:141-145: band-edge outputs from the four real sums, error, loop advance
+            V s1 = c13.x(), s3 = c13.y(), s2 = c24.x(), s4 = c24.y();
+            V lre = s1 - s2, lim = s4 + s3;
+            V hre = s1 + s2, him = s4 - s3;
+            V err = fast_amp<V>(hre, him) - fast_amp<V>(lre, lim);
+            pcl_advance<V, true>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
+        }
+        return cy;
+    }
+};
+
+// Row driver of kernel 1: delay-line replay, 16-sample input tiles, output queue, state save.
+// IO supplies the memory side (device: global/LDS accesses of one lane; host emulation: arrays):
+//   P    load_hist(int t)                 lane l <- stored delay-line sample t*16 + l
+//   P    load_in(int t, int n)            lane l <- input sample t*16 + l (0 if >= n)
+//   void store_y(int base, int cnt, P yq) lane l < cnt holds y_{base+cnt-1-l}
+//   void ring_store(int iend, int cnt, P xs)  lane l < cnt holds x_{iend-1-l}
+//   void save(const K1Row<V>&, int n)     loop state + new delay line (samples n-80..n-1)
+#define TD_K1_STEP(S, REPLAY)                                         \
+    {                                                                 \
+        P yy = R.template step<(S)&3, REPLAY>(k, cur);                \
+        cur = row_shl1(cur, cur);                                     \
+        if (!(REPLAY)) yq = row_shr1(yy, yq);                         \
+    }
+#define TD_K1_STEP_G(S) \
+    if ((S) < cnt) TD_K1_STEP(S, false)
+
+template <class V, class IO> TD_FN void k1_run(K1Row<V>& R, const K1Consts& k, IO& io, int n) {
+    typedef Pair<V> P;
+    P cur(V(0.0f), V(0.0f)), yq(V(0.0f), V(0.0f));
+    R.clear_pipeline();
+    // Rebuild the in-flight partial sums by replaying the stored delay line (steps -80..-1).
+    for (int t = 0; t < kHist / kLanes; t++) {
+        cur = io.load_hist(t);
+        TD_K1_STEP(0, true) TD_K1_STEP(1, true) TD_K1_STEP(2, true) TD_K1_STEP(3, true)
+        TD_K1_STEP(4, true) TD_K1_STEP(5, true) TD_K1_STEP(6, true) TD_K1_STEP(7, true)
+        TD_K1_STEP(8, true) TD_K1_STEP(9, true) TD_K1_STEP(10, true) TD_K1_STEP(11, true)
+        TD_K1_STEP(12, true) TD_K1_STEP(13, true) TD_K1_STEP(14, true) TD_K1_STEP(15, true)
+        io.ring_store(-kHist + kLanes * (t + 1), kLanes, R.xs);
+    }
+    const int ntiles = (n + kLanes - 1) / kLanes;
+    P nxt = io.load_in(0, n);
+    for (int t = 0; t < ntiles; t++) {
+        cur = nxt;
+        nxt = io.load_in(t + 1, n);
+        const int base = t * kLanes;
+        const int cnt = (n - base < kLanes) ? (n - base) : kLanes;
+        if (cnt == kLanes) {
+            TD_K1_STEP(0, false) TD_K1_STEP(1, false) TD_K1_STEP(2, false) TD_K1_STEP(3, false)
+            TD_K1_STEP(4, false) TD_K1_STEP(5, false) TD_K1_STEP(6, false) TD_K1_STEP(7, false)
+            TD_K1_STEP(8, false) TD_K1_STEP(9, false) TD_K1_STEP(10, false) TD_K1_STEP(11, false)
+            TD_K1_STEP(12, false) TD_K1_STEP(13, false) TD_K1_STEP(14, false) TD_K1_STEP(15, false)
+        } else {
+            TD_K1_STEP_G(0) TD_K1_STEP_G(1) TD_K1_STEP_G(2) TD_K1_STEP_G(3)
+            TD_K1_STEP_G(4) TD_K1_STEP_G(5) TD_K1_STEP_G(6) TD_K1_STEP_G(7)
+            TD_K1_STEP_G(8) TD_K1_STEP_G(9) TD_K1_STEP_G(10) TD_K1_STEP_G(11)
+            TD_K1_STEP_G(12) TD_K1_STEP_G(13) TD_K1_STEP_G(14) TD_K1_STEP_G(15)
+        }
+        io.store_y(base, cnt, yq);
+        io.ring_store(base + cnt, cnt, R.xs);
+    }
+    io.save(R, n);
+}
+#undef TD_K1_STEP
+#undef TD_K1_STEP_G
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 2 per-channel symbol step: timing recovery -> Costas -> slicer/differential decoder.
+// One lane per channel; plain float code (host builds use it for unit tests only).
+// ---------------------------------------------------------------------------------------------
+struct K2Consts {
+    float tr_alpha, tr_beta, tr_min_freq, tr_max_freq;
+    float costas_alpha, costas_beta, costas_min_freq, costas_max_freq;
+};
+
+struct K2State {
+    float mu, omega;
+    int offset;
+    float cph, cfr, ph2;
+    int prev;
+};
+
+// w[0..7]: the 8 complex samples buffer[offset..offset+7] as (re,im); rows tm1/t0/tp1: interpolator
+// bank rows max(phase-1,0), phase, min(phase+1,127).  Returns the dibit; *sym = Costas output.
+TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const float* wre, const float* wim,
+                    const float* tm1, const float* t0, const float* tp1, float* sym_re, float* sym_im) {
+    float vr = 0.0f, vi = 0.0f, ar = 0.0f, ai = 0.0f, br = 0.0f, bi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInterpTaps; j++) {
+        vr = v_fma(wre[j], t0[j], vr);  vi = v_fma(wim[j], t0[j], vi);
+        ar = v_fma(wre[j], tp1[j], ar); ai = v_fma(wim[j], tp1[j], ai);
+        br = v_fma(wre[j], tm1[j], br); bi = v_fma(wim[j], tm1[j], bi);
+    }
+    // complex_fd.cpp:107-123
+    float dr, di;
+    if (phase == 0) { dr = ar - vr; di = ai - vi; }
+    else if (phase == kInterpPhases - 1) { dr = vr - br; di = vi - bi; }
+    else { dr = (ar - br) * 0.5f; di = (ai - bi) * 0.5f; }
+    // complex_fd.cpp:126,136-137
+    float terr = ((vr > 0 ? 1.0f : -1.0f) * dr) + ((vi > 0 ? 1.0f : -1.0f) * di);
+    terr = terr > 1.0f ? 1.0f : terr;
+    terr = terr < -1.0f ? -1.0f : terr;
+    // complex_fd.cpp:140-143
+    pcl_advance<float, false>(terr, st.mu, st.omega, k.tr_alpha, k.tr_beta, k.tr_min_freq, k.tr_max_freq);
+    float delta = v_floor(st.mu);
+    st.offset += (int)delta;
+    st.mu = st.mu - delta;
+    // pi4dqpsk_costas.cpp:7-19
+    float s, c;
+    sincos_t<float>(-st.cph, s, c);
+    float xr = vr * c - vi * s;
+    float xi = vi * c + vr * s;
+    float ph2 = st.ph2 + (-kFlPi / 4.0f);
+    if (ph2 >= 2 * kFlPi) ph2 -= 2 * kFlPi;
+    else if (ph2 <= -2 * kFlPi) ph2 += 2 * kFlPi;
+    st.ph2 = ph2;
+    sincos_t<float>(ph2, s, c);
+    float zr = xr * c - xi * s;
+    float zi = xi * c + xr * s;
+    // pi4dqpsk_costas.cpp:23-28
+    float cerr = ((zr > 0 ? 1.0f : -1.0f) * zi) - ((zi > 0 ? 1.0f : -1.0f) * zr);
+    cerr = cerr < -1.0f ? -1.0f : cerr;
+    cerr = cerr > 1.0f ? 1.0f : cerr;
+    pcl_advance<float, true>(cerr, st.cph, st.cfr, k.costas_alpha, k.costas_beta, k.costas_min_freq, k.costas_max_freq);
+    *sym_re = zr;
+    *sym_im = zi;
+    // dqpsk_sym_extr.cpp:6-7,32-52
+    int a = zi < 0, b = zr < 0;
+    int symq = (a << 1) | (a != b);
+    int pd = (symq - st.prev + 4) & 3;
+    st.prev = symq;
+    return pd ^ (pd >> 1);  // {0,1,2,3} -> {0,1,3,2}
+}
+
+}  // namespace tdm

@@ -1,0 +1,794 @@
+// tetra_demod.hip -- HIP kernels (gfx950) + C ABI of the batched TETRA pi/4-DQPSK demodulator.
+//
+// Kernel 1  k1_agc_fll_rrc   AGC -> band-edge FLL -> RRC matched filter, one 16-lane DPP row per
+//                            channel (4 channels per wavefront), FIRs as a systolic array along the
+//                            row (see demod_core.hpp K1Row).  Reads iq, writes the matched-filter
+//                            output y time-major into an HBM scratch.
+// Kernel 2  k2_sync_slice    ML timing recovery -> pi/4 Costas -> slicer -> differential decoder ->
+//                            bit unpacker, one lane per channel (64 channels per wavefront), y window
+//                            and the 128x8 interpolator bank staged in LDS.
+// Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
+// src/dsp/bit_unpacker.cpp:4-10 (see include/tetra_demod.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/tetra_demod.h"
+#include "demod_core.hpp"
+#include "design.hpp"
+
+using namespace tdm;
+
+namespace {
+
+constexpr int kK1Threads = 256;                 // 4 waves = 16 channel rows
+constexpr int kK1RowsPerBlock = kK1Threads / kLanes;
+constexpr int kRing = 128;                      // per-row LDS ring of recent FLL outputs
+constexpr int kK2Threads = 64;                  // 1 wave = 64 channels
+constexpr int kK2TileRows = 128;                // y rows staged in LDS per tile
+constexpr int kYHist = kInterpTaps - 1;         // 7 delay-buffer rows in front of the new y rows
+
+struct K1Params {
+    const float2* iq;
+    long long in_ch_stride, in_t_stride;  // in complex samples
+    int n, n_channels;
+    float2* y;                            // [(kYHist + n)][n_channels], row kYHist + i = y_i
+    float* agc_g;
+    float* fll_ph;
+    float* fll_fr;
+    float2* hist;                         // [n_channels][kHist]
+    const float* be_re;                   // [kPadTaps] zero-padded at the old end
+    const float* be_im;
+    const float* rrc;
+    K1Consts k;
+};
+
+struct K2Params {
+    float2* y;
+    int n, n_channels;
+    float* mu;
+    float* omega;
+    int* offset;
+    float* cph;
+    float* cfr;
+    float* ph2;
+    int* prev;
+    const float* bank;                    // [128*8]
+    uint8_t* bits;
+    long long bits_stride;
+    int* n_bits;
+    float2* sym;                          // optional [n_channels][bits_stride/2]
+    K2Consts k;
+};
+
+__device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
+    float2 v = *p;
+    return Pair<float>(v.x, v.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel 1
+// ------------------------------------------------------------------------------------------------
+// Memory side of one lane of a channel row (see k1_run in demod_core.hpp).
+struct K1DeviceIO {
+    const K1Params& p;
+    float2* ring;            // this row's LDS ring [kRing]
+    const float2* hp;        // this channel's stored delay line
+    const float2* ip;        // this channel's input
+    int lane, ch;
+    bool active;
+
+    __device__ __forceinline__ Pair<float> load_hist(int t) const { return ld_pair(hp + t * kLanes + lane); }
+    __device__ __forceinline__ Pair<float> load_in(int t, int n) const {
+        const int i = t * kLanes + lane;
+        if (i < n) return ld_pair(ip + (long long)i * p.in_t_stride);
+        return Pair<float>(0.f, 0.f);
+    }
+    __device__ __forceinline__ void store_y(int base, int cnt, Pair<float> yq) const {
+        if (active && lane < cnt) {
+            const int i = base + cnt - 1 - lane;
+            p.y[(long long)(kYHist + i) * p.n_channels + ch] = make_float2(yq.x(), yq.y());
+        }
+    }
+    __device__ __forceinline__ void ring_store(int iend, int cnt, Pair<float> xs) const {
+        if (lane < cnt) ring[(iend - 1 - lane) & (kRing - 1)] = make_float2(xs.x(), xs.y());
+    }
+    __device__ __forceinline__ void save(const K1Row<float>& R, int n) const {
+        if (!active) return;
+        if (lane == 0) {
+            p.agc_g[ch] = R.g;
+            p.fll_ph[ch] = R.ph;
+            p.fll_fr[ch] = R.fr;
+        }
+        // new delay line = samples n-80 .. n-1 (the replayed history is in the ring too)
+        float2* ho = p.hist + (long long)ch * kHist;
+#pragma unroll
+        for (int q = 0; q < kHist / kLanes; q++) {
+            const int m = q * kLanes + lane;
+            ho[m] = ring[(n - kHist + m) & (kRing - 1)];
+        }
+    }
+};
+
+__global__ __launch_bounds__(kK1Threads) void k1_agc_fll_rrc(K1Params p) {
+    __shared__ float2 ring[kK1RowsPerBlock][kRing];
+
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int row = threadIdx.x >> 4;
+    const int ch = blockIdx.x * kK1RowsPerBlock + row;
+    const bool active = ch < p.n_channels;
+    const int chl = active ? ch : p.n_channels - 1;
+
+    K1Row<float> R;
+    // taps: padded index kp = 5*(15-lane) + j
+#pragma unroll
+    for (int j = 0; j < kTapsPerLane; j++) {
+        const int kp = kTapsPerLane * (kLanes - 1 - lane) + j;
+        const float a = p.be_re[kp], b = p.be_im[kp], h = p.rrc[kp];
+        R.t13[j] = Pair<float>(a, b);
+        R.t24[j] = Pair<float>(b, a);
+        R.th[j] = Pair<float>(h, h);
+    }
+    R.g = p.agc_g[chl];
+    R.ph = p.fll_ph[chl];
+    R.fr = p.fll_fr[chl];
+
+    K1DeviceIO io{ p, &ring[row][0], p.hist + (long long)chl * kHist, p.iq + (long long)chl * p.in_ch_stride, lane, ch,
+                   active };
+    k1_run<float, K1DeviceIO>(R, p.k, io, p.n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel 2
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        int o = __shfl_xor(v, m, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
+    __shared__ float2 tile[kK2TileRows][kK2Threads];
+    __shared__ __attribute__((aligned(16))) float bank[kInterpPhases * kInterpTaps];
+
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.x * kK2Threads + lane;
+    const bool active = ch < p.n_channels;
+    const int chl = active ? ch : p.n_channels - 1;
+
+    for (int i = lane; i < kInterpPhases * kInterpTaps; i += kK2Threads) bank[i] = p.bank[i];
+
+    K2State st;
+    st.mu = p.mu[chl];
+    st.omega = p.omega[chl];
+    st.offset = p.offset[chl];
+    st.cph = p.cph[chl];
+    st.cfr = p.cfr[chl];
+    st.ph2 = p.ph2[chl];
+    st.prev = p.prev[chl];
+
+    const int n = p.n;
+    const int nrows = n + kYHist;  // valid y rows
+    int S = 0;                     // symbols emitted by this lane
+    unsigned long long pack = 0;   // up to 4 symbols = 8 bit-bytes
+    uint8_t* brow = p.bits + (long long)chl * p.bits_stride;
+    float2* srow = p.sym ? p.sym + (long long)chl * (p.bits_stride / 2) : nullptr;
+    __syncthreads();
+
+    while (true) {
+        const bool pending = active && st.offset < n;
+        if (!__any(pending)) break;
+        const int base = wave_min_i32(pending ? st.offset : 0x7fffffff);
+        // stage rows [base, base + kK2TileRows) of this wave's 64 channels
+        __syncthreads();
+        for (int r = 0; r < kK2TileRows; r++) {
+            const int rr = base + r;
+            float2 v = make_float2(0.f, 0.f);
+            if (rr < nrows) v = p.y[(long long)rr * p.n_channels + chl];
+            tile[r][lane] = v;
+        }
+        __syncthreads();
+        while (true) {
+            const int rel = st.offset - base;
+            const bool can = active && st.offset < n && (rel + kInterpTaps <= kK2TileRows);
+            if (!__any(can)) break;
+            if (can) {
+                // complex_fd.cpp:101
+                int phase = (int)v_floor(st.mu * (float)kInterpPhases);
+                phase = phase < 0 ? 0 : phase;
+                phase = phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
+                const int pm = phase > 0 ? phase - 1 : 0;
+                const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
+                float wre[kInterpTaps], wim[kInterpTaps], t0[kInterpTaps], tm1[kInterpTaps], tp1[kInterpTaps];
+#pragma unroll
+                for (int j = 0; j < kInterpTaps; j++) {
+                    float2 w = tile[rel + j][lane];
+                    wre[j] = w.x;
+                    wim[j] = w.y;
+                }
+                const float4* b0 = reinterpret_cast<const float4*>(bank + phase * kInterpTaps);
+                const float4* bm = reinterpret_cast<const float4*>(bank + pm * kInterpTaps);
+                const float4* bp = reinterpret_cast<const float4*>(bank + pp * kInterpTaps);
+                float4 q;
+                q = b0[0]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
+                q = b0[1]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
+                q = bm[0]; tm1[0] = q.x; tm1[1] = q.y; tm1[2] = q.z; tm1[3] = q.w;
+                q = bm[1]; tm1[4] = q.x; tm1[5] = q.y; tm1[6] = q.z; tm1[7] = q.w;
+                q = bp[0]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
+                q = bp[1]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
+                float zr, zi;
+                const int d = k2_symbol(p.k, st, phase, wre, wim, tm1, t0, tp1, &zr, &zi);
+                if (srow) srow[S] = make_float2(zr, zi);
+                // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
+                const unsigned long long two = (unsigned long long)((d >> 1) & 1) | ((unsigned long long)(d & 1) << 8);
+                pack |= two << (16 * (S & 3));
+                S++;
+                if ((S & 3) == 0) {
+                    *reinterpret_cast<unsigned long long*>(brow + 2 * (S - 4)) = pack;
+                    pack = 0;
+                }
+            }
+        }
+    }
+
+    if (active) {
+        const int rem = S & 3;
+        for (int q = 0; q < 2 * rem; q++) brow[2 * (S - rem) + q] = (uint8_t)((pack >> (8 * q)) & 0xff);
+        p.n_bits[ch] = 2 * S;
+        p.mu[ch] = st.mu;
+        p.omega[ch] = st.omega;
+        p.offset[ch] = st.offset - n;   // complex_fd.cpp:145
+        p.cph[ch] = st.cph;
+        p.cfr[ch] = st.cfr;
+        p.ph2[ch] = st.ph2;
+        p.prev[ch] = st.prev;
+        // delay buffer update, complex_fd.cpp:148: rows n..n+6 become rows 0..6
+        float2 tmp[kYHist];
+#pragma unroll
+        for (int k = 0; k < kYHist; k++) tmp[k] = p.y[(long long)(n + k) * p.n_channels + ch];
+#pragma unroll
+        for (int k = 0; k < kYHist; k++) p.y[(long long)k * p.n_channels + ch] = tmp[k];
+    }
+}
+
+// Device self-test of the primitives the arithmetic contract rests on (DPP row moves, sqrt, sincos).
+// out[0][l] = row_shr1(old = 100+l, src = l), out[1][l] = row_shl1(old = 200+l, src = l),
+// out[2][l] = sqrt(in[l]), out[3][l] / out[4][l] = sin / cos of in[64 + l].
+__global__ void k_selftest(const float* in, float* out) {
+    const int l = threadIdx.x;
+    out[l] = row_shr1(100.0f + (float)l, (float)l);
+    out[64 + l] = row_shl1(200.0f + (float)l, (float)l);
+    out[128 + l] = v_sqrt(in[l]);
+    float s, c;
+    sincos_t<float>(in[64 + l], s, c);
+    out[192 + l] = s;
+    out[256 + l] = c;
+}
+
+// Small helper kernels for state management.
+__global__ void k_fill_f32(float* p, float v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Host side: handle + C ABI
+// ------------------------------------------------------------------------------------------------
+struct tetra_demod {
+    tetra_demod_config_t cfg;
+    host::DesignParams dp;
+    host::Design design;
+    int device = 0;
+    int last_hip = 0;
+    int C = 0;
+    int max_samples = 0;
+    // device memory
+    float *agc_g = nullptr, *fll_ph = nullptr, *fll_fr = nullptr;
+    float2* hist = nullptr;
+    float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
+    int *offset = nullptr, *prev = nullptr;
+    float2* y = nullptr;
+    float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
+    // host-path staging
+    float* st_iq = nullptr;
+    uint8_t* st_bits = nullptr;
+    int* st_nbits = nullptr;
+    float* st_sym = nullptr;
+    size_t st_iq_bytes = 0, st_bits_bytes = 0, st_sym_bytes = 0;
+    // ring of HIP-event triplets (start, after k1, after k2), one slot per process call
+    static constexpr int kEvSlots = 64;
+    hipEvent_t ev[kEvSlots][3] = {};
+    long long n_calls = 0;      // process calls that launched kernels
+    int last_n = 0;
+};
+
+#define HIP_TRY(h, expr)                                  \
+    do {                                                  \
+        hipError_t e__ = (expr);                          \
+        if (e__ != hipSuccess) {                          \
+            (h)->last_hip = (int)e__;                     \
+            return TETRA_ERR_HIP;                         \
+        }                                                 \
+    } while (0)
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int upload_tables(tetra_demod* h) {
+    // zero-pad the FIR taps at the old end to kPadTaps
+    std::vector<float> re(kPadTaps, 0.f), im(kPadTaps, 0.f), rr(kPadTaps, 0.f);
+    const int off = kPadTaps - h->design.ntaps;
+    for (int k = 0; k < h->design.ntaps; k++) {
+        re[off + k] = h->design.be_re[k];
+        im[off + k] = h->design.be_im[k];
+        rr[off + k] = h->design.rrc[k];
+    }
+    HIP_TRY(h, hipMemcpy(h->d_be_re, re.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_be_im, im.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_rrc, rr.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
+                         hipMemcpyHostToDevice));
+    return TETRA_OK;
+}
+
+int fill(tetra_demod* h, float* p, float v, int first, int count) {
+    if (count <= 0) return TETRA_OK;
+    hipLaunchKernelGGL(k_fill_f32, dim3((count + 255) / 256), dim3(256), 0, 0, p + first, v, count);
+    HIP_TRY(h, hipGetLastError());
+    return TETRA_OK;
+}
+
+// reset of the timing-recovery loop only (COMPLEX_FD::reset / setOmega, complex_fd.cpp:30-41,78-87)
+int reset_timing(tetra_demod* h, int first, int count) {
+    int rc;
+    if ((rc = fill(h, h->mu, 0.0f, first, count))) return rc;
+    if ((rc = fill(h, h->omega, h->design.tr_omega, first, count))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->offset + first, 0, sizeof(int) * count, 0));
+    return TETRA_OK;
+}
+
+int reset_range(tetra_demod* h, int first, int count) {
+    int rc;
+    // FastAGC::reset -> initGain 1.0; FLL::reset fll.cpp:120-127; FIR::reset clears the delay line;
+    // PLL::reset; COMPLEX_FD::reset complex_fd.cpp:78-87 (its delay buffer is NOT cleared by the reference's
+    // reset(); a fresh handle starts with zeros either way); slicer prev = 0; ph2 is a plain member that the
+    // reference never resets -- a fresh chain has 0, and so does a reset here.
+    if ((rc = fill(h, h->agc_g, 1.0f, first, count))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->fll_ph + first, 0, sizeof(float) * count, 0));
+    HIP_TRY(h, hipMemsetAsync(h->fll_fr + first, 0, sizeof(float) * count, 0));
+    HIP_TRY(h, hipMemsetAsync(h->hist + (size_t)first * kHist, 0, sizeof(float2) * kHist * (size_t)count, 0));
+    if ((rc = reset_timing(h, first, count))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->cph + first, 0, sizeof(float) * count, 0));
+    HIP_TRY(h, hipMemsetAsync(h->cfr + first, 0, sizeof(float) * count, 0));
+    HIP_TRY(h, hipMemsetAsync(h->ph2 + first, 0, sizeof(float) * count, 0));
+    HIP_TRY(h, hipMemsetAsync(h->prev + first, 0, sizeof(int) * count, 0));
+    // y delay rows (kYHist rows, time-major): columns [first, first+count)
+    HIP_TRY(h, hipMemset2DAsync(h->y + first, sizeof(float2) * (size_t)h->C, 0, sizeof(float2) * (size_t)count, kYHist, 0));
+    HIP_TRY(h, hipStreamSynchronize(0));
+    return TETRA_OK;
+}
+
+void free_all(tetra_demod* h) {
+    void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
+                     h->prev, h->y, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->st_iq, h->st_bits, h->st_nbits,
+                     h->st_sym };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& slot : h->ev)
+        for (auto& e : slot)
+            if (e) (void)hipEventDestroy(e);
+}
+
+template <class T> int dalloc(tetra_demod* h, T** p, size_t count) {
+    HIP_TRY(h, hipMalloc((void**)p, sizeof(T) * count));
+    return TETRA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tetra_demod_abi_version(void) { return TETRA_DEMOD_ABI_VERSION; }
+
+const char* tetra_demod_strerror(int status) {
+    switch (status) {
+    case TETRA_OK: return "ok";
+    case TETRA_ERR_ARG: return "invalid argument";
+    case TETRA_ERR_UNSUPPORTED: return "unsupported parameter";
+    case TETRA_ERR_NO_DEVICE: return "no usable HIP device";
+    case TETRA_ERR_HIP: return "HIP runtime error";
+    case TETRA_ERR_NOMEM: return "out of memory";
+    case TETRA_ERR_SIZE: return "size out of range";
+    case TETRA_ERR_ALIGN: return "misaligned output buffer";
+    default: return "unknown status";
+    }
+}
+
+int tetra_demod_default_config(tetra_demod_config_t* cfg) {
+    if (!cfg) return TETRA_ERR_ARG;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->n_channels = 1;
+    cfg->max_samples = 65536;
+    cfg->layout = TETRA_LAYOUT_CHANNEL_MAJOR;
+    cfg->device = -1;
+    cfg->symbolrate = 18000;
+    cfg->samplerate = 36000;
+    cfg->rrc_tap_count = 65;
+    cfg->rrc_beta = 0.35f;
+    cfg->agc_rate = 0.02f;
+    cfg->costas_bandwidth = 0.01f;
+    cfg->fll_bandwidth = 0.006f;
+    host::default_timing_gains(cfg->omega_gain, cfg->mu_gain);
+    cfg->omega_rel_limit = 0.02f;
+    return TETRA_OK;
+}
+
+int tetra_demod_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tetra_demod_bits_stride(int n_samples) {
+    if (n_samples < 0) return TETRA_ERR_ARG;
+    // bits = 2 * symbols, symbols <= n / (omega_min ~ 1.94) + 1  ->  n / 0.95 + 16 covers omega_rel_limit up to ~5 %
+    long long s = (long long)((double)n_samples / 0.95) + 16;
+    s = (s + 15) / 16 * 16;
+    return (int)s;
+}
+
+int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
+    if (!cfg || !out) return TETRA_ERR_ARG;
+    *out = nullptr;
+    if (cfg->n_channels < 1 || cfg->max_samples < 1) return TETRA_ERR_ARG;
+    if (cfg->layout != TETRA_LAYOUT_CHANNEL_MAJOR && cfg->layout != TETRA_LAYOUT_TIME_MAJOR) return TETRA_ERR_ARG;
+    int ndev = tetra_demod_device_count();
+    if (ndev <= 0) return TETRA_ERR_NO_DEVICE;
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return TETRA_ERR_NO_DEVICE;
+    }
+    if (dev >= ndev) return TETRA_ERR_NO_DEVICE;
+
+    tetra_demod* h = new (std::nothrow) tetra_demod();
+    if (!h) return TETRA_ERR_NOMEM;
+    h->cfg = *cfg;
+    h->cfg.rrc_taps = h->cfg.bandedge_taps = h->cfg.interp_bank = nullptr;
+    h->device = dev;
+    h->C = cfg->n_channels;
+    h->max_samples = cfg->max_samples;
+    h->dp.symbolrate = cfg->symbolrate;
+    h->dp.samplerate = cfg->samplerate;
+    h->dp.rrc_tap_count = cfg->rrc_tap_count;
+    h->dp.rrc_beta = cfg->rrc_beta;
+    h->dp.agc_rate = cfg->agc_rate;
+    h->dp.costas_bandwidth = cfg->costas_bandwidth;
+    h->dp.fll_bandwidth = cfg->fll_bandwidth;
+    h->dp.omega_gain = cfg->omega_gain;
+    h->dp.mu_gain = cfg->mu_gain;
+    h->dp.omega_rel_limit = cfg->omega_rel_limit;
+    if (!host::make_design(h->dp, cfg->rrc_taps, cfg->bandedge_taps, cfg->interp_bank, h->design)) {
+        delete h;
+        return TETRA_ERR_UNSUPPORTED;
+    }
+    DeviceGuard g(dev);
+    if (!g.ok) {
+        delete h;
+        return TETRA_ERR_NO_DEVICE;
+    }
+    const size_t C = (size_t)h->C;
+    int rc = TETRA_OK;
+    auto A = [&](int r) { if (rc == TETRA_OK) rc = r; };
+    A(dalloc(h, &h->agc_g, C)); A(dalloc(h, &h->fll_ph, C)); A(dalloc(h, &h->fll_fr, C));
+    A(dalloc(h, &h->hist, C * kHist));
+    A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
+    A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
+    A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
+    A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
+    A(dalloc(h, &h->d_rrc, (size_t)kPadTaps)); A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
+    for (auto& slot : h->ev)
+        for (auto& e : slot)
+            if (rc == TETRA_OK && hipEventCreate(&e) != hipSuccess) rc = TETRA_ERR_HIP;
+    if (rc == TETRA_OK) rc = upload_tables(h);
+    if (rc == TETRA_OK) rc = reset_range(h, 0, h->C);
+    if (rc != TETRA_OK) {
+        int st = (h->last_hip == (int)hipErrorOutOfMemory) ? TETRA_ERR_NOMEM : rc;
+        free_all(h);
+        delete h;
+        return st;
+    }
+    *out = h;
+    return TETRA_OK;
+}
+
+int tetra_demod_destroy(tetra_demod_t* h) {
+    if (!h) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    free_all(h);
+    delete h;
+    return TETRA_OK;
+}
+
+int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_samples, uint8_t* d_bits, int bits_stride,
+                               int32_t* d_n_bits, float* d_sym, void* hip_stream) {
+    if (!h || !d_iq || !d_bits || !d_n_bits) return TETRA_ERR_ARG;
+    if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
+    if (bits_stride < tetra_demod_bits_stride(n_samples)) return TETRA_ERR_SIZE;
+    if ((bits_stride & 7) || (reinterpret_cast<uintptr_t>(d_bits) & 7) || (reinterpret_cast<uintptr_t>(d_sym) & 7))
+        return TETRA_ERR_ALIGN;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    hipStream_t s = (hipStream_t)hip_stream;
+    h->last_n = n_samples;
+    if (n_samples == 0) {
+        HIP_TRY(h, hipMemsetAsync(d_n_bits, 0, sizeof(int32_t) * (size_t)h->C, s));
+        return TETRA_OK;
+    }
+    K1Params p1;
+    p1.iq = reinterpret_cast<const float2*>(d_iq);
+    if (h->cfg.layout == TETRA_LAYOUT_CHANNEL_MAJOR) {
+        p1.in_ch_stride = n_samples;
+        p1.in_t_stride = 1;
+    } else {
+        p1.in_ch_stride = 1;
+        p1.in_t_stride = h->C;
+    }
+    p1.n = n_samples;
+    p1.n_channels = h->C;
+    p1.y = h->y;
+    p1.agc_g = h->agc_g;
+    p1.fll_ph = h->fll_ph;
+    p1.fll_fr = h->fll_fr;
+    p1.hist = h->hist;
+    p1.be_re = h->d_be_re;
+    p1.be_im = h->d_be_im;
+    p1.rrc = h->d_rrc;
+    p1.k = h->design.k1;
+    K2Params p2;
+    p2.y = h->y;
+    p2.n = n_samples;
+    p2.n_channels = h->C;
+    p2.mu = h->mu;
+    p2.omega = h->omega;
+    p2.offset = h->offset;
+    p2.cph = h->cph;
+    p2.cfr = h->cfr;
+    p2.ph2 = h->ph2;
+    p2.prev = h->prev;
+    p2.bank = h->d_bank;
+    p2.bits = d_bits;
+    p2.bits_stride = bits_stride;
+    p2.n_bits = d_n_bits;
+    p2.sym = reinterpret_cast<float2*>(d_sym);
+    p2.k = h->design.k2;
+
+    hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
+    HIP_TRY(h, hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(k1_agc_fll_rrc, dim3((h->C + kK1RowsPerBlock - 1) / kK1RowsPerBlock), dim3(kK1Threads), 0, s, p1);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(k2_sync_slice, dim3((h->C + kK2Threads - 1) / kK2Threads), dim3(kK2Threads), 0, s, p2);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(ev[2], s));
+    h->n_calls++;
+    return TETRA_OK;
+}
+
+int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
+                        int32_t* n_bits, float* sym) {
+    if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
+    if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
+    if (bits_stride < tetra_demod_bits_stride(n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    const size_t C = (size_t)h->C;
+    const size_t iq_bytes = sizeof(float) * 2 * C * (size_t)n_samples;
+    const size_t bits_bytes = C * (size_t)bits_stride;
+    const size_t sym_bytes = sym ? sizeof(float) * 2 * C * (size_t)(bits_stride / 2) : 0;
+    if (iq_bytes > h->st_iq_bytes) {
+        if (h->st_iq) (void)hipFree(h->st_iq);
+        h->st_iq = nullptr; h->st_iq_bytes = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->st_iq, iq_bytes));
+        h->st_iq_bytes = iq_bytes;
+    }
+    if (bits_bytes > h->st_bits_bytes) {
+        if (h->st_bits) (void)hipFree(h->st_bits);
+        h->st_bits = nullptr; h->st_bits_bytes = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->st_bits, bits_bytes));
+        h->st_bits_bytes = bits_bytes;
+    }
+    if (!h->st_nbits) HIP_TRY(h, hipMalloc((void**)&h->st_nbits, sizeof(int) * C));
+    if (sym_bytes > h->st_sym_bytes) {
+        if (h->st_sym) (void)hipFree(h->st_sym);
+        h->st_sym = nullptr; h->st_sym_bytes = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->st_sym, sym_bytes));
+        h->st_sym_bytes = sym_bytes;
+    }
+    if (iq_bytes) HIP_TRY(h, hipMemcpy(h->st_iq, iq, iq_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(h->st_bits, 0, bits_bytes));
+    int rc = tetra_demod_process_device(h, h->st_iq ? h->st_iq : reinterpret_cast<const float*>(h->agc_g), n_samples,
+                                        h->st_bits, bits_stride, h->st_nbits, sym ? h->st_sym : nullptr, nullptr);
+    if (rc != TETRA_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(0));
+    HIP_TRY(h, hipMemcpy(bits, h->st_bits, bits_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(n_bits, h->st_nbits, sizeof(int) * C, hipMemcpyDeviceToHost));
+    if (sym) HIP_TRY(h, hipMemcpy(sym, h->st_sym, sym_bytes, hipMemcpyDeviceToHost));
+    return TETRA_OK;
+}
+
+int tetra_demod_reset(tetra_demod_t* h, int channel) {
+    if (!h) return TETRA_ERR_ARG;
+    if (channel < -1 || channel >= h->C) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    return channel < 0 ? reset_range(h, 0, h->C) : reset_range(h, channel, 1);
+}
+
+int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
+    if (!h) return TETRA_ERR_ARG;
+    host::DesignParams np = h->dp;
+    bool timing_reset = false;
+    switch (param_id) {
+    case TETRA_PARAM_SYMBOLRATE: np.symbolrate = value; timing_reset = true; break;
+    case TETRA_PARAM_SAMPLERATE: np.samplerate = value; timing_reset = true; break;
+    case TETRA_PARAM_RRC_TAP_COUNT: np.rrc_tap_count = (int)value; break;
+    case TETRA_PARAM_RRC_BETA: np.rrc_beta = value; break;
+    case TETRA_PARAM_AGC_RATE: np.agc_rate = value; break;
+    case TETRA_PARAM_COSTAS_BANDWIDTH: np.costas_bandwidth = value; break;
+    case TETRA_PARAM_FLL_BANDWIDTH: np.fll_bandwidth = value; break;
+    case TETRA_PARAM_OMEGA_GAIN: np.omega_gain = value; break;
+    case TETRA_PARAM_MU_GAIN: np.mu_gain = value; break;
+    case TETRA_PARAM_OMEGA_REL_LIMIT: np.omega_rel_limit = value; break;
+    default: return TETRA_ERR_ARG;
+    }
+    host::Design nd;
+    if (!host::make_design(np, nullptr, nullptr, nullptr, nd)) return TETRA_ERR_UNSUPPORTED;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    // Reference quirks kept: the FLL band-edge taps are only re-designed by setSymbolrate/setSamplerate
+    // (FLL::setSymbolrate/setSamplerate are never called by PI4DQPSK's setters -- pi4dqpsk.cpp:32-54 touch
+    // only rrc and recov), and setRRCParams re-designs only the RRC (pi4dqpsk.cpp:56-66).
+    if (param_id == TETRA_PARAM_SYMBOLRATE || param_id == TETRA_PARAM_SAMPLERATE ||
+        param_id == TETRA_PARAM_RRC_TAP_COUNT || param_id == TETRA_PARAM_RRC_BETA) {
+        if (nd.ntaps == h->design.ntaps) {
+            nd.be_re = h->design.be_re;
+            nd.be_im = h->design.be_im;
+        }
+    }
+    h->dp = np;
+    h->design = nd;
+    int rc = upload_tables(h);
+    if (rc != TETRA_OK) return rc;
+    if (timing_reset) {
+        rc = reset_timing(h, 0, h->C);
+        if (rc != TETRA_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(0));
+    }
+    return TETRA_OK;
+}
+
+int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out) {
+    if (!h || !out || channel < 0 || channel >= h->C) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int c = channel;
+#define GET1(dst, src) HIP_TRY(h, hipMemcpy(&(dst), (src) + c, sizeof(dst), hipMemcpyDeviceToHost))
+    GET1(out->agc_gain, h->agc_g); GET1(out->fll_phase, h->fll_ph); GET1(out->fll_freq, h->fll_fr);
+    GET1(out->mu, h->mu); GET1(out->omega, h->omega); GET1(out->offset, h->offset);
+    GET1(out->costas_phase, h->cph); GET1(out->costas_freq, h->cfr); GET1(out->ph2, h->ph2); GET1(out->prev, h->prev);
+#undef GET1
+    HIP_TRY(h, hipMemcpy(out->hist, h->hist + (size_t)c * kHist, sizeof(float2) * kHist, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy2D(out->ybuf, sizeof(float2), h->y + c, sizeof(float2) * (size_t)h->C, sizeof(float2), kYHist,
+                           hipMemcpyDeviceToHost));
+    return TETRA_OK;
+}
+
+int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in) {
+    if (!h || !in || channel < 0 || channel >= h->C) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int c = channel;
+#define SET1(dst, src) HIP_TRY(h, hipMemcpy((dst) + c, &(src), sizeof(src), hipMemcpyHostToDevice))
+    SET1(h->agc_g, in->agc_gain); SET1(h->fll_ph, in->fll_phase); SET1(h->fll_fr, in->fll_freq);
+    SET1(h->mu, in->mu); SET1(h->omega, in->omega); SET1(h->offset, in->offset);
+    SET1(h->cph, in->costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
+#undef SET1
+    HIP_TRY(h, hipMemcpy(h->hist + (size_t)c * kHist, in->hist, sizeof(float2) * kHist, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy2D(h->y + c, sizeof(float2) * (size_t)h->C, in->ybuf, sizeof(float2), sizeof(float2), kYHist,
+                           hipMemcpyHostToDevice));
+    return TETRA_OK;
+}
+
+int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank) {
+    if (!h) return TETRA_ERR_ARG;
+    const int nt = h->design.ntaps;
+    if (taps) *taps = nt;
+    if (rrc) std::memcpy(rrc, h->design.rrc.data(), sizeof(float) * nt);
+    if (be_re) std::memcpy(be_re, h->design.be_re.data(), sizeof(float) * nt);
+    if (be_im) std::memcpy(be_im, h->design.be_im.data(), sizeof(float) * nt);
+    if (bank) std::memcpy(bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps);
+    return TETRA_OK;
+}
+
+int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples) {
+    if (!h || !y || n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    // NOTE: k2 has already rotated the last 7 rows to the front; rows kYHist.. still hold this call's y.
+    const size_t C = (size_t)h->C;
+    std::vector<float2> tm((size_t)n_samples * C);
+    if (n_samples)
+        HIP_TRY(h, hipMemcpy(tm.data(), h->y + (size_t)kYHist * C, sizeof(float2) * tm.size(), hipMemcpyDeviceToHost));
+    float2* out = reinterpret_cast<float2*>(y);
+    for (size_t c = 0; c < C; c++)
+        for (size_t i = 0; i < (size_t)n_samples; i++) out[c * (size_t)n_samples + i] = tm[i * C + c];
+    return TETRA_OK;
+}
+
+int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* k1_ms, float* k2_ms) {
+    if (!h || n < 1 || n > tetra_demod::kEvSlots || (long long)n > h->n_calls) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    for (int i = 0; i < n; i++) {
+        hipEvent_t* ev = h->ev[(h->n_calls - n + i) % tetra_demod::kEvSlots];
+        HIP_TRY(h, hipEventSynchronize(ev[2]));
+        float a = 0, b = 0;
+        HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (k1_ms) k1_ms[i] = a;
+        if (k2_ms) k2_ms[i] = b;
+    }
+    return TETRA_OK;
+}
+
+int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms) {
+    return tetra_demod_kernel_ms_history(h, 1, k1_ms, k2_ms);
+}
+
+int tetra_demod_last_hip_error(tetra_demod_t* h) { return h ? h->last_hip : 0; }
+
+int tetra_demod_debug_selftest(tetra_demod_t* h, const float* in128, float* out320) {
+    if (!h || !in128 || !out320) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&din, sizeof(float) * 128));
+    HIP_TRY(h, hipMalloc((void**)&dout, sizeof(float) * 320));
+    HIP_TRY(h, hipMemcpy(din, in128, sizeof(float) * 128, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, din, dout);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpy(out320, dout, sizeof(float) * 320, hipMemcpyDeviceToHost));
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return TETRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import tetra_amd
+    return tetra_amd.pkg
+
+
+@pytest.fixture(scope="session")
+def synth(pkg):
+    return pkg.synth
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    binding.build()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def emul():
+    from tests.emul import emul_bind
+    emul_bind.build()
+    return emul_bind

@@ -1,0 +1,119 @@
+"""Builds and binds tests/emul/emul.cpp (host emulation of the kernels' lane-level code)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libtetra_emul.so")
+DEPS = [os.path.join(HERE, "emul.cpp"),
+        os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "demod_core.hpp"),
+        os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "design.hpp"),
+        os.path.join(ROOT, "include", "tetra_demod.h")]
+
+sys.path.insert(0, ROOT)
+import tetra_amd  # noqa: E402
+
+Config = tetra_amd.pkg.binding.Config
+ChannelState = tetra_amd.pkg.binding.ChannelState
+
+
+class K1Consts(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("agc_set_point", "agc_rate", "agc_max_gain", "fll_alpha", "fll_beta",
+                                         "fll_min_freq", "fll_max_freq")]
+
+
+class K2Consts(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("tr_alpha", "tr_beta", "tr_min_freq", "tr_max_freq", "costas_alpha",
+                                         "costas_beta", "costas_min_freq", "costas_max_freq")]
+
+
+class Tables(C.Structure):
+    _fields_ = [("ntaps", C.c_int), ("rrc", C.c_float * 80), ("be_re", C.c_float * 80), ("be_im", C.c_float * 80),
+                ("bank", C.c_float * 1024), ("k1", K1Consts), ("k2", K2Consts), ("tr_omega", C.c_float)]
+
+
+def build(force=False):
+    stale = force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+    if stale:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-mavx2", "-DTETRA_HOST_EMUL",
+                        "-shared", "-fPIC", "-o", LIB, os.path.join(HERE, "emul.cpp")], check=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        vp = C.c_void_p
+        L.emul_design.argtypes = [C.POINTER(Config), C.POINTER(Tables)]
+        L.emul_design.restype = C.c_int
+        L.emul_default_cfg.argtypes = [C.POINTER(Config)]
+        L.emul_default_cfg.restype = None
+        L.emul_reset_state.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState)]
+        L.emul_reset_state.restype = None
+        L.emul_k1.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState), C.c_int, vp, vp]
+        L.emul_k1.restype = None
+        L.emul_k2.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState), C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
+        L.emul_k2.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def default_cfg():
+    cfg = Config()
+    lib().emul_default_cfg(C.byref(cfg))
+    return cfg
+
+
+def design(cfg=None):
+    cfg = cfg if cfg is not None else default_cfg()
+    t = Tables()
+    rc = lib().emul_design(C.byref(cfg), C.byref(t))
+    if rc:
+        raise ValueError("emul_design failed")
+    return t
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def bits_stride(n):
+    s = int(n / 0.95) + 16
+    return (s + 15) // 16 * 16
+
+
+class EmulDemod:
+    """C <= 64 channels through the emulated kernels, with carried state."""
+
+    def __init__(self, n_channels=1, cfg=None):
+        self.C = n_channels
+        self.tab = design(cfg)
+        self.st = (ChannelState * n_channels)()
+        for c in range(n_channels):
+            lib().emul_reset_state(C.byref(self.tab), C.byref(self.st[c]))
+
+    def process(self, iq, want_sym=False):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        if iq.ndim == 1:
+            iq = iq[None, :]
+        Cn, n = iq.shape
+        assert Cn == self.C
+        y = np.zeros((Cn, n), np.complex64)
+        for c in range(Cn):
+            lib().emul_k1(C.byref(self.tab), C.byref(self.st[c]), n, _p(iq[c]), _p(y[c]))
+        stride = bits_stride(n)
+        bits = np.zeros((Cn, stride), np.uint8)
+        nb = np.zeros(Cn, np.int32)
+        sym = np.zeros((Cn, stride // 2), np.complex64) if want_sym else None
+        rc = lib().emul_k2(C.byref(self.tab), self.st, Cn, n, _p(y), _p(bits), stride, _p(nb), _p(sym))
+        assert rc == 0, rc
+        return dict(y=y, bits=bits, n_bits=nb, sym=sym)

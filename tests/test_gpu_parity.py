@@ -1,0 +1,197 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded inputs.  Bit-exact for bits, symbols, the RRC output and the carried state."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dump(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(obj, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+
+
+def _u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _first_diff(a, b):
+    d = np.nonzero(np.asarray(a) != np.asarray(b))[0]
+    return int(d[0]) if len(d) else None
+
+
+def test_selftest_primitives(pkg, oracle):
+    """DPP row moves, sqrt and sincos behave as the arithmetic contract assumes."""
+    import ctypes as C
+    d = pkg.Demodulator(1, 64)
+    rng = np.random.default_rng(5)
+    inp = np.concatenate([np.abs(rng.standard_normal(64)) * 10 ** rng.uniform(-20, 20, 64),
+                          rng.uniform(-7, 7, 64)]).astype(np.float32)
+    inp[0], inp[1], inp[2] = 0.0, 1e-42, 2.0  # zero, subnormal, exact
+    out = d.selftest(inp)
+    lane = np.arange(64)
+    exp_shr = np.where(lane % 16 == 0, 100 + lane, lane - 1).astype(np.float32)
+    exp_shl = np.where(lane % 16 == 15, 200 + lane, lane + 1).astype(np.float32)
+    s = C.c_float()
+    c = C.c_float()
+    es, ec = [], []
+    for x in inp[64:]:
+        oracle.lib().tetra_oracle_sincosf(C.c_float(float(x)), C.byref(s), C.byref(c))
+        es.append(s.value)
+        ec.append(c.value)
+    res = dict(shr=out[0], shl=out[1], sqrt=out[2], sin=out[3], cos=out[4])
+    _dump("selftest.json", dict(inp=inp, **res, exp_shr=exp_shr, exp_shl=exp_shl))
+    assert np.array_equal(out[0], exp_shr), "row_shr:1 semantics"
+    assert np.array_equal(out[1], exp_shl), "row_shl:1 semantics"
+    assert np.array_equal(_u32(out[2]), _u32(np.sqrt(inp[:64]))), "sqrt not correctly rounded"
+    assert np.array_equal(_u32(out[3]), _u32(np.array(es, np.float32))), "sin differs from oracle"
+    assert np.array_equal(_u32(out[4]), _u32(np.array(ec, np.float32))), "cos differs from oracle"
+
+
+def test_tables_match_oracle(pkg, oracle):
+    d = pkg.Demodulator(1, 64)
+    t = d.tables()
+    o = oracle.Oracle()
+    a, b = o.bandedge_taps()
+    assert np.array_equal(t["rrc"], o.rrc_taps())
+    assert np.array_equal(t["be_re"], a) and np.array_equal(t["be_im"], b)
+    assert np.array_equal(t["bank"], o.interp_bank())
+
+
+def _compare(tag, pkg, oracle, iq, chunks, want_state=True):
+    """Run GPU and oracle over the same chunking; return list of mismatch descriptions."""
+    Cn, N = iq.shape
+    d = pkg.Demodulator(Cn, max(chunks))
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    problems = []
+    pos = 0
+    for ci, ch in enumerate(chunks):
+        blk = iq[:, pos:pos + ch]
+        bits, nb, sym = d.process(blk, want_sym=True)
+        y = d.read_rrc_out(ch)
+        for c in range(Cn):
+            r = orcs[c].process(blk[c], stages=True)
+            if not np.array_equal(_u32(y[c]), _u32(r["y"])):
+                i = _first_diff(_u32(y[c]).reshape(-1, 2).T[0], _u32(r["y"]).reshape(-1, 2).T[0])
+                problems.append(dict(tag=tag, chunk=ci, ch=c, what="rrc_out", first=i,
+                                     gpu=y[c][max(0, (i or 0) - 1):(i or 0) + 3], ref=r["y"][max(0, (i or 0) - 1):(i or 0) + 3]))
+            if nb[c] != len(r["bits"]):
+                problems.append(dict(tag=tag, chunk=ci, ch=c, what="n_bits", gpu=int(nb[c]), ref=len(r["bits"])))
+                continue
+            if not np.array_equal(bits[c][:nb[c]], r["bits"]):
+                problems.append(dict(tag=tag, chunk=ci, ch=c, what="bits", first=_first_diff(bits[c][:nb[c]], r["bits"]),
+                                     ndiff=int(np.count_nonzero(bits[c][:nb[c]] != r["bits"]))))
+            if not np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])):
+                i = _first_diff(_u32(sym[c][:nb[c] // 2]).reshape(-1, 2).T[0], _u32(r["sym"]).reshape(-1, 2).T[0])
+                problems.append(dict(tag=tag, chunk=ci, ch=c, what="sym", first=i))
+        pos += ch
+        if len(problems) > 40:
+            break
+    if want_state and not problems:
+        for c in range(0, Cn, max(1, Cn // 8)):
+            st = d.get_state(c)
+            o = orcs[c].st
+            for f, g in (("agc_gain", "agc_gain"), ("fll_phase", "fll_phase"), ("fll_freq", "fll_freq"), ("mu", "mu"),
+                         ("omega", "omega"), ("offset", "offset"), ("costas_phase", "costas_phase"),
+                         ("costas_freq", "costas_freq"), ("ph2", "ph2"), ("prev", "prev")):
+                if getattr(st, f) != getattr(o, g):
+                    problems.append(dict(tag=tag, ch=c, what="state." + f, gpu=getattr(st, f), ref=getattr(o, g)))
+            hg = np.array(st.hist[:], np.float32)[2 * 16:]
+            ho = np.array(o.hist[:128], np.float32)
+            if not np.array_equal(_u32(hg), _u32(ho)):
+                problems.append(dict(tag=tag, ch=c, what="state.hist"))
+            if not np.array_equal(_u32(np.array(st.ybuf[:], np.float32)), _u32(np.array(o.ybuf[:], np.float32))):
+                problems.append(dict(tag=tag, ch=c, what="state.ybuf"))
+    d.close()
+    return problems
+
+
+@pytest.mark.parametrize("Cn,N,chunks", [
+    (1, 4000, [4000]),
+    (5, 3000, [3000]),                                   # ragged: not a multiple of 4/16/64 channels
+    (16, 6000, [1, 2, 3, 15, 16, 17, 33, 180, 1000, 4733]),  # ragged chunk sizes, state carried
+    (70, 2048, [7] * 20 + [1908]),
+])
+def test_parity_small(pkg, oracle, synth, Cn, N, chunks):
+    assert sum(chunks) == N
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=1000 + Cn)
+    problems = _compare("small_%d_%d" % (Cn, N), pkg, oracle, iq, chunks)
+    _dump("parity_small_%d_%d.json" % (Cn, N), problems)
+    assert not problems, problems[:5]
+
+
+def test_parity_edge_channels(pkg, oracle, synth):
+    """All-zero input, noise only, tiny and huge amplitude, large carrier offset, clock offset."""
+    N = 8000
+    rng = np.random.default_rng(77)
+    iq = np.zeros((8, N), np.complex64)
+    iq[1] = 0.1 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+    iq[2] = synth.gen_channel(N, 1, amp=1e-4)[0]
+    iq[3] = synth.gen_channel(N, 2, amp=50.0)[0]
+    iq[4] = synth.gen_channel(N, 3, cfo=0.3)[0]
+    iq[5] = synth.gen_channel(N, 4, ppm=300.0)[0]
+    iq[6] = synth.gen_channel(N, 5, esn0_db=8.0)[0]
+    iq[7] = synth.gen_channel(N, 6, esn0_db=None, cfo=0.0, tau=0.0, amp=1.0, phase0=0.0)[0]
+    problems = _compare("edge", pkg, oracle, iq, [5000, 3000])
+    _dump("parity_edge.json", problems)
+    assert not problems, problems[:5]
+
+
+def test_parity_256_channels_full_second(pkg, oracle, synth):
+    """BASELINE config 2: 256 synthetic channels @ 36 ksps, 1 s, every output bit compared with the CPU."""
+    Cn, N = 256, 36000
+    iq, txb, _ = synth.gen_batch(Cn, N, base_seed=4242)
+    d = pkg.Demodulator(Cn, N)
+    bits, nb, sym = d.process(iq, want_sym=True)
+    rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
+    bad = [c for c in range(Cn) if nb[c] != rnb[c] or not np.array_equal(bits[c][:nb[c]], rb[c][:rnb[c]])]
+    badsym = [c for c in range(Cn) if nb[c] == rnb[c] and not np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(rsym[c][:nb[c] // 2]))]
+    # known answer on top: after lock the transmitted bits come out with a constant lag
+    lags, errs = [], 0
+    for c in range(0, Cn, 16):
+        lag, e, n = synth.align_and_count_errors(bits[c][:nb[c]], txb[c], skip=nb[c] // 2)
+        lags.append(lag)
+        errs += e
+    _dump("parity_256.json", dict(bad=bad, badsym=badsym, lags=lags, errs=errs, total_bits=int(nb.sum()),
+                                  kernel_ms=d.last_kernel_ms()))
+    assert not bad and not badsym
+    assert errs == 0
+    d.close()
+
+
+def test_reset_and_state_roundtrip(pkg, oracle, synth):
+    Cn, N = 8, 3000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=31)
+    d = pkg.Demodulator(Cn, N)
+    b1, n1, _ = d.process(iq)
+    st3 = d.get_state(3)
+    b2, n2, _ = d.process(iq)           # continues from carried state: differs from a fresh run
+    d.reset()
+    b3, n3, _ = d.process(iq)           # after reset == first run
+    assert np.array_equal(n1, n3) and np.array_equal(b1, b3)
+    # per-channel reset + set_state: channel 3 resumes exactly, others restart
+    d.reset()
+    d.process(iq)
+    d.reset(-1)
+    d.set_state(3, st3)
+    b4, n4, _ = d.process(iq)
+    assert n4[3] == n2[3] and np.array_equal(b4[3], b2[3])
+    assert np.array_equal(b4[0], b1[0])
+    d.close()
+
+
+def test_errors(pkg):
+    B = pkg.binding
+    d = pkg.Demodulator(2, 100)
+    with pytest.raises(B.TetraDemodError) as e:
+        d.process(np.zeros((2, 101), np.complex64))
+    assert e.value.status == -6
+    with pytest.raises(B.TetraDemodError):
+        pkg.Demodulator(1, 64, rrc_tap_count=200)
+    d.close()
