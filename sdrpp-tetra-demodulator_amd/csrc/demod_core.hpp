@@ -29,8 +29,9 @@
 #define TD_DEVICE 1
 #else
 #include <math.h>
-#define TD_FN static inline __attribute__((always_inline))
-#define TD_MFN inline __attribute__((always_inline))
+// host builds: plain inline (forcing inlining of the unrolled row program makes g++ take minutes)
+#define TD_FN static inline
+#define TD_MFN inline
 #define TD_DEVICE 0
 #endif
 

