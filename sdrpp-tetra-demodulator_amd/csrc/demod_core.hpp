@@ -53,6 +53,8 @@ TD_FN float v_sqrt(float a) { return __builtin_sqrtf(a); }
 TD_FN float v_rint(float a) { return __builtin_rintf(a); }
 TD_FN float v_floor(float a) { return __builtin_floorf(a); }
 TD_FN float v_abs(float a) { return __builtin_fabsf(a); }
+TD_FN float v_max(float a, float b) { return __builtin_fmaxf(a, b); }
+TD_FN float v_min(float a, float b) { return __builtin_fminf(a, b); }
 TD_FN float v_sel(bool m, float a, float b) { return m ? a : b; }
 TD_FN int v_sel(bool m, int a, int b) { return m ? a : b; }
 TD_FN int v_ftoi(float a) { return (int)a; }
@@ -88,7 +90,26 @@ TD_FN float row_shl1(float old, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
                                                                  __builtin_bit_cast(int, src), 0x101, 0xf, 0xf, false));
 }
+// row_shl:1 with zero fill (bound_ctrl): lane 15 of each row receives +0.
+TD_FN float row_shl1_z(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x101, 0xf, 0xf, true));
+}
+// AGC amplitude square root: hardware v_sqrt_f32 (<= 1 ulp) + the standard two-fma correction = correctly
+// rounded for every normal input and for 0.  Inputs below 2^-96 (|out| < 3.5e-15, where hipcc's generic
+// expansion rescales) may come out inexact, which cannot change the AGC: any amp < 2^-25 gives
+// (setPoint - amp) == 1.0f exactly.  Saves 7 VALU ops per sample over __builtin_sqrtf.
+TD_FN float v_sqrt_agc(float x) {
+    float y = __builtin_amdgcn_sqrtf(x);
+    float yd = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    float yu = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    float rd = __builtin_fmaf(-yd, y, x);
+    float ru = __builtin_fmaf(-yu, y, x);
+    y = (rd <= 0.0f) ? yd : y;
+    y = (ru > 0.0f) ? yu : y;
+    return y;
+}
 #else
+TD_FN float v_sqrt_agc(float x) { return __builtin_sqrtf(x); }
 template <class V> struct Pair {
     V vx, vy;
     Pair() {}
@@ -128,6 +149,8 @@ TD_FN Row16 v_fma(Row16 a, Row16 b, Row16 c) { Row16 r; for (int i = 0; i < 16; 
 TD_FN Row16 v_sqrt(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = sqrtf(a.l[i]); return r; }
 TD_FN Row16 v_rint(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = rintf(a.l[i]); return r; }
 TD_FN Row16 v_abs(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fabsf(a.l[i]); return r; }
+TD_FN Row16 v_max(Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fmaxf(a.l[i], b.l[i]); return r; }
+TD_FN Row16 v_min(Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fminf(a.l[i], b.l[i]); return r; }
 TD_FN Row16 v_sel(Row16m m, Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = m.l[i] ? a.l[i] : b.l[i]; return r; }
 TD_FN Row16i v_ftoi(Row16 a) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = (int)a.l[i]; return r; }
 TD_FN Row16m v_ieq(Row16i a, int b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] == b; return r; }
@@ -135,6 +158,8 @@ TD_FN Row16i v_iand(Row16i a, int b) { Row16i r; for (int i = 0; i < 16; i++) r.
 template <> struct vtraits<Row16> { using M = Row16m; using I = Row16i; };
 TD_FN Row16 row_shr1(Row16 old, Row16 src) { Row16 r; r.l[0] = old.l[0]; for (int i = 1; i < 16; i++) r.l[i] = src.l[i - 1]; return r; }
 TD_FN Row16 row_shl1(Row16 old, Row16 src) { Row16 r; r.l[15] = old.l[15]; for (int i = 0; i < 15; i++) r.l[i] = src.l[i + 1]; return r; }
+TD_FN Row16 row_shl1_z(Row16 src) { Row16 r; r.l[15] = 0.0f; for (int i = 0; i < 15; i++) r.l[i] = src.l[i + 1]; return r; }
+TD_FN Row16 v_sqrt_agc(Row16 a) { return v_sqrt(a); }
 #endif  // TETRA_HOST_EMUL
 
 template <class V> TD_FN Pair<V> row_shr1(Pair<V> old, Pair<V> src) {
@@ -143,6 +168,7 @@ template <class V> TD_FN Pair<V> row_shr1(Pair<V> old, Pair<V> src) {
 template <class V> TD_FN Pair<V> row_shl1(Pair<V> old, Pair<V> src) {
     return Pair<V>(row_shl1(old.x(), src.x()), row_shl1(old.y(), src.y()));
 }
+template <class V> TD_FN Pair<V> row_shl1_z(Pair<V> src) { return Pair<V>(row_shl1_z(src.x()), row_shl1_z(src.y())); }
 
 // ---------------------------------------------------------------------------------------------
 // Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same polynomial as
@@ -169,20 +195,24 @@ template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
     c = v_sel(q0, cr, v_sel(q1, -sr, v_sel(q2, -cr, sr)));
 }
 
-// SDR++ core complex_t::fastAmplitude
+// SDR++ core complex_t::fastAmplitude: `r > i ? r + 0.4f*i : i + 0.4f*r` with r = |re|, i = |im|, written as
+// max + 0.4f*min -- the same two roundings on the same operands, so bit-identical for every non-NaN input.
 template <class V> TD_FN V fast_amp(V re, V im) {
     V r = v_abs(re), i = v_abs(im);
-    return v_sel(r > i, r + 0.4f * i, i + 0.4f * r);
+    return v_max(r, i) + 0.4f * v_min(r, i);
 }
 
 // SDR++ core PhaseControlLoop<float, CLAMP>::advance.  The reference wraps with while loops; one
 // conditional step each way is identical as long as |freq + alpha*err| < 2*pi, which the frequency
 // limits of pi4dqpsk.cpp:17,21 guarantee (|freq| <= pi/2, |alpha*err| < 1).
-template <class V, bool CLAMP> TD_FN void pcl_advance(V err, V& phase, V& freq, float alpha, float beta,
+// ALPHA0 (alpha known to be exactly 0): `freq + 0*err` equals `freq` for every finite err (it can differ
+// only in the sign of a zero, which needs freq == -0, never produced by these loops), so the two ops are skipped.
+template <class V, bool CLAMP, bool ALPHA0 = false> TD_FN void pcl_advance(V err, V& phase, V& freq, float alpha, float beta,
                                                       float minf, float maxf) {
     freq = freq + beta * err;
     freq = v_sel(freq > maxf, V(maxf), v_sel(freq < minf, V(minf), freq));
-    phase = phase + (freq + alpha * err);
+    if (ALPHA0) phase = phase + freq;
+    else phase = phase + (freq + alpha * err);
     if (CLAMP) {
         const float pmax = kFlPi, pmin = -kFlPi, pdelta = pmax - pmin;
         phase = v_sel(phase > pmax, phase - pdelta, phase);
@@ -197,7 +227,7 @@ template <class V, bool CLAMP> TD_FN void pcl_advance(V err, V& phase, V& freq, 
 // as ONE systolic array along the row.  Taps are zero-padded at the old end to 80 = 16 lanes x 5;
 // padded tap kp lives in lane 15 - kp/5, slot kp%5, so lane 0 owns the five newest taps.  The
 // derotated sample x_i is produced in lane 0 and travels outward one lane per step (row_shr:1);
-// partial sums are created in lane 15 and travel inward one lane per four steps (row_shl:1),
+// partial sums are created in lane 15 and travel inward one lane per four steps (row_shl:1, zero fill),
 // receiving their taps in ascending tap order -- bit-identical to a direct-form fmaf chain
 // `for k: acc = fmaf(hist[k], tap[k], acc)` -- and complete in lane 0 in the very step that
 // produces x_i, where the FLL error needs them.  Only the newest tap sits on the per-sample
@@ -210,29 +240,30 @@ struct K1Consts {
 
 template <class V> struct K1Row {
     typedef Pair<V> P;
-    // per-lane tap blocks: t13[j] = (a, b), t24[j] = (b, a) of band-edge tap, th[j] = (h, h) of RRC tap
-    P t13[kTapsPerLane], t24[kTapsPerLane], th[kTapsPerLane];
-    // resident partial sums (4 per lane per sum group): (S1,S3), (S2,S4), (y.re, y.im)
-    P r13[4], r24[4], ry[4];
+    // per-lane tap blocks (slot j = padded tap 5*(15-lane)+j): band-edge re / im (lower filter), RRC
+    V ta[kTapsPerLane], tb[kTapsPerLane], th[kTapsPerLane];
+    // resident partial sums (4 per lane per group): (S1,S4) = x*(a,a), (S3,S2) = x*(b,b), (y.re,y.im) = x*(h,h)
+    P r14[4], r32[4], ry[4];
     P xs;          // x pipeline register: lane l holds x_{i-l}
     V g, ph, fr;   // AGC gain, FLL phase, FLL freq (meaningful in lane 0)
 
     TD_MFN void clear_pipeline() {
-        for (int q = 0; q < 4; q++) { r13[q] = P(V(0.0f), V(0.0f)); r24[q] = P(V(0.0f), V(0.0f)); ry[q] = P(V(0.0f), V(0.0f)); }
+        for (int q = 0; q < 4; q++) { r14[q] = P(V(0.0f), V(0.0f)); r32[q] = P(V(0.0f), V(0.0f)); ry[q] = P(V(0.0f), V(0.0f)); }
         xs = P(V(0.0f), V(0.0f));
     }
 
     // One sample step.  PH = step index mod 4 (selects which resident register is oldest).
     // REPLAY: `in` is a stored delay-line sample x (no AGC/FLL, loop state untouched).
+    // ALPHA0: the FLL loop's alpha is exactly 0 (fll.cpp:25 forces it), so `freq + alpha*err` is `freq`.
     // Returns the completed RRC output y_i (valid in lane 0; don't-care when REPLAY).
-    template <int PH, bool REPLAY> TD_MFN P step(const K1Consts& k, P in) {
+    template <int PH, bool REPLAY, bool ALPHA0> TD_MFN P step(const K1Consts& k, P in) {
         P x;
         if (REPLAY) {
             x = in;
         } else {
             // FastAGC::process
             V ar = in.x() * g, ai = in.y() * g;
-            V amp = v_sqrt(ar * ar + ai * ai);
+            V amp = v_sqrt_agc(ar * ar + ai * ai);
             g = g + (k.agc_set_point - amp) * k.agc_rate;
             g = v_sel(g > k.agc_max_gain, V(k.agc_max_gain), g);
             // fll.cpp:137-138  x = in * phasor(-phase)
@@ -241,90 +272,93 @@ template <class V> struct K1Row {
             x = P(ar * c - ai * s, ai * c + ar * s);
         }
         xs = row_shr1(x, xs);
-        P xr2(xs.x(), xs.x()), xi2(xs.y(), xs.y());
         // newest tap of this lane's block on the oldest resident sums
-        P c13 = pk_fma(xr2, t13[4], r13[PH]);
-        P c24 = pk_fma(xi2, t24[4], r24[PH]);
-        P cy = pk_fma(xs, th[4], ry[PH]);
+        P c14 = pk_fma(xs, P(ta[4], ta[4]), r14[PH]);
+        P c32 = pk_fma(xs, P(tb[4], tb[4]), r32[PH]);
+        P cy = pk_fma(xs, P(th[4], th[4]), ry[PH]);
         // hop one lane inward; lane 15 starts fresh sums at +0
-        const P zero(V(0.0f), V(0.0f));
-        P h13 = row_shl1(zero, c13), h24 = row_shl1(zero, c24), hy = row_shl1(zero, cy);
-        r13[PH] = pk_fma(xr2, t13[0], h13);
-        r24[PH] = pk_fma(xi2, t24[0], h24);
-        ry[PH] = pk_fma(xs, th[0], hy);
-        r13[(PH + 1) & 3] = pk_fma(xr2, t13[3], r13[(PH + 1) & 3]);
-        r24[(PH + 1) & 3] = pk_fma(xi2, t24[3], r24[(PH + 1) & 3]);
-        ry[(PH + 1) & 3] = pk_fma(xs, th[3], ry[(PH + 1) & 3]);
-        r13[(PH + 2) & 3] = pk_fma(xr2, t13[2], r13[(PH + 2) & 3]);
-        r24[(PH + 2) & 3] = pk_fma(xi2, t24[2], r24[(PH + 2) & 3]);
-        ry[(PH + 2) & 3] = pk_fma(xs, th[2], ry[(PH + 2) & 3]);
-        r13[(PH + 3) & 3] = pk_fma(xr2, t13[1], r13[(PH + 3) & 3]);
-        r24[(PH + 3) & 3] = pk_fma(xi2, t24[1], r24[(PH + 3) & 3]);
-        ry[(PH + 3) & 3] = pk_fma(xs, th[1], ry[(PH + 3) & 3]);
+        r14[PH] = pk_fma(xs, P(ta[0], ta[0]), row_shl1_z(c14));
+        r32[PH] = pk_fma(xs, P(tb[0], tb[0]), row_shl1_z(c32));
+        ry[PH] = pk_fma(xs, P(th[0], th[0]), row_shl1_z(cy));
+        r14[(PH + 1) & 3] = pk_fma(xs, P(ta[3], ta[3]), r14[(PH + 1) & 3]);
+        r32[(PH + 1) & 3] = pk_fma(xs, P(tb[3], tb[3]), r32[(PH + 1) & 3]);
+        ry[(PH + 1) & 3] = pk_fma(xs, P(th[3], th[3]), ry[(PH + 1) & 3]);
+        r14[(PH + 2) & 3] = pk_fma(xs, P(ta[2], ta[2]), r14[(PH + 2) & 3]);
+        r32[(PH + 2) & 3] = pk_fma(xs, P(tb[2], tb[2]), r32[(PH + 2) & 3]);
+        ry[(PH + 2) & 3] = pk_fma(xs, P(th[2], th[2]), ry[(PH + 2) & 3]);
+        r14[(PH + 3) & 3] = pk_fma(xs, P(ta[1], ta[1]), r14[(PH + 3) & 3]);
+        r32[(PH + 3) & 3] = pk_fma(xs, P(tb[1], tb[1]), r32[(PH + 3) & 3]);
+        ry[(PH + 3) & 3] = pk_fma(xs, P(th[1], th[1]), ry[(PH + 3) & 3]);
         if (!REPLAY) {
             // fll.cpp:141-145: band-edge outputs from the four real sums, error, loop advance
-            V s1 = c13.x(), s3 = c13.y(), s2 = c24.x(), s4 = c24.y();
+            V s1 = c14.x(), s4 = c14.y(), s3 = c32.x(), s2 = c32.y();
             V lre = s1 - s2, lim = s4 + s3;
             V hre = s1 + s2, him = s4 - s3;
             V err = fast_amp<V>(hre, him) - fast_amp<V>(lre, lim);
-            pcl_advance<V, true>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
+            pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
         }
         return cy;
     }
 };
 
-// Row driver of kernel 1: delay-line replay, 16-sample input tiles, output queue, state save.
+// Row driver of kernel 1: delay-line replay, 16-sample tiles, state save.
 // IO supplies the memory side (device: global/LDS accesses of one lane; host emulation: arrays):
-//   P    load_hist(int t)                 lane l <- stored delay-line sample t*16 + l
-//   P    load_in(int t, int n)            lane l <- input sample t*16 + l (0 if >= n)
-//   void store_y(int base, int cnt, P yq) lane l < cnt holds y_{base+cnt-1-l}
-//   void ring_store(int iend, int cnt, P xs)  lane l < cnt holds x_{iend-1-l}
-//   void save(const K1Row<V>&, int n)     loop state + new delay line (samples n-80..n-1)
-#define TD_K1_STEP(S, REPLAY)                                         \
+//   P    load_hist(int t)                      lane l <- stored delay-line sample t*16 + l
+//   void stage_tile(int t, int n)              make input samples t*16 .. t*16+15 available
+//   P    sample(int s)                         input sample s of the staged tile, broadcast to the row
+//   void emit(int s, P y)                      lane 0 holds RRC output s of the tile
+//   void flush_tile(int base, int cnt)         write the tile's cnt outputs out
+//   void ring_store(int iend, int cnt, P xs)   lane l < cnt holds x_{iend-1-l}
+//   void save(const K1Row<V>&, int n)          loop state + new delay line (samples n-80..n-1)
+#define TD_K1_REPLAY(S)                                               \
     {                                                                 \
-        P yy = R.template step<(S)&3, REPLAY>(k, cur);                \
+        (void)R.template step<(S)&3, true, true>(k, cur);             \
         cur = row_shl1(cur, cur);                                     \
-        if (!(REPLAY)) yq = row_shr1(yy, yq);                         \
+    }
+#define TD_K1_STEP(S)                                                 \
+    {                                                                 \
+        P yy = ALPHA0 ? R.template step<(S)&3, false, true>(k, io.sample(S)) \
+                      : R.template step<(S)&3, false, false>(k, io.sample(S)); \
+        io.emit(S, yy);                                               \
     }
 #define TD_K1_STEP_G(S) \
-    if ((S) < cnt) TD_K1_STEP(S, false)
+    if ((S) < cnt) TD_K1_STEP(S)
 
-template <class V, class IO> TD_FN void k1_run(K1Row<V>& R, const K1Consts& k, IO& io, int n) {
+template <class V, class IO, bool ALPHA0> TD_FN void k1_run(K1Row<V>& R, const K1Consts& k, IO& io, int n) {
     typedef Pair<V> P;
-    P cur(V(0.0f), V(0.0f)), yq(V(0.0f), V(0.0f));
+    P cur(V(0.0f), V(0.0f));
     R.clear_pipeline();
     // Rebuild the in-flight partial sums by replaying the stored delay line (steps -80..-1).
     for (int t = 0; t < kHist / kLanes; t++) {
         cur = io.load_hist(t);
-        TD_K1_STEP(0, true) TD_K1_STEP(1, true) TD_K1_STEP(2, true) TD_K1_STEP(3, true)
-        TD_K1_STEP(4, true) TD_K1_STEP(5, true) TD_K1_STEP(6, true) TD_K1_STEP(7, true)
-        TD_K1_STEP(8, true) TD_K1_STEP(9, true) TD_K1_STEP(10, true) TD_K1_STEP(11, true)
-        TD_K1_STEP(12, true) TD_K1_STEP(13, true) TD_K1_STEP(14, true) TD_K1_STEP(15, true)
+        TD_K1_REPLAY(0) TD_K1_REPLAY(1) TD_K1_REPLAY(2) TD_K1_REPLAY(3)
+        TD_K1_REPLAY(4) TD_K1_REPLAY(5) TD_K1_REPLAY(6) TD_K1_REPLAY(7)
+        TD_K1_REPLAY(8) TD_K1_REPLAY(9) TD_K1_REPLAY(10) TD_K1_REPLAY(11)
+        TD_K1_REPLAY(12) TD_K1_REPLAY(13) TD_K1_REPLAY(14) TD_K1_REPLAY(15)
         io.ring_store(-kHist + kLanes * (t + 1), kLanes, R.xs);
     }
     const int ntiles = (n + kLanes - 1) / kLanes;
-    P nxt = io.load_in(0, n);
     for (int t = 0; t < ntiles; t++) {
-        cur = nxt;
-        nxt = io.load_in(t + 1, n);
+        io.stage_tile(t, n);
         const int base = t * kLanes;
         const int cnt = (n - base < kLanes) ? (n - base) : kLanes;
         if (cnt == kLanes) {
-            TD_K1_STEP(0, false) TD_K1_STEP(1, false) TD_K1_STEP(2, false) TD_K1_STEP(3, false)
-            TD_K1_STEP(4, false) TD_K1_STEP(5, false) TD_K1_STEP(6, false) TD_K1_STEP(7, false)
-            TD_K1_STEP(8, false) TD_K1_STEP(9, false) TD_K1_STEP(10, false) TD_K1_STEP(11, false)
-            TD_K1_STEP(12, false) TD_K1_STEP(13, false) TD_K1_STEP(14, false) TD_K1_STEP(15, false)
+            TD_K1_STEP(0) TD_K1_STEP(1) TD_K1_STEP(2) TD_K1_STEP(3)
+            TD_K1_STEP(4) TD_K1_STEP(5) TD_K1_STEP(6) TD_K1_STEP(7)
+            TD_K1_STEP(8) TD_K1_STEP(9) TD_K1_STEP(10) TD_K1_STEP(11)
+            TD_K1_STEP(12) TD_K1_STEP(13) TD_K1_STEP(14) TD_K1_STEP(15)
         } else {
             TD_K1_STEP_G(0) TD_K1_STEP_G(1) TD_K1_STEP_G(2) TD_K1_STEP_G(3)
             TD_K1_STEP_G(4) TD_K1_STEP_G(5) TD_K1_STEP_G(6) TD_K1_STEP_G(7)
             TD_K1_STEP_G(8) TD_K1_STEP_G(9) TD_K1_STEP_G(10) TD_K1_STEP_G(11)
             TD_K1_STEP_G(12) TD_K1_STEP_G(13) TD_K1_STEP_G(14) TD_K1_STEP_G(15)
         }
-        io.store_y(base, cnt, yq);
+        io.flush_tile(base, cnt);
         io.ring_store(base + cnt, cnt, R.xs);
     }
     io.save(R, n);
 }
+#undef TD_K1_REPLAY
 #undef TD_K1_STEP
 #undef TD_K1_STEP_G
 

@@ -75,14 +75,20 @@ __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
 // ------------------------------------------------------------------------------------------------
 // Kernel 1
 // ------------------------------------------------------------------------------------------------
-// Memory side of one lane of a channel row (see k1_run in demod_core.hpp).
+// Memory side of one lane of a channel row (see k1_run in demod_core.hpp).  Input samples and RRC outputs
+// move through small LDS tiles so that the per-sample work costs no VALU instructions: the tile is written
+// once per 16 samples, each step reads its sample as an LDS broadcast and drops its output with one ds_write.
 struct K1DeviceIO {
     const K1Params& p;
-    float2* ring;            // this row's LDS ring [kRing]
+    float2* ring;            // this row's LDS ring [kRing] of recent FLL outputs
+    float2* in_tile;         // this row's LDS input tile [kLanes]
+    float2* y_tile;          // this row's LDS output tile [kLanes]
+    float2* y_sink;          // where this lane's emit() lands: y_tile for lane 0, a dump area for the others
     const float2* hp;        // this channel's stored delay line
     const float2* ip;        // this channel's input
     int lane, ch;
     bool active;
+    Pair<float> nxt;         // prefetched next input tile (lane l: sample t*16 + l)
 
     __device__ __forceinline__ Pair<float> load_hist(int t) const { return ld_pair(hp + t * kLanes + lane); }
     __device__ __forceinline__ Pair<float> load_in(int t, int n) const {
@@ -90,11 +96,18 @@ struct K1DeviceIO {
         if (i < n) return ld_pair(ip + (long long)i * p.in_t_stride);
         return Pair<float>(0.f, 0.f);
     }
-    __device__ __forceinline__ void store_y(int base, int cnt, Pair<float> yq) const {
-        if (active && lane < cnt) {
-            const int i = base + cnt - 1 - lane;
-            p.y[(long long)(kYHist + i) * p.n_channels + ch] = make_float2(yq.x(), yq.y());
-        }
+    __device__ __forceinline__ void stage_tile(int t, int n) {
+        if (t == 0) nxt = load_in(0, n);
+        in_tile[lane] = make_float2(nxt.x(), nxt.y());
+        nxt = load_in(t + 1, n);
+    }
+    __device__ __forceinline__ Pair<float> sample(int s) const {
+        const float2 v = in_tile[s];
+        return Pair<float>(v.x, v.y);
+    }
+    __device__ __forceinline__ void emit(int s, Pair<float> y) const { y_sink[s] = make_float2(y.x(), y.y()); }
+    __device__ __forceinline__ void flush_tile(int base, int cnt) const {
+        if (active && lane < cnt) p.y[(long long)(kYHist + base + lane) * p.n_channels + ch] = y_tile[lane];
     }
     __device__ __forceinline__ void ring_store(int iend, int cnt, Pair<float> xs) const {
         if (lane < cnt) ring[(iend - 1 - lane) & (kRing - 1)] = make_float2(xs.x(), xs.y());
@@ -116,8 +129,11 @@ struct K1DeviceIO {
     }
 };
 
-__global__ __launch_bounds__(kK1Threads) void k1_agc_fll_rrc(K1Params p) {
+template <bool ALPHA0> __global__ __launch_bounds__(kK1Threads) void k1_agc_fll_rrc(K1Params p) {
     __shared__ float2 ring[kK1RowsPerBlock][kRing];
+    __shared__ float2 in_tile[kK1RowsPerBlock][kLanes];
+    __shared__ float2 y_tile[kK1RowsPerBlock][kLanes];
+    __shared__ float2 dump[kK1Threads + kLanes];
 
     const int lane = threadIdx.x & (kLanes - 1);
     const int row = threadIdx.x >> 4;
@@ -130,18 +146,19 @@ __global__ __launch_bounds__(kK1Threads) void k1_agc_fll_rrc(K1Params p) {
 #pragma unroll
     for (int j = 0; j < kTapsPerLane; j++) {
         const int kp = kTapsPerLane * (kLanes - 1 - lane) + j;
-        const float a = p.be_re[kp], b = p.be_im[kp], h = p.rrc[kp];
-        R.t13[j] = Pair<float>(a, b);
-        R.t24[j] = Pair<float>(b, a);
-        R.th[j] = Pair<float>(h, h);
+        R.ta[j] = p.be_re[kp];
+        R.tb[j] = p.be_im[kp];
+        R.th[j] = p.rrc[kp];
     }
     R.g = p.agc_g[chl];
     R.ph = p.fll_ph[chl];
     R.fr = p.fll_fr[chl];
 
-    K1DeviceIO io{ p, &ring[row][0], p.hist + (long long)chl * kHist, p.iq + (long long)chl * p.in_ch_stride, lane, ch,
-                   active };
-    k1_run<float, K1DeviceIO>(R, p.k, io, p.n);
+    K1DeviceIO io{ p, &ring[row][0], &in_tile[row][0], &y_tile[row][0],
+                   lane == 0 ? &y_tile[row][0] : &dump[threadIdx.x],
+                   p.hist + (long long)chl * kHist, p.iq + (long long)chl * p.in_ch_stride, lane, ch, active,
+                   Pair<float>(0.f, 0.f) };
+    k1_run<float, K1DeviceIO, ALPHA0>(R, p.k, io, p.n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,11 +207,16 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
         const int base = wave_min_i32(pending ? st.offset : 0x7fffffff);
         // stage rows [base, base + kK2TileRows) of this wave's 64 channels
         __syncthreads();
-        for (int r = 0; r < kK2TileRows; r++) {
-            const int rr = base + r;
-            float2 v = make_float2(0.f, 0.f);
-            if (rr < nrows) v = p.y[(long long)rr * p.n_channels + chl];
-            tile[r][lane] = v;
+        for (int r0 = 0; r0 < kK2TileRows; r0 += 16) {
+            float2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {      // 16 independent loads in flight
+                const int rr = base + r0 + j;
+                v[j] = make_float2(0.f, 0.f);
+                if (rr < nrows) v[j] = p.y[(long long)rr * p.n_channels + chl];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) tile[r0 + j][lane] = v[j];
         }
         __syncthreads();
         while (true) {
@@ -587,7 +609,9 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
 
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
     HIP_TRY(h, hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(k1_agc_fll_rrc, dim3((h->C + kK1RowsPerBlock - 1) / kK1RowsPerBlock), dim3(kK1Threads), 0, s, p1);
+    const dim3 g1((h->C + kK1RowsPerBlock - 1) / kK1RowsPerBlock);
+    if (p1.k.fll_alpha == 0.0f) hipLaunchKernelGGL(k1_agc_fll_rrc<true>, g1, dim3(kK1Threads), 0, s, p1);
+    else hipLaunchKernelGGL(k1_agc_fll_rrc<false>, g1, dim3(kK1Threads), 0, s, p1);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(k2_sync_slice, dim3((h->C + kK2Threads - 1) / kK2Threads), dim3(kK2Threads), 0, s, p2);

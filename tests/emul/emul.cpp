@@ -31,24 +31,25 @@ struct K1EmulIO {
     float* y;            // [n][2]
     float ring[kRing][2];
     tetra_demod_channel_state_t* st;
+    int tile = 0, nn = 0;
 
     Pair<Row16> load_hist(int t) const {
         Row16 a, b;
         for (int l = 0; l < 16; l++) { a.l[l] = hist[2 * (t * 16 + l)]; b.l[l] = hist[2 * (t * 16 + l) + 1]; }
         return Pair<Row16>(a, b);
     }
-    Pair<Row16> load_in(int t, int n) const {
-        Row16 a(0.f), b(0.f);
-        for (int l = 0; l < 16; l++) {
-            int i = t * 16 + l;
-            if (i < n) { a.l[l] = iq[2 * i]; b.l[l] = iq[2 * i + 1]; }
-        }
-        return Pair<Row16>(a, b);
+    void stage_tile(int t, int n) { tile = t; nn = n; }
+    Pair<Row16> sample(int s) const {
+        const int i = tile * 16 + s;
+        if (i < nn) return Pair<Row16>(Row16(iq[2 * i]), Row16(iq[2 * i + 1]));
+        return Pair<Row16>(Row16(0.f), Row16(0.f));
     }
-    void store_y(int base, int cnt, Pair<Row16> yq) {
-        for (int l = 0; l < 16; l++)
-            if (l < cnt) { int i = base + cnt - 1 - l; y[2 * i] = yq.x().l[l]; y[2 * i + 1] = yq.y().l[l]; }
+    void emit(int s, Pair<Row16> yy) {
+        const int i = tile * 16 + s;
+        y[2 * i] = yy.x().l[0];
+        y[2 * i + 1] = yy.y().l[0];
     }
+    void flush_tile(int, int) {}
     void ring_store(int iend, int cnt, Pair<Row16> xs) {
         for (int l = 0; l < 16; l++)
             if (l < cnt) { int k = (iend - 1 - l) & (kRing - 1); ring[k][0] = xs.x().l[l]; ring[k][1] = xs.y().l[l]; }
@@ -122,9 +123,9 @@ void emul_k1(const emul_tables* t, tetra_demod_channel_state_t* st, int n, const
             const int kp = kTapsPerLane * (kLanes - 1 - l) + j;
             a.l[l] = re[kp]; b.l[l] = im[kp]; h.l[l] = rr[kp];
         }
-        R.t13[j] = Pair<Row16>(a, b);
-        R.t24[j] = Pair<Row16>(b, a);
-        R.th[j] = Pair<Row16>(h, h);
+        R.ta[j] = a;
+        R.tb[j] = b;
+        R.th[j] = h;
     }
     R.g = Row16(st->agc_gain);
     R.ph = Row16(st->fll_phase);
@@ -133,7 +134,8 @@ void emul_k1(const emul_tables* t, tetra_demod_channel_state_t* st, int n, const
     std::vector<float> hist(st->hist, st->hist + 2 * kHist);
     io.hist = hist.data(); io.iq = iq; io.y = y; io.st = st;
     std::memset(io.ring, 0, sizeof(io.ring));
-    k1_run<Row16, K1EmulIO>(R, t->k1, io, n);
+    if (t->k1.fll_alpha == 0.0f) k1_run<Row16, K1EmulIO, true>(R, t->k1, io, n);
+    else k1_run<Row16, K1EmulIO, false>(R, t->k1, io, n);
 }
 
 // Kernel 2 for C <= 64 channels in one emulated wave.  y: [C][n] channel-major input (this call's
