@@ -39,6 +39,13 @@ enum {
     TETRA_ERR_ALIGN = -7        /* output pointer / stride not 8-byte aligned */
 };
 
+/* tetra_demod_config_t.flags */
+enum {
+    TETRA_FLAG_TWO_KERNEL = 1,   /* run the two-kernel pipeline (AGC+FLL+RRC kernel -> HBM scratch -> timing/Costas kernel)
+                                    instead of the fused single-kernel pipeline */
+    TETRA_FLAG_KEEP_RRC_OUT = 2  /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
+};
+
 /* Input sample layout of process(): element (channel c, sample n) of the complex64 stream. */
 enum {
     TETRA_LAYOUT_CHANNEL_MAJOR = 0, /* iq[c][n]: each channel contiguous = the reference's complex_t in[count] per channel */
@@ -56,8 +63,8 @@ typedef struct tetra_demod_config {
     int32_t device;          /* HIP device ordinal; -1 = current device */
     double symbolrate;       /* 18000 */
     double samplerate;       /* 36000 */
-    int32_t rrc_tap_count;   /* 65; 2..80 supported */
-    int32_t reserved0;
+    int32_t rrc_tap_count;   /* 65; 2..80 supported (the fused kernel covers <= 72, longer filters run the two-kernel pipeline) */
+    int32_t flags;           /* TETRA_FLAG_* */
     double rrc_beta;         /* 0.35 */
     double agc_rate;         /* 0.02 */
     double costas_bandwidth; /* 0.01 */
@@ -153,11 +160,13 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
 int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank);
 
 /* Debug/verification tap: RRC output (timing-recovery input) of the last process call,
- * y[n_channels][n_samples] complex64 channel-major, copied to host memory. */
+ * y[n_channels][n_samples] complex64 channel-major, copied to host memory.  Needs TETRA_FLAG_TWO_KERNEL or
+ * TETRA_FLAG_KEEP_RRC_OUT (TETRA_ERR_UNSUPPORTED otherwise). */
 int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples);
 
-/* GPU time of the two kernels of the most recent process call, from HIP events recorded on the
- * call's stream (synchronises on them).  k1 = AGC+FLL+RRC, k2 = timing+Costas+slicer. */
+/* GPU time of the kernels of the most recent process call, from HIP events recorded on the call's stream
+ * (synchronises on them).  Fused pipeline: k1 = the fused kernel, k2 = 0.  Two-kernel pipeline:
+ * k1 = AGC+FLL+RRC, k2 = timing+Costas+slicer. */
 int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms);
 /* Same for the n (1..64) most recent kernel-launching process calls, oldest first: k1_ms[n], k2_ms[n]
  * (either may be NULL).  The events are recorded on each call's own stream, so a benchmark can read the

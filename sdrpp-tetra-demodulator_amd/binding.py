@@ -15,6 +15,8 @@ from . import build as _build
 
 LAYOUT_CHANNEL_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1
+FLAG_TWO_KERNEL = 1
+FLAG_KEEP_RRC_OUT = 2
 
 PARAMS = dict(symbolrate=0, samplerate=1, rrc_tap_count=2, rrc_beta=3, agc_rate=4, costas_bandwidth=5,
               fll_bandwidth=6, omega_gain=7, mu_gain=8, omega_rel_limit=9)
@@ -32,7 +34,7 @@ class Config(C.Structure):
     _fields_ = [
         ("n_channels", C.c_int32), ("max_samples", C.c_int32), ("layout", C.c_int32), ("device", C.c_int32),
         ("symbolrate", C.c_double), ("samplerate", C.c_double),
-        ("rrc_tap_count", C.c_int32), ("reserved0", C.c_int32),
+        ("rrc_tap_count", C.c_int32), ("flags", C.c_int32),
         ("rrc_beta", C.c_double), ("agc_rate", C.c_double), ("costas_bandwidth", C.c_double),
         ("fll_bandwidth", C.c_double), ("omega_gain", C.c_double), ("mu_gain", C.c_double),
         ("omega_rel_limit", C.c_double),
@@ -132,13 +134,14 @@ class Demodulator:
     """C batched reference chains on one GPU."""
 
     def __init__(self, n_channels=1, max_samples=65536, layout=LAYOUT_CHANNEL_MAJOR, device=-1,
-                 rrc_taps=None, bandedge_taps=None, interp_bank=None, **params):
+                 rrc_taps=None, bandedge_taps=None, interp_bank=None, flags=0, **params):
         self._lib = load_library()
         cfg = default_config()
         cfg.n_channels = n_channels
         cfg.max_samples = max_samples
         cfg.layout = layout
         cfg.device = device
+        cfg.flags = flags
         for k, v in params.items():
             if k not in PARAMS:
                 raise TypeError("unknown parameter %r" % k)

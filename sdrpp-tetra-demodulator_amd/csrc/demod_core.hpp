@@ -90,6 +90,18 @@ TD_FN float row_shl1(float old, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
                                                                  __builtin_bit_cast(int, src), 0x101, 0xf, 0xf, false));
 }
+// Two-lane variants for rows that interleave two channels on even/odd lanes (8 lanes per channel).
+TD_FN float row_shr2(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x112, 0xf, 0xf, false));
+}
+TD_FN float row_shl2(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x102, 0xf, 0xf, false));
+}
+TD_FN float row_shl2_z(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x102, 0xf, 0xf, true));
+}
 // row_shl:1 with zero fill (bound_ctrl): lane 15 of each row receives +0.
 TD_FN float row_shl1_z(float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x101, 0xf, 0xf, true));
@@ -160,6 +172,9 @@ TD_FN Row16 row_shr1(Row16 old, Row16 src) { Row16 r; r.l[0] = old.l[0]; for (in
 TD_FN Row16 row_shl1(Row16 old, Row16 src) { Row16 r; r.l[15] = old.l[15]; for (int i = 0; i < 15; i++) r.l[i] = src.l[i + 1]; return r; }
 TD_FN Row16 row_shl1_z(Row16 src) { Row16 r; r.l[15] = 0.0f; for (int i = 0; i < 15; i++) r.l[i] = src.l[i + 1]; return r; }
 TD_FN Row16 v_sqrt_agc(Row16 a) { return v_sqrt(a); }
+TD_FN Row16 row_shr2(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 2 ? old.l[i] : src.l[i - 2]; return r; }
+TD_FN Row16 row_shl2(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 14 ? src.l[i + 2] : old.l[i]; return r; }
+TD_FN Row16 row_shl2_z(Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 14 ? src.l[i + 2] : 0.0f; return r; }
 #endif  // TETRA_HOST_EMUL
 
 template <class V> TD_FN Pair<V> row_shr1(Pair<V> old, Pair<V> src) {
@@ -169,6 +184,13 @@ template <class V> TD_FN Pair<V> row_shl1(Pair<V> old, Pair<V> src) {
     return Pair<V>(row_shl1(old.x(), src.x()), row_shl1(old.y(), src.y()));
 }
 template <class V> TD_FN Pair<V> row_shl1_z(Pair<V> src) { return Pair<V>(row_shl1_z(src.x()), row_shl1_z(src.y())); }
+template <class V> TD_FN Pair<V> row_shr2(Pair<V> old, Pair<V> src) {
+    return Pair<V>(row_shr2(old.x(), src.x()), row_shr2(old.y(), src.y()));
+}
+template <class V> TD_FN Pair<V> row_shl2(Pair<V> old, Pair<V> src) {
+    return Pair<V>(row_shl2(old.x(), src.x()), row_shl2(old.y(), src.y()));
+}
+template <class V> TD_FN Pair<V> row_shl2_z(Pair<V> src) { return Pair<V>(row_shl2_z(src.x()), row_shl2_z(src.y())); }
 
 // ---------------------------------------------------------------------------------------------
 // Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same polynomial as
@@ -238,6 +260,15 @@ struct K1Consts {
     float fll_alpha, fll_beta, fll_min_freq, fll_max_freq;
 };
 
+// SDR++ core loop::FastAGC<complex_t>::process, one sample (called at src/dsp/pi4dqpsk.cpp:134).
+template <class V> TD_FN Pair<V> agc_step(const K1Consts& k, Pair<V> in, V& g) {
+    V ar = in.x() * g, ai = in.y() * g;
+    V amp = v_sqrt_agc(ar * ar + ai * ai);
+    g = g + (k.agc_set_point - amp) * k.agc_rate;
+    g = v_sel(g > k.agc_max_gain, V(k.agc_max_gain), g);
+    return Pair<V>(ar, ai);
+}
+
 template <class V> struct K1Row {
     typedef Pair<V> P;
     // per-lane tap blocks (slot j = padded tap 5*(15-lane)+j): band-edge re / im (lower filter), RRC
@@ -261,15 +292,11 @@ template <class V> struct K1Row {
         if (REPLAY) {
             x = in;
         } else {
-            // FastAGC::process
-            V ar = in.x() * g, ai = in.y() * g;
-            V amp = v_sqrt_agc(ar * ar + ai * ai);
-            g = g + (k.agc_set_point - amp) * k.agc_rate;
-            g = v_sel(g > k.agc_max_gain, V(k.agc_max_gain), g);
+            P a = agc_step<V>(k, in, g);
             // fll.cpp:137-138  x = in * phasor(-phase)
             V s, c;
             sincos_t<V>(-ph, s, c);
-            x = P(ar * c - ai * s, ai * c + ar * s);
+            x = P(a.x() * c - a.y() * s, a.y() * c + a.x() * s);
         }
         xs = row_shr1(x, xs);
         // newest tap of this lane's block on the oldest resident sums
@@ -363,6 +390,145 @@ template <class V, class IO, bool ALPHA0> TD_FN void k1_run(K1Row<V>& R, const K
 #undef TD_K1_STEP_G
 
 // ---------------------------------------------------------------------------------------------
+// Fused kernel building blocks.
+//
+// FLL row with 8 lanes per channel: a 16-lane row carries TWO channels interleaved on even/odd
+// lanes, so every cross-lane move is a two-lane DPP shift and both channels' heads (lanes 0,1) and
+// tails (lanes 14,15) fall on the row boundary where DPP's keep-old / zero-fill do the right thing.
+// Band-edge taps are zero-padded at the old end to 72 = 8 positions x 9; padded tap kp lives at
+// position 7 - kp/9 (lane 2*pos + parity), slot kp%9.  Same schedule as K1Row otherwise: x travels
+// outward one position per step, partial sums travel inward one position per eight steps, ascending
+// tap order, newest tap applied in the head lane in the step that produces x.
+// ---------------------------------------------------------------------------------------------
+constexpr int kF8Lanes = 8;
+constexpr int kF8Taps = 9;
+constexpr int kF8Pad = kF8Lanes * kF8Taps;   // 72
+
+template <class V> struct FllRow8 {
+    typedef Pair<V> P;
+    V ta[kF8Taps], tb[kF8Taps];
+    P r14[8], r32[8];
+    P xs;        // lane (pos, parity) holds x_{i-pos} of its channel
+    V ph, fr;    // FLL phase / freq (meaningful in the head lanes 0 and 1)
+
+    TD_MFN void clear_pipeline() {
+        for (int q = 0; q < 8; q++) { r14[q] = P(V(0.0f), V(0.0f)); r32[q] = P(V(0.0f), V(0.0f)); }
+        xs = P(V(0.0f), V(0.0f));
+    }
+
+    // One sample step; PH = step index mod 8.  `a` = AGC output (or a stored x when REPLAY), valid in
+    // the head lanes.  After the step xs holds the new x pipeline.
+    template <int PH, bool REPLAY, bool ALPHA0> TD_MFN void step(const K1Consts& k, P a) {
+        P x;
+        if (REPLAY) {
+            x = a;
+        } else {
+            V s, c;
+            sincos_t<V>(-ph, s, c);                                   // fll.cpp:137-138
+            x = P(a.x() * c - a.y() * s, a.y() * c + a.x() * s);
+        }
+        xs = row_shr2(x, xs);
+        P c14 = pk_fma(xs, P(ta[8], ta[8]), r14[PH]);
+        P c32 = pk_fma(xs, P(tb[8], tb[8]), r32[PH]);
+        r14[PH] = pk_fma(xs, P(ta[0], ta[0]), row_shl2_z(c14));
+        r32[PH] = pk_fma(xs, P(tb[0], tb[0]), row_shl2_z(c32));
+#define TD_F8_TAP(Q)                                                                              \
+        r14[(PH + Q) & 7] = pk_fma(xs, P(ta[8 - Q], ta[8 - Q]), r14[(PH + Q) & 7]);               \
+        r32[(PH + Q) & 7] = pk_fma(xs, P(tb[8 - Q], tb[8 - Q]), r32[(PH + Q) & 7]);
+        TD_F8_TAP(1) TD_F8_TAP(2) TD_F8_TAP(3) TD_F8_TAP(4) TD_F8_TAP(5) TD_F8_TAP(6) TD_F8_TAP(7)
+#undef TD_F8_TAP
+        if (!REPLAY) {
+            V s1 = c14.x(), s4 = c14.y(), s3 = c32.x(), s2 = c32.y();   // fll.cpp:141-145
+            V lre = s1 - s2, lim = s4 + s3;
+            V hre = s1 + s2, him = s4 - s3;
+            V err = fast_amp<V>(hre, him) - fast_amp<V>(lre, lim);
+            pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
+        }
+    }
+};
+
+// Drivers of an FLL row.  IO (device: LDS accesses of one lane; host emulation: arrays):
+//   P    load_hist(int g)               lane (pos,par) <- stored delay-line sample g*8 + pos (of the last 72)
+//   P    sample(int s)                  AGC output s of the current tile, broadcast to each channel's lanes
+//   void xs_store(int iend, int cnt, P xs)   lane with pos < cnt holds x_{iend-1-pos} (tile-relative iend)
+#define TD_F8_STEP(S, REPLAY)                                                                   \
+    {                                                                                           \
+        if (REPLAY) { R.template step<(S)&7, true, true>(k, cur); cur = row_shl2(cur, cur); }   \
+        else if (ALPHA0) R.template step<(S)&7, false, true>(k, io.sample(s0 + (S)));           \
+        else R.template step<(S)&7, false, false>(k, io.sample(s0 + (S)));                      \
+    }
+template <class V, class IO> TD_FN void fll8_replay(FllRow8<V>& R, const K1Consts& k, IO& io) {
+    typedef Pair<V> P;
+    const bool ALPHA0 = true;
+    const int s0 = 0;
+    (void)ALPHA0; (void)s0;
+    R.clear_pipeline();
+    for (int g = 0; g < kF8Pad / 8; g++) {
+        P cur = io.load_hist(g);
+        TD_F8_STEP(0, true) TD_F8_STEP(1, true) TD_F8_STEP(2, true) TD_F8_STEP(3, true)
+        TD_F8_STEP(4, true) TD_F8_STEP(5, true) TD_F8_STEP(6, true) TD_F8_STEP(7, true)
+    }
+}
+// One tile of cnt <= tile_len samples (tile_len a multiple of 8).
+template <class V, class IO, bool ALPHA0> TD_FN void fll8_tile(FllRow8<V>& R, const K1Consts& k, IO& io, int cnt) {
+    typedef Pair<V> P;
+    P cur(V(0.0f), V(0.0f));
+    (void)cur;
+    for (int s0 = 0; s0 < cnt; s0 += 8) {
+        const int c8 = (cnt - s0 < 8) ? (cnt - s0) : 8;
+        if (c8 == 8) {
+            TD_F8_STEP(0, false) TD_F8_STEP(1, false) TD_F8_STEP(2, false) TD_F8_STEP(3, false)
+            TD_F8_STEP(4, false) TD_F8_STEP(5, false) TD_F8_STEP(6, false) TD_F8_STEP(7, false)
+        } else {
+            if (0 < c8) TD_F8_STEP(0, false)
+            if (1 < c8) TD_F8_STEP(1, false)
+            if (2 < c8) TD_F8_STEP(2, false)
+            if (3 < c8) TD_F8_STEP(3, false)
+            if (4 < c8) TD_F8_STEP(4, false)
+            if (5 < c8) TD_F8_STEP(5, false)
+            if (6 < c8) TD_F8_STEP(6, false)
+        }
+        io.xs_store(s0 + c8, c8, R.xs);
+    }
+}
+#undef TD_F8_STEP
+
+// RRC matched filter, direct form, eight consecutive outputs per lane (SDR++ core FIR<complex_t,float>,
+// called at src/dsp/pi4dqpsk.cpp:136).  ld(p) = x_{i0-71+p} for p = 0..79 (p = 79 is never weighted);
+// tap(q) = RRC taps zero-padded at the old end to 72 and then by 7 zeros in front and 8 behind, i.e.
+// tap(q) = h72[q-7] for 7 <= q < 79, else 0; out[m] = y_{i0+m}.  Every output is one fmaf chain per
+// component in ascending tap order; the zero taps outside a chain's 72 leave its accumulator untouched
+// bit for bit (x finite: x*0 = +-0, and acc + +-0 == acc because a chain started at +0 is never -0).
+// Written as a runtime loop over ten 8-sample chunks so that only one chunk is live in registers.
+constexpr int kRrcPad = 72;
+constexpr int kRrcOut = 8;
+constexpr int kRrcExt = 7 + kRrcPad + 8;   // 87
+template <class LD, class LT> TD_FN void rrc_direct8(LD ld, LT tap, Pair<float>* out) {
+    Pair<float> acc[kRrcOut];
+#pragma unroll
+    for (int m = 0; m < kRrcOut; m++) acc[m] = Pair<float>(0.0f, 0.0f);
+#pragma unroll 1
+    for (int p0 = 0; p0 < 80; p0 += 8) {
+        Pair<float> x[8];
+        float h[15];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = ld(p0 + j);
+#pragma unroll
+        for (int q = 0; q < 15; q++) h[q] = tap(p0 + q);       // tap index kk = p0 - 7 + q  ->  ext index kk + 7
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int m = 0; m < kRrcOut; m++) {
+                // sample p0+j meets tap kk = p0 + j - m of output m  ->  h[j - m + 7]
+                acc[m] = pk_fma(x[j], Pair<float>(h[j - m + 7], h[j - m + 7]), acc[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kRrcOut; m++) out[m] = acc[m];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Kernel 2 per-channel symbol step: timing recovery -> Costas -> slicer/differential decoder.
 // One lane per channel; plain float code (host builds use it for unit tests only).
 // ---------------------------------------------------------------------------------------------
@@ -378,10 +544,11 @@ struct K2State {
     int prev;
 };
 
-// w[0..7]: the 8 complex samples buffer[offset..offset+7] as (re,im); rows tm1/t0/tp1: interpolator
-// bank rows max(phase-1,0), phase, min(phase+1,127).  Returns the dibit; *sym = Costas output.
-TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const float* wre, const float* wim,
-                    const float* tm1, const float* t0, const float* tp1, float* sym_re, float* sym_im) {
+// Timing recovery step (complex_fd.cpp:101-143).  w[0..7]: the 8 complex samples buffer[offset..offset+7];
+// rows tm1/t0/tp1: interpolator bank rows max(phase-1,0), phase, min(phase+1,127).  Returns the interpolated
+// symbol (vr, vi) and advances mu / omega / offset.
+TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const float* wre, const float* wim,
+                     const float* tm1, const float* t0, const float* tp1, float* out_re, float* out_im) {
     float vr = 0.0f, vi = 0.0f, ar = 0.0f, ai = 0.0f, br = 0.0f, bi = 0.0f;
 #pragma unroll
     for (int j = 0; j < kInterpTaps; j++) {
@@ -403,7 +570,20 @@ TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const float* wre,
     float delta = v_floor(st.mu);
     st.offset += (int)delta;
     st.mu = st.mu - delta;
-    // pi4dqpsk_costas.cpp:7-19
+    *out_re = vr;
+    *out_im = vi;
+}
+
+// complex_fd.cpp:101: interpolator phase of the next symbol.
+TD_FN int k2_phase(float mu) {
+    int phase = (int)v_floor(mu * (float)kInterpPhases);
+    phase = phase < 0 ? 0 : phase;
+    return phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
+}
+
+// Costas loop + slicer + differential decoder for one symbol (pi4dqpsk_costas.cpp:7-28,
+// dqpsk_sym_extr.cpp:6-7,32-52).  Returns the dibit; (*zr, *zi) = PI4DQPSK::process output.
+TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
     float s, c;
     sincos_t<float>(-st.cph, s, c);
     float xr = vr * c - vi * s;
@@ -415,19 +595,25 @@ TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const float* wre,
     sincos_t<float>(ph2, s, c);
     float zr = xr * c - xi * s;
     float zi = xi * c + xr * s;
-    // pi4dqpsk_costas.cpp:23-28
     float cerr = ((zr > 0 ? 1.0f : -1.0f) * zi) - ((zi > 0 ? 1.0f : -1.0f) * zr);
     cerr = cerr < -1.0f ? -1.0f : cerr;
     cerr = cerr > 1.0f ? 1.0f : cerr;
     pcl_advance<float, true>(cerr, st.cph, st.cfr, k.costas_alpha, k.costas_beta, k.costas_min_freq, k.costas_max_freq);
-    *sym_re = zr;
-    *sym_im = zi;
-    // dqpsk_sym_extr.cpp:6-7,32-52
+    *zr_out = zr;
+    *zi_out = zi;
     int a = zi < 0, b = zr < 0;
     int symq = (a << 1) | (a != b);
     int pd = (symq - st.prev + 4) & 3;
     st.prev = symq;
     return pd ^ (pd >> 1);  // {0,1,2,3} -> {0,1,3,2}
+}
+
+// Both halves for one symbol (kernel 2 of the two-kernel pipeline).
+TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const float* wre, const float* wim,
+                    const float* tm1, const float* t0, const float* tp1, float* sym_re, float* sym_im) {
+    float vr, vi;
+    k2_timing(k, st, phase, wre, wim, tm1, t0, tp1, &vr, &vi);
+    return k2_costas(k, st, vr, vi, sym_re, sym_im);
 }
 
 }  // namespace tdm

@@ -282,6 +282,12 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
     }
 }
 
+}  // namespace
+
+#include "kernel_fused.hpp"
+
+namespace {
+
 // Device self-test of the primitives the arithmetic contract rests on (DPP row moves, sqrt, sincos).
 // out[0][l] = row_shr1(old = 100+l, src = l), out[1][l] = row_shl1(old = 200+l, src = l),
 // out[2][l] = sqrt(in[l]), out[3][l] / out[4][l] = sin / cos of in[64 + l].
@@ -320,8 +326,12 @@ struct tetra_demod {
     float2* hist = nullptr;
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
-    float2* y = nullptr;
+    float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
+    float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
+    bool fused = true;          // pipeline in use
+    bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
+    float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc72 = nullptr;   // fused kernel: padded to 72
     // host-path staging
     float* st_iq = nullptr;
     uint8_t* st_bits = nullptr;
@@ -372,6 +382,18 @@ int upload_tables(tetra_demod* h) {
     HIP_TRY(h, hipMemcpy(h->d_rrc, rr.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
+    if (h->design.ntaps <= kF8Pad) {
+        std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rr72(kF8Pad, 0.f);
+        const int o72 = kF8Pad - h->design.ntaps;
+        for (int k = 0; k < h->design.ntaps; k++) {
+            re72[o72 + k] = h->design.be_re[k];
+            im72[o72 + k] = h->design.be_im[k];
+            rr72[o72 + k] = h->design.rrc[k];
+        }
+        HIP_TRY(h, hipMemcpy(h->d_be_re72, re72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_im72, im72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_rrc72, rr72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
+    }
     return TETRA_OK;
 }
 
@@ -406,16 +428,19 @@ int reset_range(tetra_demod* h, int first, int count) {
     HIP_TRY(h, hipMemsetAsync(h->cfr + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->ph2 + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->prev + first, 0, sizeof(int) * count, 0));
-    // y delay rows (kYHist rows, time-major): columns [first, first+count)
-    HIP_TRY(h, hipMemset2DAsync(h->y + first, sizeof(float2) * (size_t)h->C, 0, sizeof(float2) * (size_t)count, kYHist, 0));
+    // COMPLEX_FD delay buffer: fused pipeline keeps it in ybuf, the two-kernel pipeline in the first kYHist
+    // rows of the time-major y scratch (columns [first, first+count))
+    HIP_TRY(h, hipMemsetAsync(h->ybuf + (size_t)first * kYHist, 0, sizeof(float2) * kYHist * (size_t)count, 0));
+    if (h->y)
+        HIP_TRY(h, hipMemset2DAsync(h->y + first, sizeof(float2) * (size_t)h->C, 0, sizeof(float2) * (size_t)count, kYHist, 0));
     HIP_TRY(h, hipStreamSynchronize(0));
     return TETRA_OK;
 }
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->y, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->st_iq, h->st_bits, h->st_nbits,
-                     h->st_sym };
+                     h->prev, h->y, h->ybuf, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->d_rrc72, h->st_iq, h->st_bits, h->st_nbits, h->st_sym };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& slot : h->ev)
@@ -527,7 +552,12 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     A(dalloc(h, &h->hist, C * kHist));
     A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
     A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
-    A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
+    h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL) && h->design.ntaps <= kF8Pad;
+    h->keep_y = !h->fused || (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT);
+    if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
+    A(dalloc(h, &h->ybuf, C * kYHist));
+    A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
+    A(dalloc(h, &h->d_rrc72, (size_t)kF8Pad));
     A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
     A(dalloc(h, &h->d_rrc, (size_t)kPadTaps)); A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
     for (auto& slot : h->ev)
@@ -608,6 +638,27 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
     p2.k = h->design.k2;
 
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
+    if (h->fused) {
+        FusedParams pf;
+        pf.iq = p1.iq; pf.in_ch_stride = p1.in_ch_stride; pf.in_t_stride = p1.in_t_stride;
+        pf.n = n_samples; pf.n_channels = h->C;
+        pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
+        pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
+        pf.cph = h->cph; pf.cfr = h->cfr; pf.ph2 = h->ph2; pf.prev = h->prev; pf.ybuf = h->ybuf;
+        pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc72 = h->d_rrc72; pf.bank = h->d_bank;
+        pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
+        pf.y_dbg = h->keep_y ? h->y : nullptr;
+        pf.k1 = h->design.k1; pf.k2 = h->design.k2;
+        const dim3 gf((h->C + kFCh - 1) / kFCh);
+        HIP_TRY(h, hipEventRecord(ev[0], s));
+        if (pf.k1.fll_alpha == 0.0f) hipLaunchKernelGGL(k_fused<true>, gf, dim3(kFThreads), 0, s, pf);
+        else hipLaunchKernelGGL(k_fused<false>, gf, dim3(kFThreads), 0, s, pf);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(ev[1], s));
+        HIP_TRY(h, hipEventRecord(ev[2], s));
+        h->n_calls++;
+        return TETRA_OK;
+    }
     HIP_TRY(h, hipEventRecord(ev[0], s));
     const dim3 g1((h->C + kK1RowsPerBlock - 1) / kK1RowsPerBlock);
     if (p1.k.fll_alpha == 0.0f) hipLaunchKernelGGL(k1_agc_fll_rrc<true>, g1, dim3(kK1Threads), 0, s, p1);
@@ -691,6 +742,7 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     }
     host::Design nd;
     if (!host::make_design(np, nullptr, nullptr, nullptr, nd)) return TETRA_ERR_UNSUPPORTED;
+    if (h->fused && nd.ntaps > kF8Pad) return TETRA_ERR_UNSUPPORTED;   // fused kernel covers <= 72 taps
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
@@ -728,8 +780,11 @@ int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_sta
     GET1(out->costas_phase, h->cph); GET1(out->costas_freq, h->cfr); GET1(out->ph2, h->ph2); GET1(out->prev, h->prev);
 #undef GET1
     HIP_TRY(h, hipMemcpy(out->hist, h->hist + (size_t)c * kHist, sizeof(float2) * kHist, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy2D(out->ybuf, sizeof(float2), h->y + c, sizeof(float2) * (size_t)h->C, sizeof(float2), kYHist,
-                           hipMemcpyDeviceToHost));
+    if (h->fused)
+        HIP_TRY(h, hipMemcpy(out->ybuf, h->ybuf + (size_t)c * kYHist, sizeof(float2) * kYHist, hipMemcpyDeviceToHost));
+    else
+        HIP_TRY(h, hipMemcpy2D(out->ybuf, sizeof(float2), h->y + c, sizeof(float2) * (size_t)h->C, sizeof(float2), kYHist,
+                               hipMemcpyDeviceToHost));
     return TETRA_OK;
 }
 
@@ -745,8 +800,10 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     SET1(h->cph, in->costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
 #undef SET1
     HIP_TRY(h, hipMemcpy(h->hist + (size_t)c * kHist, in->hist, sizeof(float2) * kHist, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy2D(h->y + c, sizeof(float2) * (size_t)h->C, in->ybuf, sizeof(float2), sizeof(float2), kYHist,
-                           hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->ybuf + (size_t)c * kYHist, in->ybuf, sizeof(float2) * kYHist, hipMemcpyHostToDevice));
+    if (h->y)
+        HIP_TRY(h, hipMemcpy2D(h->y + c, sizeof(float2) * (size_t)h->C, in->ybuf, sizeof(float2), sizeof(float2), kYHist,
+                               hipMemcpyHostToDevice));
     return TETRA_OK;
 }
 
@@ -763,6 +820,7 @@ int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re
 
 int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples) {
     if (!h || !y || n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_ARG;
+    if (!h->y) return TETRA_ERR_UNSUPPORTED;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());

@@ -10,6 +10,7 @@
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -mfma -mavx2 -DTETRA_HOST_EMUL -shared -fPIC
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -202,6 +203,164 @@ int emul_k2(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n,
         st[c].mu = ks[c].mu; st[c].omega = ks[c].omega; st[c].offset = ks[c].offset - n;
         st[c].costas_phase = ks[c].cph; st[c].costas_freq = ks[c].cfr; st[c].ph2 = ks[c].ph2; st[c].prev = ks[c].prev;
         for (int k = 0; k < kYHist; k++) { st[c].ybuf[2 * k] = ys[((size_t)(n + k) * C + c) * 2]; st[c].ybuf[2 * k + 1] = ys[((size_t)(n + k) * C + c) * 2 + 1]; }
+    }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllRow8 + fll8_replay/fll8_tile,
+// rrc_direct8, k2_timing, k2_costas) run stage after stage over linear arrays -- a valid serialisation of the
+// device's barrier-synchronised software pipeline.  (The LDS ring/epoch bookkeeping itself is device-only.)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Fll8EmulIO {
+    const float* hist[2];   // per parity: stored delay line [80][2]
+    const float* a[2];      // per parity: AGC output of the whole chunk [n][2]
+    float* x[2];            // per parity: FLL output [n][2]
+    int tile_base = 0;
+    int n = 0;
+
+    Pair<Row16> load_hist(int g) const {
+        Row16 re, im;
+        for (int l = 0; l < 16; l++) {
+            const int pos = l >> 1, par = l & 1;
+            const int m = (kHist - kF8Pad) + g * 8 + pos;
+            re.l[l] = hist[par][2 * m];
+            im.l[l] = hist[par][2 * m + 1];
+        }
+        return Pair<Row16>(re, im);
+    }
+    Pair<Row16> sample(int s) const {
+        Row16 re, im;
+        const int i = tile_base + s;
+        for (int l = 0; l < 16; l++) {
+            const int par = l & 1;
+            re.l[l] = i < n ? a[par][2 * i] : 0.f;
+            im.l[l] = i < n ? a[par][2 * i + 1] : 0.f;
+        }
+        return Pair<Row16>(re, im);
+    }
+    void xs_store(int iend, int cnt, Pair<Row16> xs) {
+        for (int l = 0; l < 16; l++) {
+            const int pos = l >> 1, par = l & 1;
+            if (pos < cnt) {
+                const int i = tile_base + iend - 1 - pos;
+                x[par][2 * i] = xs.x().l[l];
+                x[par][2 * i + 1] = xs.y().l[l];
+            }
+        }
+    }
+};
+}  // namespace
+
+// C <= 64 channels (processed in rows of two).  iq [C][n] channel-major.  Outputs like emul_k2, plus y_out [C][n].
+int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
+               uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym) {
+    if (C < 1 || C > 64 || t->ntaps > kF8Pad) return -1;
+    const int tile = 32;
+    float re72[kF8Pad] = { 0 }, im72[kF8Pad] = { 0 };
+    float rrc_ext[kRrcExt + 1] = { 0 };
+    const int o72 = kF8Pad - t->ntaps;
+    for (int k = 0; k < t->ntaps; k++) { re72[o72 + k] = t->be_re[k]; im72[o72 + k] = t->be_im[k]; rrc_ext[7 + o72 + k] = t->rrc[k]; }
+    std::vector<float> a((size_t)C * n * 2), x((size_t)C * n * 2);
+    // A: AGC
+    for (int c = 0; c < C; c++) {
+        float g = st[c].agc_gain;
+        for (int i = 0; i < n; i++) {
+            Pair<float> o = agc_step<float>(t->k1, Pair<float>(iq[((size_t)c * n + i) * 2], iq[((size_t)c * n + i) * 2 + 1]), g);
+            a[((size_t)c * n + i) * 2] = o.x();
+            a[((size_t)c * n + i) * 2 + 1] = o.y();
+        }
+        st[c].agc_gain = g;
+    }
+    // F: FLL rows of two interleaved channels
+    std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kHist, 0.f), dump((size_t)std::max(n, 1) * 2);
+    for (int c0 = 0; c0 < C; c0 += 2) {
+        const bool two = c0 + 1 < C;
+        FllRow8<Row16> R;
+        for (int j = 0; j < kF8Taps; j++) {
+            Row16 ta, tb;
+            for (int l = 0; l < 16; l++) {
+                const int pos = l >> 1;
+                const int kp = kF8Taps * (kF8Lanes - 1 - pos) + j;
+                ta.l[l] = re72[kp];
+                tb.l[l] = im72[kp];
+            }
+            R.ta[j] = ta;
+            R.tb[j] = tb;
+        }
+        for (int l = 0; l < 16; l++) {
+            const int c = (l & 1) && two ? c0 + 1 : c0;
+            R.ph.l[l] = st[c].fll_phase;
+            R.fr.l[l] = st[c].fll_freq;
+        }
+        Fll8EmulIO io;
+        io.hist[0] = st[c0].hist; io.hist[1] = two ? st[c0 + 1].hist : zhist.data();
+        io.a[0] = &a[(size_t)c0 * n * 2]; io.a[1] = two ? &a[(size_t)(c0 + 1) * n * 2] : zeros.data();
+        io.x[0] = &x[(size_t)c0 * n * 2]; io.x[1] = two ? &x[(size_t)(c0 + 1) * n * 2] : dump.data();
+        io.n = n;
+        fll8_replay<Row16, Fll8EmulIO>(R, t->k1, io);
+        for (int base = 0; base < n; base += tile) {
+            io.tile_base = base;
+            const int cnt = n - base < tile ? n - base : tile;
+            if (t->k1.fll_alpha == 0.0f) fll8_tile<Row16, Fll8EmulIO, true>(R, t->k1, io, cnt);
+            else fll8_tile<Row16, Fll8EmulIO, false>(R, t->k1, io, cnt);
+        }
+        st[c0].fll_phase = R.ph.l[0]; st[c0].fll_freq = R.fr.l[0];
+        if (two) { st[c0 + 1].fll_phase = R.ph.l[1]; st[c0 + 1].fll_freq = R.fr.l[1]; }
+    }
+    // C: RRC, eight outputs at a time, over [history | x]
+    std::vector<float> y((size_t)C * n * 2);
+    for (int c = 0; c < C; c++) {
+        std::vector<float> xf((size_t)(kHist + n + 8) * 2, 0.f);
+        std::memcpy(xf.data(), st[c].hist, sizeof(float) * 2 * kHist);
+        if (n) std::memcpy(xf.data() + 2 * kHist, &x[(size_t)c * n * 2], sizeof(float) * 2 * n);
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            Pair<float> out[kRrcOut];
+            const float* w = xf.data() + 2 * (kHist + i0 - (kRrcPad - 1));
+            rrc_direct8([&](int q) { const int qq = q < 79 ? q : 78; return Pair<float>(w[2 * qq], w[2 * qq + 1]); },
+                        [&](int k) { return rrc_ext[k]; }, out);
+            for (int m = 0; m < kRrcOut && i0 + m < n; m++) {
+                y[((size_t)c * n + i0 + m) * 2] = out[m].x();
+                y[((size_t)c * n + i0 + m) * 2 + 1] = out[m].y();
+            }
+        }
+        // new delay line
+        std::vector<float> nh(2 * kHist);
+        std::memcpy(nh.data(), xf.data() + 2 * n, sizeof(float) * 2 * kHist);
+        std::memcpy(st[c].hist, nh.data(), sizeof(float) * 2 * kHist);
+    }
+    if (y_out && n) std::memcpy(y_out, y.data(), sizeof(float) * y.size());
+    // D + E
+    for (int c = 0; c < C; c++) {
+        std::vector<float> yf((size_t)(kYHist + n) * 2);
+        std::memcpy(yf.data(), st[c].ybuf, sizeof(float) * 2 * kYHist);
+        if (n) std::memcpy(yf.data() + 2 * kYHist, &y[(size_t)c * n * 2], sizeof(float) * 2 * n);
+        K2State ks;
+        ks.mu = st[c].mu; ks.omega = st[c].omega; ks.offset = st[c].offset;
+        ks.cph = st[c].costas_phase; ks.cfr = st[c].costas_freq; ks.ph2 = st[c].ph2; ks.prev = st[c].prev;
+        int S = 0;
+        while (ks.offset < n) {
+            const int phase = k2_phase(ks.mu);
+            const int pm = phase > 0 ? phase - 1 : 0;
+            const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
+            float wre[kInterpTaps], wim[kInterpTaps];
+            for (int j = 0; j < kInterpTaps; j++) { wre[j] = yf[2 * (ks.offset + j)]; wim[j] = yf[2 * (ks.offset + j) + 1]; }
+            float vr, vi, zr, zi;
+            k2_timing(t->k2, ks, phase, wre, wim, t->bank + pm * kInterpTaps, t->bank + phase * kInterpTaps,
+                      t->bank + pp * kInterpTaps, &vr, &vi);
+            const int d = k2_costas(t->k2, ks, vr, vi, &zr, &zi);
+            if (2 * S + 2 > bits_stride) return -2;
+            if (sym) { sym[((size_t)c * (bits_stride / 2) + S) * 2] = zr; sym[((size_t)c * (bits_stride / 2) + S) * 2 + 1] = zi; }
+            bits[(size_t)c * bits_stride + 2 * S] = (uint8_t)((d >> 1) & 1);
+            bits[(size_t)c * bits_stride + 2 * S + 1] = (uint8_t)(d & 1);
+            S++;
+        }
+        n_bits[c] = 2 * S;
+        st[c].mu = ks.mu; st[c].omega = ks.omega; st[c].offset = ks.offset - n;
+        st[c].costas_phase = ks.cph; st[c].costas_freq = ks.cfr; st[c].ph2 = ks.ph2; st[c].prev = ks.prev;
+        std::memcpy(st[c].ybuf, yf.data() + 2 * n, sizeof(float) * 2 * kYHist);
     }
     return 0;
 }

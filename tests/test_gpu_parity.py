@@ -64,10 +64,13 @@ def test_tables_match_oracle(pkg, oracle):
     assert np.array_equal(t["bank"], o.interp_bank())
 
 
-def _compare(tag, pkg, oracle, iq, chunks, want_state=True):
+PIPELINES = {"fused": 2, "two_kernel": 1}   # flags: fused + keep RRC output for the stage check / two-kernel
+
+
+def _compare(tag, pkg, oracle, iq, chunks, want_state=True, flags=2):
     """Run GPU and oracle over the same chunking; return list of mismatch descriptions."""
     Cn, N = iq.shape
-    d = pkg.Demodulator(Cn, max(chunks))
+    d = pkg.Demodulator(Cn, max(chunks), flags=flags)
     orcs = [oracle.Oracle() for _ in range(Cn)]
     problems = []
     pos = 0
@@ -112,21 +115,23 @@ def _compare(tag, pkg, oracle, iq, chunks, want_state=True):
     return problems
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 @pytest.mark.parametrize("Cn,N,chunks", [
     (1, 4000, [4000]),
     (5, 3000, [3000]),                                   # ragged: not a multiple of 4/16/64 channels
     (16, 6000, [1, 2, 3, 15, 16, 17, 33, 180, 1000, 4733]),  # ragged chunk sizes, state carried
     (70, 2048, [7] * 20 + [1908]),
 ])
-def test_parity_small(pkg, oracle, synth, Cn, N, chunks):
+def test_parity_small(pkg, oracle, synth, Cn, N, chunks, pipeline):
     assert sum(chunks) == N
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=1000 + Cn)
-    problems = _compare("small_%d_%d" % (Cn, N), pkg, oracle, iq, chunks)
-    _dump("parity_small_%d_%d.json" % (Cn, N), problems)
+    problems = _compare("small_%d_%d" % (Cn, N), pkg, oracle, iq, chunks, flags=PIPELINES[pipeline])
+    _dump("parity_small_%s_%d_%d.json" % (pipeline, Cn, N), problems)
     assert not problems, problems[:5]
 
 
-def test_parity_edge_channels(pkg, oracle, synth):
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_parity_edge_channels(pkg, oracle, synth, pipeline):
     """All-zero input, noise only, tiny and huge amplitude, large carrier offset, clock offset."""
     N = 8000
     rng = np.random.default_rng(77)
@@ -138,16 +143,17 @@ def test_parity_edge_channels(pkg, oracle, synth):
     iq[5] = synth.gen_channel(N, 4, ppm=300.0)[0]
     iq[6] = synth.gen_channel(N, 5, esn0_db=8.0)[0]
     iq[7] = synth.gen_channel(N, 6, esn0_db=None, cfo=0.0, tau=0.0, amp=1.0, phase0=0.0)[0]
-    problems = _compare("edge", pkg, oracle, iq, [5000, 3000])
-    _dump("parity_edge.json", problems)
+    problems = _compare("edge", pkg, oracle, iq, [5000, 3000], flags=PIPELINES[pipeline])
+    _dump("parity_edge_%s.json" % pipeline, problems)
     assert not problems, problems[:5]
 
 
-def test_parity_256_channels_full_second(pkg, oracle, synth):
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_parity_256_channels_full_second(pkg, oracle, synth, pipeline):
     """BASELINE config 2: 256 synthetic channels @ 36 ksps, 1 s, every output bit compared with the CPU."""
     Cn, N = 256, 36000
     iq, txb, _ = synth.gen_batch(Cn, N, base_seed=4242)
-    d = pkg.Demodulator(Cn, N)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1)
     bits, nb, sym = d.process(iq, want_sym=True)
     rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
     bad = [c for c in range(Cn) if nb[c] != rnb[c] or not np.array_equal(bits[c][:nb[c]], rb[c][:rnb[c]])]
@@ -160,17 +166,18 @@ def test_parity_256_channels_full_second(pkg, oracle, synth):
         lags.append(lag)
         errs += e
         ncmp += n
-    _dump("parity_256.json", dict(bad=bad, badsym=badsym, lags=lags, errs=errs, total_bits=int(nb.sum()),
+    _dump("parity_256_%s.json" % pipeline, dict(bad=bad, badsym=badsym, lags=lags, errs=errs, total_bits=int(nb.sum()),
                                   kernel_ms=d.last_kernel_ms()))
     assert not bad and not badsym
     assert errs <= 1e-3 * ncmp, (errs, ncmp)
     d.close()
 
 
-def test_reset_and_state_roundtrip(pkg, oracle, synth):
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_reset_and_state_roundtrip(pkg, oracle, synth, pipeline):
     Cn, N = 8, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=31)
-    d = pkg.Demodulator(Cn, N)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1)
     b1, n1, _ = d.process(iq)
     st3 = d.get_state(3)
     b2, n2, _ = d.process(iq)           # continues from carried state: differs from a fresh run
