@@ -58,6 +58,19 @@ def make_input(torch, synth, device, n_channels, n_samples, seed):
     return out, txb
 
 
+def pmc_traffic(pipeline, channels, samples):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/run_rocprof.sh:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md
+    prescribes).  Counters cannot be collected from inside this process, so the committed measurement for
+    the same workload is reported; None if there is none."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%dx%d.json" % (pipeline, channels, samples))
+    try:
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(synth, n_samples, budget_s=12.0):
     """Time the CPU oracle (all host threads) on a bounded sample of the same workload."""
     from oracle import binding as ob
@@ -177,7 +190,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_agc_fll_rrc" if args.two_kernel else "k_fused",
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic": pmc_traffic("two_kernel" if args.two_kernel else "fused", C, N),
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(k1_ms, 4), "second_kernel_ms": round(k2_ms, 4),
                          "note": "HBM is the roofline BASELINE.json names; the kernel itself is VALU-issue bound "
                                  "(per-channel serial recurrences), see DESIGN.md"},
