@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--two-kernel", action="store_true", help="run the two-kernel pipeline instead of the fused kernel")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -118,10 +119,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     C, N = args.channels, args.samples
-    iq, txb = make_input(torch, pkg.synth, device, C, N, seed=20260000 + rank)
+    # rank r demodulates global channels [r*C, (r+1)*C) of a (world*C)-channel bank: independent channels,
+    # per-GPU ranges, nothing exchanged on the data path
+    ch_lo, ch_hi = pkg.shard.channel_range(C * world, world, rank)
+    assert ch_hi - ch_lo == C
+    iq, txb = make_input(torch, pkg.synth, device, C, N, seed=20260000 + ch_lo)
     stride = pkg.binding.bits_stride(N)
     bits = torch.zeros((C, stride), dtype=torch.uint8, device=device)
     nbits = torch.zeros(C, dtype=torch.int32, device=device)
@@ -146,9 +154,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = pkg.shard.max_over_ranks(dist, elapsed, device=device if args.backend == "nccl" else None)
 
     # per-launch kernel durations of the timed region (HIP events on the launch stream)
     nh = min(args.steps, 64)

@@ -53,6 +53,12 @@ TD_FN float v_sqrt(float a) { return __builtin_sqrtf(a); }
 TD_FN float v_rint(float a) { return __builtin_rintf(a); }
 TD_FN float v_floor(float a) { return __builtin_floorf(a); }
 TD_FN float v_abs(float a) { return __builtin_fabsf(a); }
+// clamp to [lo, hi] (lo <= hi): `x > hi ? hi : (x < lo ? lo : x)`; one v_med3_f32 on the device
+#if TD_DEVICE
+TD_FN float v_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+#else
+TD_FN float v_clamp(float x, float lo, float hi) { return x > hi ? hi : (x < lo ? lo : x); }
+#endif
 TD_FN float v_max(float a, float b) { return __builtin_fmaxf(a, b); }
 TD_FN float v_min(float a, float b) { return __builtin_fminf(a, b); }
 TD_FN float v_sel(bool m, float a, float b) { return m ? a : b; }
@@ -80,6 +86,9 @@ TD_FN Pair<float> pk_fma(Pair<float> a, Pair<float> b, Pair<float> c) {
     r.v = __builtin_elementwise_fma(a.v, b.v, c.v);
     return r;
 }
+TD_FN Pair<float> pk_mul(Pair<float> a, Pair<float> b) { Pair<float> r; r.v = a.v * b.v; return r; }
+TD_FN Pair<float> pk_add(Pair<float> a, Pair<float> b) { Pair<float> r; r.v = a.v + b.v; return r; }
+TD_FN Pair<float> pk_swap(Pair<float> a) { Pair<float> r; r.v = __builtin_shufflevector(a.v, a.v, 1, 0); return r; }
 // DPP row moves (gfx9 DPP controls): row_shr:1 = 0x111 (lane l <- lane l-1), row_shl:1 = 0x101
 // (lane l <- lane l+1).  With bound_ctrl off, lanes whose source is outside the 16-lane row keep `old`.
 TD_FN float row_shr1(float old, float src) {
@@ -132,6 +141,9 @@ template <class V> struct Pair {
 template <class V> TD_FN Pair<V> pk_fma(Pair<V> a, Pair<V> b, Pair<V> c) {
     return Pair<V>(v_fma(a.x(), b.x(), c.x()), v_fma(a.y(), b.y(), c.y()));
 }
+template <class V> TD_FN Pair<V> pk_mul(Pair<V> a, Pair<V> b) { return Pair<V>(a.x() * b.x(), a.y() * b.y()); }
+template <class V> TD_FN Pair<V> pk_add(Pair<V> a, Pair<V> b) { return Pair<V>(a.x() + b.x(), a.y() + b.y()); }
+template <class V> TD_FN Pair<V> pk_swap(Pair<V> a) { return Pair<V>(a.y(), a.x()); }
 #endif
 
 #if defined(TETRA_HOST_EMUL)
@@ -163,6 +175,7 @@ TD_FN Row16 v_rint(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = rin
 TD_FN Row16 v_abs(Row16 a) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fabsf(a.l[i]); return r; }
 TD_FN Row16 v_max(Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fmaxf(a.l[i], b.l[i]); return r; }
 TD_FN Row16 v_min(Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = fminf(a.l[i], b.l[i]); return r; }
+TD_FN Row16 v_clamp(Row16 x, float lo, float hi) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = x.l[i] > hi ? hi : (x.l[i] < lo ? lo : x.l[i]); return r; }
 TD_FN Row16 v_sel(Row16m m, Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = m.l[i] ? a.l[i] : b.l[i]; return r; }
 TD_FN Row16i v_ftoi(Row16 a) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = (int)a.l[i]; return r; }
 TD_FN Row16m v_ieq(Row16i a, int b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] == b; return r; }
@@ -217,6 +230,14 @@ template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
     c = v_sel(q0, cr, v_sel(q1, -sr, v_sel(q2, -cr, sr)));
 }
 
+// SDR++ core complex_t::operator*: a * (c + j s) = (a.re*c - a.im*s, a.im*c + a.re*s), every product and the
+// sum/difference rounded separately.  Written with packed ops: (ar*c, ai*c) + (-(ai*s), ar*s).
+template <class V> TD_FN Pair<V> cmul_phasor(Pair<V> a, V c, V s) {
+    Pair<V> t1 = pk_mul(a, Pair<V>(c, c));
+    Pair<V> t2 = pk_mul(pk_swap(a), Pair<V>(s, s));
+    return pk_add(t1, Pair<V>(-t2.x(), t2.y()));
+}
+
 // SDR++ core complex_t::fastAmplitude: `r > i ? r + 0.4f*i : i + 0.4f*r` with r = |re|, i = |im|, written as
 // max + 0.4f*min -- the same two roundings on the same operands, so bit-identical for every non-NaN input.
 template <class V> TD_FN V fast_amp(V re, V im) {
@@ -231,8 +252,7 @@ template <class V> TD_FN V fast_amp(V re, V im) {
 // only in the sign of a zero, which needs freq == -0, never produced by these loops), so the two ops are skipped.
 template <class V, bool CLAMP, bool ALPHA0 = false> TD_FN void pcl_advance(V err, V& phase, V& freq, float alpha, float beta,
                                                       float minf, float maxf) {
-    freq = freq + beta * err;
-    freq = v_sel(freq > maxf, V(maxf), v_sel(freq < minf, V(minf), freq));
+    freq = v_clamp(freq + beta * err, minf, maxf);
     if (ALPHA0) phase = phase + freq;
     else phase = phase + (freq + alpha * err);
     if (CLAMP) {
@@ -296,7 +316,7 @@ template <class V> struct K1Row {
             // fll.cpp:137-138  x = in * phasor(-phase)
             V s, c;
             sincos_t<V>(-ph, s, c);
-            x = P(a.x() * c - a.y() * s, a.y() * c + a.x() * s);
+            x = cmul_phasor<V>(a, c, s);
         }
         xs = row_shr1(x, xs);
         // newest tap of this lane's block on the oldest resident sums
@@ -425,7 +445,7 @@ template <class V> struct FllRow8 {
         } else {
             V s, c;
             sincos_t<V>(-ph, s, c);                                   // fll.cpp:137-138
-            x = P(a.x() * c - a.y() * s, a.y() * c + a.x() * s);
+            x = cmul_phasor<V>(a, c, s);
         }
         xs = row_shr2(x, xs);
         P c14 = pk_fma(xs, P(ta[8], ta[8]), r14[PH]);
@@ -494,32 +514,38 @@ template <class V, class IO, bool ALPHA0> TD_FN void fll8_tile(FllRow8<V>& R, co
 #undef TD_F8_STEP
 
 // RRC matched filter, direct form, eight consecutive outputs per lane (SDR++ core FIR<complex_t,float>,
-// called at src/dsp/pi4dqpsk.cpp:136).  ld(p) = x_{i0-71+p} for p = 0..79 (p = 79 is never weighted);
-// tap(q) = RRC taps zero-padded at the old end to 72 and then by 7 zeros in front and 8 behind, i.e.
-// tap(q) = h72[q-7] for 7 <= q < 79, else 0; out[m] = y_{i0+m}.  Every output is one fmaf chain per
-// component in ascending tap order; the zero taps outside a chain's 72 leave its accumulator untouched
+// called at src/dsp/pi4dqpsk.cpp:136).  With nt taps, output i0+m needs x_{i0+m-(nt-1)} .. x_{i0+m}; the
+// eight outputs share the window x_{i0-(nt-1)} .. x_{i0+7} = nt+7 samples, walked in nchunks = ceil((nt+7)/8)
+// chunks of 8.  ld(p) = x_{i0-(nt-1)+p}; tap4(q) = taps [4q, 4q+4) of the EXTENDED tap array
+// ext[7 + k] = h[k] (k < nt), zero elsewhere (7 zeros in front, >= 16 behind).  Every output is one fmaf
+// chain per component in ascending tap order; the zero taps outside a chain leave its accumulator untouched
 // bit for bit (x finite: x*0 = +-0, and acc + +-0 == acc because a chain started at +0 is never -0).
-// Written as a runtime loop over ten 8-sample chunks so that only one chunk is live in registers.
-constexpr int kRrcPad = 72;
+// A runtime loop over chunks keeps only one chunk live in registers.
+constexpr int kRrcMaxTaps = 72;
 constexpr int kRrcOut = 8;
-constexpr int kRrcExt = 7 + kRrcPad + 8;   // 87
-template <class LD, class LT> TD_FN void rrc_direct8(LD ld, LT tap, Pair<float>* out) {
+constexpr int kRrcExt = 7 + kRrcMaxTaps + 17;   // 96
+struct Tap4 { float v[4]; };
+template <class LD, class LT> TD_FN void rrc_direct8(int nchunks, LD ld, LT tap4, Pair<float>* out) {
     Pair<float> acc[kRrcOut];
 #pragma unroll
     for (int m = 0; m < kRrcOut; m++) acc[m] = Pair<float>(0.0f, 0.0f);
 #pragma unroll 1
-    for (int p0 = 0; p0 < 80; p0 += 8) {
+    for (int ck = 0; ck < nchunks; ck++) {
+        const int p0 = ck * 8;
         Pair<float> x[8];
-        float h[15];
+        float h[16];
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = ld(p0 + j);
 #pragma unroll
-        for (int q = 0; q < 15; q++) h[q] = tap(p0 + q);       // tap index kk = p0 - 7 + q  ->  ext index kk + 7
+        for (int q = 0; q < 4; q++) {            // ext[p0 .. p0+15]: tap index kk = p0 - 7 + q'
+            const Tap4 t = tap4(2 * ck + q);
+            h[4 * q] = t.v[0]; h[4 * q + 1] = t.v[1]; h[4 * q + 2] = t.v[2]; h[4 * q + 3] = t.v[3];
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
 #pragma unroll
             for (int m = 0; m < kRrcOut; m++) {
-                // sample p0+j meets tap kk = p0 + j - m of output m  ->  h[j - m + 7]
+                // sample p0+j meets tap kk = p0 + j - m of output m  ->  ext index kk + 7 = p0 + (j - m + 7)
                 acc[m] = pk_fma(x[j], Pair<float>(h[j - m + 7], h[j - m + 7]), acc[m]);
             }
         }
@@ -546,25 +572,27 @@ struct K2State {
 
 // Timing recovery step (complex_fd.cpp:101-143).  w[0..7]: the 8 complex samples buffer[offset..offset+7];
 // rows tm1/t0/tp1: interpolator bank rows max(phase-1,0), phase, min(phase+1,127).  Returns the interpolated
-// symbol (vr, vi) and advances mu / omega / offset.
-TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const float* wre, const float* wim,
+// symbol (vr, vi) and advances mu / omega / offset.  The three 8-tap dots run as packed (re,im) fmaf chains.
+TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float>* w,
                      const float* tm1, const float* t0, const float* tp1, float* out_re, float* out_im) {
-    float vr = 0.0f, vi = 0.0f, ar = 0.0f, ai = 0.0f, br = 0.0f, bi = 0.0f;
+    Pair<float> v(0.0f, 0.0f), a(0.0f, 0.0f), b(0.0f, 0.0f);
 #pragma unroll
     for (int j = 0; j < kInterpTaps; j++) {
-        vr = v_fma(wre[j], t0[j], vr);  vi = v_fma(wim[j], t0[j], vi);
-        ar = v_fma(wre[j], tp1[j], ar); ai = v_fma(wim[j], tp1[j], ai);
-        br = v_fma(wre[j], tm1[j], br); bi = v_fma(wim[j], tm1[j], bi);
+        v = pk_fma(w[j], Pair<float>(t0[j], t0[j]), v);
+        a = pk_fma(w[j], Pair<float>(tp1[j], tp1[j]), a);
+        b = pk_fma(w[j], Pair<float>(tm1[j], tm1[j]), b);
     }
-    // complex_fd.cpp:107-123
-    float dr, di;
-    if (phase == 0) { dr = ar - vr; di = ai - vi; }
-    else if (phase == kInterpPhases - 1) { dr = vr - br; di = vi - bi; }
-    else { dr = (ar - br) * 0.5f; di = (ai - bi) * 0.5f; }
+    const float vr = v.x(), vi = v.y(), ar = a.x(), ai = a.y(), br = b.x(), bi = b.y();
+    // complex_fd.cpp:107-123, branch-free: one-sided differences at the bank edges, central difference inside
+    // (the unused neighbour row is a clamped copy, so every candidate is finite)
+    const bool lo = phase == 0, hi = phase == kInterpPhases - 1;
+    const float pr = lo ? vr : br, pi = lo ? vi : bi;     // subtrahend: f(T-1), or f(T) at the low edge
+    const float qr = hi ? vr : ar, qi = hi ? vi : ai;     // minuend:    f(T+1), or f(T) at the high edge
+    const float sc = (lo || hi) ? 1.0f : 0.5f;            // x*1.0f is exact, so the edge cases stay `a - b`
+    const float dr = (qr - pr) * sc, di = (qi - pi) * sc;
     // complex_fd.cpp:126,136-137
     float terr = ((vr > 0 ? 1.0f : -1.0f) * dr) + ((vi > 0 ? 1.0f : -1.0f) * di);
-    terr = terr > 1.0f ? 1.0f : terr;
-    terr = terr < -1.0f ? -1.0f : terr;
+    terr = v_clamp(terr, -1.0f, 1.0f);
     // complex_fd.cpp:140-143
     pcl_advance<float, false>(terr, st.mu, st.omega, k.tr_alpha, k.tr_beta, k.tr_min_freq, k.tr_max_freq);
     float delta = v_floor(st.mu);
@@ -586,18 +614,16 @@ TD_FN int k2_phase(float mu) {
 TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
     float s, c;
     sincos_t<float>(-st.cph, s, c);
-    float xr = vr * c - vi * s;
-    float xi = vi * c + vr * s;
+    const Pair<float> xx = cmul_phasor<float>(Pair<float>(vr, vi), c, s);
     float ph2 = st.ph2 + (-kFlPi / 4.0f);
     if (ph2 >= 2 * kFlPi) ph2 -= 2 * kFlPi;
     else if (ph2 <= -2 * kFlPi) ph2 += 2 * kFlPi;
     st.ph2 = ph2;
     sincos_t<float>(ph2, s, c);
-    float zr = xr * c - xi * s;
-    float zi = xi * c + xr * s;
+    const Pair<float> zz = cmul_phasor<float>(xx, c, s);
+    const float zr = zz.x(), zi = zz.y();
     float cerr = ((zr > 0 ? 1.0f : -1.0f) * zi) - ((zi > 0 ? 1.0f : -1.0f) * zr);
-    cerr = cerr < -1.0f ? -1.0f : cerr;
-    cerr = cerr > 1.0f ? 1.0f : cerr;
+    cerr = v_clamp(cerr, -1.0f, 1.0f);
     pcl_advance<float, true>(cerr, st.cph, st.cfr, k.costas_alpha, k.costas_beta, k.costas_min_freq, k.costas_max_freq);
     *zr_out = zr;
     *zi_out = zi;
@@ -609,10 +635,10 @@ TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* z
 }
 
 // Both halves for one symbol (kernel 2 of the two-kernel pipeline).
-TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const float* wre, const float* wim,
+TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const Pair<float>* w,
                     const float* tm1, const float* t0, const float* tp1, float* sym_re, float* sym_im) {
     float vr, vi;
-    k2_timing(k, st, phase, wre, wim, tm1, t0, tp1, &vr, &vi);
+    k2_timing(k, st, phase, w, tm1, t0, tp1, &vr, &vi);
     return k2_costas(k, st, vr, vi, sym_re, sym_im);
 }
 

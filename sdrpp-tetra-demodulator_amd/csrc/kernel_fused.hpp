@@ -28,7 +28,7 @@ constexpr int kFT = 32;                  // samples per tile (pipeline epoch)
 constexpr int kFCh = 16;                 // channels per workgroup
 constexpr int kFThreads = 384;           // 6 waves
 constexpr int kFX = 256;                 // x ring (FLL output) per channel ...
-constexpr int kFXM = 80;                 // ... plus a mirror of the first slots so 79-sample windows never wrap
+constexpr int kFXM = 88;                 // ... plus a mirror of the first slots so RRC windows (<= 86 samples) never wrap
 constexpr int kFXS = kFX + kFXM + 1;     // row stride (odd: spreads channels over LDS banks)
 constexpr int kFY = 128;                 // y ring (RRC output) per channel
 constexpr int kFYM = 8;
@@ -54,7 +54,8 @@ struct FusedParams {
     // tables
     const float* be_re72;   // band-edge taps zero-padded (old end) to 72
     const float* be_im72;
-    const float* rrc72;
+    const float* rrc_ext;   // [kRrcExt] RRC taps as rrc_direct8 wants them: ext[7 + k] = h[k], zero elsewhere
+    int ntaps;
     const float* bank;
     // outputs
     uint8_t* bits;
@@ -64,6 +65,7 @@ struct FusedParams {
     float2* y_dbg;       // optional: time-major scratch [(7+n)][C], row 7+i = y_i
     K1Consts k1;
     K2Consts k2;
+    int ablate;          // debug/profiling only: bit r set = role r keeps its barriers but skips its work (results invalid)
 };
 
 struct FusedLds {
@@ -73,7 +75,7 @@ struct FusedLds {
     float2 s_ring[kFCh][kFS];
     int s_avail[kFCh];
     __attribute__((aligned(16))) float bank[kInterpPhases * kInterpTaps];
-    __attribute__((aligned(16))) float rrc[kRrcExt + 1];   // zero-extended taps, see rrc_direct8
+    __attribute__((aligned(16))) float rrc[kRrcExt];       // zero-extended taps, see rrc_direct8
 };
 
 __device__ __forceinline__ void x_ring_put(FusedLds& L, int c, int i, float2 v) {
@@ -131,7 +133,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
 
     // ---- prologue: tables and delay lines into LDS -------------------------------------------------
     for (int i = tid; i < kInterpPhases * kInterpTaps; i += kFThreads) L.bank[i] = p.bank[i];
-    if (tid < kRrcExt + 1) L.rrc[tid] = (tid >= 7 && tid < 7 + kRrcPad) ? p.rrc72[tid - 7] : 0.0f;
+    if (tid < kRrcExt) L.rrc[tid] = p.rrc_ext[tid];
     // rings start at zero: the RRC window may touch slots that were never written (weighted by zero taps)
     for (int i = tid; i < kFCh * kFXS; i += kFThreads) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < kFCh * kFYS; i += kFThreads) (&L.y_ring[0][0])[i] = make_float2(0.f, 0.f);
@@ -160,7 +162,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
         }
         __syncthreads();
         FUSED_EPOCHS(
-            if (e < ntiles && on) {
+            if (e < ntiles && on && !(p.ablate & 1)) {
                 const int base = e * kFT;
                 float2* dst = &L.a_buf[e & 1][c][0];
                 _Pragma("unroll")
@@ -197,7 +199,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
         __syncthreads();
         FUSED_EPOCHS(
             const int t = e - 1;
-            if (t >= 0 && t < ntiles) {
+            if (t >= 0 && t < ntiles && !(p.ablate & 2)) {
                 const int base = t * kFT;
                 const int cnt = (n - base < kFT) ? (n - base) : kFT;
                 FllDeviceIO io{ L, nullptr, &L.a_buf[t & 1][f_c][0], f_c, f_pos, base };
@@ -211,16 +213,20 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
     } else if (wave == kRoleC) {
         // ---- RRC: lane -> (channel c = lane & 15, j = lane >> 4), outputs base + 8j + m; tile e-2 -------
         const int c = lane & 15;
+        const int rrc_chunks = (p.ntaps + 7 + 7) / 8;
         __syncthreads();
         FUSED_EPOCHS(
             const int t = e - 2;
-            if (t >= 0 && t < ntiles) {
+            if (t >= 0 && t < ntiles && !(p.ablate & 4)) {
                 const int i0 = t * kFT + 8 * (lane >> 4);
                 if (i0 < n) {
-                    const float2* xw = &L.x_ring[c][(i0 - (kRrcPad - 1)) & (kFX - 1)];
+                    // window x_{i0-(nt-1)} .. x_{i0+7} (+ up to 7 zero-weighted slots of chunk padding, inside the mirror)
+                    const float2* xw = &L.x_ring[c][(i0 - (p.ntaps - 1)) & (kFX - 1)];
                     Pair<float> out[kRrcOut];
-                    rrc_direct8([&](int q) { const float2 v = xw[q < 79 ? q : 78]; return Pair<float>(v.x, v.y); },
-                                [&](int k) { return L.rrc[k]; }, out);
+                    rrc_direct8(rrc_chunks,
+                                [&](int q) { const float2 v = xw[q]; return Pair<float>(v.x, v.y); },
+                                [&](int q) { const float4 t = reinterpret_cast<const float4*>(L.rrc)[q];
+                                             Tap4 r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }, out);
                     _Pragma("unroll")
                     for (int m = 0; m < kRrcOut; m++) {
                         if (i0 + m < n) {
@@ -245,7 +251,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
         int S = 0;
         __syncthreads();
         FUSED_EPOCHS(
-            if (e >= 3 && on) {
+            if (e >= 3 && on && !(p.ablate & 8)) {
                 const int avail = (e - 2) * kFT;
                 const int limit = avail < n ? avail : n;
                 while (st.offset < limit) {
@@ -253,12 +259,11 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
                     const int pm = phase > 0 ? phase - 1 : 0;
                     const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
                     const float2* yw = &L.y_ring[c][(st.offset - (kInterpTaps - 1)) & (kFY - 1)];
-                    float wre[kInterpTaps]; float wim[kInterpTaps]; float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
+                    Pair<float> w[kInterpTaps]; float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
                     _Pragma("unroll")
                     for (int j = 0; j < kInterpTaps; j++) {
-                        const float2 w = yw[j];
-                        wre[j] = w.x;
-                        wim[j] = w.y;
+                        const float2 wv = yw[j];
+                        w[j] = Pair<float>(wv.x, wv.y);
                     }
                     const float4* b0 = reinterpret_cast<const float4*>(L.bank + phase * kInterpTaps);
                     const float4* bm = reinterpret_cast<const float4*>(L.bank + pm * kInterpTaps);
@@ -271,7 +276,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
                     q = bp[0]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
                     q = bp[1]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
                     float vr; float vi;
-                    k2_timing(p.k2, st, phase, wre, wim, tm1, t0, tp1, &vr, &vi);
+                    k2_timing(p.k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
                     L.s_ring[c][S & (kFS - 1)] = make_float2(vr, vi);
                     S++;
                 }
@@ -299,7 +304,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
         const bool wr = on && live(c);
         __syncthreads();
         FUSED_EPOCHS(
-            if (e >= 4 && on) {
+            if (e >= 4 && on && !(p.ablate & 16)) {
                 const int avail = L.s_avail[c];
                 while (S < avail) {
                     const float2 v = L.s_ring[c][S & (kFS - 1)];

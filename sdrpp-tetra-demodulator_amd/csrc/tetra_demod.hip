@@ -230,12 +230,12 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
                 phase = phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
                 const int pm = phase > 0 ? phase - 1 : 0;
                 const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
-                float wre[kInterpTaps], wim[kInterpTaps], t0[kInterpTaps], tm1[kInterpTaps], tp1[kInterpTaps];
+                Pair<float> w[kInterpTaps];
+                float t0[kInterpTaps], tm1[kInterpTaps], tp1[kInterpTaps];
 #pragma unroll
                 for (int j = 0; j < kInterpTaps; j++) {
-                    float2 w = tile[rel + j][lane];
-                    wre[j] = w.x;
-                    wim[j] = w.y;
+                    const float2 wv = tile[rel + j][lane];
+                    w[j] = Pair<float>(wv.x, wv.y);
                 }
                 const float4* b0 = reinterpret_cast<const float4*>(bank + phase * kInterpTaps);
                 const float4* bm = reinterpret_cast<const float4*>(bank + pm * kInterpTaps);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
                 q = bp[0]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
                 q = bp[1]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
                 float zr, zi;
-                const int d = k2_symbol(p.k, st, phase, wre, wim, tm1, t0, tp1, &zr, &zi);
+                const int d = k2_symbol(p.k, st, phase, w, tm1, t0, tp1, &zr, &zi);
                 if (srow) srow[S] = make_float2(zr, zi);
                 // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
                 const unsigned long long two = (unsigned long long)((d >> 1) & 1) | ((unsigned long long)(d & 1) << 8);
@@ -331,7 +331,7 @@ struct tetra_demod {
     bool fused = true;          // pipeline in use
     bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
-    float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc72 = nullptr;   // fused kernel: padded to 72
+    float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 72, RRC zero-extended
     // host-path staging
     float* st_iq = nullptr;
     uint8_t* st_bits = nullptr;
@@ -383,16 +383,16 @@ int upload_tables(tetra_demod* h) {
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
     if (h->design.ntaps <= kF8Pad) {
-        std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rr72(kF8Pad, 0.f);
+        std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rr72(kRrcExt, 0.f);
         const int o72 = kF8Pad - h->design.ntaps;
         for (int k = 0; k < h->design.ntaps; k++) {
             re72[o72 + k] = h->design.be_re[k];
             im72[o72 + k] = h->design.be_im[k];
-            rr72[o72 + k] = h->design.rrc[k];
+            rr72[7 + k] = h->design.rrc[k];
         }
         HIP_TRY(h, hipMemcpy(h->d_be_re72, re72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_be_im72, im72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_rrc72, rr72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rr72.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
     }
     return TETRA_OK;
 }
@@ -440,7 +440,7 @@ int reset_range(tetra_demod* h, int first, int count) {
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
                      h->prev, h->y, h->ybuf, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
-                     h->d_rrc72, h->st_iq, h->st_bits, h->st_nbits, h->st_sym };
+                     h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& slot : h->ev)
@@ -557,7 +557,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
     A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
-    A(dalloc(h, &h->d_rrc72, (size_t)kF8Pad));
+    A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
     A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
     A(dalloc(h, &h->d_rrc, (size_t)kPadTaps)); A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
     for (auto& slot : h->ev)
@@ -645,10 +645,15 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
         pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
         pf.cph = h->cph; pf.cfr = h->cfr; pf.ph2 = h->ph2; pf.prev = h->prev; pf.ybuf = h->ybuf;
-        pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc72 = h->d_rrc72; pf.bank = h->d_bank;
+        pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
+        pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
+        {
+            const char* ab = std::getenv("TETRA_DEMOD_ABLATE");   // profiling aid, see kernel_fused.hpp
+            pf.ablate = ab ? std::atoi(ab) : 0;
+        }
         const dim3 gf((h->C + kFCh - 1) / kFCh);
         HIP_TRY(h, hipEventRecord(ev[0], s));
         if (pf.k1.fll_alpha == 0.0f) hipLaunchKernelGGL(k_fused<true>, gf, dim3(kFThreads), 0, s, pf);

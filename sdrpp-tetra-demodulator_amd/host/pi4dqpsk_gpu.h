@@ -1,0 +1,106 @@
+// pi4dqpsk_gpu.h -- host-side mirror of the reference's demodulator block, backed by the HIP kernels
+// through the C ABI (include/tetra_demod.h).  No DSP arithmetic happens on the host.
+//
+// dsp::demod::PI4DQPSK        same class name, init() signature, run()/process() contract, twelve setters and
+//                             reset() as src/dsp/pi4dqpsk.h:27-81 / src/dsp/pi4dqpsk.cpp:11-140 -- replace that
+//                             pair of files with this header + pi4dqpsk_gpu.cpp and the rest of the plugin
+//                             (src/main.cpp:84-114) builds unchanged: `out` still carries the Costas-locked
+//                             symbols that DQPSKSymbolExtractor slices (sign tests only, so its dibits equal
+//                             the GPU's).  One instance = one channel = a C = 1 handle.
+// dsp::demod::PI4DQPSKBank    the batched form the GPU is built for: C channels per call, returns the unpacked
+//                             bit streams tetra_burst_sync_in() eats (src/decoder/src/phy/tetra_burst_sync.c:54),
+//                             i.e. PI4DQPSK + DQPSKSymbolExtractor + BitUnpacker for every channel at once.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/tetra_demod.h"
+#include "dsp_compat.h"
+
+namespace dsp {
+namespace demod {
+
+class PI4DQPSK : public Processor<complex_t, complex_t> {
+    using base_type = Processor<complex_t, complex_t>;
+
+public:
+    PI4DQPSK() {}
+    PI4DQPSK(stream<complex_t>* in, double symbolrate, double samplerate, int rrcTapCount, double rrcBeta, double agcRate,
+             double costasBandwidth, double fllBandwidth, double omegaGain, double muGain, double omegaRelLimit = 0.01) {
+        init(in, symbolrate, samplerate, rrcTapCount, rrcBeta, agcRate, costasBandwidth, fllBandwidth, omegaGain, muGain,
+             omegaRelLimit);
+    }
+    ~PI4DQPSK();
+
+    // src/dsp/pi4dqpsk.h:36.  Throws nothing; a failed GPU set-up leaves the block un-initialised (lastStatus() < 0).
+    void init(stream<complex_t>* in, double symbolrate, double samplerate, int rrcTapCount, double rrcBeta, double agcRate,
+              double costasBandwidth, double fllBandwidth, double omegaGain, double muGain, double omegaRelLimit = 0.01);
+
+    // src/dsp/pi4dqpsk.h:38-50
+    int run() override {
+        int count = base_type::_in->read();
+        if (count < 0) { return -1; }
+        int outCount = process(count, base_type::_in->readBuf, base_type::out.writeBuf);
+        base_type::_in->flush();
+        if (outCount) {
+            if (!base_type::out.swap(outCount)) { return -1; }
+        }
+        return outCount;
+    }
+
+    void setSymbolrate(double symbolrate);
+    void setSamplerate(double samplerate);
+    void setRRCParams(int rrcTapCount, double rrcBeta);
+    void setRRCTapCount(int rrcTapCount);
+    void setRRCBeta(double rrcBeta);
+    void setAGCRate(double agcRate);
+    void setCostasBandwidth(double bandwidth);
+    void setFllBandwidth(double fllBandwidth);
+    void setMMParams(double omegaGain, double muGain, double omegaRelLimit = 0.01);
+    void setOmegaGain(double omegaGain);
+    void setMuGain(double muGain);
+    void setOmegaRelLimit(double omegaRelLimit);
+    void reset();
+
+    // src/dsp/pi4dqpsk.h:67: count input samples -> returns the number of symbols written to out
+    // (in == out allowed, like the reference).  < 0 only if the GPU call failed (lastStatus()).
+    int process(int count, const complex_t* in, complex_t* out);
+
+    // Extras the GPU path gives for free: the unpacked bits of the last process() call
+    // (= DQPSKSymbolExtractor + BitUnpacker output for the same symbols).
+    const std::vector<uint8_t>& lastBits() const { return bits_; }
+    int lastStatus() const { return status_; }
+
+private:
+    void set(int id, double v);
+    tetra_demod_t* h_ = nullptr;
+    int status_ = TETRA_ERR_ARG;
+    std::vector<uint8_t> bitbuf_, bits_;
+    std::vector<float> symbuf_;
+};
+
+class PI4DQPSKBank {
+public:
+    PI4DQPSKBank() {}
+    ~PI4DQPSKBank();
+    PI4DQPSKBank(const PI4DQPSKBank&) = delete;
+    PI4DQPSKBank& operator=(const PI4DQPSKBank&) = delete;
+
+    // cfg: tetra_demod_default_config() + n_channels / max_samples / layout / device.  Returns a TETRA_* status.
+    int init(const tetra_demod_config_t& cfg);
+    // in: n_channels x count complex samples in cfg.layout; bits: [n_channels][bitsStride(count)];
+    // nBits: [n_channels].  Returns a TETRA_* status.
+    int process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits, complex_t* symbols = nullptr);
+    int bitsStride(int count) const { return tetra_demod_bits_stride(count); }
+    int reset(int channel = -1);
+    int setParam(int paramId, double value);
+    int channels() const { return channels_; }
+    tetra_demod_t* handle() { return h_; }
+
+private:
+    tetra_demod_t* h_ = nullptr;
+    int channels_ = 0;
+};
+
+}  // namespace demod
+}  // namespace dsp

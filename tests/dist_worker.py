@@ -1,0 +1,45 @@
+"""Worker for tests/test_dist_gloo.py: one rank of the sharded demodulator host logic, gloo backend, CPU.
+
+Each rank takes its contiguous channel range (sdrpp-tetra-demodulator_amd/shard.py), runs the per-channel chain
+for its channels (the CPU oracle stands in for the GPU here -- this test is about the sharding/gather/timing
+logic, which is identical on RCCL), and the ranks reassemble the per-channel results in channel order."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tetra_amd  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    C, N = int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    shard = tetra_amd.pkg.shard
+    lo, hi = shard.channel_range(C, world, rank)
+    # every rank generates only its own channels (seed = base + global channel index)
+    iq = np.stack([tetra_amd.pkg.synth.gen_channel(N, 500 + c)[0] for c in range(lo, hi)]) if hi > lo else np.zeros((0, N), np.complex64)
+    t0 = time.perf_counter()
+    bits, nb, _, _ = ob.process_batch(iq) if hi > lo else (np.zeros((0, ob.bits_stride(N)), np.uint8), np.zeros(0, np.int32), None, None)
+    elapsed = time.perf_counter() - t0 + 0.01 * rank          # make the ranks' times differ
+    dist.barrier()
+    tmax = shard.max_over_ranks(dist, elapsed)
+    rows = torch.from_numpy(np.concatenate([nb[:, None].astype(np.int64),
+                                            bits[:, :64].astype(np.int64)], axis=1))
+    allrows = shard.gather_channel_rows(dist, rows, C, world)
+    if rank == 0:
+        json.dump(dict(world=world, ranges=[shard.channel_range(C, world, r) for r in range(world)], tmax=tmax,
+                       my_elapsed=elapsed, rows=allrows.numpy().tolist()), open(out_path, "w"))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,10 +184,10 @@ int emul_k2(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n,
                 phase = phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
                 const int pm = phase > 0 ? phase - 1 : 0;
                 const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
-                float wre[kInterpTaps], wim[kInterpTaps];
-                for (int j = 0; j < kInterpTaps; j++) { wre[j] = tile[((size_t)(rel + j) * C + c) * 2]; wim[j] = tile[((size_t)(rel + j) * C + c) * 2 + 1]; }
+                Pair<float> w[kInterpTaps];
+                for (int j = 0; j < kInterpTaps; j++) w[j] = Pair<float>(tile[((size_t)(rel + j) * C + c) * 2], tile[((size_t)(rel + j) * C + c) * 2 + 1]);
                 float zr, zi;
-                const int d = k2_symbol(t->k2, ks[c], phase, wre, wim, t->bank + pm * kInterpTaps, t->bank + phase * kInterpTaps,
+                const int d = k2_symbol(t->k2, ks[c], phase, w, t->bank + pm * kInterpTaps, t->bank + phase * kInterpTaps,
                                         t->bank + pp * kInterpTaps, &zr, &zi);
                 if (2 * S[c] + 2 > bits_stride) return -2;
                 if (sym) { sym[((size_t)c * (bits_stride / 2) + S[c]) * 2] = zr; sym[((size_t)c * (bits_stride / 2) + S[c]) * 2 + 1] = zi; }
@@ -260,9 +260,10 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
     if (C < 1 || C > 64 || t->ntaps > kF8Pad) return -1;
     const int tile = 32;
     float re72[kF8Pad] = { 0 }, im72[kF8Pad] = { 0 };
-    float rrc_ext[kRrcExt + 1] = { 0 };
+    float rrc_ext[kRrcExt] = { 0 };
     const int o72 = kF8Pad - t->ntaps;
-    for (int k = 0; k < t->ntaps; k++) { re72[o72 + k] = t->be_re[k]; im72[o72 + k] = t->be_im[k]; rrc_ext[7 + o72 + k] = t->rrc[k]; }
+    for (int k = 0; k < t->ntaps; k++) { re72[o72 + k] = t->be_re[k]; im72[o72 + k] = t->be_im[k]; rrc_ext[7 + k] = t->rrc[k]; }
+    const int rrc_chunks = (t->ntaps + 7 + 7) / 8;
     std::vector<float> a((size_t)C * n * 2), x((size_t)C * n * 2);
     // A: AGC
     for (int c = 0; c < C; c++) {
@@ -313,14 +314,14 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
     // C: RRC, eight outputs at a time, over [history | x]
     std::vector<float> y((size_t)C * n * 2);
     for (int c = 0; c < C; c++) {
-        std::vector<float> xf((size_t)(kHist + n + 8) * 2, 0.f);
+        std::vector<float> xf((size_t)(kHist + n + 16) * 2, 0.f);
         std::memcpy(xf.data(), st[c].hist, sizeof(float) * 2 * kHist);
         if (n) std::memcpy(xf.data() + 2 * kHist, &x[(size_t)c * n * 2], sizeof(float) * 2 * n);
         for (int i0 = 0; i0 < n; i0 += 8) {
             Pair<float> out[kRrcOut];
-            const float* w = xf.data() + 2 * (kHist + i0 - (kRrcPad - 1));
-            rrc_direct8([&](int q) { const int qq = q < 79 ? q : 78; return Pair<float>(w[2 * qq], w[2 * qq + 1]); },
-                        [&](int k) { return rrc_ext[k]; }, out);
+            const float* w = xf.data() + 2 * (kHist + i0 - (t->ntaps - 1));
+            rrc_direct8(rrc_chunks, [&](int q) { return Pair<float>(w[2 * q], w[2 * q + 1]); },
+                        [&](int q) { Tap4 r; for (int z = 0; z < 4; z++) r.v[z] = rrc_ext[4 * q + z]; return r; }, out);
             for (int m = 0; m < kRrcOut && i0 + m < n; m++) {
                 y[((size_t)c * n + i0 + m) * 2] = out[m].x();
                 y[((size_t)c * n + i0 + m) * 2 + 1] = out[m].y();
@@ -345,10 +346,10 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
             const int phase = k2_phase(ks.mu);
             const int pm = phase > 0 ? phase - 1 : 0;
             const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
-            float wre[kInterpTaps], wim[kInterpTaps];
-            for (int j = 0; j < kInterpTaps; j++) { wre[j] = yf[2 * (ks.offset + j)]; wim[j] = yf[2 * (ks.offset + j) + 1]; }
+            Pair<float> w[kInterpTaps];
+            for (int j = 0; j < kInterpTaps; j++) w[j] = Pair<float>(yf[2 * (ks.offset + j)], yf[2 * (ks.offset + j) + 1]);
             float vr, vi, zr, zi;
-            k2_timing(t->k2, ks, phase, wre, wim, t->bank + pm * kInterpTaps, t->bank + phase * kInterpTaps,
+            k2_timing(t->k2, ks, phase, w, t->bank + pm * kInterpTaps, t->bank + phase * kInterpTaps,
                       t->bank + pp * kInterpTaps, &vr, &vi);
             const int d = k2_costas(t->k2, ks, vr, vi, &zr, &zi);
             if (2 * S + 2 > bits_stride) return -2;

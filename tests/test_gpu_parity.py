@@ -195,6 +195,70 @@ def test_reset_and_state_roundtrip(pkg, oracle, synth, pipeline):
     d.close()
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_time_major_layout(pkg, oracle, synth, pipeline):
+    """TETRA_LAYOUT_TIME_MAJOR: iq[n][c] frames (what a channeliser emits) give the same bits as channel-major."""
+    Cn, N = 19, 2500
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=61)
+    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, flags=PIPELINES[pipeline] & 1)
+    bits, nb, sym = d.process(np.ascontiguousarray(iq.T), want_sym=True)
+    rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
+    assert np.array_equal(nb, rnb)
+    for c in range(Cn):
+        assert np.array_equal(bits[c][:nb[c]], rb[c][:nb[c]])
+        assert np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(rsym[c][:nb[c] // 2]))
+    d.close()
+
+
+@pytest.mark.parametrize("pipeline,nt", [("fused", 33), ("fused", 72), ("two_kernel", 33), ("two_kernel", 79), ("fused", 79)])
+def test_other_tap_counts(pkg, oracle, synth, pipeline, nt):
+    """rrcTapCount is a PI4DQPSK parameter; > 72 taps silently uses the two-kernel pipeline."""
+    Cn, N = 6, 3000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=71)
+    d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & 1, rrc_tap_count=nt)
+    ocfg = oracle.default_cfg()
+    ocfg.rrc_tap_count = nt
+    orcs = [oracle.Oracle(ocfg) for _ in range(Cn)]
+    for pos in (0, 1500):
+        bits, nb, _ = d.process(iq[:, pos:pos + 1500])
+        for c in range(Cn):
+            r = orcs[c].process(iq[c, pos:pos + 1500])
+            assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (nt, c)
+    d.close()
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_setters_match_oracle_with_same_parameters(pkg, oracle, synth, pipeline):
+    """set_param (the PI4DQPSK setters) mid-stream == an oracle built with those parameters from that point on,
+    for the parameters that only change loop constants (no tap re-design, no timing reset)."""
+    import ctypes as C
+    Cn, N = 4, 4000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=81)
+    d = pkg.Demodulator(Cn, 2000, flags=PIPELINES[pipeline] & 1)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    b1, n1, _ = d.process(iq[:, :2000])
+    for c in range(Cn):
+        r = orcs[c].process(iq[c, :2000])
+        assert np.array_equal(b1[c][:n1[c]], r["bits"])
+    d.set_param("agc_rate", 0.05)
+    d.set_param("costas_bandwidth", 0.02)
+    d.set_param("fll_bandwidth", 0.003)
+    d.set_param("omega_rel_limit", 0.01)
+    b2, n2, _ = d.process(iq[:, 2000:])
+    for c in range(Cn):
+        o = orcs[c]
+        cfg = oracle.default_cfg()
+        cfg.agc_rate, cfg.costas_bandwidth, cfg.fll_bandwidth, cfg.omega_rel_limit = 0.05, 0.02, 0.003, 0.01
+        tab = oracle.Tables()
+        assert oracle.lib().tetra_oracle_design(C.byref(cfg), C.byref(tab)) == 0
+        o.tab = tab                                   # new constants, state kept (what the reference's setters do)
+        r = o.process(iq[c, 2000:])
+        assert n2[c] == r["bits"].size and np.array_equal(b2[c][:n2[c]], r["bits"]), c
+    with pytest.raises(pkg.TetraDemodError):
+        d.set_param("rrc_tap_count", 500)
+    d.close()
+
+
 def test_errors(pkg):
     B = pkg.binding
     d = pkg.Demodulator(2, 100)
