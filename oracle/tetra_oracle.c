@@ -24,35 +24,31 @@
 #define DB_M_PI 3.14159265358979323846
 
 /* ------------------------------------------------------------------------- */
-/* Run-time phasor: fixed-polynomial sin/cos (replaces the libm cosf/sinf of    */
+/* Run-time phasor: fixed-polynomial sin/cos (replaces the libm cosf/sinf of      */
 /* SDR++ core math::phasor, called at fll.cpp:137, pi4dqpsk_costas.cpp:7,16).   */
-/* Three-term Cody-Waite reduction by pi/2 + Cephes single-precision minimax    */
-/* polynomials on [-pi/4, pi/4].                                                */
+/* Three-term Cody-Waite reduction by pi (k = rint(x/pi), r in [-pi/2, pi/2]),   */
+/* minimax polynomials in r^2 (degree-9 sine, degree-10 cosine, fitted for this */
+/* project; |error| <= 1.6e-7 over [-2pi, 2pi]), sign = (-1)^k for both.         */
 /* ------------------------------------------------------------------------- */
 void tetra_oracle_sincosf(float x, float* s, float* c) {
-    float k = rintf(x * 0.636619772367581343f);
-    float r = fmaf(-k, 1.5703125f, x);
-    r = fmaf(-k, 4.837512969970703125e-4f, r);
-    r = fmaf(-k, 7.54978995489188216e-8f, r);
-    int q = ((int)k) & 3;
+    float k = rintf(x * 0.318309886183790672f);
+    float r = fmaf(-k, 3.140625f, x);
+    r = fmaf(-k, 9.67502593994140625e-4f, r);
+    r = fmaf(-k, 1.509957990978376432e-7f, r);
     float z = r * r;
-    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float ps = fmaf(2.597026877992903e-06f, z, -0.0001980524102691561f);
+    ps = fmaf(ps, z, 0.008332998491823673f);
+    ps = fmaf(ps, z, -0.16666656732559204f);
     ps = ps * z;
     float sr = fmaf(ps, r, r);
-    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    pc = fmaf(pc, z, 4.166664568298827e-2f);
-    pc = pc * z;
-    float cr = fmaf(pc, z, fmaf(-0.5f, z, 1.0f));
-    float so, co;
-    switch (q) {
-    case 0:  so = sr;  co = cr;  break;
-    case 1:  so = cr;  co = -sr; break;
-    case 2:  so = -sr; co = -cr; break;
-    default: so = -cr; co = sr;  break;
-    }
-    *s = so;
-    *c = co;
+    float pc = fmaf(-2.604826931928983e-07f, z, 2.476031113474164e-05f);
+    pc = fmaf(pc, z, -0.0013888374669477344f);
+    pc = fmaf(pc, z, 0.04166663810610771f);
+    pc = fmaf(pc, z, -0.5f);
+    float cr = fmaf(pc, z, 1.0f);
+    if (((int)k) & 1) { sr = -sr; cr = -cr; }
+    *s = sr;
+    *c = cr;
 }
 
 /* ------------------------------------------------------------------------- */

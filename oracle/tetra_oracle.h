@@ -32,7 +32,7 @@
  *     multiplies) is plain non-fused mul/add in the order the reference source
  *     writes it;
  *   - cosf/sinf of the run-time loop phases go through tetra_oracle_sincosf()
- *     below (a fixed polynomial, <= ~1.5 ulp), because host libm and GPU ocml
+ *     below (a fixed polynomial, |error| <= 1.6e-7), because host libm and GPU ocml
  *     differ in the last ulp; init-time tap design uses the host libm like the
  *     reference does;
  *   - sqrtf is the correctly rounded IEEE square root.

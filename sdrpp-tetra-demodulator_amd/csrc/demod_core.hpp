@@ -66,6 +66,15 @@ TD_FN int v_sel(bool m, int a, int b) { return m ? a : b; }
 TD_FN int v_ftoi(float a) { return (int)a; }
 TD_FN bool v_ieq(int a, int b) { return a == b; }
 TD_FN int v_iand(int a, int b) { return a & b; }
+// x with its sign flipped when k is odd
+TD_FN float v_flip_if_odd(float x, int k) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) ^ (int)((unsigned)k << 31));
+}
+// |x| > lim ? x - copysign(delta, x) : x   -- the phase wrap of PhaseControlLoop for symmetric limits
+TD_FN float v_wrap_sym(float x, float lim, float delta) {
+    const float t = x - __builtin_copysignf(delta, x);
+    return __builtin_fabsf(x) > lim ? t : x;
+}
 
 template <class V> struct vtraits;
 template <> struct vtraits<float> { using M = bool; using I = int; };
@@ -179,6 +188,8 @@ TD_FN Row16 v_clamp(Row16 x, float lo, float hi) { Row16 r; for (int i = 0; i < 
 TD_FN Row16 v_sel(Row16m m, Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = m.l[i] ? a.l[i] : b.l[i]; return r; }
 TD_FN Row16i v_ftoi(Row16 a) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = (int)a.l[i]; return r; }
 TD_FN Row16m v_ieq(Row16i a, int b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] == b; return r; }
+TD_FN Row16 v_flip_if_odd(Row16 x, Row16i k) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = v_flip_if_odd(x.l[i], k.l[i]); return r; }
+TD_FN Row16 v_wrap_sym(Row16 x, float lim, float delta) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = v_wrap_sym(x.l[i], lim, delta); return r; }
 TD_FN Row16i v_iand(Row16i a, int b) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] & b; return r; }
 template <> struct vtraits<Row16> { using M = Row16m; using I = Row16i; };
 TD_FN Row16 row_shr1(Row16 old, Row16 src) { Row16 r; r.l[0] = old.l[0]; for (int i = 1; i < 16; i++) r.l[i] = src.l[i - 1]; return r; }
@@ -206,28 +217,29 @@ template <class V> TD_FN Pair<V> row_shl2(Pair<V> old, Pair<V> src) {
 template <class V> TD_FN Pair<V> row_shl2_z(Pair<V> src) { return Pair<V>(row_shl2_z(src.x()), row_shl2_z(src.y())); }
 
 // ---------------------------------------------------------------------------------------------
-// Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same polynomial as
-// tetra_oracle_sincosf).  Valid for |x| up to a few hundred.
-// ---------------------------------------------------------------------------------------------
+// Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same function as
+// tetra_oracle_sincosf): k = rint(x/pi), three-term Cody-Waite reduction to r in [-pi/2, pi/2], minimax
+// polynomials in r^2, sign (-1)^k applied to both results with one shift and two xors.  |error| <= 1.6e-7.
 template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
-    V k = v_rint(x * 0.636619772367581343f);
+    V k = v_rint(x * 0.318309886183790672f);
     V nk = -k;
-    V r = v_fma(nk, V(1.5703125f), x);
-    r = v_fma(nk, V(4.837512969970703125e-4f), r);
-    r = v_fma(nk, V(7.54978995489188216e-8f), r);
-    typename vtraits<V>::I q = v_iand(v_ftoi(k), 3);
+    V r = v_fma(nk, V(3.140625f), x);
+    r = v_fma(nk, V(9.67502593994140625e-4f), r);
+    r = v_fma(nk, V(1.509957990978376432e-7f), r);
     V z = r * r;
-    V ps = v_fma(V(-1.9515295891e-4f), z, V(8.3321608736e-3f));
-    ps = v_fma(ps, z, V(-1.6666654611e-1f));
+    V ps = v_fma(V(2.597026877992903e-06f), z, V(-0.0001980524102691561f));
+    ps = v_fma(ps, z, V(0.008332998491823673f));
+    ps = v_fma(ps, z, V(-0.16666656732559204f));
     ps = ps * z;
     V sr = v_fma(ps, r, r);
-    V pc = v_fma(V(2.443315711809948e-5f), z, V(-1.388731625493765e-3f));
-    pc = v_fma(pc, z, V(4.166664568298827e-2f));
-    pc = pc * z;
-    V cr = v_fma(pc, z, v_fma(V(-0.5f), z, V(1.0f)));
-    typename vtraits<V>::M q0 = v_ieq(q, 0), q1 = v_ieq(q, 1), q2 = v_ieq(q, 2);
-    s = v_sel(q0, sr, v_sel(q1, cr, v_sel(q2, -sr, -cr)));
-    c = v_sel(q0, cr, v_sel(q1, -sr, v_sel(q2, -cr, sr)));
+    V pc = v_fma(V(-2.604826931928983e-07f), z, V(2.476031113474164e-05f));
+    pc = v_fma(pc, z, V(-0.0013888374669477344f));
+    pc = v_fma(pc, z, V(0.04166663810610771f));
+    pc = v_fma(pc, z, V(-0.5f));
+    V cr = v_fma(pc, z, V(1.0f));
+    typename vtraits<V>::I ki = v_ftoi(k);
+    s = v_flip_if_odd(sr, ki);
+    c = v_flip_if_odd(cr, ki);
 }
 
 // SDR++ core complex_t::operator*: a * (c + j s) = (a.re*c - a.im*s, a.im*c + a.re*s), every product and the
@@ -256,9 +268,10 @@ template <class V, bool CLAMP, bool ALPHA0 = false> TD_FN void pcl_advance(V err
     if (ALPHA0) phase = phase + freq;
     else phase = phase + (freq + alpha * err);
     if (CLAMP) {
-        const float pmax = kFlPi, pmin = -kFlPi, pdelta = pmax - pmin;
-        phase = v_sel(phase > pmax, phase - pdelta, phase);
-        phase = v_sel(phase < pmin, phase + pdelta, phase);
+        // limits are +-FL_M_PI: `phase > pi -> phase - 2pi`, `phase < -pi -> phase + 2pi` as one select
+        // (x - (-d) is x + d exactly)
+        const float pmax = kFlPi, pdelta = pmax - (-kFlPi);
+        phase = v_wrap_sym(phase, pmax, pdelta);
     }
 }
 
