@@ -609,7 +609,10 @@ TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float
     // complex_fd.cpp:140-143
     pcl_advance<float, false>(terr, st.mu, st.omega, k.tr_alpha, k.tr_beta, k.tr_min_freq, k.tr_max_freq);
     float delta = v_floor(st.mu);
-    st.offset += (int)delta;
+    // A finite stream always advances by >= 1 sample (omega >= 2(1 - rel_limit) > 1 + |alpha|), so the max() is
+    // neutral there; it guarantees forward progress (loop termination) when NaN/Inf has poisoned mu.
+    const int adv = (int)delta;
+    st.offset += adv > 1 ? adv : 1;
     st.mu = st.mu - delta;
     *out_re = vr;
     *out_im = vi;

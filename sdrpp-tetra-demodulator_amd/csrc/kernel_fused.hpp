@@ -249,12 +249,13 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
         st.offset = p.offset[chan(c)];
         st.cph = 0; st.cfr = 0; st.ph2 = 0; st.prev = 0;
         int S = 0;
+        const int sym_cap = (int)(p.bits_stride / 2);
         __syncthreads();
         FUSED_EPOCHS(
             if (e >= 3 && on && !(p.ablate & 8)) {
                 const int avail = (e - 2) * kFT;
                 const int limit = avail < n ? avail : n;
-                while (st.offset < limit) {
+                auto one_symbol = [&]() {
                     const int phase = k2_phase(st.mu);
                     const int pm = phase > 0 ? phase - 1 : 0;
                     const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
@@ -279,6 +280,19 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
                     k2_timing(p.k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
                     L.s_ring[c][S & (kFS - 1)] = make_float2(vr, vi);
                     S++;
+                };
+                // Output capacity guard.  Every symbol advances the offset by >= 1 sample (k2_timing), so this
+                // epoch adds at most limit - offset symbols.  If even that fits the output row the loop runs
+                // unchecked (always the case for a finite stream except near the end of very short calls);
+                // otherwise it checks per symbol, and a NaN/Inf-poisoned channel whose loop has stopped advancing
+                // properly is cut off at the row capacity instead of overrunning it.
+                if (S + (limit - st.offset) <= sym_cap) {
+                    while (st.offset < limit) one_symbol();
+                } else {
+                    while (st.offset < limit) {
+                        if (S >= sym_cap) { st.offset = limit; break; }
+                        one_symbol();
+                    }
                 }
                 L.s_avail[c] = S;
             }

@@ -221,6 +221,8 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
         __syncthreads();
         while (true) {
             const int rel = st.offset - base;
+            // output capacity guard (see kernel_fused.hpp): never reached by a finite stream
+            if (S >= (int)(p.bits_stride / 2) && st.offset < n) st.offset = n;
             const bool can = active && st.offset < n && (rel + kInterpTaps <= kK2TileRows);
             if (!__any(can)) break;
             if (can) {

@@ -259,6 +259,69 @@ def test_setters_match_oracle_with_same_parameters(pkg, oracle, synth, pipeline)
     d.close()
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_non_finite_input_cannot_hang_or_overrun(pkg, synth, pipeline):
+    """NaN/Inf in one channel poisons that channel's loops (as it would the reference's) but the call returns,
+    its output stays inside its row, and the neighbours are untouched."""
+    Cn, N = 18, 3000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=91)
+    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1).process(iq)
+    bad = iq.copy()
+    bad[3, 100] = np.nan
+    bad[7, 200] = np.inf
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1)
+    bits, nb, _ = d.process(bad)
+    stride = bits.shape[1]
+    assert (nb >= 0).all() and (nb <= stride).all()
+    for c in range(Cn):
+        if c not in (3, 7):
+            assert nb[c] == clean[1][c] and np.array_equal(bits[c][:nb[c]], clean[0][c][:nb[c]]), c
+    d.close()
+
+
+def test_maximum_call_size_matches_chunked(pkg, synth):
+    """count up to STREAM_BUFFER_SIZE (1e6) per call, as the reference allows: one 1e6-sample call == the same
+    stream in 62500-sample calls (size-independent property: chunk invariance)."""
+    Cn, N = 3, 1000000
+    base, _, _ = synth.gen_batch(Cn, 50000, base_seed=101)
+    iq = np.ascontiguousarray(np.tile(base, (1, N // 50000)))
+    d1 = pkg.Demodulator(Cn, N)
+    b1, n1, _ = d1.process(iq)
+    d1.close()
+    d2 = pkg.Demodulator(Cn, 62500)
+    parts = [[] for _ in range(Cn)]
+    for pos in range(0, N, 62500):
+        b, nb, _ = d2.process(iq[:, pos:pos + 62500])
+        for c in range(Cn):
+            parts[c].append(b[c][:nb[c]].copy())
+    d2.close()
+    for c in range(Cn):
+        cat = np.concatenate(parts[c])
+        assert cat.size == n1[c] and np.array_equal(cat, b1[c][:n1[c]])
+
+
+def test_parity_4096_channels_full_second(pkg, oracle, synth):
+    """BASELINE config 3 at full size: 4096 channels x 36000 samples, EVERY output bit compared with the CPU
+    oracle (all host threads).  256 generated channels x 16 copies with their own amplitude / rotation."""
+    Cb, Cn, N = 256, 4096, 36000
+    base, _, _ = synth.gen_batch(Cb, N, base_seed=777)
+    rng = np.random.default_rng(5)
+    iq = np.empty((Cn, N), np.complex64)
+    for k in range(Cn // Cb):
+        amp = rng.uniform(0.1, 2.0, (Cb, 1)).astype(np.float32)
+        rot = np.exp(1j * rng.uniform(-np.pi, np.pi, (Cb, 1))).astype(np.complex64)
+        iq[k * Cb:(k + 1) * Cb] = base * (amp * rot)
+    d = pkg.Demodulator(Cn, N)
+    bits, nb, _ = d.process(iq)
+    k1, _ = d.last_kernel_ms()
+    d.close()
+    rb, rnb, _, _ = oracle.process_batch(iq)
+    assert np.array_equal(nb, rnb)
+    bad = [c for c in range(Cn) if not np.array_equal(bits[c][:nb[c]], rb[c][:nb[c]])]
+    _dump("parity_4096.json", dict(bad=bad[:20], nbad=len(bad), total_bits=int(nb.sum()), kernel_ms=k1))
+    assert not bad
+
+
 def test_errors(pkg):
     B = pkg.binding
     d = pkg.Demodulator(2, 100)
