@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--two-kernel", action="store_true", help="run the two-kernel pipeline instead of the fused kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time tetra_demod_process (host buffers: H2D + kernel + D2H) and report it as "
+                         "host_path_msamples_s (informational; never the metric value)")
     args = ap.parse_args()
 
     import torch
@@ -178,6 +181,16 @@ def main():
         if errs > 1e-3 * ncmp:
             raise SystemExit("known-answer check failed: %d bit errors in %d bits after lock" % (errs, ncmp))
 
+    host_path = None
+    if args.host_path and rank == 0:
+        h_iq = iq.cpu().numpy()
+        dem.reset()
+        dem.process(h_iq)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dem.process(h_iq)
+        host_path = 3.0 * C * N / (time.perf_counter() - t1) / 1e6
+
     if rank == 0:
         total_samples = float(world) * C * N * args.steps
         value = total_samples / elapsed / 1e6
@@ -204,6 +217,8 @@ def main():
                                  "(per-channel serial recurrences), see DESIGN.md"},
             "check": check,
         }
+        if host_path is not None:
+            out["host_path_msamples_s"] = round(host_path, 1)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg.synth, N)
         print(json.dumps(out))

@@ -43,7 +43,8 @@ enum {
 enum {
     TETRA_FLAG_TWO_KERNEL = 1,   /* run the two-kernel pipeline (AGC+FLL+RRC kernel -> HBM scratch -> timing/Costas kernel)
                                     instead of the fused single-kernel pipeline */
-    TETRA_FLAG_KEEP_RRC_OUT = 2  /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
+    TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
+    TETRA_FLAG_QUALITY = 4       /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
 };
 
 /* Input sample layout of process(): element (channel c, sample n) of the complex64 stream. */
@@ -158,6 +159,14 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
 /* Copies of the designed tables (any pointer may be NULL): rrc[taps], be_re[taps], be_im[taps]
  * (lower band-edge filter), bank[128*8]; *taps receives the tap count. */
 int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank);
+
+/* DQPSKSymbolExtractor's public `standarderr` / `sync` members (src/dsp/dqpsk_sym_extr.h:36-37; computed at
+ * dqpsk_sym_extr.cpp:8-31, read by the GUI at src/main.cpp:211,215) for every channel: the mean angular distance of
+ * the last 4096 symbols from their ideal constellation points, refreshed every 256 symbols, and sync = that < 0.35.
+ * standarderr[n_channels] / sync[n_channels] host arrays (either may be NULL).  A GUI float, not on the bit path: held
+ * to a tolerance (1e-4) against the reference formula rather than bit equality.  Needs TETRA_FLAG_QUALITY
+ * (TETRA_ERR_UNSUPPORTED otherwise); costs ~15 % throughput when enabled. */
+int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync);
 
 /* Debug/verification tap: RRC output (timing-recovery input) of the last process call,
  * y[n_channels][n_samples] complex64 channel-major, copied to host memory.  Needs TETRA_FLAG_TWO_KERNEL or

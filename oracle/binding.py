@@ -39,6 +39,9 @@ class State(C.Structure):
         ("costas_phase", C.c_float), ("costas_freq", C.c_float),
         ("ph2", C.c_float),
         ("prev", C.c_uint8),
+        ("errorbuf", C.c_float * 4096),
+        ("errorptr", C.c_int32), ("errordisplayptr", C.c_int32),
+        ("standarderr", C.c_float), ("sync", C.c_int32),
     ]
 
 

@@ -380,6 +380,23 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
 
         /* slicer + differential decoder, dqpsk_sym_extr.cpp:6-7, 32-52 */
         int a = zi < 0, b = zr < 0;
+        {
+            /* sync/quality statistic, dqpsk_sym_extr.cpp:8-31 (complex_t::phase() = atan2f(im, re)) */
+            float ideal_re = b ? -0.7071f : 0.7071f, ideal_im = a ? -0.7071f : 0.7071f;
+            float dist = fabsf(atan2f(ideal_im, ideal_re) - atan2f(zi, zr));
+            st->errorbuf[st->errorptr] = dist;
+            st->errorptr++;
+            if (st->errorptr >= 4096) st->errorptr = 0;
+            st->errordisplayptr++;
+            if (st->errordisplayptr >= 256) {
+                float xerr = 0;
+                for (int q = 0; q < 4096; q++) xerr += st->errorbuf[q];
+                xerr /= (float)4096;
+                st->standarderr = xerr;
+                st->sync = (xerr >= 0.35f) ? 0 : 1;
+                st->errordisplayptr = 0;
+            }
+        }
         uint8_t sym = (uint8_t)((a << 1) | (a != b));
         uint8_t pd = (uint8_t)((sym - prev + 4) % 4);
         static const uint8_t remap[4] = { 0, 1, 3, 2 };

@@ -75,6 +75,12 @@ typedef struct {
     float costas_phase, costas_freq;/* PLL pcl */
     float ph2;                      /* pi4dqpsk_costas.h:32 */
     uint8_t prev;                   /* dqpsk_sym_extr.h:42 */
+    /* sync/quality statistic of DQPSKSymbolExtractor (dqpsk_sym_extr.h:36-46, .cpp:9-31).  The reference leaves
+     * errorbuf uninitialised; a fresh state here starts it at zero. */
+    float errorbuf[4096];           /* SYNC_DETECT_BUF */
+    int32_t errorptr, errordisplayptr;
+    float standarderr;
+    int32_t sync;
 } tetra_oracle_state_t;
 
 /* Derived constants + tables, shared by all channels. */

@@ -17,6 +17,7 @@ LAYOUT_CHANNEL_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1
 FLAG_TWO_KERNEL = 1
 FLAG_KEEP_RRC_OUT = 2
+FLAG_QUALITY = 4
 
 PARAMS = dict(symbolrate=0, samplerate=1, rrc_tap_count=2, rrc_beta=3, agc_rate=4, costas_bandwidth=5,
               fll_bandwidth=6, omega_gain=7, mu_gain=8, omega_rel_limit=9)
@@ -26,7 +27,7 @@ EXPORTS = [
     "tetra_demod_bits_stride", "tetra_demod_process_device", "tetra_demod_process", "tetra_demod_reset",
     "tetra_demod_set_param", "tetra_demod_get_state", "tetra_demod_set_state", "tetra_demod_get_tables",
     "tetra_demod_debug_read_rrc_out", "tetra_demod_last_kernel_ms", "tetra_demod_strerror",
-    "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history",
+    "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history", "tetra_demod_get_quality",
 ]
 
 
@@ -96,6 +97,7 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_abi_version.argtypes = []
     L.tetra_demod_debug_selftest.argtypes = [vp, vp, vp]
     L.tetra_demod_kernel_ms_history.argtypes = [vp, i32, vp, vp]
+    L.tetra_demod_get_quality.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         if name != "tetra_demod_strerror":
             getattr(L, name).restype = i32
@@ -248,6 +250,13 @@ class Demodulator:
         out = np.zeros(320, np.float32)
         self._check(self._lib.tetra_demod_debug_selftest(self._h, _np_ptr(a), _np_ptr(out)), "tetra_demod_debug_selftest")
         return out.reshape(5, 64)
+
+    def quality(self):
+        """(standarderr float32[C], sync bool[C]) -- DQPSKSymbolExtractor's public members per channel."""
+        err = np.zeros(self.n_channels, np.float32)
+        sync = np.zeros(self.n_channels, np.uint8)
+        self._check(self._lib.tetra_demod_get_quality(self._h, _np_ptr(err), _np_ptr(sync)), "tetra_demod_get_quality")
+        return err, sync.astype(bool)
 
     def kernel_ms_history(self, n):
         k1 = np.zeros(n, np.float32)

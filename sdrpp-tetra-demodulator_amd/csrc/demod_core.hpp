@@ -243,11 +243,11 @@ template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
 }
 
 // SDR++ core complex_t::operator*: a * (c + j s) = (a.re*c - a.im*s, a.im*c + a.re*s), every product and the
-// sum/difference rounded separately.  Written with packed ops: (ar*c, ai*c) + (-(ai*s), ar*s).
+// sum/difference rounded separately.  Written with packed ops: (ar*c, ai*c) + (ai*(-s), ar*s).
 template <class V> TD_FN Pair<V> cmul_phasor(Pair<V> a, V c, V s) {
     Pair<V> t1 = pk_mul(a, Pair<V>(c, c));
-    Pair<V> t2 = pk_mul(pk_swap(a), Pair<V>(s, s));
-    return pk_add(t1, Pair<V>(-t2.x(), t2.y()));
+    Pair<V> t2 = pk_mul(pk_swap(a), Pair<V>(-s, s));      // (-(ai*s), ar*s): negating a factor is exact
+    return pk_add(t1, t2);
 }
 
 // SDR++ core complex_t::fastAmplitude: `r > i ? r + 0.4f*i : i + 0.4f*r` with r = |re|, i = |im|, written as
@@ -648,6 +648,53 @@ TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* z
     int pd = (symq - st.prev + 4) & 3;
     st.prev = symq;
     return pd ^ (pd >> 1);  // {0,1,2,3} -> {0,1,3,2}
+}
+
+// Sync/quality statistic of DQPSKSymbolExtractor::process (dqpsk_sym_extr.cpp:8-31): per symbol the angular distance
+// between the symbol and its quadrant's ideal point goes into a 4096-entry ring; every 256 symbols the ring's mean is
+// published as `standarderr`, and `sync = standarderr < 0.35`.  This is the GUI's signal-quality meter, NOT on the bit
+// path, so it is held to a tolerance instead of bit equality: the distance is pi/4 - atan(min/max) of the symbol's
+// |re|,|im| (equal to |atan2(ideal) - atan2(sym)| up to float rounding; Abramowitz-Stegun 4.4.49 polynomial,
+// |error| <= 2e-8, hardware reciprocal), and the ring mean is kept as a double running sum (new - old).
+struct QualityState {
+    double sum;
+    int ptr, disp;
+    float standarderr;
+    int sync;
+};
+TD_FN float quality_distance(float zr, float zi) {
+    const float ar = v_abs(zr), ai = v_abs(zi);
+    const float hi = v_max(ar, ai), lo = v_min(ar, ai);
+#if TD_DEVICE
+    const float inv = __builtin_amdgcn_rcpf(hi);
+#else
+    const float inv = 1.0f / hi;
+#endif
+    const float r = hi > 0.0f ? lo * inv : 0.0f;     // atan2f(0, 0) = 0 in the reference -> distance pi/4
+    const float z = r * r;
+    float p = v_fma(0.0028662257f, z, -0.0161657367f);
+    p = v_fma(p, z, 0.0429096138f);
+    p = v_fma(p, z, -0.0752896400f);
+    p = v_fma(p, z, 0.1065626393f);
+    p = v_fma(p, z, -0.1420889944f);
+    p = v_fma(p, z, 0.1999355085f);
+    p = v_fma(p, z, -0.3333314528f);
+    p = v_fma(p, z, 1.0f);
+    return 0.785398163397448f - p * r;
+}
+// ring: this channel's 4096 floats.
+TD_FN void quality_step(QualityState& q, float* ring, float zr, float zi) {
+    const float d = quality_distance(zr, zi);
+    const float old = ring[q.ptr];
+    ring[q.ptr] = d;
+    q.sum += (double)d - (double)old;
+    q.ptr = (q.ptr + 1) & 4095;
+    q.disp++;
+    if (q.disp >= 256) {
+        q.standarderr = (float)(q.sum * (1.0 / 4096.0));
+        q.sync = q.standarderr >= 0.35f ? 0 : 1;
+        q.disp = 0;
+    }
 }
 
 // Both halves for one symbol (kernel 2 of the two-kernel pipeline).

@@ -63,6 +63,11 @@ struct FusedParams {
     int* n_bits;
     float2* sym;         // optional
     float2* y_dbg;       // optional: time-major scratch [(7+n)][C], row 7+i = y_i
+    // optional sync/quality statistic (TETRA_FLAG_QUALITY): ring [C][4096] + per-channel state; null = off
+    float* q_ring;
+    double* q_sum;
+    int *q_ptr, *q_disp, *q_sync;
+    float* q_err;
     K1Consts k1;
     K2Consts k2;
     int ablate;          // debug/profiling only: bit r set = role r keeps its barriers but skips its work (results invalid)
@@ -120,7 +125,7 @@ struct FllDeviceIO {
         __syncthreads();                          \
     }
 
-template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(FusedParams p) {
+template <bool ALPHA0, bool QUALITY> __global__ __launch_bounds__(kFThreads) void k_fused(FusedParams p) {
     __shared__ FusedLds L;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,6 +321,15 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
         uint8_t* brow = p.bits + (long long)chan(c) * p.bits_stride;
         float2* srow = p.sym ? p.sym + (long long)chan(c) * (p.bits_stride / 2) : nullptr;
         const bool wr = on && live(c);
+        const bool qon = QUALITY;   // compile-time: the statistic's code must not weigh on the default kernel
+        QualityState q;
+        q.sum = 0.0; q.ptr = 0; q.disp = 0; q.standarderr = 0.0f; q.sync = 0;
+        float* qring = nullptr;
+        if (qon) {
+            q.sum = p.q_sum[chan(c)]; q.ptr = p.q_ptr[chan(c)]; q.disp = p.q_disp[chan(c)];
+            q.standarderr = p.q_err[chan(c)]; q.sync = p.q_sync[chan(c)];
+            qring = p.q_ring + (long long)chan(c) * 4096;
+        }
         __syncthreads();
         FUSED_EPOCHS(
             if (e >= 4 && on && !(p.ablate & 16)) {
@@ -328,6 +342,7 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
                         // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
                         *reinterpret_cast<unsigned short*>(brow + 2 * S) = (unsigned short)(((d >> 1) & 1) | ((d & 1) << 8));
                         if (srow) srow[S] = make_float2(zr, zi);
+                        if (qon) quality_step(q, qring, zr, zi);
                     }
                     S++;
                 }
@@ -339,6 +354,10 @@ template <bool ALPHA0> __global__ __launch_bounds__(kFThreads) void k_fused(Fuse
             p.ph2[ch0 + c] = st.ph2;
             p.prev[ch0 + c] = st.prev;
             p.n_bits[ch0 + c] = 2 * S;
+            if (qon) {
+                p.q_sum[ch0 + c] = q.sum; p.q_ptr[ch0 + c] = q.ptr; p.q_disp[ch0 + c] = q.disp;
+                p.q_err[ch0 + c] = q.standarderr; p.q_sync[ch0 + c] = q.sync;
+            }
         }
     }
     // delay lines: last 80 FLL outputs, last 7 RRC outputs (both rings still hold them; the loops end on a barrier)

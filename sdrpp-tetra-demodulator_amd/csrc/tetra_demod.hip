@@ -64,6 +64,10 @@ struct K2Params {
     long long bits_stride;
     int* n_bits;
     float2* sym;                          // optional [n_channels][bits_stride/2]
+    float* q_ring;                        // optional sync/quality statistic (see FusedParams)
+    double* q_sum;
+    int *q_ptr, *q_disp, *q_sync;
+    float* q_err;
     K2Consts k;
 };
 
@@ -199,6 +203,14 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
     unsigned long long pack = 0;   // up to 4 symbols = 8 bit-bytes
     uint8_t* brow = p.bits + (long long)chl * p.bits_stride;
     float2* srow = p.sym ? p.sym + (long long)chl * (p.bits_stride / 2) : nullptr;
+    const bool qon = p.q_ring != nullptr;
+    QualityState qs;
+    qs.sum = 0.0; qs.ptr = 0; qs.disp = 0; qs.standarderr = 0.0f; qs.sync = 0;
+    float* qring = nullptr;
+    if (qon) {
+        qs.sum = p.q_sum[chl]; qs.ptr = p.q_ptr[chl]; qs.disp = p.q_disp[chl]; qs.standarderr = p.q_err[chl]; qs.sync = p.q_sync[chl];
+        qring = p.q_ring + (long long)chl * 4096;
+    }
     __syncthreads();
 
     while (true) {
@@ -252,6 +264,7 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
                 float zr, zi;
                 const int d = k2_symbol(p.k, st, phase, w, tm1, t0, tp1, &zr, &zi);
                 if (srow) srow[S] = make_float2(zr, zi);
+                if (qon) quality_step(qs, qring, zr, zi);
                 // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
                 const unsigned long long two = (unsigned long long)((d >> 1) & 1) | ((unsigned long long)(d & 1) << 8);
                 pack |= two << (16 * (S & 3));
@@ -275,6 +288,9 @@ __global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
         p.cfr[ch] = st.cfr;
         p.ph2[ch] = st.ph2;
         p.prev[ch] = st.prev;
+        if (qon) {
+            p.q_sum[ch] = qs.sum; p.q_ptr[ch] = qs.ptr; p.q_disp[ch] = qs.disp; p.q_err[ch] = qs.standarderr; p.q_sync[ch] = qs.sync;
+        }
         // delay buffer update, complex_fd.cpp:148: rows n..n+6 become rows 0..6
         float2 tmp[kYHist];
 #pragma unroll
@@ -330,6 +346,10 @@ struct tetra_demod {
     int *offset = nullptr, *prev = nullptr;
     float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
+    float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state
+    double* q_sum = nullptr;
+    int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
+    float* q_err = nullptr;
     bool fused = true;          // pipeline in use
     bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
@@ -430,6 +450,14 @@ int reset_range(tetra_demod* h, int first, int count) {
     HIP_TRY(h, hipMemsetAsync(h->cfr + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->ph2 + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->prev + first, 0, sizeof(int) * count, 0));
+    if (h->q_ring) {   // DQPSKSymbolExtractor's statistic: ring and counters back to a fresh block's (zeros)
+        HIP_TRY(h, hipMemsetAsync(h->q_ring + (size_t)first * 4096, 0, sizeof(float) * 4096 * (size_t)count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->q_sum + first, 0, sizeof(double) * count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->q_ptr + first, 0, sizeof(int) * count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->q_disp + first, 0, sizeof(int) * count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->q_sync + first, 0, sizeof(int) * count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->q_err + first, 0, sizeof(float) * count, 0));
+    }
     // COMPLEX_FD delay buffer: fused pipeline keeps it in ybuf, the two-kernel pipeline in the first kYHist
     // rows of the time-major y scratch (columns [first, first+count))
     HIP_TRY(h, hipMemsetAsync(h->ybuf + (size_t)first * kYHist, 0, sizeof(float2) * kYHist * (size_t)count, 0));
@@ -441,7 +469,7 @@ int reset_range(tetra_demod* h, int first, int count) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->y, h->ybuf, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -558,6 +586,10 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     h->keep_y = !h->fused || (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT);
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
+    if (cfg->flags & TETRA_FLAG_QUALITY) {
+        A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_sum, C)); A(dalloc(h, &h->q_ptr, C));
+        A(dalloc(h, &h->q_disp, C)); A(dalloc(h, &h->q_sync, C)); A(dalloc(h, &h->q_err, C));
+    }
     A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
     A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
     A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
@@ -637,6 +669,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
     p2.bits_stride = bits_stride;
     p2.n_bits = d_n_bits;
     p2.sym = reinterpret_cast<float2*>(d_sym);
+    p2.q_ring = h->q_ring; p2.q_sum = h->q_sum; p2.q_ptr = h->q_ptr; p2.q_disp = h->q_disp; p2.q_sync = h->q_sync;
+    p2.q_err = h->q_err;
     p2.k = h->design.k2;
 
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
@@ -651,6 +685,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
+        pf.q_ring = h->q_ring; pf.q_sum = h->q_sum; pf.q_ptr = h->q_ptr; pf.q_disp = h->q_disp; pf.q_sync = h->q_sync;
+        pf.q_err = h->q_err;
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
         {
             const char* ab = std::getenv("TETRA_DEMOD_ABLATE");   // profiling aid, see kernel_fused.hpp
@@ -658,8 +694,11 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         }
         const dim3 gf((h->C + kFCh - 1) / kFCh);
         HIP_TRY(h, hipEventRecord(ev[0], s));
-        if (pf.k1.fll_alpha == 0.0f) hipLaunchKernelGGL(k_fused<true>, gf, dim3(kFThreads), 0, s, pf);
-        else hipLaunchKernelGGL(k_fused<false>, gf, dim3(kFThreads), 0, s, pf);
+        const bool a0 = pf.k1.fll_alpha == 0.0f, ql = pf.q_ring != nullptr;
+        if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
+        else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
+        else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false>), gf, dim3(kFThreads), 0, s, pf);
+        else hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(ev[1], s));
         HIP_TRY(h, hipEventRecord(ev[2], s));
@@ -860,6 +899,21 @@ int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* k1_ms, float* 
 
 int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms) {
     return tetra_demod_kernel_ms_history(h, 1, k1_ms, k2_ms);
+}
+
+int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync) {
+    if (!h) return TETRA_ERR_ARG;
+    if (!h->q_ring) return TETRA_ERR_UNSUPPORTED;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (standarderr) HIP_TRY(h, hipMemcpy(standarderr, h->q_err, sizeof(float) * (size_t)h->C, hipMemcpyDeviceToHost));
+    if (sync) {
+        std::vector<int> tmp((size_t)h->C);
+        HIP_TRY(h, hipMemcpy(tmp.data(), h->q_sync, sizeof(int) * (size_t)h->C, hipMemcpyDeviceToHost));
+        for (int c = 0; c < h->C; c++) sync[c] = (uint8_t)(tmp[c] != 0);
+    }
+    return TETRA_OK;
 }
 
 int tetra_demod_last_hip_error(tetra_demod_t* h) { return h ? h->last_hip : 0; }

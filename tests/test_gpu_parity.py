@@ -322,6 +322,32 @@ def test_parity_4096_channels_full_second(pkg, oracle, synth):
     assert not bad
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_quality_statistic(pkg, oracle, synth, pipeline):
+    """standarderr / sync (dqpsk_sym_extr.cpp:8-31) per channel vs the oracle's faithful restatement (libm atan2f,
+    float ring, sequential sum): tolerance 1e-4 (GUI meter, not on the bit path); bits stay bit-exact with it on."""
+    Cn, N = 12, 9000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=111)
+    rng = np.random.default_rng(3)
+    iq[2] = (0.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)   # noise: no sync
+    iq[5] = synth.gen_channel(N, 9, esn0_db=12.0)[0]
+    d = pkg.Demodulator(Cn, 3000, flags=(PIPELINES[pipeline] & 1) | pkg.binding.FLAG_QUALITY)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    for pos in range(0, N, 3000):
+        bits, nb, _ = d.process(iq[:, pos:pos + 3000])
+        err, sync = d.quality()
+        for c in range(Cn):
+            r = orcs[c].process(iq[c, pos:pos + 3000])
+            assert np.array_equal(bits[c][:nb[c]], r["bits"])
+            assert abs(err[c] - orcs[c].st.standarderr) < 1e-4, (c, err[c], orcs[c].st.standarderr)
+            if abs(orcs[c].st.standarderr - 0.35) > 1e-3:
+                assert bool(sync[c]) == bool(orcs[c].st.sync), c
+    assert not sync[2] and sync[0]
+    with pytest.raises(pkg.TetraDemodError):
+        pkg.Demodulator(1, 64).quality()
+    d.close()
+
+
 def test_errors(pkg):
     B = pkg.binding
     d = pkg.Demodulator(2, 100)
