@@ -193,3 +193,47 @@ def bits_stride(n_samples):
 
 def max_threads():
     return int(lib().tetra_oracle_max_threads())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Channeliser front-end definition (oracle/chan_oracle.c) -- test infrastructure, like everything in here.
+# ---------------------------------------------------------------------------------------------------------
+_CHAN_LIB_PATH = os.path.join(_HERE, "libchan_oracle.so")
+_chan = None
+
+
+def chan_lib():
+    global _chan
+    if _chan is None:
+        src = os.path.join(_HERE, "chan_oracle.c")
+        if not os.path.exists(_CHAN_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_CHAN_LIB_PATH):
+            subprocess.run(["make", "-C", _HERE, "-B", "libchan_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(_CHAN_LIB_PATH)
+        vp = C.c_void_p
+        L.chan_oracle_prototype.argtypes = [C.c_int, C.c_int, C.c_double, vp]
+        L.chan_oracle_prototype.restype = None
+        L.chan_oracle_process.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                                          C.c_int, vp, vp]
+        L.chan_oracle_process.restype = C.c_int
+        _chan = L
+    return _chan
+
+
+class ChanOracle:
+    """Definition-level analysis filter bank in double precision (slow: O(M * L) per frame)."""
+
+    def __init__(self, M, P, D, cutoff_rel=1.2):
+        self.M, self.P, self.D = M, P, D
+        self.h = np.zeros(M * P, np.float32)
+        chan_lib().chan_oracle_prototype(M, P, cutoff_rel, _ptr(self.h))
+        self.hist = np.zeros(M * P - 1, np.complex64)
+        self.phase = C.c_int(0)
+        self.frame = C.c_int64(0)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        nf = (self.phase.value + x.shape[0]) // self.D
+        out = np.zeros((max(nf, 1), self.M), np.complex64)
+        got = chan_lib().chan_oracle_process(self.M, self.P, self.D, _ptr(self.h), _ptr(self.hist), C.byref(self.phase),
+                                             C.byref(self.frame), x.shape[0], _ptr(x), _ptr(out))
+        return out[:got]

@@ -1,0 +1,100 @@
+/*
+ * chan_oracle.c -- CPU restatement of the polyphase channeliser front-end (TEST INFRASTRUCTURE ONLY).
+ *
+ * The reference plugin has no channeliser: it asks SDR++ for one VFO per instance (src/main.cpp:75,
+ * sigpath::vfoManager.createVFO(..., VFO_SAMPLERATE ...)), i.e. a per-channel DDC that lives in SDR++
+ * core.  BASELINE.json config 5 / SURVEY.md section 8(f) #1 replace N such VFOs by one analysis filter
+ * bank.  There is therefore no reference code to follow; this file states the DEFINITION the GPU kernel
+ * is checked against, evaluated the slow, obvious way in double precision:
+ *
+ *   y_k[m] = sum_{l=0}^{L-1} h[l] * x[m*D - l] * exp(-j*2*pi*k*(m*D - l)/M),   k = 0..M-1
+ *
+ * = channel k is the band centred at k*Fs/M (k > M/2: negative frequencies), mixed to baseband, low-pass
+ * filtered by the prototype h (L = P*M taps) and decimated by D.  Samples before the start of the stream
+ * (index < 0) come from the carried history (zeros initially).  Frames are emitted time-major: out[m][k].
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define CH_PI 3.14159265358979323846
+
+/* Prototype low-pass: Kaiser-windowed sinc (beta 9), cutoff = cutoff_rel * (Fs/M)/2 ... in cycles/sample
+ * fc = cutoff_rel / (2*M); unity DC gain.  Same formula as csrc/chan_design.hpp. */
+static double bessel_i0(double x) {
+    double s = 1.0, t = 1.0;
+    for (int k = 1; k < 60; k++) {
+        t *= (x / (2.0 * k)) * (x / (2.0 * k));
+        s += t;
+        if (t < 1e-18 * s) break;
+    }
+    return s;
+}
+
+void chan_oracle_prototype(int M, int P, double cutoff_rel, float* h) {
+    const int L = M * P;
+    const double fc = cutoff_rel / (2.0 * (double)M);
+    const double beta = 9.0;
+    double sum = 0.0;
+    double* t = (double*)malloc(sizeof(double) * (size_t)L);
+    for (int l = 0; l < L; l++) {
+        const double u = (double)l - 0.5 * (double)(L - 1);
+        const double sinc = (u == 0.0) ? 2.0 * fc : sin(2.0 * CH_PI * fc * u) / (CH_PI * u);
+        const double r = 2.0 * u / (double)(L - 1);
+        const double w = bessel_i0(beta * sqrt(1.0 - r * r > 0 ? 1.0 - r * r : 0.0)) / bessel_i0(beta);
+        t[l] = sinc * w;
+        sum += t[l];
+    }
+    for (int l = 0; l < L; l++) h[l] = (float)(t[l] / sum);
+    free(t);
+}
+
+/* x: n_in wideband samples (re,im); hist: the L-1 samples preceding x[0] (oldest first), updated on return.
+ * Emits frames m = 0 .. n_frames-1 with n_frames = floor((phase + n_in) / D) where `phase` in [0, D) is the number of
+ * samples already consumed towards the next frame (carried in *phase).  Frame j of this call is aligned so that its
+ * newest sample is x[(j+1)*D - 1 - phase0].  out: [n_frames][M] complex (re,im).  Returns n_frames. */
+int chan_oracle_process(int M, int P, int D, const float* h, float* hist, int* phase, int64_t* frame_index,
+                        int n_in, const float* x, float* out) {
+    const int L = M * P;
+    const int ph0 = *phase;
+    const int n_frames = (ph0 + n_in) / D;
+    /* linear buffer: hist (L-1) + x */
+    double* br = (double*)malloc(sizeof(double) * (size_t)(L - 1 + n_in) * 2);
+    for (int i = 0; i < L - 1; i++) { br[2 * i] = hist[2 * i]; br[2 * i + 1] = hist[2 * i + 1]; }
+    for (int i = 0; i < n_in; i++) { br[2 * (L - 1 + i)] = x[2 * i]; br[2 * (L - 1 + i) + 1] = x[2 * i + 1]; }
+    const int64_t f0 = *frame_index;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int j = 0; j < n_frames; j++) {
+        const int newest = (j + 1) * D - 1 - ph0;            /* index into x of this frame's newest sample */
+        /* absolute sample time of the newest sample: n_abs = (f0 + j + 1)*D - 1  (stream starts at n = 0) */
+        const int64_t n_abs = (f0 + j + 1) * (int64_t)D - 1;
+        for (int k = 0; k < M; k++) {
+            double ar = 0.0, ai = 0.0;
+            for (int l = 0; l < L; l++) {
+                const int bi = (L - 1) + newest - l;          /* >= 0 */
+                const int64_t n = n_abs - l;
+                const int64_t kn = ((int64_t)k * (n % M + M)) % M; /* k*n mod M */
+                const double ang = -2.0 * CH_PI * (double)kn / (double)M;
+                const double c = cos(ang), s = sin(ang);
+                const double xr = br[2 * bi], xi = br[2 * bi + 1];
+                ar += (double)h[l] * (xr * c - xi * s);
+                ai += (double)h[l] * (xr * s + xi * c);
+            }
+            out[((size_t)j * M + k) * 2] = (float)ar;
+            out[((size_t)j * M + k) * 2 + 1] = (float)ai;
+        }
+    }
+    /* carry */
+    const int consumed = n_in;
+    for (int i = 0; i < L - 1; i++) { hist[2 * i] = (float)br[2 * (consumed + i)]; hist[2 * i + 1] = (float)br[2 * (consumed + i) + 1]; }
+    *phase = (ph0 + n_in) % D;
+    *frame_index = f0 + n_frames;
+    free(br);
+    return n_frames;
+}

@@ -6,8 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtetra_demod_hip.so")
-SOURCES = ["tetra_demod.hip"]
-DEPS = ["tetra_demod.hip", "demod_core.hpp", "design.hpp", os.path.join("..", "..", "include", "tetra_demod.h")]
+SOURCES = ["tetra_demod.hip", "tetra_chan.hip"]
+DEPS = ["tetra_demod.hip", "tetra_chan.hip", "demod_core.hpp", "design.hpp", "kernel_fused.hpp",
+        os.path.join("..", "..", "include", "tetra_demod.h"), os.path.join("..", "..", "include", "tetra_chan.h")]
 
 # -ffp-contract=off + correctly rounded sqrt: the arithmetic contract shared with the oracle.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",

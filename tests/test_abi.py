@@ -25,6 +25,16 @@ def test_header_symbols_all_exported(pkg):
     assert L.tetra_demod_abi_version() == 1
 
 
+def test_channeliser_header_symbols_all_exported(pkg):
+    src = open(os.path.join(ROOT, "include", "tetra_chan.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(tetra_chan_[a-z0-9_]+)\s*\(", src)))
+    L = pkg.load_library()
+    assert len(names) == 9 and set(names) == set(pkg.chan_binding.CHAN_EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+
+
 def test_default_config_is_the_plugins(pkg):
     cfg = pkg.binding.default_config()
     # src/main.cpp:35-44,78-84
