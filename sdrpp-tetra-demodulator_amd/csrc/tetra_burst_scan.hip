@@ -1,0 +1,168 @@
+// tetra_burst_scan.hip -- batched training-sequence search (include/tetra_burst_scan.h), bit-exact with the reference's
+// tetra_find_train_seq() (src/decoder/src/phy/tetra_burst.c:271-341).
+//
+// One 256-thread workgroup per channel.  The row is walked in tiles of 8192 positions: the tile's bytes (one bit each)
+// are read once with coalesced dword loads and packed MSB-first into 32-bit words in LDS; every position then pulls its
+// 22-bit look-ahead window out of two adjacent words with a funnel shift and compares it with the five sequence heads.
+// Candidates are verified against the full sequence (bytes, rare) and reduced with an LDS atomicMin on
+// (position << 3 | check order), which is exactly "first position, then the reference's if-chain order".  The first 21
+// positions reproduce the reference's misaligned pre-filter (see the header).  Integer/byte work: HBM-bound, every input
+// byte is read from HBM once.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/tetra_burst_scan.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTile = 8192;                  // positions per tile
+constexpr int kTileWords = kTile / 32 + 2;   // + look-ahead
+
+// ETSI EN 300 392-2 9.4.4.3.2-4 (the reference holds the same bits at tetra_burst.c:61-72)
+__constant__ uint8_t c_seq[5][38] = {
+    /* check order of the reference's if-chain: y (sync), n, p, q (normal 1-3), x (extended) */
+    { 1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1 },
+    { 1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0 },
+    { 0,1, 1,1, 1,0, 1,0, 0,1, 0,0, 0,0, 1,1, 0,1, 1,1, 1,0 },
+    { 1,0, 1,1, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 1,0, 1,1, 0,1 },
+    { 1,0, 0,1, 1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0, 0,0, 1,1 },
+};
+__constant__ int c_len[5] = { 38, 22, 22, 22, 30 };
+__constant__ int c_type[5] = { TETRA_TRAIN_SYNC, TETRA_TRAIN_NORM_1, TETRA_TRAIN_NORM_2, TETRA_TRAIN_NORM_3, TETRA_TRAIN_EXT };
+
+__device__ __forceinline__ unsigned head22(int s) {
+    unsigned v = 0;
+    for (int i = 0; i < 22; i++) v = (v << 1) | c_seq[s][i];
+    return v;
+}
+
+// full check of the reference's if-chain at position cur; returns the check-order index 0..4 or 5 for none
+__device__ int verify(const uint8_t* in, int cur, int end_of_in, unsigned mask) {
+    const int remain = end_of_in - cur;
+    for (int s = 0; s < 5; s++) {
+        if (!(mask & (1u << c_type[s])) || remain < c_len[s]) continue;
+        bool eq = true;
+        for (int i = 0; i < c_len[s]; i++)
+            if (in[cur + i] != c_seq[s][i]) { eq = false; break; }
+        if (eq) return s;
+    }
+    return 5;
+}
+
+__global__ __launch_bounds__(kThreads) void k_find_train_seq(const uint8_t* bits, int bits_stride, const int* end_of_in,
+                                                             unsigned mask, int* type_out, int* off_out) {
+    __shared__ unsigned packed[kTileWords];
+    __shared__ unsigned best;              // (cur << 3) | check-order index
+    __shared__ unsigned heads[5];
+    const int ch = blockIdx.x;
+    const uint8_t* in = bits + (long long)ch * bits_stride;
+    const int end = end_of_in[ch];
+    if (threadIdx.x == 0) best = 0xffffffffu;
+    if (threadIdx.x < 5) heads[threadIdx.x] = head22(threadIdx.x);
+    __syncthreads();
+
+    // positions 0..20: the reference's pre-filter is seeded with in[0..19] and then receives in[cur+21] (in[20] is skipped)
+    if (threadIdx.x == 0 && end > 0) {
+        unsigned filter = 0;
+        for (int i = 0; i < 20; i++) filter = (filter << 1) | in[i];
+        const int lim = end < 21 ? end : 21;
+        for (int cur = 0; cur < lim; cur++) {
+            filter = ((filter << 1) | in[cur + 21]) & 0x3fffffu;
+            bool m = false;
+            for (int s = 0; s < 5; s++) m |= (filter == heads[s]);
+            if (m) {
+                const int s = verify(in, cur, end, mask);
+                if (s < 5) { atomicMin(&best, ((unsigned)cur << 3) | (unsigned)s); break; }
+            }
+        }
+    }
+
+    for (int base = 0; base < end; base += kTile) {
+        __syncthreads();
+        if (best != 0xffffffffu && (int)(best >> 3) < base) break;      // an earlier match ends the scan (uniform)
+        // pack bytes [base, base + kTile + 64) to bits, MSB first; bytes past the row are taken as 0 (never reached by
+        // a position < end whose 22-bit window lies inside end + 21 <= bits_stride)
+        for (int w = threadIdx.x; w < kTileWords; w += kThreads) {
+            unsigned v = 0;
+            const int b0 = base + 32 * w;
+            for (int q = 0; q < 8; q++) {
+                const int b = b0 + 4 * q;
+                unsigned d = 0;
+                if (b + 3 < bits_stride) d = *reinterpret_cast<const unsigned*>(in + b);   // rows are 4-byte aligned
+                else for (int z = 0; z < 4; z++) if (b + z < bits_stride) d |= (unsigned)in[b + z] << (8 * z);
+                // little-endian dword: byte z = bit position 4q + z of the word
+                v |= ((d & 1u) << (31 - 4 * q)) | (((d >> 8) & 1u) << (30 - 4 * q)) | (((d >> 16) & 1u) << (29 - 4 * q)) |
+                     (((d >> 24) & 1u) << (28 - 4 * q));
+            }
+            packed[w] = v;
+        }
+        __syncthreads();
+        const int lim = (end - base < kTile) ? (end - base) : kTile;
+        for (int r = threadIdx.x; r < lim; r += kThreads) {
+            const int cur = base + r;
+            if (cur < 21) continue;                                      // handled above
+            const unsigned long long two = ((unsigned long long)packed[r >> 5] << 32) | packed[(r >> 5) + 1];
+            const unsigned f = (unsigned)(two >> (64 - 22 - (r & 31))) & 0x3fffffu;
+            if (f == heads[0] || f == heads[1] || f == heads[2] || f == heads[3] || f == heads[4]) {
+                const int s = verify(in, cur, end, mask);
+                if (s < 5) atomicMin(&best, ((unsigned)cur << 3) | (unsigned)s);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (best == 0xffffffffu) { type_out[ch] = -1; off_out[ch] = -1; }
+        else { type_out[ch] = c_type[best & 7u]; off_out[ch] = (int)(best >> 3); }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tetra_find_train_seq_batch_device(const uint8_t* d_bits, int n_channels, int bits_stride, const int32_t* d_end_of_in,
+                                      uint32_t mask, int32_t* d_type, int32_t* d_offset, void* hip_stream) {
+    if (!d_bits || !d_end_of_in || !d_type || !d_offset || n_channels < 1 || bits_stride < 4) return TETRA_ERR_ARG;
+    if ((bits_stride & 3) || (reinterpret_cast<uintptr_t>(d_bits) & 3)) return TETRA_ERR_ALIGN;
+    hipLaunchKernelGGL(k_find_train_seq, dim3(n_channels), dim3(kThreads), 0, (hipStream_t)hip_stream, d_bits, bits_stride,
+                       d_end_of_in, mask, d_type, d_offset);
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_find_train_seq_batch(const uint8_t* bits, int n_channels, int bits_stride, const int32_t* end_of_in, uint32_t mask,
+                               int32_t* type, int32_t* offset, int device) {
+    if (!bits || !end_of_in || !type || !offset || n_channels < 1 || bits_stride < 4) return TETRA_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TETRA_ERR_NO_DEVICE;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (device >= 0) {
+        if (device >= ndev || hipSetDevice(device) != hipSuccess) return TETRA_ERR_NO_DEVICE;
+    }
+    uint8_t* d_bits = nullptr;
+    int *d_end = nullptr, *d_t = nullptr, *d_o = nullptr;
+    const size_t nb = (size_t)n_channels * (size_t)bits_stride;
+    int rc = TETRA_OK;
+    if (hipMalloc((void**)&d_bits, nb) != hipSuccess || hipMalloc((void**)&d_end, sizeof(int) * n_channels) != hipSuccess ||
+        hipMalloc((void**)&d_t, sizeof(int) * n_channels) != hipSuccess || hipMalloc((void**)&d_o, sizeof(int) * n_channels) != hipSuccess)
+        rc = TETRA_ERR_NOMEM;
+    if (rc == TETRA_OK && (hipMemcpy(d_bits, bits, nb, hipMemcpyHostToDevice) != hipSuccess ||
+                           hipMemcpy(d_end, end_of_in, sizeof(int) * n_channels, hipMemcpyHostToDevice) != hipSuccess))
+        rc = TETRA_ERR_HIP;
+    if (rc == TETRA_OK) rc = tetra_find_train_seq_batch_device(d_bits, n_channels, bits_stride, d_end, mask, d_t, d_o, nullptr);
+    if (rc == TETRA_OK && (hipStreamSynchronize(0) != hipSuccess ||
+                           hipMemcpy(type, d_t, sizeof(int) * n_channels, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(offset, d_o, sizeof(int) * n_channels, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = TETRA_ERR_HIP;
+    if (d_bits) (void)hipFree(d_bits);
+    if (d_end) (void)hipFree(d_end);
+    if (d_t) (void)hipFree(d_t);
+    if (d_o) (void)hipFree(d_o);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // extern "C"

@@ -35,3 +35,12 @@ def emul():
     from tests.emul import emul_bind
     emul_bind.build()
     return emul_bind
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The reference's own phy/tetra_burst.c built into oracle/_ref (oracle/build_ref.sh)."""
+    from oracle import ref_binding
+    if not ref_binding.available():
+        pytest.skip("oracle/_ref not built and /root/reference not present")
+    return ref_binding

@@ -35,6 +35,16 @@ def test_channeliser_header_symbols_all_exported(pkg):
         assert hasattr(L, n), n
 
 
+def test_burst_scan_header_symbols_all_exported(pkg):
+    src = open(os.path.join(ROOT, "include", "tetra_burst_scan.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(tetra_find_train_seq_batch[a-z_]*)\s*\(", src)))
+    L = pkg.load_library()
+    assert set(names) == set(pkg.scan_binding.SCAN_EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+
+
 def test_default_config_is_the_plugins(pkg):
     cfg = pkg.binding.default_config()
     # src/main.cpp:35-44,78-84

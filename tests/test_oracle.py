@@ -98,6 +98,41 @@ def test_training_sequence_found_at_slot_spacing(oracle, synth):
     assert all((good[i + 1] - good[i]) % 510 == 0 for i in range(len(good) - 1))
 
 
+def test_reference_built_bursts_lock_on_the_oracle(oracle, synth, ref):
+    """Reference-anchored known answer: bursts from the reference's OWN builders (tetra_burst.c:171-269, via
+    oracle/_ref) -> IQ -> oracle chain -> the reference's OWN tetra_find_train_seq finds sync bursts every 4 slots
+    and normal bursts at 510-bit spacing in the demodulated stream."""
+    rng = np.random.default_rng(17)
+    nslots = 40
+    slots = []
+    for s in range(nslots):
+        if s % 4 == 0:
+            slots.append(ref.build_sync_burst(rng.integers(0, 2, 120), rng.integers(0, 2, 30), rng.integers(0, 2, 216)))
+        else:
+            slots.append(ref.build_norm_burst(rng.integers(0, 2, 216), rng.integers(0, 2, 30), rng.integers(0, 2, 216), s % 2))
+    tx = np.concatenate(slots)
+    N = nslots * 510 - 200
+    iq, _, _ = synth.gen_channel(N, 5, bits=tx)
+    rx = oracle.Oracle().process(iq)["bits"]
+    hits, pos = [], 6000
+    while pos < rx.size - 600:
+        t, o = ref.find_train_seq(rx[pos:], int(rx.size - pos - 64))
+        if t < 0:
+            break
+        hits.append((t, pos + o))
+        pos += o + 60
+    sync = [o for t, o in hits if t == ref.TRAIN_SYNC]
+    norm = [o for t, o in hits if t in (ref.TRAIN_NORM_1, ref.TRAIN_NORM_2)]
+    assert len(hits) >= 25 and len(sync) >= 5
+    assert all((b - a) % (4 * 510) == 0 for a, b in zip(sync, sync[1:]))
+    assert all((b - a) % 510 == 0 for a, b in zip(norm, norm[1:]))
+    # the demodulated slot payload equals the transmitted burst bit for bit (constant lag)
+    lag = sync[-1] - 214 - ((sync[-1] - 214) // 510) * 510
+    seg = rx[sync[-1] - 214: sync[-1] - 214 + 510]
+    k = [i for i in range(nslots) if np.array_equal(seg, slots[i])]
+    assert len(k) == 1 and k[0] % 4 == 0, lag
+
+
 def test_chunk_invariance(oracle, synth):
     N = 9000
     iq, _, _ = synth.gen_channel(N, 5)
