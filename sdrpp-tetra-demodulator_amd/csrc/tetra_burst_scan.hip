@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTile = 8192;                  // positions per tile
+constexpr int kTile = 32768;                 // positions per tile
 constexpr int kTileWords = kTile / 32 + 2;   // + look-ahead
 
 // ETSI EN 300 392-2 9.4.4.3.2-4 (the reference holds the same bits at tetra_burst.c:61-72)
@@ -86,16 +86,27 @@ __global__ __launch_bounds__(kThreads) void k_find_train_seq(const uint8_t* bits
         // pack bytes [base, base + kTile + 64) to bits, MSB first; bytes past the row are taken as 0 (never reached by
         // a position < end whose 22-bit window lies inside end + 21 <= bits_stride)
         for (int w = threadIdx.x; w < kTileWords; w += kThreads) {
-            unsigned v = 0;
             const int b0 = base + 32 * w;
-            for (int q = 0; q < 8; q++) {
-                const int b = b0 + 4 * q;
-                unsigned d = 0;
-                if (b + 3 < bits_stride) d = *reinterpret_cast<const unsigned*>(in + b);   // rows are 4-byte aligned
-                else for (int z = 0; z < 4; z++) if (b + z < bits_stride) d |= (unsigned)in[b + z] << (8 * z);
-                // little-endian dword: byte z = bit position 4q + z of the word
-                v |= ((d & 1u) << (31 - 4 * q)) | (((d >> 8) & 1u) << (30 - 4 * q)) | (((d >> 16) & 1u) << (29 - 4 * q)) |
-                     (((d >> 24) & 1u) << (28 - 4 * q));
+            unsigned v = 0;
+            if (b0 + 32 <= bits_stride) {
+                // 32 bytes as two 16-byte loads (rows and tiles are 16-byte aligned when bits_stride % 16 == 0; otherwise the
+                // dword path below is used); 8 bytes -> 8 bits, first byte = MSB, with one multiply: the partial products
+                // of x * 0x8040201008040201 land on distinct bit positions, byte i reaching bit 63 - i.
+                unsigned long long q[4];
+                if (((bits_stride | b0) & 15) == 0) {
+                    const uint4 lo = *reinterpret_cast<const uint4*>(in + b0);
+                    const uint4 hi = *reinterpret_cast<const uint4*>(in + b0 + 16);
+                    q[0] = ((unsigned long long)lo.y << 32) | lo.x; q[1] = ((unsigned long long)lo.w << 32) | lo.z;
+                    q[2] = ((unsigned long long)hi.y << 32) | hi.x; q[3] = ((unsigned long long)hi.w << 32) | hi.z;
+                } else {
+                    const unsigned* pd = reinterpret_cast<const unsigned*>(in + b0);     // rows are 4-byte aligned
+                    for (int z = 0; z < 4; z++) q[z] = ((unsigned long long)pd[2 * z + 1] << 32) | pd[2 * z];
+                }
+                for (int z = 0; z < 4; z++)
+                    v |= (unsigned)(((q[z] & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56) << (24 - 8 * z);
+            } else {
+                for (int z = 0; z < 32; z++)
+                    if (b0 + z < bits_stride) v |= (unsigned)(in[b0 + z] & 1u) << (31 - z);
             }
             packed[w] = v;
         }
