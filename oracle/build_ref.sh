@@ -1,5 +1,5 @@
 #!/bin/sh
-# Builds oracle/_ref/libtetra_burst_ref.so from the REFERENCE's own source file, compiled where it lies under
+# Builds oracle/_ref/libtetra_burst_ref.so (and libtetra_lmac_ref.so, below) from the REFERENCE's own source files, compiled where it lies under
 # /root/reference (nothing is copied, no stand-in headers or stubs are written): src/decoder/src/phy/tetra_burst.c
 # holds tetra_find_train_seq() (the training-sequence search, :271-341) and the burst builders
 # build_sync_c_d_burst() / build_norm_c_d_burst() (:171-269).  The file also defines tetra_burst_rx_cb(), which calls into
@@ -17,3 +17,13 @@ fi
 mkdir -p "$HERE/_ref"
 gcc -O2 -std=gnu11 -fPIC -shared -w -I"$SRC" -o "$HERE/_ref/libtetra_burst_ref.so" "$SRC/phy/tetra_burst.c" "$SRC/phy/tetra_burst_sync.c"
 echo "built $HERE/_ref/libtetra_burst_ref.so from $SRC/phy/tetra_burst.c"
+# Lower-MAC channel-coding primitives, again the reference's own files compiled in place:
+# scrambler, block (de)interleaver, RCPC (de)puncturer + mother-code encoder, CRC16, and the K=5 rate-1/4 Viterbi decoder
+# (viterbi_dec_sb1_wrapper -> conv_cch_decode -> osmo_conv_decode).  tetra_lower_mac.c itself (tp_sap_udata_ind) is NOT
+# built: it needs the upper MAC / crypto / codec objects; the checker chains the primitives in the order its lines
+# :181-227 call them (oracle/ref_binding.py: lmac_decode).
+LM="$SRC/lower_mac"
+gcc -O2 -std=gnu11 -fPIC -shared -w -I"$SRC" -o "$HERE/_ref/libtetra_lmac_ref.so" \
+    "$LM/tetra_scramb.c" "$LM/tetra_interleave.c" "$LM/tetra_conv_enc.c" "$LM/crc_simple.c" \
+    "$LM/viterbi.c" "$LM/viterbi_cch.c" "$LM/osmo_conv.c"
+echo "built $HERE/_ref/libtetra_lmac_ref.so from $LM/{tetra_scramb,tetra_interleave,tetra_conv_enc,crc_simple,viterbi,viterbi_cch,osmo_conv}.c"

@@ -79,3 +79,114 @@ def build_sync_burst(sb, bb, bkn):
     n = lib().build_sync_c_d_burst(_p(buf), _p(np.ascontiguousarray(sb, np.uint8)), _p(np.ascontiguousarray(bb, np.uint8)),
                                    _p(np.ascontiguousarray(bkn, np.uint8)))
     return buf[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Lower-MAC channel coding: oracle/_ref/libtetra_lmac_ref.so = the reference's own
+# lower_mac/{tetra_scramb,tetra_interleave,tetra_conv_enc,crc_simple,viterbi,viterbi_cch,osmo_conv}.c
+# ---------------------------------------------------------------------------------------------------------------------
+LMAC_LIB_PATH = os.path.join(_HERE, "_ref", "libtetra_lmac_ref.so")
+# enum tp_sap_data_type, phy/tetra_burst.h:9-16
+TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
+# tetra_blk_param[], lower_mac/tetra_lower_mac.c:58-105: (type345_bits, type2_bits, type1_bits, interleave_a, have_crc16)
+BLK_PARAM = {
+    TPSAP_T_SB1: (120, 80, 60, 11, 1),
+    TPSAP_T_SB2: (216, 144, 124, 101, 1),
+    TPSAP_T_NDB: (216, 144, 124, 101, 1),
+    TPSAP_T_BBK: (30, 30, 14, 0, 0),
+    TPSAP_T_SCH_HU: (168, 112, 92, 13, 1),
+    TPSAP_T_SCH_F: (432, 288, 268, 103, 1),
+}
+SCRAMB_INIT = 3            # lower_mac/tetra_scramb.h:14
+TETRA_CRC_OK = 0x1d0f      # tetra_common.h:330
+RCPC_PUNCT_2_3 = 0         # enum tetra_rcpc_puncturer, first entry (lower_mac/tetra_conv_enc.h)
+
+_lmac = None
+
+
+def lmac_available():
+    if not os.path.exists(LMAC_LIB_PATH):
+        try:
+            build()
+        except Exception:
+            return False
+    return os.path.exists(LMAC_LIB_PATH)
+
+
+def lmac_lib():
+    global _lmac
+    if _lmac is None:
+        if not lmac_available():
+            raise RuntimeError("oracle/_ref/libtetra_lmac_ref.so is not built and /root/reference is not present")
+        L = C.CDLL(LMAC_LIB_PATH)
+        vp = C.c_void_p
+        L.tetra_scramb_bits.argtypes = [C.c_uint32, vp, C.c_int]
+        L.tetra_scramb_get_init.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8]
+        L.tetra_scramb_get_init.restype = C.c_uint32
+        L.block_interleave.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
+        L.block_interleave.restype = None
+        L.block_deinterleave.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
+        L.block_deinterleave.restype = None
+        L.tetra_rcpc_depunct.argtypes = [C.c_int, vp, C.c_uint32, vp]
+        L.get_punctured_rate.argtypes = [C.c_int, vp, C.c_uint32, vp]
+        L.viterbi_dec_sb1_wrapper.argtypes = [vp, vp, C.c_uint]
+        L.viterbi_dec_sb1_wrapper.restype = None
+        L.crc16_ccitt_bits.argtypes = [vp, C.c_uint]
+        L.crc16_ccitt_bits.restype = C.c_uint16
+        L.conv_enc_init.argtypes = [vp]
+        L.conv_enc_input.argtypes = [vp, vp, C.c_int, vp]
+        L.tetra_punct_test.restype = C.c_int
+        _lmac = L
+    return _lmac
+
+
+def scramb_get_init(mcc, mnc, colour):
+    return int(lmac_lib().tetra_scramb_get_init(int(mcc), int(mnc), int(colour)))
+
+
+def lmac_decode(blk_type, type5, scramb_init):
+    """One block through the reference's primitives in the order tp_sap_udata_ind calls them
+    (lower_mac/tetra_lower_mac.c:181-227) -> (type2 bits [type2_bits], crc_ok)."""
+    L = lmac_lib()
+    n345, n2, n1, a, have_crc = BLK_PARAM[blk_type]
+    type4 = np.zeros(512, np.uint8)
+    type4[:n345] = np.asarray(type5, np.uint8)[:n345]                                   # :184 memcpy
+    L.tetra_scramb_bits(SCRAMB_INIT if blk_type == TPSAP_T_SB1 else int(scramb_init) & 0xffffffff, _p(type4), n345)
+    type2 = np.zeros(512, np.uint8)
+    if a:
+        type3 = np.zeros(512, np.uint8)
+        L.block_deinterleave(n345, a, _p(type4), _p(type3))                             # :204
+        type3dp = np.full(512 * 4, 0xff, np.uint8)                                      # :208 memset 0xff
+        L.tetra_rcpc_depunct(RCPC_PUNCT_2_3, _p(type3), n345, _p(type3dp))              # :209
+        L.viterbi_dec_sb1_wrapper(_p(type3dp), _p(type2), n2)                           # :212
+    crc_ok = 0
+    if have_crc:
+        crc_ok = int(L.crc16_ccitt_bits(_p(type2), n1 + 16) == TETRA_CRC_OK)            # :218-220
+    elif blk_type == TPSAP_T_BBK:
+        crc_ok = 1                                                                      # :231-234 (RM decode is a FIXME)
+        type2[:n2] = type4[:n2]
+    return type2[:n2].copy(), crc_ok
+
+
+def lmac_encode(blk_type, type1, scramb_init):
+    """Transmit side built from the reference's own encoder primitives (conv_enc_input, get_punctured_rate,
+    block_interleave, tetra_scramb_bits; EN 300 392-2 8.2): type1 bits -> type5 bits.  Used to make known-answer
+    blocks; the CRC16 appended is the ones' complement of crc16_ccitt_bits over the type1 bits, MSB first."""
+    L = lmac_lib()
+    n345, n2, n1, a, have_crc = BLK_PARAM[blk_type]
+    assert have_crc and a
+    t1 = np.ascontiguousarray(type1, np.uint8)[:n1]
+    crc = (~int(L.crc16_ccitt_bits(_p(t1.copy()), n1))) & 0xffff
+    type2 = np.zeros(n2, np.uint8)
+    type2[:n1] = t1
+    type2[n1:n1 + 16] = [(crc >> (15 - i)) & 1 for i in range(16)]                       # + 4 zero tail bits
+    ces = np.zeros(64, np.uint8)
+    L.conv_enc_init(_p(ces))
+    mother = np.zeros(4 * n2, np.uint8)
+    L.conv_enc_input(_p(ces), _p(type2), n2, _p(mother))
+    type3 = np.zeros(n345, np.uint8)
+    L.get_punctured_rate(RCPC_PUNCT_2_3, _p(mother), n345, _p(type3))
+    type4 = np.zeros(n345, np.uint8)
+    L.block_interleave(n345, a, _p(type3), _p(type4))
+    L.tetra_scramb_bits(SCRAMB_INIT if blk_type == TPSAP_T_SB1 else int(scramb_init) & 0xffffffff, _p(type4), n345)
+    return type4

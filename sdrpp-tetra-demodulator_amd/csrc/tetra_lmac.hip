@@ -1,0 +1,196 @@
+// tetra_lmac.hip -- batched lower-MAC channel decoding (include/tetra_lmac.h), bit-exact with the reference's
+// tp_sap_udata_ind() decoding chain (src/decoder/src/lower_mac/tetra_lower_mac.c:181-236).
+//
+// One 64-lane workgroup (one wavefront) decodes 64 blocks, one block per lane (lane-level code: lmac_core.hpp):
+//   1. the 64 rows are read from HBM once, with coalesced dword loads, into LDS (row stride 109 dwords = odd, so that
+//      "every lane reads the same column of its own row" is bank-conflict free);
+//   2. each lane descrambles its row (its own LFSR) and packs the soft classes 2 bits per type-4 bit into LDS words laid
+//      out [word][lane];
+//   3. forward recursion: 16 path metrics in registers, the three soft values of a step pair gathered from the class
+//      words at the deinterleaved positions, 16 decision bits per step stored as one ushort in LDS [step][lane] (this
+//      array overlays the row buffer of step 1, which is dead by then);
+//   4. traceback from LDS (the addresses do not depend on the surviving state, only the bit picked does, so the loads
+//      pipeline), decoded bits packed 16 per ushort into LDS [half][lane], CRC16 over them;
+//   5. the 64 decoded rows are written back with coalesced dword stores, 4 bits -> 4 bytes per lane.
+// LDS per workgroup: 37376 (rows / decisions) + 6912 (classes) + 2304 (decoded) = 46592 B -> 3 workgroups per CU.
+// The work is integer add/compare/select, VALU-bound; HBM traffic is the rows in and the decoded rows out, once each.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/tetra_lmac.h"
+#include "lmac_core.hpp"
+
+namespace {
+
+using namespace tetra_lmac;
+
+constexpr int kLanes = 64;
+constexpr int kRowDwords = 109;                        // >= 432/4, odd
+constexpr int kSteps = kMaxType2 + kFlush;             // 292
+constexpr int kClsWords = (kMaxType345 + 15) / 16;     // 27
+constexpr int kOutHalves = kMaxType2 / 16;             // 18
+
+struct BlkParam { int type345, type2, type1, a, crc; };
+// tetra_blk_param[], tetra_lower_mac.c:58-105 (values of EN 300 392-2 table 8.x / 8.2.4.1)
+const BlkParam kBlk[6] = {
+    { 120, 80, 60, 11, 1 },     // SB1
+    { 216, 144, 124, 101, 1 },  // SB2
+    { 216, 144, 124, 101, 1 },  // NDB
+    { 30, 30, 14, 0, 0 },       // BBK
+    { 168, 112, 92, 13, 1 },    // SCH/HU
+    { 432, 288, 268, 103, 1 },  // SCH/F
+};
+
+union RowsOrDecisions {
+    uint32_t rows[kLanes][kRowDwords];
+    uint16_t dec[kSteps][kLanes];
+};
+
+__global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
+                                                        const uint32_t* __restrict__ scramb_init, int fixed_init,
+                                                        int type345, int type2, int type1, int a,
+                                                        uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok) {
+    __shared__ RowsOrDecisions rd;
+    __shared__ uint32_t cls[kClsWords][kLanes];
+    __shared__ uint16_t outw[kOutHalves][kLanes];
+    const int lane = threadIdx.x;
+    const int blk0 = blockIdx.x * kLanes;
+    const int blk = blk0 + lane;
+    const int rows_here = min(kLanes, n_blocks - blk0);
+
+    // 1. rows -> LDS
+    const int row_dw = type345 >> 2;
+    for (int q = 0; q < rows_here; ++q) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(type5 + (size_t)(blk0 + q) * in_stride);
+        for (int d = lane; d < row_dw; d += kLanes) rd.rows[q][d] = src[d];
+    }
+    for (int q = rows_here; q < kLanes; ++q)
+        for (int d = lane; d < row_dw; d += kLanes) rd.rows[q][d] = 0;
+    __syncthreads();
+
+    // 2. descramble + soft classes
+    const uint32_t init = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[blk];
+    descramble_to_classes(type345, init, [&](int d) { return rd.rows[lane][d]; },
+                          [&](int w, uint32_t word) { cls[w][lane] = word; });
+    __syncthreads();   // rows are dead from here: decisions overlay them
+
+    // 3. forward recursion
+    viterbi_forward(type2, type345, a,
+                    [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; },
+                    [&](int t, uint32_t mask) { rd.dec[t][lane] = (uint16_t)mask; });
+
+    // 4. traceback + CRC (own lane's data only: no barrier needed)
+    viterbi_traceback(type2, [&](int t) { return (uint32_t)rd.dec[t][lane]; },
+                      [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; });
+    const uint32_t crc = crc16_bits(type1 + 16, [&](int h) { return (uint32_t)outw[h][lane]; });
+    if (blk < n_blocks) crc_ok[blk] = crc == kCrcOk;
+    __syncthreads();
+
+    // 5. decoded rows -> HBM
+    const int out_dw = type2 >> 2;
+    for (int q = 0; q < rows_here; ++q) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)(blk0 + q) * out_stride);
+        for (int d = lane; d < out_dw; d += kLanes) dst[d] = spread4(((uint32_t)outw[d >> 2][q] >> (4 * (d & 3))) & 0xfu);
+    }
+}
+
+// TPSAP_T_BBK: the reference only descrambles (tetra_lower_mac.c:231-236); 30 bits per block, one lane per block.
+__global__ __launch_bounds__(256) void k_lmac_bbk(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
+                                                  const uint32_t* __restrict__ scramb_init, int nbits,
+                                                  uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok) {
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= n_blocks) return;
+    uint32_t lfsr = scramb_init[blk];
+    const uint8_t* src = type5 + (size_t)blk * in_stride;
+    uint8_t* dst = out + (size_t)blk * out_stride;
+    for (int j = 0; j < nbits; ++j) dst[j] = src[j] ^ (uint8_t)lfsr_next(lfsr);
+    crc_ok[blk] = 1;
+}
+
+int check_args(int type, const void* in, int n_blocks, int in_stride, const void* init, const void* out, int out_stride,
+               const void* ok, bool device_ptrs) {
+    if (type < 0 || type > 5 || n_blocks < 0) return TETRA_ERR_ARG;
+    if (n_blocks == 0) return TETRA_OK;
+    if (!in || !out || !ok) return TETRA_ERR_ARG;
+    if (type != TETRA_TPSAP_T_SB1 && !init) return TETRA_ERR_ARG;
+    const BlkParam& p = kBlk[type];
+    if (in_stride < p.type345 || out_stride < p.type2) return TETRA_ERR_ARG;
+    if ((in_stride & 3) || (out_stride & 3)) return TETRA_ERR_ALIGN;
+    if (device_ptrs && (((uintptr_t)in & 3) || ((uintptr_t)out & 3))) return TETRA_ERR_ALIGN;
+    return TETRA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tetra_lmac_blk_param(int type, tetra_lmac_blk_param_t* out) {
+    if (type < 0 || type > 5 || !out) return TETRA_ERR_ARG;
+    out->type345_bits = kBlk[type].type345;
+    out->type2_bits = kBlk[type].type2;
+    out->type1_bits = kBlk[type].type1;
+    out->interleave_a = kBlk[type].a;
+    out->have_crc16 = kBlk[type].crc;
+    return TETRA_OK;
+}
+
+uint32_t tetra_lmac_scramb_init(uint16_t mcc, uint16_t mnc, uint8_t colour) {
+    // tetra_scramb.c:87-99: colour (6 bits) | MNC (14) << 6 | MCC (10) << 20, then two 1 bits shifted in below
+    const uint32_t v = (uint32_t)(colour & 0x3f) | ((uint32_t)(mnc & 0x3fff) << 6) | ((uint32_t)(mcc & 0x3ff) << 20);
+    return (v << 2) | kScrambInitSb1;
+}
+
+int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_blocks, int in_stride, const uint32_t* d_scramb_init,
+                                   uint8_t* d_type2, int out_stride, int32_t* d_crc_ok, void* hip_stream) {
+    const int rc = check_args(type, d_type5, n_blocks, in_stride, d_scramb_init, d_type2, out_stride, d_crc_ok, true);
+    if (rc != TETRA_OK || n_blocks == 0) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const BlkParam& p = kBlk[type];
+    if (type == TETRA_TPSAP_T_BBK) {
+        hipLaunchKernelGGL(k_lmac_bbk, dim3((n_blocks + 255) / 256), dim3(256), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
+                           p.type345, d_type2, out_stride, d_crc_ok);
+    } else {
+        hipLaunchKernelGGL(k_lmac_decode, dim3((n_blocks + kLanes - 1) / kLanes), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride,
+                           d_scramb_init, type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride,
+                           d_crc_ok);
+    }
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
+                            uint8_t* type2, int out_stride, int32_t* crc_ok, int device) {
+    int rc = check_args(type, type5, n_blocks, in_stride, scramb_init, type2, out_stride, crc_ok, false);
+    if (rc != TETRA_OK || n_blocks == 0) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TETRA_ERR_NO_DEVICE;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return TETRA_ERR_HIP;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint32_t* d_init = nullptr;
+    int32_t* d_ok = nullptr;
+    const size_t in_bytes = (size_t)n_blocks * in_stride, out_bytes = (size_t)n_blocks * out_stride;
+    rc = TETRA_ERR_HIP;
+    do {
+        if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess ||
+            hipMalloc(&d_ok, sizeof(int32_t) * n_blocks) != hipSuccess) { rc = TETRA_ERR_NOMEM; break; }
+        if (scramb_init) {
+            if (hipMalloc(&d_init, sizeof(uint32_t) * n_blocks) != hipSuccess) { rc = TETRA_ERR_NOMEM; break; }
+            if (hipMemcpy(d_init, scramb_init, sizeof(uint32_t) * n_blocks, hipMemcpyHostToDevice) != hipSuccess) break;
+        }
+        if (hipMemcpy(d_in, type5, in_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+        const int krc = tetra_lmac_decode_batch_device(type, d_in, n_blocks, in_stride, d_init, d_out, out_stride, d_ok, nullptr);
+        if (krc != TETRA_OK) { rc = krc; break; }
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        // only the type2_bits columns: the caller's row padding is left alone
+        if (hipMemcpy2D(type2, out_stride, d_out, out_stride, kBlk[type].type2, n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(crc_ok, d_ok, sizeof(int32_t) * n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = TETRA_OK;
+    } while (false);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipFree(d_init);
+    (void)hipFree(d_ok);
+    return rc;
+}
+
+}  // extern "C"

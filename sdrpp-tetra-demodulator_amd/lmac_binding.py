@@ -1,0 +1,79 @@
+"""ctypes binding of the batched lower-MAC channel decoding (include/tetra_lmac.h)."""
+import ctypes as C
+
+import numpy as np
+
+from .binding import TetraDemodError, load_library
+
+LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch"]
+# enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
+TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
+
+
+class BlkParam(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("type345_bits", "type2_bits", "type1_bits", "interleave_a", "have_crc16")]
+
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = load_library()
+    if not _ready:
+        vp, i32 = C.c_void_p, C.c_int
+        L.tetra_lmac_blk_param.argtypes = [i32, C.POINTER(BlkParam)]
+        L.tetra_lmac_blk_param.restype = i32
+        L.tetra_lmac_scramb_init.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8]
+        L.tetra_lmac_scramb_init.restype = C.c_uint32
+        L.tetra_lmac_decode_batch_device.argtypes = [i32, vp, i32, i32, vp, vp, i32, vp, vp]
+        L.tetra_lmac_decode_batch_device.restype = i32
+        L.tetra_lmac_decode_batch.argtypes = [i32, vp, i32, i32, vp, vp, i32, vp, i32]
+        L.tetra_lmac_decode_batch.restype = i32
+        _ready = True
+    return L
+
+
+def blk_param(blk_type):
+    p = BlkParam()
+    rc = _lib().tetra_lmac_blk_param(int(blk_type), C.byref(p))
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_blk_param")
+    return p
+
+
+def scramb_init(mcc, mnc, colour):
+    return int(_lib().tetra_lmac_scramb_init(int(mcc) & 0xffff, int(mnc) & 0xffff, int(colour) & 0xff))
+
+
+def out_stride_for(blk_type):
+    return (blk_param(blk_type).type2_bits + 3) & ~3
+
+
+def decode_batch(blk_type, type5, scramb=None, device=-1):
+    """type5 uint8 [n][in_stride] (in_stride % 4 == 0), scramb uint32 [n] (None for SB1)
+    -> (type2 uint8 [n][type2_bits rounded up to 4], crc_ok int32 [n])."""
+    rows = np.ascontiguousarray(type5, np.uint8)
+    n, in_stride = rows.shape
+    ost = out_stride_for(blk_type)
+    out = np.zeros((n, ost), np.uint8)
+    ok = np.zeros(n, np.int32)
+    si = None if scramb is None else np.ascontiguousarray(scramb, np.uint32)
+    rc = _lib().tetra_lmac_decode_batch(int(blk_type), rows.ctypes.data_as(C.c_void_p), n, in_stride,
+                                        None if si is None else si.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), ost, ok.ctypes.data_as(C.c_void_p), device)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_decode_batch")
+    return out, ok
+
+
+def decode_batch_device(blk_type, d_type5, n_blocks, in_stride, d_scramb, d_type2, out_stride, d_crc_ok, stream=None):
+    """torch tensors already on the GPU; enqueues on `stream` (torch stream or raw handle), no synchronisation."""
+    s = None
+    if stream is not None:
+        s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+    rc = _lib().tetra_lmac_decode_batch_device(int(blk_type), C.c_void_p(d_type5.data_ptr()), int(n_blocks), int(in_stride),
+                                               None if d_scramb is None else C.c_void_p(d_scramb.data_ptr()),
+                                               C.c_void_p(d_type2.data_ptr()), int(out_stride), C.c_void_p(d_crc_ok.data_ptr()), s)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_decode_batch_device")

@@ -45,6 +45,31 @@ def test_burst_scan_header_symbols_all_exported(pkg):
         assert hasattr(L, n), n
 
 
+def test_lmac_header_symbols_all_exported_and_host_helpers(pkg):
+    """include/tetra_lmac.h: every declared entry point is exported; the two host-only helpers (no GPU needed) give the
+    reference's block parameters (tetra_lower_mac.c:58-105) and scrambling code (tetra_scramb.c:87-99)."""
+    src = open(os.path.join(ROOT, "include", "tetra_lmac.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(tetra_lmac_[a-z0-9_]+)\s*\(", src)))
+    L = pkg.load_library()
+    assert set(names) == set(pkg.lmac_binding.LMAC_EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    want = {0: (120, 80, 60, 11, 1), 1: (216, 144, 124, 101, 1), 2: (216, 144, 124, 101, 1), 3: (30, 30, 14, 0, 0),
+            4: (168, 112, 92, 13, 1), 5: (432, 288, 268, 103, 1)}
+    for t, w in want.items():
+        p = pkg.lmac_binding.blk_param(t)
+        assert (p.type345_bits, p.type2_bits, p.type1_bits, p.interleave_a, p.have_crc16) == w
+    from tests.emul import lmac_emul_bind
+    for t, w in lmac_emul_bind.BLK_PARAM.items():
+        assert w == want[t][:4]
+    assert pkg.lmac_binding.scramb_init(262, 1, 5) == 0x41800117      # value of the reference's tetra_scramb_get_init
+    from oracle import ref_binding
+    if ref_binding.lmac_available():
+        for mcc, mnc, cc in ((262, 1, 5), (1023, 16383, 63), (0, 0, 0), (234, 14, 1)):
+            assert pkg.lmac_binding.scramb_init(mcc, mnc, cc) == ref_binding.scramb_get_init(mcc, mnc, cc)
+
+
 def test_default_config_is_the_plugins(pkg):
     cfg = pkg.binding.default_config()
     # src/main.cpp:35-44,78-84

@@ -1,0 +1,196 @@
+"""Lower-MAC channel decoding against the REFERENCE ITSELF: oracle/_ref/libtetra_lmac_ref.so is
+the reference's lower_mac/{tetra_scramb,tetra_interleave,tetra_conv_enc,crc_simple,viterbi,viterbi_cch,osmo_conv}.c compiled
+from /root/reference (oracle/build_ref.sh), chained in the order tp_sap_udata_ind calls them (oracle/ref_binding.lmac_decode),
+so parity for this entry point is pinned.  tests/golden/lmac_golden.npz holds inputs + the reference's outputs for boxes
+without /root/reference or a prebuilt oracle/_ref."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CODED = (0, 1, 2, 4, 5)     # SB1, SB2, NDB, SCH/HU, SCH/F
+STRIDE = 436                # a row stride that is not the row length
+
+
+@pytest.fixture(scope="module")
+def lref(ref):
+    if not ref.lmac_available():
+        pytest.skip("oracle/_ref/libtetra_lmac_ref.so not built and /root/reference not present")
+    return ref
+
+
+def make_rows(ref, blk_type, n, seed):
+    """n input rows of one block kind: clean encoded blocks, encoded blocks with ~6 % bit errors, random bits, and
+    arbitrary bytes (0xff / 0xfe / 2 / 7 ...: the reference's soft mapping has three classes)."""
+    rng = np.random.default_rng(seed)
+    n345, n2, n1, a, _ = ref.BLK_PARAM[blk_type]
+    si = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    if blk_type == ref.TPSAP_T_SB1:
+        si[:] = ref.SCRAMB_INIT
+    rows = rng.integers(0, 256, (n, STRIDE), dtype=np.uint8)          # padding bytes are garbage on purpose
+    sent = np.zeros((n, n1), np.uint8)
+    for b in range(n):
+        mode = b % 4
+        if mode <= 1:
+            sent[b] = rng.integers(0, 2, n1)
+            r = ref.lmac_encode(blk_type, sent[b], si[b])
+            if mode == 1:
+                r = r ^ (rng.random(n345) < 0.06)
+            rows[b, :n345] = r
+        elif mode == 2:
+            rows[b, :n345] = rng.integers(0, 2, n345)
+        else:
+            rows[b, :n345] = rng.choice(np.array([0, 1, 0xff, 0xfe, 2, 7], np.uint8), n345)
+    return rows, si, sent
+
+
+def ref_decode_rows(ref, blk_type, rows, si):
+    n2 = ref.BLK_PARAM[blk_type][1]
+    out = np.zeros((len(rows), n2), np.uint8)
+    ok = np.zeros(len(rows), np.int32)
+    for b in range(len(rows)):
+        out[b], ok[b] = ref.lmac_decode(blk_type, rows[b], si[b])
+    return out, ok
+
+
+def test_reference_self_test_and_round_trip(lref):
+    """The reference's own puncturer self-test (tetra_conv_enc.c:340, tetra_punct_test) passes on the library built here,
+    and blocks made with its encoder primitives decode with crc_ok through its decoder primitives."""
+    assert lref.lmac_lib().tetra_punct_test() == 0
+    rng = np.random.default_rng(1)
+    si = lref.scramb_get_init(262, 1, 5)
+    for t in CODED:
+        n345, n2, n1, a, _ = lref.BLK_PARAM[t]
+        t1 = rng.integers(0, 2, n1).astype(np.uint8)
+        t5 = lref.lmac_encode(t, t1, si)
+        t2, ok = lref.lmac_decode(t, t5, si)
+        assert ok == 1 and np.array_equal(t2[:n1], t1) and not t2[n1 + 16:].any()
+        t5[rng.choice(n345, 3, replace=False)] ^= 1
+        t2, ok = lref.lmac_decode(t, t5, si)
+        assert ok == 1 and np.array_equal(t2[:n1], t1)
+
+
+def test_lane_code_equals_reference(lref):
+    """The kernel's lane-level source (csrc/lmac_core.hpp) built for the host == the reference, bit for bit, on clean,
+    noisy, random and arbitrary-byte blocks of every coded kind."""
+    from tests.emul import lmac_emul_bind
+    for t in CODED:
+        rows, si, sent = make_rows(lref, t, 240, 100 + t)
+        want, want_ok = ref_decode_rows(lref, t, rows, si)
+        got, got_ok = lmac_emul_bind.decode_batch(t, rows, si)
+        assert np.array_equal(got, want), t
+        assert np.array_equal(got_ok, want_ok), t
+        n1 = lref.BLK_PARAM[t][2]
+        clean = np.arange(len(rows)) % 4 == 0
+        assert want_ok[clean].all() and np.array_equal(want[clean][:, :n1], sent[clean])
+        assert 0 < want_ok.sum() < len(rows)
+
+
+def test_lane_code_equals_golden():
+    """Same check against the committed fixture (inputs + reference outputs; tests/golden/make_lmac_golden.py)."""
+    from tests.emul import lmac_emul_bind
+    g = np.load(os.path.join(HERE, "golden", "lmac_golden.npz"))
+    for t in CODED:
+        got, got_ok = lmac_emul_bind.decode_batch(t, g[f"rows_{t}"], g[f"scramb_{t}"])
+        assert np.array_equal(got, g[f"type2_{t}"]) and np.array_equal(got_ok, g[f"crc_ok_{t}"])
+
+
+@pytest.mark.gpu
+def test_gpu_lmac_equals_golden(pkg):
+    g = np.load(os.path.join(HERE, "golden", "lmac_golden.npz"))
+    for t in CODED:
+        n2 = g[f"type2_{t}"].shape[1]
+        got, got_ok = pkg.lmac_binding.decode_batch(t, g[f"rows_{t}"], None if t == 0 else g[f"scramb_{t}"])
+        assert np.array_equal(got[:, :n2], g[f"type2_{t}"]) and np.array_equal(got_ok, g[f"crc_ok_{t}"])
+    got, got_ok = pkg.lmac_binding.decode_batch(3, g["rows_3"], g["scramb_3"])
+    assert np.array_equal(got[:, :30], g["type2_3"]) and got_ok.all()
+
+
+@pytest.mark.gpu
+def test_gpu_lmac_equals_reference(pkg, lref):
+    """Ragged batch sizes (1, 63, 64, 65, 1000 blocks), a padded and a tight row stride."""
+    for t in CODED:
+        n345, n2 = lref.BLK_PARAM[t][:2]
+        rows, si, _ = make_rows(lref, t, 1000, 200 + t)
+        want, want_ok = ref_decode_rows(lref, t, rows, si)
+        for n in (1000, 65, 64, 63, 1):
+            got, got_ok = pkg.lmac_binding.decode_batch(t, rows[:n], None if t == 0 else si[:n])
+            assert np.array_equal(got[:, :n2], want[:n]), (t, n)
+            assert np.array_equal(got_ok, want_ok[:n]), (t, n)
+        tight = np.ascontiguousarray(rows[:200, :n345])
+        got, got_ok = pkg.lmac_binding.decode_batch(t, tight, si[:200])
+        assert np.array_equal(got[:, :n2], want[:200]) and np.array_equal(got_ok, want_ok[:200])
+
+
+@pytest.mark.gpu
+def test_gpu_lmac_bbk_and_argument_errors(pkg, lref):
+    rng = np.random.default_rng(5)
+    rows = rng.integers(0, 2, (300, 32), dtype=np.uint8)
+    si = rng.integers(0, 2 ** 32, 300, dtype=np.uint64).astype(np.uint32)
+    got, ok = pkg.lmac_binding.decode_batch(lref.TPSAP_T_BBK, rows, si)
+    for b in range(300):
+        t2, okr = lref.lmac_decode(lref.TPSAP_T_BBK, rows[b], si[b])
+        assert np.array_equal(got[b, :30], t2) and ok[b] == okr == 1
+    lb = pkg.lmac_binding
+    with pytest.raises(pkg.TetraDemodError):                  # coded block without scrambling codes
+        lb.decode_batch(lref.TPSAP_T_NDB, np.zeros((4, 216), np.uint8), None)
+    with pytest.raises(pkg.TetraDemodError):                  # stride not a multiple of 4
+        lb.decode_batch(lref.TPSAP_T_SB1, np.zeros((4, 121), np.uint8), None)
+    with pytest.raises(pkg.TetraDemodError):                  # row shorter than the block
+        lb.decode_batch(lref.TPSAP_T_SCH_F, np.zeros((4, 216), np.uint8), np.zeros(4, np.uint32))
+    with pytest.raises(pkg.TetraDemodError):
+        lb.decode_batch(7, np.zeros((4, 216), np.uint8), np.zeros(4, np.uint32))
+    out, ok = lb.decode_batch(lref.TPSAP_T_SB1, np.zeros((0, 120), np.uint8), None)   # empty batch is a no-op
+    assert out.shape[0] == 0 and ok.size == 0
+
+
+@pytest.mark.gpu
+def test_gpu_iq_to_sync_pdu(pkg, lref, synth):
+    """Whole receive path on the GPU with a reference-built transmit side: SYNC PDUs -> reference encoder primitives ->
+    reference burst builder -> pi/4-DQPSK IQ -> GPU demodulator -> GPU training-sequence search -> block extraction at the
+    reference's SB_BLK1_OFFSET -> GPU lower-MAC decode -> CRC good and the PDU bits recovered."""
+    rng = np.random.default_rng(11)
+    Cn, nslots = 8, 36
+    SB_BLK1_OFFSET, SYNC_TRAIN_OFFSET = 94, 214         # tetra_burst.c:33 and the sync training sequence position
+    pdus, tx = [], []
+    for c in range(Cn):
+        slots = []
+        for s in range(nslots):
+            if s % 3 == 0:
+                t1 = rng.integers(0, 2, 60).astype(np.uint8)
+                pdus.append((c, t1))
+                slots.append(lref.build_sync_burst(lref.lmac_encode(lref.TPSAP_T_SB1, t1, 3), rng.integers(0, 2, 30), rng.integers(0, 2, 216)))
+            else:
+                slots.append(lref.build_norm_burst(rng.integers(0, 2, 216), rng.integers(0, 2, 30), rng.integers(0, 2, 216), s % 2))
+        tx.append(np.concatenate(slots))
+    N = nslots * 510 - 200
+    iq = np.stack([synth.gen_channel(N, 900 + c, bits=tx[c])[0] for c in range(Cn)])
+    d = pkg.Demodulator(Cn, N)
+    bits, nb, _ = d.process(iq)
+    d.close()
+    # sync-burst search window by window (3 slots = 1530 bits per window, after the loops have locked)
+    rows, owner = [], []
+    for c in range(Cn):
+        pos = 7000
+        while pos + 1530 + 600 < nb[c]:
+            win = np.ascontiguousarray(bits[c:c + 1, pos:pos + 1530 + 66])   # stride % 4 == 0
+            t, o = pkg.scan_binding.find_train_seq_batch(win, np.array([1530], np.int32), 1 << lref.TRAIN_SYNC)
+            if t[0] != lref.TRAIN_SYNC:
+                pos += 1530
+                continue
+            burst = pos + int(o[0]) - SYNC_TRAIN_OFFSET
+            if burst >= 0:
+                rows.append(bits[c, burst + SB_BLK1_OFFSET: burst + SB_BLK1_OFFSET + 120])
+                owner.append(c)
+            pos += int(o[0]) + 60
+    assert len(rows) >= Cn * 4
+    type2, ok = pkg.lmac_binding.decode_batch(lref.TPSAP_T_SB1, np.stack(rows), None)
+    for r in range(len(rows)):                          # bit-exact with the reference on the demodulated rows
+        t2, okr = lref.lmac_decode(lref.TPSAP_T_SB1, rows[r], 3)
+        assert np.array_equal(type2[r, :80], t2) and ok[r] == okr
+    assert ok.mean() > 0.9                              # a channel may still be settling at the first window
+    sent = {c: [p.tobytes() for cc, p in pdus if cc == c] for c in range(Cn)}
+    for r in range(len(rows)):
+        if ok[r]:
+            assert type2[r, :60].tobytes() in sent[owner[r]]
