@@ -237,3 +237,70 @@ class ChanOracle:
         got = chan_lib().chan_oracle_process(self.M, self.P, self.D, _ptr(self.h), _ptr(self.hist), C.byref(self.phase),
                                              C.byref(self.frame), x.shape[0], _ptr(x), _ptr(out))
         return out[:got]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Burst synchroniser + burst demultiplexer restatement (oracle/burst_sync_oracle.c)
+# ---------------------------------------------------------------------------------------------------------------------
+_BSYNC_LIB_PATH = os.path.join(_HERE, "libbsync_oracle.so")
+_bsync = None
+RX_S_UNLOCKED, RX_S_KNOW_FSTART, RX_S_LOCKED = 0, 1, 2
+
+
+def bsync_lib():
+    global _bsync
+    if _bsync is None:
+        src = os.path.join(_HERE, "burst_sync_oracle.c")
+        if not os.path.exists(_BSYNC_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_BSYNC_LIB_PATH):
+            subprocess.run(["make", "-C", _HERE, "-B", "libbsync_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(_BSYNC_LIB_PATH)
+        vp = C.c_void_p
+        L.bs_oracle_find_train_seq.argtypes = [vp, C.c_uint, C.c_uint32, C.POINTER(C.c_uint)]
+        L.bs_oracle_find_train_seq.restype = C.c_int
+        L.bs_oracle_reset.argtypes = [vp]
+        L.bs_oracle_reset.restype = None
+        L.bs_oracle_feed.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
+        L.bs_oracle_feed.restype = C.c_int
+        L.bs_oracle_demux.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.bs_oracle_demux.restype = C.c_int
+        L.bs_oracle_state_size.restype = C.c_int
+        _bsync = L
+    return _bsync
+
+
+def bsync_find_train_seq(bits, end_of_in, mask=0x1f):
+    b = np.ascontiguousarray(bits, np.uint8)
+    assert b.size >= end_of_in + 21
+    off = C.c_uint(0)
+    t = bsync_lib().bs_oracle_find_train_seq(_ptr(b), int(end_of_in), int(mask), C.byref(off))
+    return (t, int(off.value)) if t >= 0 else (-1, -1)
+
+
+class BurstSyncOracle:
+    """One channel's tetra_rx_state restatement.  feed() returns (frames uint8 [n][510], types int32 [n], bitnums
+    uint32 [n]) for the frames the LOCKED state consumed during the call(s)."""
+
+    def __init__(self):
+        self._st = np.zeros(bsync_lib().bs_oracle_state_size(), np.uint8)
+
+    @property
+    def state(self):
+        v = self._st[:16].view(np.uint32)
+        return int(v[0]), int(v[1]), int(v[2]), int(v[3])     # state, bits_in_buf, bitbuf_start_bitnum, next_frame_start
+
+    def feed(self, bits, chunk=1):
+        b = np.ascontiguousarray(bits, np.uint8)
+        cap = b.size // 510 + 16
+        frames = np.zeros((cap, 512), np.uint8)
+        types = np.zeros(cap, np.int32)
+        bitnums = np.zeros(cap, np.uint32)
+        n = bsync_lib().bs_oracle_feed(_ptr(self._st), _ptr(b), b.size, int(chunk), _ptr(frames), _ptr(types), _ptr(bitnums), cap)
+        assert n <= cap
+        return frames[:n, :510].copy(), types[:n].copy(), bitnums[:n].copy()
+
+
+def bsync_demux(burst, train, tpsap, blk_num):
+    b = np.ascontiguousarray(burst, np.uint8)
+    out = np.zeros(432, np.uint8)
+    n = bsync_lib().bs_oracle_demux(_ptr(b), int(train), int(tpsap), int(blk_num), _ptr(out))
+    return out[:n].copy()

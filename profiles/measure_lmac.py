@@ -18,7 +18,7 @@ g = torch.Generator(device=dev)
 g.manual_seed(1)
 s = torch.cuda.current_stream(dev)
 for blk_type, name, n in ((lb.TPSAP_T_SCH_F, "SCH/F", 4096 * 70), (lb.TPSAP_T_NDB, "NDB half slot", 2 * 4096 * 70),
-                          (lb.TPSAP_T_SB1, "SB1", 4096 * 18)):
+                          (lb.TPSAP_T_SB1, "SB1", 4096 * 18), (lb.TPSAP_T_SCH_F, "SCH/F, 4 s of signal", 4 * 4096 * 70)):
     p = lb.blk_param(blk_type)
     in_stride, out_stride = p.type345_bits, p.type2_bits
     rows = torch.randint(0, 2, (n, in_stride), dtype=torch.uint8, device=dev, generator=g)

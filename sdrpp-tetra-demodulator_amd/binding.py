@@ -66,7 +66,9 @@ _lib = None
 
 
 def load_library(rebuild_if_stale=True):
-    """Load libtetra_demod_hip.so (building it with hipcc when missing/stale).  Raises if impossible."""
+    """Load libtetra_demod_hip.so (building it with hipcc when missing/stale).  Raises if impossible.
+    When the process also uses torch on the GPU, `import torch` BEFORE calling this: torch bundles its own HIP runtime, this
+    library links the system one, and the first one loaded serves both (a torch imported second finds no GPU)."""
     global _lib
     if _lib is not None:
         return _lib

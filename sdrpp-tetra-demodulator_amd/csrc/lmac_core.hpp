@@ -20,7 +20,8 @@
 //                      on zero soft bits (viterbi.c:8) and tracebacks from state 0 (:567-612).
 //     The reference keeps int16 path metrics and subtracts the minimum every 59 steps (:137-153, :642); with the
 //     rate-2/3 depunctured input at most two soft values per step are non-zero, so its sums stay far inside int16 and
-//     renormalisation never changes a comparison: int32 sums without renormalisation take the same decisions.
+//     renormalisation never changes a comparison.  Here the metrics are kept in units of 127 (all soft values are
+//     0 or +-127), two per register in packed int16 lanes, without renormalisation: same decisions.
 //   * generators       EN 300 392-2 8.2.3.1.1 (tetra_conv_enc.c:45-60 conv_enc_in_bit): g1 = 1+D+D^4, g2 = 1+D^2+D^3+D^4,
 //                      g3 = 1+D+D^2+D^4, g4 = 1+D+D^3+D^4.  With i = (d0 d1 d2) the three newer delay bits of the even
 //                      predecessor and input 0: g1 = d0, g2 = d1^d2 (g3, g4 only ever meet erasures here).
@@ -56,55 +57,101 @@ LM_FN uint32_t lfsr_next(uint32_t& lfsr) {
 // 2-bit signed class of a descrambled byte: +1 (strong 0), 0 (erasure), -1 = 0b11 (strong 1)
 LM_FN uint32_t soft_class(uint32_t v) { return v == 0u ? 1u : (v == 0xffu ? 0u : 3u); }
 
-// Descrambles one row and packs the soft classes 16 per word.  ld4(d) returns bytes 4d..4d+3 of the row (little endian);
-// st(w, word) receives word w = classes of bits 16w..16w+15 (2 bits each, bit 16w+u at bits 2u..2u+1).
+// Descrambles up to 64 bits of one row (a staging chunk) and packs the soft classes 16 per word.  `remaining` = type-5
+// bits left in the row from the start of this chunk (a multiple of 4 for every coded block kind); ld4(d) returns bytes
+// 4d..4d+3 of the chunk (little endian); st(w, word) receives chunk word w = classes of chunk bits 16w..16w+15 (2 bits
+// each, bit 16w+u at bits 2u..2u+1).  Returns the LFSR state for the next chunk.
 template <class Ld4, class St>
-LM_FN void descramble_to_classes(int K, uint32_t lfsr, Ld4 ld4, St st) {
-    for (int w = 0; w * 16 < K; ++w) {
-        uint32_t word = 0;
+LM_FN uint32_t descramble_chunk(int remaining, uint32_t lfsr, Ld4 ld4, St st) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const bool live = (16 * w + 4 * d) < K;   // K is a multiple of 4 for every coded block kind
-            const uint32_t four = live ? ld4(4 * w + d) : 0u;
+    for (int w = 0; w < 4; ++w) {
+        if (16 * w < remaining) {
+            uint32_t word = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t bit = lfsr_next(lfsr);
-                const uint32_t v = ((four >> (8 * b)) & 0xffu) ^ bit;
-                const uint32_t c = live ? soft_class(v) : 0u;
-                word |= c << (2 * (4 * d + b));
+            for (int d = 0; d < 4; ++d) {
+                const bool live = (16 * w + 4 * d) < remaining;
+                const uint32_t four = live ? ld4(4 * w + d) : 0u;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t bit = lfsr_next(lfsr);
+                    const uint32_t v = ((four >> (8 * b)) & 0xffu) ^ bit;
+                    const uint32_t c = live ? soft_class(v) : 0u;
+                    word |= c << (2 * (4 * d + b));
+                }
             }
+            st(w, word);
         }
-        st(w, word);
     }
+    return lfsr;
 }
 
-// One add-compare-select step over the 8 butterflies; returns the 16 decision bits (bit s = state s took its odd
-// predecessor 2(s&7)+1).
-LM_FN uint32_t acs(int (&S)[16], const int (&m)[8]) {
-    int N[16];
-    uint32_t dec = 0;
+// ---- packed 16-bit lanes: two path metrics per 32-bit register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16) --------
+// In units of 127 a path metric never leaves [-2*292, 20 + 2*292], so int16 needs no renormalisation at all.
+#if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
+typedef short Pk __attribute__((ext_vector_type(2)));
+LM_FN Pk pk_make(int lo, int hi) { Pk r; r.x = (short)lo; r.y = (short)hi; return r; }
+LM_FN Pk pk_add(Pk a, Pk b) { return a + b; }
+LM_FN Pk pk_sub(Pk a, Pk b) { return a - b; }
+LM_FN Pk pk_max(Pk a, Pk b) { return __builtin_elementwise_max(a, b); }
+LM_FN Pk pk_lolo(Pk x, Pk y) { return __builtin_shufflevector(x, y, 0, 2); }
+LM_FN Pk pk_hihi(Pk x, Pk y) { return __builtin_shufflevector(x, y, 1, 3); }
+LM_FN Pk pk_swap(Pk x) { return __builtin_shufflevector(x, x, 1, 0); }
+LM_FN uint32_t pk_bits(Pk a) { return __builtin_bit_cast(uint32_t, a); }
+#else
+struct Pk { int16_t x, y; };
+LM_FN Pk pk_make(int lo, int hi) { return Pk{ (int16_t)lo, (int16_t)hi }; }
+LM_FN Pk pk_add(Pk a, Pk b) { return Pk{ (int16_t)(a.x + b.x), (int16_t)(a.y + b.y) }; }
+LM_FN Pk pk_sub(Pk a, Pk b) { return Pk{ (int16_t)(a.x - b.x), (int16_t)(a.y - b.y) }; }
+LM_FN Pk pk_max(Pk a, Pk b) { return Pk{ a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y }; }
+LM_FN Pk pk_lolo(Pk x, Pk y) { return Pk{ x.x, y.x }; }
+LM_FN Pk pk_hihi(Pk x, Pk y) { return Pk{ x.y, y.y }; }
+LM_FN Pk pk_swap(Pk x) { return Pk{ x.y, x.x }; }
+LM_FN uint32_t pk_bits(Pk a) { return (uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16); }
+#endif
+
+// Path metrics of the 16 states, packed for the butterflies: butterfly j has predecessors 2j (even) and 2j+1 (odd) and
+// produces states j and j+8.  E[k] = (S[4k], S[4k+2]) and O[k] = (S[4k+1], S[4k+3]) are the even / odd predecessors of
+// butterflies 2k (low half) and 2k+1 (high half).
+struct PathMetrics { Pk E[4], O[4]; };
+
+// One add-compare-select step.  M0 = (m_0, m_1), M1 = (m_2, m_3) are the branch metrics of butterflies 0..3; butterflies
+// 4..7 have m_4..7 = (-m_2, -m_3, -m_0, -m_1)... expressed by the caller through (M2, M3) = the metrics of butterflies
+// (4,5) and (6,7).  Returns the 16 decision bits, state s at bit 15 - s (1 = state s took its odd predecessor).
+LM_FN uint32_t acs_pk(PathMetrics& pm, Pk M0, Pk M1, Pk M2, Pk M3) {
+    const Pk M[4] = { M0, M1, M2, M3 };
+    Pk NN[8];      // NN[j] = (S'[2j], S'[2j+1])
+    Pk D[8];       // sign bits = decisions of states (2r, 2r+1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e0 = S[2 * i] + m[i], o0 = S[2 * i + 1] - m[i];
-        const int e1 = S[2 * i] - m[i], o1 = S[2 * i + 1] + m[i];
-        dec |= (uint32_t)(o0 > e0) << i;
-        dec |= (uint32_t)(o1 > e1) << (i + 8);
-        N[i] = o0 > e0 ? o0 : e0;
-        N[i + 8] = o1 > e1 ? o1 : e1;
+    for (int k = 0; k < 4; ++k) {
+        const Pk e0 = pk_add(pm.E[k], M[k]), o0 = pk_sub(pm.O[k], M[k]);   // into states 2k, 2k+1
+        const Pk e1 = pk_sub(pm.E[k], M[k]), o1 = pk_add(pm.O[k], M[k]);   // into states 2k+8, 2k+9
+        NN[k] = pk_max(e0, o0);
+        NN[k + 4] = pk_max(e1, o1);
+        D[k] = pk_sub(e0, o0);          // negative <=> odd predecessor strictly better (ties keep the even one)
+        D[k + 4] = pk_sub(e1, o1);
     }
+    uint32_t acc = 0;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) S[s] = N[s];
-    return dec;
+    for (int r = 7; r >= 0; --r) acc = (acc >> 2) | (pk_bits(D[r]) & 0x80008000u);
+    // low-half sign of D[r] (state 2r) now sits at bit 15 - 2r, high-half sign (state 2r+1) at bit 31 - 2r
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pm.E[k] = pk_lolo(NN[2 * k], NN[2 * k + 1]);
+        pm.O[k] = pk_hihi(NN[2 * k], NN[2 * k + 1]);
+    }
+    return (acc & 0xaaaau) | ((acc >> 17) & 0x5555u);
 }
+
+LM_FN Pk pk_neg(Pk a) { return pk_sub(pk_make(0, 0), a); }
 
 // Forward recursion over n2 + 4 steps.  cls(idx) returns the soft class (-1, 0, +1) of type-4 bit idx (0-based);
-// st(t, mask) receives the decision mask of step t.
+// st(t, mask) receives the decision mask of step t (state s at bit 15 - s).
 template <class Cls, class St>
 LM_FN void viterbi_forward(int n2, int K, int a, Cls cls, St st) {
-    int S[16];
+    PathMetrics pm;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) S[s] = 0;
-    S[0] = 4 * 5;                      // 127 * N * K in units of 127
+    for (int k = 0; k < 4; ++k) { pm.E[k] = pk_make(0, 0); pm.O[k] = pk_make(0, 0); }
+    pm.E[0] = pk_make(4 * 5, 0);       // S[0] = 127 * N * K in units of 127
     int pos = a;                       // (a * i) % K for i = 1 (a < K for every block kind)
     for (int u = 0; u < n2 / 2; ++u) {
         const int sa = cls(pos);
@@ -113,36 +160,36 @@ LM_FN void viterbi_forward(int n2, int K, int a, Cls cls, St st) {
         pos += a; pos = pos >= K ? pos - K : pos;
         const int sc = cls(pos);
         pos += a; pos = pos >= K ? pos - K : pos;
-        {   // even step: g1 -> sa, g2 -> sb.  i = (d0 d1 d2): sign(g1) = d0, sign(g2) = d1 ^ d2
-            const int p = sa + sb, q = sa - sb;
-            const int m[8] = { p, q, q, p, -q, -p, -p, -q };
-            st(2 * u, acs(S, m));
+        {   // even step: g1 -> sa, g2 -> sb.  butterfly i = (d0 d1 d2): sign(g1) = d0, sign(g2) = d1 ^ d2, so with
+            // p = sa + sb, q = sa - sb the metrics are m_0..7 = p, q, q, p, -q, -p, -p, -q
+            const Pk pq = pk_make(sa + sb, sa - sb), qp = pk_swap(pq);
+            st(2 * u, acs_pk(pm, pq, qp, pk_neg(qp), pk_neg(pq)));
         }
-        {   // odd step: g1 -> sc only
-            const int m[8] = { sc, sc, sc, sc, -sc, -sc, -sc, -sc };
-            st(2 * u + 1, acs(S, m));
+        {   // odd step: g1 -> sc only: m_0..3 = sc, m_4..7 = -sc
+            const Pk cc = pk_make(sc, sc), nc = pk_neg(cc);
+            st(2 * u + 1, acs_pk(pm, cc, cc, nc, nc));
         }
     }
 #pragma unroll
     for (int f = 0; f < kFlush; ++f) {
-        const int m[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        st(n2 + f, acs(S, m));
+        const Pk z = pk_make(0, 0);
+        st(n2 + f, acs_pk(pm, z, z, z, z));
     }
 }
 
-// Traceback from state 0 after the flush steps.  ld(t) returns the decision mask of step t; st(h, half) receives
-// decoded bits 16h..16h+15 (bit 16h+b at bit b).  n2 is a multiple of 16 for every coded block kind.
+// Traceback from state 0 after the flush steps.  ld(t) returns the decision mask of step t (state s at bit 15 - s);
+// st(h, half) receives decoded bits 16h..16h+15 (bit 16h+b at bit b).  n2 is a multiple of 16 for every coded block kind.
 template <class Ld, class St>
 LM_FN void viterbi_traceback(int n2, Ld ld, St st) {
     uint32_t state = 0;
 #pragma unroll
-    for (int f = kFlush - 1; f >= 0; --f) state = ((state << 1) & 0xfu) | ((ld(n2 + f) >> state) & 1u);
+    for (int f = kFlush - 1; f >= 0; --f) state = ((state << 1) & 0xfu) | ((ld(n2 + f) >> (state ^ 15u)) & 1u);
     for (int h = n2 / 16 - 1; h >= 0; --h) {
         uint32_t half = 0;
 #pragma unroll
         for (int b = 15; b >= 0; --b) {
             half |= (state >> 3) << b;                                        // vals[state]: the newest input bit
-            state = ((state << 1) & 0xfu) | ((ld(16 * h + b) >> state) & 1u);
+            state = ((state << 1) & 0xfu) | ((ld(16 * h + b) >> (state ^ 15u)) & 1u);
         }
         st(h, half);
     }

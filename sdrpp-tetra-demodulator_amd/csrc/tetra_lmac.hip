@@ -2,18 +2,20 @@
 // tp_sap_udata_ind() decoding chain (src/decoder/src/lower_mac/tetra_lower_mac.c:181-236).
 //
 // One 64-lane workgroup (one wavefront) decodes 64 blocks, one block per lane (lane-level code: lmac_core.hpp):
-//   1. the 64 rows are read from HBM once, with coalesced dword loads, into LDS (row stride 109 dwords = odd, so that
-//      "every lane reads the same column of its own row" is bank-conflict free);
-//   2. each lane descrambles its row (its own LFSR) and packs the soft classes 2 bits per type-4 bit into LDS words laid
-//      out [word][lane];
+//   1. the 64 rows are read from HBM once, 64 bits per row at a time (coalesced 64-byte segments, 4 rows per load
+//      instruction), into a small LDS stage (row stride 17 dwords = odd, so that "every lane reads the same column of
+//      its own row" is bank-conflict free);
+//   2. each lane descrambles its row chunk (its own LFSR) and packs the soft classes 2 bits per type-4 bit into LDS
+//      words laid out [word][lane];
 //   3. forward recursion: 16 path metrics in registers, the three soft values of a step pair gathered from the class
-//      words at the deinterleaved positions, 16 decision bits per step stored as one ushort in LDS [step][lane] (this
-//      array overlays the row buffer of step 1, which is dead by then);
-//   4. traceback from LDS (the addresses do not depend on the surviving state, only the bit picked does, so the loads
-//      pipeline), decoded bits packed 16 per ushort into LDS [half][lane], CRC16 over them;
+//      words at the deinterleaved positions, 16 decision bits per step stored as one ushort to a global scratch laid
+//      out [workgroup][step][lane] (one 128-byte line per step; written once, read once, normally from L2 / MALL);
+//   4. traceback from the scratch (the addresses do not depend on the surviving state, only the bit picked does, so the
+//      loads pipeline), decoded bits packed 16 per ushort into LDS [half][lane], CRC16 over them;
 //   5. the 64 decoded rows are written back with coalesced dword stores, 4 bits -> 4 bytes per lane.
-// LDS per workgroup: 37376 (rows / decisions) + 6912 (classes) + 2304 (decoded) = 46592 B -> 3 workgroups per CU.
-// The work is integer add/compare/select, VALU-bound; HBM traffic is the rows in and the decoded rows out, once each.
+// LDS per workgroup: 4352 (stage) + 6912 (classes) + 2304 (decoded) = 13568 B, 70 VGPRs -> 11 workgroups per CU (the
+// first version kept the decisions in LDS: 46.6 KB, 3 waves per CU, 3x slower).  The work is integer
+// add/compare/select, VALU-bound.
 #include <hip/hip_runtime.h>
 
 #include <vector>
@@ -26,7 +28,7 @@ namespace {
 using namespace tetra_lmac;
 
 constexpr int kLanes = 64;
-constexpr int kRowDwords = 109;                        // >= 432/4, odd
+constexpr int kChunkDwords = 16;                       // 64 type-5 bits per row per staging chunk
 constexpr int kSteps = kMaxType2 + kFlush;             // 292
 constexpr int kClsWords = (kMaxType345 + 15) / 16;     // 27
 constexpr int kOutHalves = kMaxType2 / 16;             // 18
@@ -42,16 +44,12 @@ const BlkParam kBlk[6] = {
     { 432, 288, 268, 103, 1 },  // SCH/F
 };
 
-union RowsOrDecisions {
-    uint32_t rows[kLanes][kRowDwords];
-    uint16_t dec[kSteps][kLanes];
-};
-
 __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
                                                         const uint32_t* __restrict__ scramb_init, int fixed_init,
                                                         int type345, int type2, int type1, int a,
-                                                        uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok) {
-    __shared__ RowsOrDecisions rd;
+                                                        uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
+                                                        uint16_t* __restrict__ dec_scratch, int dec_steps) {
+    __shared__ uint32_t stage[kLanes][kChunkDwords + 1];     // +1: odd row stride, conflict-free column reads
     __shared__ uint32_t cls[kClsWords][kLanes];
     __shared__ uint16_t outw[kOutHalves][kLanes];
     const int lane = threadIdx.x;
@@ -59,29 +57,33 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
     const int blk = blk0 + lane;
     const int rows_here = min(kLanes, n_blocks - blk0);
 
-    // 1. rows -> LDS
+    // 1+2. rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
+    //      descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
+    uint32_t lfsr = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[blk];
     const int row_dw = type345 >> 2;
-    for (int q = 0; q < rows_here; ++q) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(type5 + (size_t)(blk0 + q) * in_stride);
-        for (int d = lane; d < row_dw; d += kLanes) rd.rows[q][d] = src[d];
+    for (int c0 = 0; c0 < row_dw; c0 += kChunkDwords) {
+#pragma unroll 4
+        for (int it = 0; it < kLanes * kChunkDwords / kLanes; ++it) {
+            const int q = it * (kLanes / kChunkDwords) + lane / kChunkDwords, d = lane % kChunkDwords;
+            uint32_t v = 0;
+            if (q < rows_here && c0 + d < row_dw)
+                v = reinterpret_cast<const uint32_t*>(type5 + (size_t)(blk0 + q) * in_stride)[c0 + d];
+            stage[q][d] = v;
+        }
+        __syncthreads();
+        lfsr = descramble_chunk(type345 - 4 * c0, lfsr, [&](int d) { return stage[lane][d]; },
+                                [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
+        __syncthreads();
     }
-    for (int q = rows_here; q < kLanes; ++q)
-        for (int d = lane; d < row_dw; d += kLanes) rd.rows[q][d] = 0;
-    __syncthreads();
 
-    // 2. descramble + soft classes
-    const uint32_t init = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[blk];
-    descramble_to_classes(type345, init, [&](int d) { return rd.rows[lane][d]; },
-                          [&](int w, uint32_t word) { cls[w][lane] = word; });
-    __syncthreads();   // rows are dead from here: decisions overlay them
-
-    // 3. forward recursion
+    // 3. forward recursion: decisions of step t of this workgroup's 64 blocks = one 128-byte line of the scratch
+    uint16_t* dec = dec_scratch + (size_t)blockIdx.x * dec_steps * kLanes + lane;
     viterbi_forward(type2, type345, a,
                     [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; },
-                    [&](int t, uint32_t mask) { rd.dec[t][lane] = (uint16_t)mask; });
+                    [&](int t, uint32_t mask) { dec[t * kLanes] = (uint16_t)mask; });
 
-    // 4. traceback + CRC (own lane's data only: no barrier needed)
-    viterbi_traceback(type2, [&](int t) { return (uint32_t)rd.dec[t][lane]; },
+    // 4. traceback + CRC (own lane's data only: program order is enough)
+    viterbi_traceback(type2, [&](int t) { return (uint32_t)dec[t * kLanes]; },
                       [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; });
     const uint32_t crc = crc16_bits(type1 + 16, [&](int h) { return (uint32_t)outw[h][lane]; });
     if (blk < n_blocks) crc_ok[blk] = crc == kCrcOk;
@@ -151,9 +153,19 @@ int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_block
         hipLaunchKernelGGL(k_lmac_bbk, dim3((n_blocks + 255) / 256), dim3(256), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
                            p.type345, d_type2, out_stride, d_crc_ok);
     } else {
-        hipLaunchKernelGGL(k_lmac_decode, dim3((n_blocks + kLanes - 1) / kLanes), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride,
-                           d_scramb_init, type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride,
-                           d_crc_ok);
+        // decision scratch: (type2 + 4) steps x 64 lanes x u16 per workgroup, from the stream-ordered allocator (pooled:
+        // after the first call it is a free-list hit), released in stream order right behind the kernel
+        const int groups = (n_blocks + kLanes - 1) / kLanes;
+        const int dec_steps = p.type2 + kFlush;
+        uint16_t* scratch = nullptr;
+        if (hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)groups * dec_steps * kLanes * sizeof(uint16_t), s) != hipSuccess)
+            return TETRA_ERR_NOMEM;
+        hipLaunchKernelGGL(k_lmac_decode, dim3(groups), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
+                           type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride, d_crc_ok,
+                           scratch, dec_steps);
+        const hipError_t launch = hipGetLastError();
+        if (hipFreeAsync(scratch, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
+        return TETRA_OK;
     }
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }

@@ -14,6 +14,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
+    # torch first: torch bundles its own HIP runtime, the C-ABI library links the system one; whichever is loaded first
+    # serves the whole process, and a torch that comes second finds no GPU.  Tests that hand torch device tensors to the
+    # *_device entry points need torch's, so it is loaded before the library (same order as bench.py).
+    import torch  # noqa: F401
     import tetra_amd
     return tetra_amd.pkg
 

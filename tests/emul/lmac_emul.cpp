@@ -17,9 +17,11 @@ extern "C" int lmac_emul_decode(int type345, int type2, int type1, int a, const 
         uint32_t cls[(kMaxType345 + 15) / 16];
         uint16_t dec[kMaxType2 + kFlush];
         uint16_t outw[kMaxType2 / 16];
-        descramble_to_classes(type345, scramb_init[blk],
-                              [&](int d) { uint32_t v; std::memcpy(&v, row + 4 * d, 4); return v; },
-                              [&](int w, uint32_t word) { cls[w] = word; });
+        uint32_t lfsr = scramb_init[blk];
+        for (int c0 = 0; c0 < type345 / 4; c0 += 16)      // the kernel's 64-bit staging chunks
+            lfsr = descramble_chunk(type345 - 4 * c0, lfsr,
+                                    [&](int d) { uint32_t v; std::memcpy(&v, row + 4 * (c0 + d), 4); return v; },
+                                    [&](int w, uint32_t word) { cls[c0 / 4 + w] = word; });
         viterbi_forward(type2, type345, a,
                         [&](int idx) { return (int)(cls[idx >> 4] << (30 - 2 * (idx & 15))) >> 30; },
                         [&](int t, uint32_t mask) { dec[t] = (uint16_t)mask; });

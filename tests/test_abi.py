@@ -70,6 +70,17 @@ def test_lmac_header_symbols_all_exported_and_host_helpers(pkg):
             assert pkg.lmac_binding.scramb_init(mcc, mnc, cc) == ref_binding.scramb_get_init(mcc, mnc, cc)
 
 
+def test_burst_sync_header_symbols_all_exported(pkg):
+    src = open(os.path.join(ROOT, "include", "tetra_burst_sync.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(tetra_bsync_[a-z0-9_]+|tetra_burst_demux_device)\s*\(", src)))
+    L = pkg.load_library()
+    assert set(names) == set(pkg.bsync_binding.BSYNC_EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    assert C.sizeof(pkg.bsync_binding.BsyncState) == 16
+
+
 def test_default_config_is_the_plugins(pkg):
     cfg = pkg.binding.default_config()
     # src/main.cpp:35-44,78-84
