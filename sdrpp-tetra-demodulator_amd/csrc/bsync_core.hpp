@@ -64,19 +64,55 @@ BS_FN uint32_t window(const uint32_t* s, int x, int len) {
     return (uint32_t)(two >> (64 - len - (x & 31))) & (uint32_t)((1ull << len) - 1);
 }
 
+// 32 stream bits starting k bits after the start of word w (k = 0..63), first bit most significant
+BS_FN uint32_t shifted_word(uint32_t w0, uint32_t w1, uint32_t w2, int k) {
+    const uint32_t hi = k < 32 ? w0 : w1, lo = k < 32 ? w1 : w2;
+    const int r = k & 31;
+    return r == 0 ? hi : (uint32_t)((((uint64_t)hi << 32) | lo) >> (32 - r));
+}
+
+BS_FN uint32_t bit_reverse(uint32_t v) {
+#if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+
+// bit b (LSB = position 32w) set where positions lo <= 32w + b < hi
+BS_FN uint32_t range_mask(int w, int lo, int hi) {
+    int a = lo - 32 * w, b = hi - 32 * w;
+    a = a < 0 ? 0 : a;
+    b = b > 32 ? 32 : b;
+    if (a >= b) return 0u;
+    const uint32_t upto_b = b == 32 ? 0xffffffffu : ((1u << b) - 1u);
+    return upto_b & (0xffffffffu << a);
+}
+
 // match bits of the 32 positions 32w .. 32w+31 (LSB = position 32w) for the three sequences; a position counts only if
-// the whole sequence lies inside [x0, xe)
+// the whole sequence lies inside [x0, xe).  Bit-sliced: for every offset k into the sequence, the 32 candidate windows'
+// k-th bits are one funnel-shifted word, AND-ed (or AND-NOT-ed) into the three running match words.
 BS_FN void match_word(const uint32_t* s, int w, int x0, int xe, uint32_t& m_sync, uint32_t& m_n1, uint32_t& m_n2) {
-    m_sync = m_n1 = m_n2 = 0;
-    const uint64_t two = ((uint64_t)s[w] << 32) | s[w + 1];
-    for (int b = 0; b < 32; ++b) {
-        const int x = 32 * w + b;
-        const uint32_t f = (uint32_t)(two >> (42 - b)) & 0x3fffffu;
-        if (x < x0 || x + 22 > xe) continue;
-        if (f == kHeadN) m_n1 |= 1u << b;
-        if (f == kHeadP) m_n2 |= 1u << b;
-        if (f == kHeadY && x + 38 <= xe && window(s, x + 22, 16) == kTailY) m_sync |= 1u << b;
+    const uint32_t w0 = s[w], w1 = s[w + 1], w2 = s[w + 2];
+    uint32_t ay = 0xffffffffu, an = 0xffffffffu, ap = 0xffffffffu;
+    constexpr uint64_t seq_y = ((uint64_t)kHeadY << 16) | kTailY;          // 38 bits, first bit = bit 37
+#pragma unroll
+    for (int k = 0; k < 38; ++k) {
+        const uint32_t v = shifted_word(w0, w1, w2, k);
+        ay &= ((seq_y >> (37 - k)) & 1u) ? v : ~v;
+        if (k < 22) {
+            an &= ((kHeadN >> (21 - k)) & 1u) ? v : ~v;
+            ap &= ((kHeadP >> (21 - k)) & 1u) ? v : ~v;
+        }
     }
+    // ay/an/ap: bit 31 - b = position 32w + b  ->  bit b
+    m_sync = bit_reverse(ay) & range_mask(w, x0, xe - 38 + 1);
+    m_n1 = bit_reverse(an) & range_mask(w, x0, xe - 22 + 1);
+    m_n2 = bit_reverse(ap) & range_mask(w, x0, xe - 22 + 1);
 }
 
 // first set bit of bitmap m (bit x at word x>>5, bit x&31) in [a, b), or -1
@@ -107,14 +143,27 @@ BS_FN int literal_find(const uint32_t* s, int bx, int n, uint32_t mask, int& off
     return -1;
 }
 
-// the LOCKED state's search over the buffer [bx, bx + n), n >= 510: first of {sync, normal 1, normal 2}
-BS_FN int locked_find(const uint32_t* s, const uint32_t* m_sync, const uint32_t* m_n1, const uint32_t* m_n2, int bx, int n, int& offs) {
+// `first(m, a, b)` below is the "first set bit of bitmap m in [a, b)" primitive: first_set on the host, a wave-cooperative
+// version (one word per lane + ballot) in the kernel, where all 64 lanes run the state machine in lock step.
+
+// the LOCKED state's search over the buffer [bx, bx + n), n >= 510: first of {sync, normal 1, normal 2}.
+// m_any = m_sync | m_n1 | m_n2 answers the common case with one search.
+template <class First>
+BS_FN int locked_find(const uint32_t* s, const uint32_t* m_sync, const uint32_t* m_n1, const uint32_t* m_n2, const uint32_t* m_any,
+                      int bx, int n, int& offs, First first) {
     const uint32_t mask = (1u << kNorm1) | (1u << kNorm2) | (1u << kSync);
-    if (first_set(m_sync, bx, bx + 21) >= 0 || first_set(m_n1, bx, bx + 21) >= 0 || first_set(m_n2, bx, bx + 21) >= 0)
-        return literal_find(s, bx, n, mask, offs);
-    const int ps = first_set(m_sync, bx + 21, bx + n - 38 + 1);
-    const int p1 = first_set(m_n1, bx + 21, bx + n - 22 + 1);
-    const int p2 = first_set(m_n2, bx + 21, bx + n - 22 + 1);
+    const int p = first(m_any, bx, bx + n - 22 + 1);
+    if (p < 0) return -1;
+    if (p < bx + 21) return literal_find(s, bx, n, mask, offs);            // misaligned-filter zone: evaluate literally
+    const bool is_sync = (m_sync[p >> 5] >> (p & 31)) & 1u;
+    if (!is_sync || p + 38 <= bx + n) {
+        offs = p - bx;
+        return is_sync ? kSync : (((m_n1[p >> 5] >> (p & 31)) & 1u) ? kNorm1 : kNorm2);
+    }
+    // a sync sequence that does not fit the buffer any more: the three sequences separately
+    const int ps = first(m_sync, bx + 21, bx + n - 38 + 1);
+    const int p1 = first(m_n1, bx + 21, bx + n - 22 + 1);
+    const int p2 = first(m_n2, bx + 21, bx + n - 22 + 1);
     int best = -1, type = -1;
     if (ps >= 0) { best = ps; type = kSync; }
     if (p1 >= 0 && (best < 0 || p1 < best)) { best = p1; type = kNorm1; }
@@ -126,9 +175,9 @@ BS_FN int locked_find(const uint32_t* s, const uint32_t* m_sync, const uint32_t*
 // Runs the state machine over the new bits.  emit(f, bx, type, bitnum) is called for the f-th consumed frame (buffer
 // coordinate of its first bit, the reference's rx_cb type or -1, absolute bit number of its first bit).  On return
 // st holds the new state and carry_x the coordinate of the first bit that stays buffered ([carry_x, xe) = the new bitbuf).
-template <class Emit>
-BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32_t* m_n1, const uint32_t* m_n2, int n_new,
-              int& carry_x, Emit emit) {
+template <class First, class Emit>
+BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32_t* m_n1, const uint32_t* m_n2, const uint32_t* m_any,
+              int n_new, int& carry_x, First first, Emit emit) {
     const int x0 = kOff - (int)st.bits_in_buf, xe = kOff + n_new;
     const uint32_t abs0 = st.bitbuf_start_bitnum;               // absolute bit number of coordinate x0
     auto abs_of = [&](int x) { return abs0 + (uint32_t)(x - x0); };
@@ -139,7 +188,7 @@ BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32
         const int n = a - bx;
         if (n < kTs) return;
         int offs = 0, reported = -1;
-        const int rc = locked_find(s, m_sync, m_n1, m_n2, bx, n, offs);
+        const int rc = locked_find(s, m_sync, m_n1, m_n2, m_any, bx, n, offs, first);
         if (rc == kSync) {
             if (offs == 214) reported = rc;
             else state = kUnlocked;
@@ -158,7 +207,7 @@ BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32
             const int a1 = (a + 1 > bx + 2 * kTs) ? a + 1 : bx + 2 * kTs;
             if (a1 > xe) { a = xe; break; }
             const int bx1 = (a1 - kBuf > bx) ? a1 - kBuf : bx;
-            if (first_set(m_sync, bx1, bx1 + 21) >= 0) {        // a true match in the misaligned-filter zone: literal call
+            if (first(m_sync, bx1, bx1 + 21) >= 0) {        // a true match in the misaligned-filter zone: literal call
                 int offs = 0;
                 const int rc = literal_find(s, bx1, a1 - bx1, 1u << kSync, offs);
                 a = a1;
@@ -166,7 +215,7 @@ BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32
                 if (rc >= 0) { nfs = abs_of(bx) + (uint32_t)offs + 296u; state = kKnowFstart; }
                 continue;
             }
-            const int p = first_set(m_sync, bx1 + 21, xe - 38 + 1);
+            const int p = first(m_sync, bx1 + 21, xe - 38 + 1);
             if (p < 0) { a = xe; break; }
             a = (p + 38 > a1) ? p + 38 : a1;
             bx = (a - kBuf > bx) ? a - kBuf : bx;

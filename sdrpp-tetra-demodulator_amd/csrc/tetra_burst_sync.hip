@@ -5,8 +5,9 @@
 //      bits -- is packed 32 bits per word into LDS; the new bits start word-aligned, 32 bytes -> one word per lane-step
 //      with 16-byte loads and one multiply per 8 bytes (the scan kernel's trick);
 //   2. three match bitmaps (sync / normal 1 / normal 2 training sequence present at x) are built 32 positions per lane-step;
-//   3. lane 0 walks the event-driven state machine of bsync_core.hpp over the bitmaps (about 70 events per second of
-//      signal) and lists the consumed frames in LDS;
+//   3. the wave walks the event-driven state machine of bsync_core.hpp (about 70 events per second of signal) in lock
+//      step; its "first set bit in [a, b)" searches over the bitmaps are wave-cooperative (one word per lane + ballot);
+//      the consumed frames are listed in LDS;
 //   4. all lanes expand the listed frames to one byte per bit with coalesced dword stores, and write the new carried
 //      buffer and the state.
 // Byte work: every input byte is read from HBM once, every output byte written once.
@@ -38,7 +39,8 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
     uint32_t* m_sync = s + words;
     uint32_t* m_n1 = m_sync + words;
     uint32_t* m_n2 = m_n1 + words;
-    FrameRec* rec = reinterpret_cast<FrameRec*>(m_n2 + words);
+    uint32_t* m_any = m_n2 + words;
+    FrameRec* rec = reinterpret_cast<FrameRec*>(m_any + words);
     __shared__ int sh_nframes, sh_carry_x;
     __shared__ State sh_state;
 
@@ -85,16 +87,33 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
         m_sync[w] = a;
         m_n1[w] = b;
         m_n2[w] = c;
+        m_any[w] = a | b | c;
     }
     __syncthreads();
 
-    // 3. state machine
+    // 3. state machine: all lanes in lock step (uniform control flow); the bitmap searches are wave-cooperative
+    auto first_wave = [&](const uint32_t* m, int a, int b) -> int {
+        if (a >= b) return -1;
+        const int w0 = a >> 5, w1 = (b - 1) >> 5;
+        for (int base = w0; base <= w1; base += kLanes) {
+            const int w = base + lane;
+            uint32_t v = (w <= w1) ? m[w] : 0u;
+            if (w == w0) v &= 0xffffffffu << (a & 31);
+            if (w == w1 && (b & 31) != 0) v &= (1u << (b & 31)) - 1u;
+            const unsigned long long hit = __ballot(v != 0u);
+            if (hit) {
+                const int l = __builtin_ctzll(hit);
+                return 32 * (base + l) + __builtin_ctz(__shfl(v, l));
+            }
+        }
+        return -1;
+    };
+    int carry_x = 0;
+    const int nrun = run(st, s, m_sync, m_n1, m_n2, m_any, n_new, carry_x, first_wave, [&](int f, int bx, int type, uint32_t bitnum) {
+        if (lane == 0 && f < max_frames) rec[f] = FrameRec{ bx, type, bitnum };
+    });
     if (lane == 0) {
-        int carry_x = 0;
-        const int n = run(st, s, m_sync, m_n1, m_n2, n_new, carry_x, [&](int f, int bx, int type, uint32_t bitnum) {
-            if (f < max_frames) rec[f] = FrameRec{ bx, type, bitnum };
-        });
-        sh_nframes = n < max_frames ? n : max_frames;
+        sh_nframes = nrun < max_frames ? nrun : max_frames;
         sh_carry_x = carry_x;
         sh_state = st;
     }
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(256) void k_burst_demux(const uint8_t* __restrict__
     if (d == 0) valid[r] = p.len0 > 0;
 }
 
-size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 4 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
+size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 5 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
 
 }  // namespace
 

@@ -131,3 +131,24 @@ def align_and_count_errors(rx_bits, tx_bits, max_lag=400, skip=0, window=None):
         if err < best[1]:
             best = (lag, err, hi - lo)
     return best
+
+
+# EN 300 392-2 9.4.4.3.2 / 9.4.4.3.4: normal training sequences 1, 2 and the synchronisation training sequence
+TRAIN_NORM_1 = np.array([1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0], np.uint8)
+TRAIN_NORM_2 = np.array([0,1, 1,1, 1,0, 1,0, 0,1, 0,0, 0,0, 1,1, 0,1, 1,1, 1,0], np.uint8)
+TRAIN_SYNC = np.array([1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1], np.uint8)
+
+
+def gen_slot_bits(n_slots, seed):
+    """A continuous downlink as far as the burst synchroniser is concerned: 510-bit slots of random payload with the
+    synchronisation training sequence at bit 214 in every 4th slot and normal training sequence 1 (2 in odd slots) at bit
+    244 in the others (EN 300 392-2 9.4.4.2.5/6).  Payload blocks are random, i.e. not channel coded: bench/profiling
+    input for the demodulator -> synchroniser -> demultiplexer -> decoder chain, where only the work matters."""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, (n_slots, 510), dtype=np.uint8)
+    for s in range(n_slots):
+        if s % 4 == 0:
+            bits[s, 214:214 + 38] = TRAIN_SYNC
+        else:
+            bits[s, 244:244 + 22] = TRAIN_NORM_2 if s % 2 else TRAIN_NORM_1
+    return bits.reshape(-1)

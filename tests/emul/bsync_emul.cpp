@@ -13,13 +13,14 @@ using namespace bsync_core;
 extern "C" int bsync_emul_process(State* st, uint8_t* carry, const uint8_t* bits, int n_new, uint8_t* frames, int32_t* types,
                                   uint32_t* bitnums, int max_frames) {
     const int words = stream_words(n_new);
-    std::vector<uint32_t> s(words, 0), ms(words, 0), m1(words, 0), m2(words, 0);
+    std::vector<uint32_t> s(words, 0), ms(words, 0), m1(words, 0), m2(words, 0), ma(words, 0);
     const int x0 = kOff - (int)st->bits_in_buf, xe = kOff + n_new;
     for (int x = x0; x < kOff; ++x) s[x >> 5] |= (uint32_t)(carry[x - x0] & 1u) << (31 - (x & 31));
     for (int j = 0; j < n_new; ++j) s[(kOff + j) >> 5] |= (uint32_t)(bits[j] & 1u) << (31 - ((kOff + j) & 31));
-    for (int w = x0 >> 5; w <= (xe - 1) >> 5 && w + 2 < words; ++w) match_word(s.data(), w, x0, xe, ms[w], m1[w], m2[w]);
+    for (int w = x0 >> 5; w <= (xe - 1) >> 5 && w + 2 < words; ++w) { match_word(s.data(), w, x0, xe, ms[w], m1[w], m2[w]); ma[w] = ms[w] | m1[w] | m2[w]; }
     int carry_x = 0, overflow = 0;
-    const int n = run(*st, s.data(), ms.data(), m1.data(), m2.data(), n_new, carry_x, [&](int f, int bx, int type, uint32_t bitnum) {
+    const int n = run(*st, s.data(), ms.data(), m1.data(), m2.data(), ma.data(), n_new, carry_x,
+                      [](const uint32_t* m, int a, int b) { return first_set(m, a, b); }, [&](int f, int bx, int type, uint32_t bitnum) {
         if (f >= max_frames) { overflow = 1; return; }
         for (int i = 0; i < kTs; ++i) frames[(size_t)f * 512 + i] = (uint8_t)get_bit(s.data(), bx + i);
         types[f] = type;
