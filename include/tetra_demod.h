@@ -97,7 +97,9 @@ typedef struct tetra_demod_channel_state {
 enum {
     TETRA_PARAM_SYMBOLRATE = 0,       /* setSymbolrate      pi4dqpsk.cpp:32-42  (also resets timing recovery, complex_fd.cpp:30-41) */
     TETRA_PARAM_SAMPLERATE = 1,       /* setSamplerate      pi4dqpsk.cpp:44-54 */
-    TETRA_PARAM_RRC_TAP_COUNT = 2,    /* setRRCTapCount     pi4dqpsk.cpp:68-70 */
+    TETRA_PARAM_RRC_TAP_COUNT = 2,    /* setRRCTapCount     pi4dqpsk.cpp:68-70.  Deviation: a NEW count also re-designs the FLL's band-edge filters
+                                       * to that length (the kernels share one delay line of taps-1 samples between the three FIRs); the
+                                       * reference re-designs only the RRC here and keeps the FLL at its construction-time length */
     TETRA_PARAM_RRC_BETA = 3,         /* setRRCParams beta  pi4dqpsk.cpp:56-66 (double; the reference's setRRCBeta(int) truncation quirk is NOT reproduced) */
     TETRA_PARAM_AGC_RATE = 4,         /* setAGCRate         pi4dqpsk.cpp:76-80 */
     TETRA_PARAM_COSTAS_BANDWIDTH = 5, /* setCostasBandwidth pi4dqpsk.cpp:82-86 */

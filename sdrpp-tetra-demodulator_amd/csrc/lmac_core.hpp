@@ -114,9 +114,8 @@ LM_FN uint32_t pk_bits(Pk a) { return (uint32_t)(uint16_t)a.x | ((uint32_t)(uint
 // butterflies 2k (low half) and 2k+1 (high half).
 struct PathMetrics { Pk E[4], O[4]; };
 
-// One add-compare-select step.  M0 = (m_0, m_1), M1 = (m_2, m_3) are the branch metrics of butterflies 0..3; butterflies
-// 4..7 have m_4..7 = (-m_2, -m_3, -m_0, -m_1)... expressed by the caller through (M2, M3) = the metrics of butterflies
-// (4,5) and (6,7).  Returns the 16 decision bits, state s at bit 15 - s (1 = state s took its odd predecessor).
+// One add-compare-select step.  Mk = (m_2k, m_2k+1) are the branch metrics of butterflies 2k and 2k+1.  Returns the 16
+// decision bits, state s at bit 15 - s (1 = state s took its odd predecessor).
 LM_FN uint32_t acs_pk(PathMetrics& pm, Pk M0, Pk M1, Pk M2, Pk M3) {
     const Pk M[4] = { M0, M1, M2, M3 };
     Pk NN[8];      // NN[j] = (S'[2j], S'[2j+1])

@@ -14,8 +14,6 @@
 // k_burst_demux: one thread per output dword; a gather with the offsets of tetra_burst_rx_cb().
 #include <hip/hip_runtime.h>
 
-#include <vector>
-
 #include "../../include/tetra_burst_sync.h"
 #include "bsync_core.hpp"
 

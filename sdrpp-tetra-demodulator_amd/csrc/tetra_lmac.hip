@@ -18,8 +18,6 @@
 // add/compare/select, VALU-bound.
 #include <hip/hip_runtime.h>
 
-#include <vector>
-
 #include "../../include/tetra_lmac.h"
 #include "lmac_core.hpp"
 
