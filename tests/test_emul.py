@@ -92,3 +92,44 @@ def test_other_tap_counts(emul, oracle, synth):
             assert np.array_equal(_u32(q["y"][0]), _u32(r["y"])), nt
             nb = int(q["n_bits"][0])
             assert np.array_equal(q["bits"][0][:nb], r["bits"]), nt
+
+
+def test_fused_stage_code_equals_oracle(emul, oracle, synth, lanes=True):
+    """The fused kernel's building blocks (agc_step, the FLL row with its delay-line replay and 32-sample tiles,
+    rrc_direct8, k2_timing, k2_costas -- same source as the device) run stage after stage == the oracle, bit for bit:
+    RRC output, bits, symbols; ragged call lengths with carried state (1, 7, 31, 33 ... samples: partial tiles, partial
+    8-step groups), 5 channels."""
+    Cn = 5
+    N = 4200
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=321)
+    e = emul.EmulDemod(Cn, fused=lanes)
+    orc = [oracle.Oracle() for _ in range(Cn)]
+    pos = 0
+    for n in (1, 7, 31, 33, 64, 17, 1000, 0, 2047, 1000):
+        n = min(n, N - pos)
+        q = e.process(iq[:, pos:pos + n], want_sym=True)
+        for c in range(Cn):
+            r = orc[c].process(iq[c, pos:pos + n], stages=True)
+            assert np.array_equal(_u32(q["y"][c]), _u32(r["y"])), (lanes, n, c)
+            nb = int(q["n_bits"][c])
+            assert nb == r["bits"].size and np.array_equal(q["bits"][c][:nb], r["bits"]), (lanes, n, c)
+            assert np.array_equal(_u32(q["sym"][c][:nb // 2]), _u32(r["sym"])), (lanes, n, c)
+        pos += n
+
+
+@pytest.mark.parametrize("nt", [33, 72])
+def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, lanes=True):
+    N = 2500
+    iq, _, _ = synth.gen_channel(N, 77)
+    ocfg = oracle.default_cfg()
+    ocfg.rrc_tap_count = nt
+    o = oracle.Oracle(ocfg)
+    ecfg = emul.default_cfg()
+    ecfg.rrc_tap_count = nt
+    e = emul.EmulDemod(1, ecfg, fused=lanes)
+    for pos in (0, 1250):
+        r = o.process(iq[pos:pos + 1250], stages=True)
+        q = e.process(iq[pos:pos + 1250])
+        assert np.array_equal(_u32(q["y"][0]), _u32(r["y"])), (lanes, nt)
+        nb = int(q["n_bits"][0])
+        assert np.array_equal(q["bits"][0][:nb], r["bits"]), (lanes, nt)
