@@ -274,3 +274,34 @@ def test_gpu_iq_to_type1_blocks_all_on_device(pkg, ref, synth):
             assert len(good) >= (4 if name == "sb1" else 12), (c, name, len(good))
             assert all(t1[c, f].tobytes() in sent[c] for f in good)
             assert sum(valid[c, :nf[c]]) - len(good) <= 1          # at most the first frame after lock may still be settling
+
+
+@pytest.mark.gpu
+def test_gpu_burst_sync_reset_clamp_and_argument_errors(pkg, ref, oracle):
+    """reset() returns every receiver to UNLOCKED/empty; n_bits above max_bits is clamped (documented), negative counts are
+    treated as 0; bad arguments are refused."""
+    bb = pkg.bsync_binding
+    tx = make_stream(ref, 4242)[:6000]
+    bs = bb.BurstSync(3, 4096)
+    rows = np.zeros((3, 6016), np.uint8)
+    rows[:, :6000] = tx
+    nb = np.array([4096, 6000, -5], np.int32)                  # exact, clamped to 4096, treated as 0
+    f1, t1, b1, n1 = bs.process(rows, nb)
+    o = oracle.BurstSyncOracle()
+    fo = o.feed(tx[:4096], 1)
+    for c in (0, 1):
+        assert n1[c] == len(fo[0]) and np.array_equal(f1[c, :n1[c], :510], fo[0]) and bs.states()[c] == o.state
+    assert n1[2] == 0 and bs.states()[2] == (0, 0, 0, 0)
+    bs.reset()
+    assert all(s == (0, 0, 0, 0) for s in bs.states())
+    f2, t2, b2, n2 = bs.process(rows, nb)                      # after reset the same input gives the same output
+    assert np.array_equal(n1, n2) and np.array_equal(t1, t2) and np.array_equal(f1, f2) and np.array_equal(b1, b2)
+    with pytest.raises(pkg.TetraDemodError):
+        bs.process(np.zeros((3, 6001), np.uint8), nb)          # stride not a multiple of 4
+    with pytest.raises(pkg.TetraDemodError):
+        bs.states(2, 5)                                        # range outside the handle
+    bs.close()
+    with pytest.raises(pkg.TetraDemodError):
+        bb.BurstSync(0, 100)
+    with pytest.raises(pkg.TetraDemodError):
+        bb.BurstSync(4, 1 << 20)                               # more than the kernel's LDS stream buffer can hold

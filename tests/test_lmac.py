@@ -194,3 +194,29 @@ def test_gpu_iq_to_sync_pdu(pkg, lref, synth):
     for r in range(len(rows)):
         if ok[r]:
             assert type2[r, :60].tobytes() in sent[owner[r]]
+
+
+@pytest.mark.gpu
+def test_gpu_lmac_device_entry_with_wide_output_rows_on_a_side_stream(pkg, lref):
+    """The *_device entry point on a non-default stream, output rows wider than type2_bits (the padding must be left
+    untouched), two back-to-back launches sharing the stream-ordered decision scratch."""
+    import torch
+    lb = pkg.lmac_binding
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    t = lref.TPSAP_T_SCH_F
+    rows, si, _ = make_rows(lref, t, 333, 909)
+    want, want_ok = ref_decode_rows(lref, t, rows, si)
+    d_rows = torch.from_numpy(rows).to(dev)
+    d_si = torch.from_numpy(si.view(np.int32)).to(dev)
+    outs = []
+    torch.cuda.synchronize()
+    for rep in range(2):
+        d_out = torch.full((333, 304), 7, dtype=torch.uint8, device=dev)
+        d_ok = torch.full((333,), -1, dtype=torch.int32, device=dev)
+        lb.decode_batch_device(t, d_rows, 333, STRIDE, d_si, d_out, 304, d_ok, st)
+        outs.append((d_out, d_ok))
+    st.synchronize()
+    for d_out, d_ok in outs:
+        out, ok = d_out.cpu().numpy(), d_ok.cpu().numpy()
+        assert np.array_equal(out[:, :288], want) and (out[:, 288:] == 7).all() and np.array_equal(ok, want_ok)
