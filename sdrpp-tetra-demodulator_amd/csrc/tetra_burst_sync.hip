@@ -207,8 +207,10 @@ int tetra_bsync_create(int n_channels, int max_bits, int device, tetra_bsync_t**
         delete h;
         return TETRA_ERR_NOMEM;
     }
+    // the attribute belongs to the kernel, not to the handle: always raise it to the ceiling so that handles of different
+    // sizes can coexist
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_burst_sync), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes(max_bits, h->max_frames)) != hipSuccess) {
+                            160 * 1024 - 64) != hipSuccess) {
         tetra_bsync_destroy(h);
         return TETRA_ERR_HIP;
     }

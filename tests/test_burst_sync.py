@@ -305,3 +305,24 @@ def test_gpu_burst_sync_reset_clamp_and_argument_errors(pkg, ref, oracle):
         bb.BurstSync(0, 100)
     with pytest.raises(pkg.TetraDemodError):
         bb.BurstSync(4, 1 << 20)                               # more than the kernel's LDS stream buffer can hold
+
+
+@pytest.mark.gpu
+def test_gpu_burst_sync_handles_of_different_sizes_coexist(pkg, ref, oracle):
+    """A large handle created first keeps working after a small one is created (the kernel's dynamic-LDS ceiling is a
+    per-kernel attribute, not a per-handle one)."""
+    bb = pkg.bsync_binding
+    tx = make_stream(ref, 777)
+    n = min(tx.size, 120000)
+    big = bb.BurstSync(2, 120000)
+    small = bb.BurstSync(2, 2000)
+    rows = np.zeros((2, 120000), np.uint8)
+    rows[:, :n] = tx[:n]
+    f, t, b, nf = big.process(rows, np.array([n, n], np.int32))
+    o = oracle.BurstSyncOracle()
+    fo = o.feed(tx[:n], 1)
+    assert nf[0] == nf[1] == len(fo[0]) and np.array_equal(t[0, :nf[0]], fo[1]) and big.states()[1] == o.state
+    fs, ts, bsn, nfs = small.process(rows[:, :2000].copy(), np.array([2000, 0], np.int32))
+    assert nfs[1] == 0 and small.states()[0][1] == 2000 or nfs[0] > 0
+    big.close()
+    small.close()
