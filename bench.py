@@ -66,9 +66,10 @@ def pmc_traffic(pipeline, channels, samples):
     path = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%dx%d.json" % (pipeline, channels, samples))
     try:
         with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
+            d = json.load(f)
+            return float(d["traffic_bytes_per_launch"]), d.get("issue")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(synth, n_samples, budget_s=12.0):
@@ -261,6 +262,7 @@ def main():
         total_samples = float(world) * C * N * args.steps
         value = total_samples / elapsed / 1e6
         algo_bytes = ALGO_BYTES_PER_SAMPLE * C * N
+        traffic, issue = pmc_traffic("two_kernel" if args.two_kernel else "fused", C, N)
         achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
         out = {
             "metric": "IQ Msamples/s demodulated to bits, batched TETRA channels",
@@ -275,12 +277,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_agc_fll_rrc" if args.two_kernel else "k_fused",
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": pmc_traffic("two_kernel" if args.two_kernel else "fused", C, N),
+                         "traffic": traffic,
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(k1_ms, 4), "second_kernel_ms": round(k2_ms, 4),
                          "note": "HBM is the roofline BASELINE.json names; the kernel itself is VALU-issue bound "
-                                 "(per-channel serial recurrences), see DESIGN.md"},
+                                 "(per-channel serial recurrences), see DESIGN.md",
+                         "issue_counters": issue},
             "check": check,
         }
         if host_path is not None:
