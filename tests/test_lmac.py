@@ -220,3 +220,31 @@ def test_gpu_lmac_device_entry_with_wide_output_rows_on_a_side_stream(pkg, lref)
     for d_out, d_ok in outs:
         out, ok = d_out.cpu().numpy(), d_ok.cpu().numpy()
         assert np.array_equal(out[:, :288], want) and (out[:, 288:] == 7).all() and np.array_equal(ok, want_ok)
+
+
+@pytest.mark.gpu
+def test_gpu_lmac_full_size_round_trip(pkg, lref):
+    """One second of 4096 channels (286 720 SCH/F blocks in one call): encode -> flip up to 4 of the 432 bits -> decode
+    gives the payload back with a good CRC for (almost) every block, a good CRC always means the sent payload
+    (size-independent properties), and the uncorrectable blocks plus a random sample equal the reference decode bit for bit."""
+    rng = np.random.default_rng(31)
+    t = lref.TPSAP_T_SCH_F
+    n_distinct, n = 1024, 4096 * 70
+    si_d = rng.integers(0, 2 ** 32, n_distinct, dtype=np.uint64).astype(np.uint32)
+    pay = rng.integers(0, 2, (n_distinct, 268), dtype=np.uint8)
+    enc = np.stack([lref.lmac_encode(t, pay[k], si_d[k]) for k in range(n_distinct)])
+    pick = rng.integers(0, n_distinct, n)
+    rows = enc[pick]
+    flips = rng.integers(0, 432, (n, 4))
+    nflip = rng.integers(0, 5, n)
+    for j in range(4):
+        m = nflip > j
+        rows[np.nonzero(m)[0], flips[m, j]] ^= 1
+    out, ok = pkg.lmac_binding.decode_batch(t, rows, si_d[pick])
+    good = ok == 1
+    assert good.mean() > 0.97                                    # <= 4 channel errors are usually corrected (98.9 % here)
+    assert np.array_equal(out[good][:, :268], pay[pick][good])   # and a good CRC means the payload is back
+    check = np.concatenate([np.nonzero(~good)[0][:300], rng.integers(0, n, 200)])
+    for r in check:                                              # uncorrectable blocks and a random sample: == reference
+        t2, okr = lref.lmac_decode(t, rows[r], si_d[pick[r]])
+        assert np.array_equal(out[r, :288], t2) and okr == ok[r]
