@@ -76,6 +76,25 @@ int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_block
 int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
                             uint8_t* type2, int out_stride, int32_t* crc_ok, int device);
 
+/*
+ * The one piece of the SYNC-PDU read-out (tetra_lower_mac.c:246-275) that feeds back into the decoding chain: every SB1
+ * block with a good CRC sets the cell's scrambling code, tcd->scramb_init = tetra_scramb_get_init(mcc, mnc, colour code)
+ * with colour code = type2[4..9], mcc = type2[31..40], mnc = type2[41..54] (bits_to_uint, MSB first; :258-266), and every
+ * later block of that receiver -- starting with the BBK and SB2 of the same burst, which tetra_burst_rx_cb hands over
+ * after the SB1 -- is descrambled with it.  The reference keeps one process-global tcd (:116); here every channel has one.
+ *
+ * d_sb1_type2   [n_channels * frames_per_channel][type2_stride] decoded SB1 rows, frame slots in time order per channel
+ *               (the layout tetra_bsync_process_device + tetra_burst_demux_device + tetra_lmac_decode_batch_device produce)
+ * d_crc_ok, d_valid  per row: the decoder's crc_ok, the demultiplexer's valid (row is an SB1 at all)
+ * d_chan_scramb [n_channels] uint32 in/out: the code in force when the call starts / after its last frame (0 for a fresh
+ *               receiver, as the reference's zero-initialised tcd)
+ * d_row_scramb  [n_channels * frames_per_channel] uint32 out: the code in force for the non-SB1 blocks of each frame slot
+ *               -- feed it to tetra_lmac_decode_batch_device as d_scramb_init for SB2 / NDB / SCH-F / BBK rows
+ */
+int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
+                                   int n_channels, int frames_per_channel, uint32_t* d_chan_scramb, uint32_t* d_row_scramb,
+                                   void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

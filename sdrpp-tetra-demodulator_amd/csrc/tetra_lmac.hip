@@ -108,6 +108,26 @@ __global__ __launch_bounds__(256) void k_lmac_bbk(const uint8_t* __restrict__ ty
     crc_ok[blk] = 1;
 }
 
+// tetra_lower_mac.c:258-266 per channel: walk the frame slots in time order, a good SB1 replaces the scrambling code
+__global__ __launch_bounds__(256) void k_track_scramb(const uint8_t* __restrict__ sb1, int stride, const int* __restrict__ crc_ok,
+                                                      const int* __restrict__ valid, int n_channels, int frames,
+                                                      uint32_t* __restrict__ chan_scramb, uint32_t* __restrict__ row_scramb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) return;
+    uint32_t cur = chan_scramb[c];
+    for (int f = 0; f < frames; ++f) {
+        const size_t r = (size_t)c * frames + f;
+        if (valid[r] && crc_ok[r]) {
+            const uint8_t* t2 = sb1 + r * stride;
+            auto field = [&](int first, int len) { uint32_t v = 0; for (int i = 0; i < len; ++i) v = (v << 1) | (t2[first + i] & 1u); return v; };
+            const uint32_t cc = field(4, 6), mcc = field(31, 10), mnc = field(41, 14);
+            cur = (((cc & 0x3f) | ((mnc & 0x3fff) << 6) | ((mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1;   // tetra_scramb.c:87-99
+        }
+        row_scramb[r] = cur;
+    }
+    chan_scramb[c] = cur;
+}
+
 int check_args(int type, const void* in, int n_blocks, int in_stride, const void* init, const void* out, int out_stride,
                const void* ok, bool device_ptrs) {
     if (type < 0 || type > 5 || n_blocks < 0) return TETRA_ERR_ARG;
@@ -165,6 +185,16 @@ int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_block
         if (hipFreeAsync(scratch, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
         return TETRA_OK;
     }
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
+                                   int n_channels, int frames_per_channel, uint32_t* d_chan_scramb, uint32_t* d_row_scramb,
+                                   void* hip_stream) {
+    if (!d_sb1_type2 || !d_crc_ok || !d_valid || !d_chan_scramb || !d_row_scramb) return TETRA_ERR_ARG;
+    if (n_channels < 1 || frames_per_channel < 0 || type2_stride < 60) return TETRA_ERR_ARG;
+    hipLaunchKernelGGL(k_track_scramb, dim3((n_channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2,
+                       type2_stride, d_crc_ok, d_valid, n_channels, frames_per_channel, d_chan_scramb, d_row_scramb);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 

@@ -5,7 +5,8 @@ import numpy as np
 
 from .binding import TetraDemodError, load_library
 
-LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch"]
+LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch",
+                "tetra_lmac_track_scramb_device"]
 # enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
 TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
 
@@ -30,6 +31,8 @@ def _lib():
         L.tetra_lmac_decode_batch_device.restype = i32
         L.tetra_lmac_decode_batch.argtypes = [i32, vp, i32, i32, vp, vp, i32, vp, i32]
         L.tetra_lmac_decode_batch.restype = i32
+        L.tetra_lmac_track_scramb_device.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
+        L.tetra_lmac_track_scramb_device.restype = i32
         _ready = True
     return L
 
@@ -77,3 +80,16 @@ def decode_batch_device(blk_type, d_type5, n_blocks, in_stride, d_scramb, d_type
                                                C.c_void_p(d_type2.data_ptr()), int(out_stride), C.c_void_p(d_crc_ok.data_ptr()), s)
     if rc:
         raise TetraDemodError(rc, "tetra_lmac_decode_batch_device")
+
+
+def track_scramb_device(d_sb1_type2, type2_stride, d_crc_ok, d_valid, n_channels, frames_per_channel, d_chan_scramb, d_row_scramb,
+                        stream=None):
+    s = None
+    if stream is not None:
+        s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+    vp = C.c_void_p
+    rc = _lib().tetra_lmac_track_scramb_device(vp(d_sb1_type2.data_ptr()), int(type2_stride), vp(d_crc_ok.data_ptr()),
+                                               vp(d_valid.data_ptr()), int(n_channels), int(frames_per_channel),
+                                               vp(d_chan_scramb.data_ptr()), vp(d_row_scramb.data_ptr()), s)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_track_scramb_device")

@@ -207,31 +207,41 @@ def test_gpu_demux_equals_restated_rx_cb(pkg, ref, oracle):
         pkg.bsync_binding.demux_device(d_frames, d_types, n, 5, 0, d_rows, 216, d_valid)
 
 
+def _uint_bits(v, n):
+    return [(v >> (n - 1 - i)) & 1 for i in range(n)]
+
+
 @pytest.mark.gpu
 def test_gpu_iq_to_type1_blocks_all_on_device(pkg, ref, synth):
     """IQ -> demodulator -> burst synchroniser -> demultiplexer -> lower-MAC decoder, every stage a *_device entry point on
     one stream with no host round trip in between; transmit side = the reference's encoder primitives and burst builders.
-    The SYNC PDUs (SB1) and the SCH/F blocks the reference would hand to its upper MAC come back with good CRCs."""
+    Every channel is a different cell: its SYNC PDUs carry its own MCC / MNC / colour code, its SCH/F blocks are
+    scrambled with the code the reference derives from them, and the device chain finds that code itself
+    (tetra_lmac_track_scramb_device on the decoded SB1 rows) -- nothing but IQ goes in.  The SYNC PDUs and the SCH/F
+    blocks the reference would hand to its upper MAC come back with good CRCs."""
     import torch
     if not ref.lmac_available():
         pytest.skip("oracle/_ref/libtetra_lmac_ref.so not available")
     lb, bb_ = pkg.lmac_binding, pkg.bsync_binding
     rng = np.random.default_rng(21)
     Cn, nslots = 8, 44
-    cell = ref.scramb_get_init(262, 3, 17)
+    cells = [(int(rng.integers(0, 1024)), int(rng.integers(0, 16384)), int(rng.integers(0, 64))) for _ in range(Cn)]
+    codes = [ref.scramb_get_init(*cell) for cell in cells]
     sent_sb1, sent_schf, tx = [set() for _ in range(Cn)], [set() for _ in range(Cn)], []
     for c in range(Cn):
+        mcc, mnc, cc = cells[c]
         slots = []
         for s in range(nslots):
             bbk = rng.integers(0, 2, 30)
             if s % 4 == 0:
                 t1 = rng.integers(0, 2, 60).astype(np.uint8)
+                t1[4:10], t1[31:41], t1[41:55] = _uint_bits(cc, 6), _uint_bits(mcc, 10), _uint_bits(mnc, 14)
                 sent_sb1[c].add(t1.tobytes())
                 slots.append(ref.build_sync_burst(ref.lmac_encode(ref.TPSAP_T_SB1, t1, 3), bbk, rng.integers(0, 2, 216)))
             else:
                 t1 = rng.integers(0, 2, 268).astype(np.uint8)
                 sent_schf[c].add(t1.tobytes())
-                t5 = ref.lmac_encode(ref.TPSAP_T_SCH_F, t1, cell)
+                t5 = ref.lmac_encode(ref.TPSAP_T_SCH_F, t1, codes[c])
                 slots.append(ref.build_norm_burst(t5[:216], bbk, t5[216:], 0))
         tx.append(np.concatenate(slots))
     N = nslots * 510 - 100
@@ -250,30 +260,42 @@ def test_gpu_iq_to_type1_blocks_all_on_device(pkg, ref, synth):
     d_fb = torch.zeros((Cn, F), dtype=torch.int32, device=dev)
     d_nf = torch.zeros(Cn, dtype=torch.int32, device=dev)
     d_rows = torch.zeros((Cn * F, 432), dtype=torch.uint8, device=dev)
+    d_valid_sb1 = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
     d_valid = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
-    d_scr = torch.full((Cn * F,), cell, dtype=torch.int64, device=dev).to(torch.int32)
+    d_chan_scr = torch.zeros(Cn, dtype=torch.int32, device=dev)          # fresh receivers: code 0, like the reference's tcd
+    d_row_scr = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
+    d_sb1 = torch.zeros((Cn * F, 80), dtype=torch.uint8, device=dev)
+    d_ok_sb1 = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
     d_t2 = torch.zeros((Cn * F, 288), dtype=torch.uint8, device=dev)
     d_ok = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
     d.process_device(d_iq, N, d_bits, stride, d_nbits, stream=stream)
     bs.process_device(d_bits, stride, d_nbits, d_frames, d_ft, d_fb, d_nf, stream)
-    out = {}
-    for name, tpsap, blk, n1 in (("sb1", lb.TPSAP_T_SB1, 1, 60), ("schf", lb.TPSAP_T_SCH_F, 0, 268)):
-        bb_.demux_device(d_frames, d_ft, Cn * F, tpsap, blk, d_rows, 432, d_valid, stream)
-        lb.decode_batch_device(tpsap, d_rows, Cn * F, 432, d_scr, d_t2, 288, d_ok, stream)
-        torch.cuda.synchronize()
-        out[name] = (d_t2.cpu().numpy().reshape(Cn, F, 288)[:, :, :n1].copy(), d_ok.cpu().numpy().reshape(Cn, F).copy(),
-                     d_valid.cpu().numpy().reshape(Cn, F).copy())
+    bb_.demux_device(d_frames, d_ft, Cn * F, lb.TPSAP_T_SB1, 1, d_rows, 432, d_valid_sb1, stream)
+    lb.decode_batch_device(lb.TPSAP_T_SB1, d_rows, Cn * F, 432, None, d_sb1, 80, d_ok_sb1, stream)
+    lb.track_scramb_device(d_sb1, 80, d_ok_sb1, d_valid_sb1, Cn, F, d_chan_scr, d_row_scr, stream)
+    bb_.demux_device(d_frames, d_ft, Cn * F, lb.TPSAP_T_SCH_F, 0, d_rows, 432, d_valid, stream)
+    lb.decode_batch_device(lb.TPSAP_T_SCH_F, d_rows, Cn * F, 432, d_row_scr, d_t2, 288, d_ok, stream)
+    torch.cuda.synchronize()
+    out = {"sb1": (d_sb1.cpu().numpy().reshape(Cn, F, 80)[:, :, :60], d_ok_sb1.cpu().numpy().reshape(Cn, F), d_valid_sb1.cpu().numpy().reshape(Cn, F)),
+           "schf": (d_t2.cpu().numpy().reshape(Cn, F, 288)[:, :, :268], d_ok.cpu().numpy().reshape(Cn, F), d_valid.cpu().numpy().reshape(Cn, F))}
     nf, states = d_nf.cpu().numpy(), bs.states()
+    chan_scr = d_chan_scr.cpu().numpy().view(np.uint32)
+    row_scr = d_row_scr.cpu().numpy().view(np.uint32).reshape(Cn, F)
     d.close()
     bs.close()
     for c in range(Cn):
         assert states[c][0] == bb_.RX_S_LOCKED and nf[c] >= nslots // 2      # the demodulator's loops take ~12 slots to settle
+        assert chan_scr[c] == codes[c]                                       # the device found the cell's scrambling code
+        t1, ok, valid = out["sb1"]
+        first_good = min(f for f in range(nf[c]) if valid[c, f] and ok[c, f])
+        assert (row_scr[c, :first_good] == 0).all() and (row_scr[c, first_good:] == codes[c]).all()
         for name, sent in (("sb1", sent_sb1), ("schf", sent_schf)):
             t1, ok, valid = out[name]
             good = [f for f in range(nf[c]) if valid[c, f] and ok[c, f]]
             assert len(good) >= (4 if name == "sb1" else 12), (c, name, len(good))
             assert all(t1[c, f].tobytes() in sent[c] for f in good)
-            assert sum(valid[c, :nf[c]]) - len(good) <= 1          # at most the first frame after lock may still be settling
+            if name == "sb1":
+                assert sum(valid[c, :nf[c]]) - len(good) <= 1                # at most the first frame after lock may still be settling
 
 
 @pytest.mark.gpu

@@ -248,3 +248,38 @@ def test_gpu_lmac_full_size_round_trip(pkg, lref):
     for r in check:                                              # uncorrectable blocks and a random sample: == reference
         t2, okr = lref.lmac_decode(t, rows[r], si_d[pick[r]])
         assert np.array_equal(out[r, :288], t2) and okr == ok[r]
+
+
+@pytest.mark.gpu
+def test_gpu_track_scramb_equals_reference_rule(pkg, lref):
+    """tetra_lmac_track_scramb_device == the reference's rule (tetra_lower_mac.c:258-266 with tetra_scramb_get_init from the
+    reference build): per channel in time order, a valid SB1 row with a good CRC replaces the code; carried across calls."""
+    import torch
+    rng = np.random.default_rng(8)
+    Cn, F = 37, 23
+    dev = torch.device("cuda", 0)
+    chan = rng.integers(0, 2 ** 32, Cn, dtype=np.uint64).astype(np.uint32)
+    chan[:5] = 0
+    want_chan = chan.copy()
+    d_chan = torch.from_numpy(chan.view(np.int32).copy()).to(dev)
+    for call in range(3):
+        t2 = rng.integers(0, 2, (Cn * F, 80), dtype=np.uint8)
+        ok = (rng.random(Cn * F) < 0.3).astype(np.int32)
+        valid = (rng.random(Cn * F) < 0.4).astype(np.int32)
+        want_rows = np.zeros(Cn * F, np.uint32)
+        for c in range(Cn):
+            cur = want_chan[c]
+            for f in range(F):
+                r = c * F + f
+                if valid[r] and ok[r]:
+                    bits = t2[r]
+                    val = lambda a, n: int("".join(map(str, bits[a:a + n])), 2)
+                    cur = np.uint32(lref.scramb_get_init(val(31, 10), val(41, 14), val(4, 6)))
+                want_rows[r] = cur
+            want_chan[c] = cur
+        d_rows = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
+        pkg.lmac_binding.track_scramb_device(torch.from_numpy(t2).to(dev), 80, torch.from_numpy(ok).to(dev), torch.from_numpy(valid).to(dev),
+                                             Cn, F, d_chan, d_rows)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_rows.cpu().numpy().view(np.uint32), want_rows), call
+        assert np.array_equal(d_chan.cpu().numpy().view(np.uint32), want_chan), call
