@@ -132,3 +132,43 @@ def test_product_sources_do_not_reference_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "tetra_oracle" not in txt.replace("tetra_oracle.c", "").replace("tetra_oracle_sincosf", ""), f
                 assert "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_public_headers_are_plain_c99_and_cxx11():
+    """Every header under include/ must be consumable by a C compiler (the drop-in boundary is a C ABI) and by C++11."""
+    import glob
+    import subprocess
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        for lang, std in (("c", "-std=c99"), ("c++", "-std=c++11")):
+            subprocess.run(["gcc" if lang == "c" else "g++", std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", lang, h],
+                           check=True)
+
+
+def test_c_program_links_against_the_library_and_runs_host_only_entry_points(pkg, tmp_path):
+    """A C translation unit, compiled by gcc, linked against libtetra_demod_hip.so: the entry points that need no GPU work."""
+    import subprocess
+    lib = pkg.load_library()._name
+    src = tmp_path / "link.c"
+    src.write_text('''
+#include <stdio.h>
+#include "tetra_demod.h"
+#include "tetra_chan.h"
+#include "tetra_burst_scan.h"
+#include "tetra_lmac.h"
+#include "tetra_burst_sync.h"
+int main(void) {
+    tetra_demod_config_t cfg; tetra_chan_config_t cc; tetra_lmac_blk_param_t bp;
+    if (tetra_demod_default_config(&cfg) != TETRA_OK || tetra_chan_default_config(&cc) != TETRA_OK) return 1;
+    if (tetra_lmac_blk_param(TETRA_TPSAP_T_SCH_F, &bp) != TETRA_OK || bp.type345_bits != 432 || bp.type1_bits != 268) return 2;
+    if (tetra_lmac_scramb_init(262, 1, 5) != 0x41800117u) return 3;
+    if (tetra_demod_bits_stride(36000) < 36000) return 4;
+    if (tetra_bsync_max_frames(NULL) != TETRA_ERR_ARG) return 5;
+    printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "link"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), lib, "-Wl,-rpath," + os.path.dirname(lib),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["65", "800", "1"]
