@@ -71,6 +71,8 @@ struct FusedParams {
     K1Consts k1;
     K2Consts k2;
     int ablate;          // debug/profiling only: bit r set = role r keeps its barriers but skips its work (results invalid)
+    long long* prof;     // debug/profiling only (TETRA_DEMOD_PROFILE): [workgroups][8] = busy clocks of waves 0..5 inside their epoch
+                         // bodies (barrier waits excluded), [6] = clocks from kernel entry to exit of wave 0; null = off
 };
 
 struct FusedLds {
@@ -119,13 +121,15 @@ struct FllDeviceIO {
 // Every role runs its own copy of the epoch loop (same trip count, one workgroup barrier per epoch): the
 // branch on the wave index is wave-uniform, and keeping the roles in separate code paths keeps each role's
 // registers out of the others' live ranges.
-#define FUSED_EPOCHS(...)                         \
-    for (int e = 0; e < ntiles + 4; e++) {        \
-        __VA_ARGS__                               \
-        __syncthreads();                          \
+#define FUSED_EPOCHS(...)                                                        \
+    for (int e = 0; e < ntiles + 4; e++) {                                       \
+        const long long tb_ = PROF ? __builtin_readcyclecounter() : 0;           \
+        __VA_ARGS__                                                              \
+        if (PROF) busy_ += __builtin_readcyclecounter() - tb_;                   \
+        __syncthreads();                                                         \
     }
 
-template <bool ALPHA0, bool QUALITY> __global__ __launch_bounds__(kFThreads) void k_fused(FusedParams p) {
+template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_bounds__(kFThreads) void k_fused(FusedParams p) {
     __shared__ FusedLds L;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,6 +137,8 @@ template <bool ALPHA0, bool QUALITY> __global__ __launch_bounds__(kFThreads) voi
     const int ch0 = blockIdx.x * kFCh;
     const int n = p.n;
     const int ntiles = (n + kFT - 1) / kFT;
+    long long busy_ = 0;
+    const long long t_entry_ = PROF ? __builtin_readcyclecounter() : 0;
     auto chan = [&](int c) { const int ch = ch0 + c; return ch < p.n_channels ? ch : p.n_channels - 1; };
     auto live = [&](int c) { return ch0 + c < p.n_channels; };
 
@@ -359,6 +365,10 @@ template <bool ALPHA0, bool QUALITY> __global__ __launch_bounds__(kFThreads) voi
                 p.q_err[ch0 + c] = q.standarderr; p.q_sync[ch0 + c] = q.sync;
             }
         }
+    }
+    if (PROF && lane == 0) {
+        p.prof[(long long)blockIdx.x * 8 + wave] = busy_;
+        if (wave == 0) p.prof[(long long)blockIdx.x * 8 + 6] = __builtin_readcyclecounter() - t_entry_;
     }
     // delay lines: last 80 FLL outputs, last 7 RRC outputs (both rings still hold them; the loops end on a barrier)
     for (int i = tid; i < kFCh * kHist; i += kFThreads) {

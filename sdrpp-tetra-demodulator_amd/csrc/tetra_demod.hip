@@ -364,6 +364,7 @@ struct tetra_demod {
     static constexpr int kEvSlots = 64;
     hipEvent_t ev[kEvSlots][3] = {};
     long long n_calls = 0;      // process calls that launched kernels
+    long long* d_prof = nullptr;   // TETRA_DEMOD_PROFILE scratch
     int last_n = 0;
 };
 
@@ -470,7 +471,7 @@ int reset_range(tetra_demod* h, int first, int count) {
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
                      h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
-                     h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym };
+                     h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& slot : h->ev)
@@ -691,11 +692,20 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         {
             const char* ab = std::getenv("TETRA_DEMOD_ABLATE");   // profiling aid, see kernel_fused.hpp
             pf.ablate = ab ? std::atoi(ab) : 0;
+            // TETRA_DEMOD_PROFILE=<file>: per-role busy clocks of the launch are appended to <file> (synchronises; debug only)
+            pf.prof = nullptr;
+            if (std::getenv("TETRA_DEMOD_PROFILE") && !h->q_ring) {
+                if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * ((size_t)(h->C + kFCh - 1) / kFCh)));
+                HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * ((size_t)(h->C + kFCh - 1) / kFCh), s));
+                pf.prof = h->d_prof;
+            }
         }
         const dim3 gf((h->C + kFCh - 1) / kFCh);
         HIP_TRY(h, hipEventRecord(ev[0], s));
         const bool a0 = pf.k1.fll_alpha == 0.0f, ql = pf.q_ring != nullptr;
-        if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
+        if (pf.prof && a0) hipLaunchKernelGGL((k_fused<true, false, true>), gf, dim3(kFThreads), 0, s, pf);
+        else if (pf.prof) hipLaunchKernelGGL((k_fused<false, false, true>), gf, dim3(kFThreads), 0, s, pf);
+        else if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
         else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
         else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false>), gf, dim3(kFThreads), 0, s, pf);
         else hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
@@ -703,6 +713,20 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         HIP_TRY(h, hipEventRecord(ev[1], s));
         HIP_TRY(h, hipEventRecord(ev[2], s));
         h->n_calls++;
+        if (pf.prof) {
+            const size_t nwg = (size_t)(h->C + kFCh - 1) / kFCh;
+            std::vector<long long> host(8 * nwg);
+            HIP_TRY(h, hipStreamSynchronize(s));
+            HIP_TRY(h, hipMemcpy(host.data(), h->d_prof, sizeof(long long) * host.size(), hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(std::getenv("TETRA_DEMOD_PROFILE"), "a")) {
+                double sum[8] = { 0 };
+                for (size_t w = 0; w < nwg; w++)
+                    for (int r = 0; r < 8; r++) sum[r] += (double)host[8 * w + r];
+                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"A\": %.0f, \"C\": %.0f, \"F0\": %.0f, \"F1\": %.0f, \"E\": %.0f, \"D\": %.0f}, \"mean_total_clocks\": %.0f}\n",
+                             n_samples, nwg, sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg);
+                std::fclose(f);
+            }
+        }
         return TETRA_OK;
     }
     HIP_TRY(h, hipEventRecord(ev[0], s));
