@@ -357,3 +357,32 @@ def test_errors(pkg):
     with pytest.raises(B.TetraDemodError):
         pkg.Demodulator(1, 64, rrc_tap_count=200)
     d.close()
+
+
+@pytest.mark.gpu
+def test_soak_twelve_seconds_of_signal_with_carried_state(pkg, oracle, synth):
+    """64 channels, twelve consecutive one-second calls (432 000 samples per channel, ~221 000 symbols) with the loop state
+    carried on the device: every call's bits and bit counts equal the oracle's, and the state read back at the end equals
+    the oracle's state -- nothing drifts between the two over long runs."""
+    Cn, N, SEC = 64, 36000, 12
+    iq = np.concatenate([synth.gen_batch(Cn, N, base_seed=5000 + 17 * s)[0] for s in range(SEC)], axis=1)
+    d = pkg.Demodulator(Cn, N)
+    states = None
+    total = 0
+    for s in range(SEC):
+        chunk = np.ascontiguousarray(iq[:, s * N:(s + 1) * N])
+        bits, nb, _ = d.process(chunk)
+        rb, rnb, _, states = oracle.process_batch(chunk, states=states)
+        assert np.array_equal(nb, rnb), s
+        for c in range(Cn):
+            assert np.array_equal(bits[c][:nb[c]], rb[c][:nb[c]]), (s, c)
+        total += int(nb.sum())
+    for c in (0, 17, 63):
+        st = d.get_state(c)
+        o = states[c]
+        assert np.float32(st.agc_gain).tobytes() == np.float32(o.agc_gain).tobytes()
+        assert np.float32(st.fll_phase).tobytes() == np.float32(o.fll_phase).tobytes()
+        assert np.float32(st.costas_phase).tobytes() == np.float32(o.costas_phase).tobytes()
+        assert np.float32(st.mu).tobytes() == np.float32(o.mu).tobytes() and st.offset == o.offset
+    d.close()
+    assert total > Cn * SEC * 35000
