@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--host-path", action="store_true",
                     help="also time tetra_demod_process (host buffers: H2D + kernel + D2H) and report it as "
                          "host_path_msamples_s (informational; never the metric value)")
+    ap.add_argument("--chain", action="store_true",
+                    help="also run the device-resident receive chain behind the demodulator (burst synchroniser -> demultiplexer "
+                         "-> lower-MAC decoder; profiles/measure_pipeline*.py) and attach its timings as \"chain\" (informational)")
     args = ap.parse_args()
 
     import torch
@@ -291,8 +294,19 @@ def main():
             out["host_path_pinned_msamples_s"] = round(host_path_pinned, 1)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg.synth, N)
+        if args.chain and world == 1:
+            dem.close()
+            dem = None
+            import subprocess
+            chain = {}
+            for key, script in (("stages", "measure_pipeline.py"), ("overlapped", "measure_pipeline_overlap.py")):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", script)], capture_output=True, text=True)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                chain[key] = json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
+            out["chain"] = chain
         print(json.dumps(out))
-    dem.close()
+    if dem is not None:
+        dem.close()
     if dist is not None:
         dist.destroy_process_group()
 
