@@ -70,6 +70,19 @@ TD_FN int v_iand(int a, int b) { return a & b; }
 TD_FN float v_flip_if_odd(float x, int k) {
     return __builtin_bit_cast(float, __builtin_bit_cast(int, x) ^ (int)((unsigned)k << 31));
 }
+// x with its sign flipped when the float k (an integer value with |k| <= 2) is odd: the exponent field of +-1.0f has its
+// lowest bit set and that of 0.0f / +-2.0f has not, so `bits(k) << 8` is exactly the sign mask -- one shift instead of
+// a convert and a shift.  Identical to v_flip_if_odd(x, (int)k) for |k| <= 2.
+TD_FN float v_flip_by_k8(float x, float k) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) ^ (int)(__builtin_bit_cast(unsigned, k) << 8));
+}
+// Keep a loop-invariant value in a vector register (device): the constant-bus limit lets a VOP3 instruction read only one
+// scalar register, and without this the compiler re-materialises the second scalar operand of v_med3 with a v_mov per use.
+#if TD_DEVICE
+TD_FN float v_pin(float x) { asm volatile("" : "+v"(x)); return x; }
+#else
+TD_FN float v_pin(float x) { return x; }
+#endif
 // |x| > lim ? x - copysign(delta, x) : x   -- the phase wrap of PhaseControlLoop for symmetric limits
 TD_FN float v_wrap_sym(float x, float lim, float delta) {
     const float t = x - __builtin_copysignf(delta, x);
@@ -97,6 +110,7 @@ TD_FN Pair<float> pk_fma(Pair<float> a, Pair<float> b, Pair<float> c) {
 }
 TD_FN Pair<float> pk_mul(Pair<float> a, Pair<float> b) { Pair<float> r; r.v = a.v * b.v; return r; }
 TD_FN Pair<float> pk_add(Pair<float> a, Pair<float> b) { Pair<float> r; r.v = a.v + b.v; return r; }
+TD_FN Pair<float> pk_sub(Pair<float> a, Pair<float> b) { Pair<float> r; r.v = a.v - b.v; return r; }
 TD_FN Pair<float> pk_swap(Pair<float> a) { Pair<float> r; r.v = __builtin_shufflevector(a.v, a.v, 1, 0); return r; }
 // DPP row moves (gfx9 DPP controls): row_shr:1 = 0x111 (lane l <- lane l-1), row_shl:1 = 0x101
 // (lane l <- lane l+1).  With bound_ctrl off, lanes whose source is outside the 16-lane row keep `old`.
@@ -152,6 +166,7 @@ template <class V> TD_FN Pair<V> pk_fma(Pair<V> a, Pair<V> b, Pair<V> c) {
 }
 template <class V> TD_FN Pair<V> pk_mul(Pair<V> a, Pair<V> b) { return Pair<V>(a.x() * b.x(), a.y() * b.y()); }
 template <class V> TD_FN Pair<V> pk_add(Pair<V> a, Pair<V> b) { return Pair<V>(a.x() + b.x(), a.y() + b.y()); }
+template <class V> TD_FN Pair<V> pk_sub(Pair<V> a, Pair<V> b) { return Pair<V>(a.x() - b.x(), a.y() - b.y()); }
 template <class V> TD_FN Pair<V> pk_swap(Pair<V> a) { return Pair<V>(a.y(), a.x()); }
 #endif
 
@@ -189,6 +204,7 @@ TD_FN Row16 v_sel(Row16m m, Row16 a, Row16 b) { Row16 r; for (int i = 0; i < 16;
 TD_FN Row16i v_ftoi(Row16 a) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = (int)a.l[i]; return r; }
 TD_FN Row16m v_ieq(Row16i a, int b) { Row16m r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] == b; return r; }
 TD_FN Row16 v_flip_if_odd(Row16 x, Row16i k) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = v_flip_if_odd(x.l[i], k.l[i]); return r; }
+TD_FN Row16 v_flip_by_k8(Row16 x, Row16 k) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = v_flip_by_k8(x.l[i], k.l[i]); return r; }
 TD_FN Row16 v_wrap_sym(Row16 x, float lim, float delta) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = v_wrap_sym(x.l[i], lim, delta); return r; }
 TD_FN Row16i v_iand(Row16i a, int b) { Row16i r; for (int i = 0; i < 16; i++) r.l[i] = a.l[i] & b; return r; }
 template <> struct vtraits<Row16> { using M = Row16m; using I = Row16i; };
@@ -220,7 +236,9 @@ template <class V> TD_FN Pair<V> row_shl2_z(Pair<V> src) { return Pair<V>(row_sh
 // Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same function as
 // tetra_oracle_sincosf): k = rint(x/pi), three-term Cody-Waite reduction to r in [-pi/2, pi/2], minimax
 // polynomials in r^2, sign (-1)^k applied to both results with one shift and two xors.  |error| <= 1.6e-7.
-template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
+// SMALL: the caller guarantees |x| <= 2.5 pi (every phase the loops hand over is wrapped to [-pi, pi] or (-2 pi, 2 pi)),
+// so k is in {-2..2} and the sign is applied with v_flip_by_k8 -- same bits, one instruction less.
+template <class V, bool SMALL = false> TD_FN void sincos_t(V x, V& s, V& c) {
     V k = v_rint(x * 0.318309886183790672f);
     V nk = -k;
     V r = v_fma(nk, V(3.140625f), x);
@@ -237,9 +255,40 @@ template <class V> TD_FN void sincos_t(V x, V& s, V& c) {
     pc = v_fma(pc, z, V(0.04166663810610771f));
     pc = v_fma(pc, z, V(-0.5f));
     V cr = v_fma(pc, z, V(1.0f));
-    typename vtraits<V>::I ki = v_ftoi(k);
-    s = v_flip_if_odd(sr, ki);
-    c = v_flip_if_odd(cr, ki);
+    if (SMALL) {
+        s = v_flip_by_k8(sr, k);
+        c = v_flip_by_k8(cr, k);
+    } else {
+        typename vtraits<V>::I ki = v_ftoi(k);
+        s = v_flip_if_odd(sr, ki);
+        c = v_flip_if_odd(cr, ki);
+    }
+}
+
+// Two independent angles at once, (x.x, x.y) -> s = (sin x.x, sin x.y), c = (cos x.x, cos x.y): the same operations as two
+// sincos_t<float, true> calls, issued as packed instructions (the Costas wave evaluates its loop phasor and the pi/4
+// rotation phasor of pi4dqpsk_costas.cpp:7,16 together).  |x| <= 2.5 pi.
+TD_FN void sincos_pair(Pair<float> x, Pair<float>& s, Pair<float>& c) {
+    typedef Pair<float> P;
+    const P t = pk_mul(x, P(0.318309886183790672f, 0.318309886183790672f));
+    const P k(v_rint(t.x()), v_rint(t.y()));
+    const P nk(-k.x(), -k.y());
+    P r = pk_fma(nk, P(3.140625f, 3.140625f), x);
+    r = pk_fma(nk, P(9.67502593994140625e-4f, 9.67502593994140625e-4f), r);
+    r = pk_fma(nk, P(1.509957990978376432e-7f, 1.509957990978376432e-7f), r);
+    const P z = pk_mul(r, r);
+    P ps = pk_fma(P(2.597026877992903e-06f, 2.597026877992903e-06f), z, P(-0.0001980524102691561f, -0.0001980524102691561f));
+    ps = pk_fma(ps, z, P(0.008332998491823673f, 0.008332998491823673f));
+    ps = pk_fma(ps, z, P(-0.16666656732559204f, -0.16666656732559204f));
+    ps = pk_mul(ps, z);
+    const P sr = pk_fma(ps, r, r);
+    P pc = pk_fma(P(-2.604826931928983e-07f, -2.604826931928983e-07f), z, P(2.476031113474164e-05f, 2.476031113474164e-05f));
+    pc = pk_fma(pc, z, P(-0.0013888374669477344f, -0.0013888374669477344f));
+    pc = pk_fma(pc, z, P(0.04166663810610771f, 0.04166663810610771f));
+    pc = pk_fma(pc, z, P(-0.5f, -0.5f));
+    const P cr = pk_fma(pc, z, P(1.0f, 1.0f));
+    s = P(v_flip_by_k8(sr.x(), k.x()), v_flip_by_k8(sr.y(), k.y()));
+    c = P(v_flip_by_k8(cr.x(), k.x()), v_flip_by_k8(cr.y(), k.y()));
 }
 
 // SDR++ core complex_t::operator*: a * (c + j s) = (a.re*c - a.im*s, a.im*c + a.re*s), every product and the
@@ -255,6 +304,20 @@ template <class V> TD_FN Pair<V> cmul_phasor(Pair<V> a, V c, V s) {
 template <class V> TD_FN V fast_amp(V re, V im) {
     V r = v_abs(re), i = v_abs(im);
     return v_max(r, i) + 0.4f * v_min(r, i);
+}
+
+// fll.cpp:141-145 from the four real band-edge sums c14 = (S1, S4), c32 = (S3, S2):
+//   lbe = (S1 - S2, S4 + S3), hbe = (S1 + S2, S4 - S3), err = fastAmplitude(hbe) - fastAmplitude(lbe).
+// Written on pairs so that the device issues two packed adds, one packed multiply and one packed add:
+// d = (S1 - S2, S4 - S3) = (lbe.re, hbe.im), u = (S1 + S2, S4 + S3) = (hbe.re, lbe.im); every scalar operation and its
+// rounding is the one fast_amp() performs.
+template <class V> TD_FN V fll_error(Pair<V> c14, Pair<V> c32) {
+    const Pair<V> sw = pk_swap(c32);                 // (S2, S3)
+    const Pair<V> d = pk_sub(c14, sw), u = pk_add(c14, sw);
+    const V hr = v_abs(u.x()), hi = v_abs(d.y()), lr = v_abs(d.x()), li = v_abs(u.y());
+    const Pair<V> mx(v_max(hr, hi), v_max(lr, li)), mn(v_min(hr, hi), v_min(lr, li));
+    const Pair<V> fa = pk_add(mx, pk_mul(Pair<V>(V(0.4f), V(0.4f)), mn));     // max + 0.4f*min, see fast_amp
+    return fa.x() - fa.y();
 }
 
 // SDR++ core PhaseControlLoop<float, CLAMP>::advance.  The reference wraps with while loops; one
@@ -328,7 +391,7 @@ template <class V> struct K1Row {
             P a = agc_step<V>(k, in, g);
             // fll.cpp:137-138  x = in * phasor(-phase)
             V s, c;
-            sincos_t<V>(-ph, s, c);
+            sincos_t<V, true>(-ph, s, c);
             x = cmul_phasor<V>(a, c, s);
         }
         xs = row_shr1(x, xs);
@@ -351,10 +414,7 @@ template <class V> struct K1Row {
         ry[(PH + 3) & 3] = pk_fma(xs, P(th[1], th[1]), ry[(PH + 3) & 3]);
         if (!REPLAY) {
             // fll.cpp:141-145: band-edge outputs from the four real sums, error, loop advance
-            V s1 = c14.x(), s4 = c14.y(), s3 = c32.x(), s2 = c32.y();
-            V lre = s1 - s2, lim = s4 + s3;
-            V hre = s1 + s2, him = s4 - s3;
-            V err = fast_amp<V>(hre, him) - fast_amp<V>(lre, lim);
+            V err = fll_error<V>(c14, c32);
             pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
         }
         return cy;
@@ -457,7 +517,7 @@ template <class V> struct FllRow8 {
             x = a;
         } else {
             V s, c;
-            sincos_t<V>(-ph, s, c);                                   // fll.cpp:137-138
+            sincos_t<V, true>(-ph, s, c);                             // fll.cpp:137-138
             x = cmul_phasor<V>(a, c, s);
         }
         xs = row_shr2(x, xs);
@@ -471,10 +531,7 @@ template <class V> struct FllRow8 {
         TD_F8_TAP(1) TD_F8_TAP(2) TD_F8_TAP(3) TD_F8_TAP(4) TD_F8_TAP(5) TD_F8_TAP(6) TD_F8_TAP(7)
 #undef TD_F8_TAP
         if (!REPLAY) {
-            V s1 = c14.x(), s4 = c14.y(), s3 = c32.x(), s2 = c32.y();   // fll.cpp:141-145
-            V lre = s1 - s2, lim = s4 + s3;
-            V hre = s1 + s2, him = s4 - s3;
-            V err = fast_amp<V>(hre, him) - fast_amp<V>(lre, lim);
+            V err = fll_error<V>(c14, c32);                              // fll.cpp:141-145
             pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
         }
     }
@@ -597,12 +654,11 @@ TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float
     }
     const float vr = v.x(), vi = v.y(), ar = a.x(), ai = a.y(), br = b.x(), bi = b.y();
     // complex_fd.cpp:107-123, branch-free: one-sided differences at the bank edges, central difference inside
-    // (the unused neighbour row is a clamped copy, so every candidate is finite)
-    const bool lo = phase == 0, hi = phase == kInterpPhases - 1;
-    const float pr = lo ? vr : br, pi = lo ? vi : bi;     // subtrahend: f(T-1), or f(T) at the low edge
-    const float qr = hi ? vr : ar, qi = hi ? vi : ai;     // minuend:    f(T+1), or f(T) at the high edge
-    const float sc = (lo || hi) ? 1.0f : 0.5f;            // x*1.0f is exact, so the edge cases stay `a - b`
-    const float dr = (qr - pr) * sc, di = (qi - pi) * sc;
+        // At the low edge tm1 IS row `phase` (the caller clamps the neighbour rows), so b equals v bit for bit and a - b is the
+    // reference's one-sided f(T+1) - f(T); likewise a == v at the high edge.
+    const bool edge = phase == 0 || phase == kInterpPhases - 1;
+    const float sc = edge ? 1.0f : 0.5f;                  // x*1.0f is exact, so the edge cases stay `a - b`
+    const float dr = (ar - br) * sc, di = (ai - bi) * sc;
     // complex_fd.cpp:126,136-137
     float terr = ((vr > 0 ? 1.0f : -1.0f) * dr) + ((vi > 0 ? 1.0f : -1.0f) * di);
     terr = v_clamp(terr, -1.0f, 1.0f);
@@ -628,15 +684,14 @@ TD_FN int k2_phase(float mu) {
 // Costas loop + slicer + differential decoder for one symbol (pi4dqpsk_costas.cpp:7-28,
 // dqpsk_sym_extr.cpp:6-7,32-52).  Returns the dibit; (*zr, *zi) = PI4DQPSK::process output.
 TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
-    float s, c;
-    sincos_t<float>(-st.cph, s, c);
-    const Pair<float> xx = cmul_phasor<float>(Pair<float>(vr, vi), c, s);
     float ph2 = st.ph2 + (-kFlPi / 4.0f);
     if (ph2 >= 2 * kFlPi) ph2 -= 2 * kFlPi;
     else if (ph2 <= -2 * kFlPi) ph2 += 2 * kFlPi;
     st.ph2 = ph2;
-    sincos_t<float>(ph2, s, c);
-    const Pair<float> zz = cmul_phasor<float>(xx, c, s);
+    Pair<float> s2, c2;                                   // (loop phasor, pi/4-rotation phasor) in one packed evaluation
+    sincos_pair(Pair<float>(-st.cph, ph2), s2, c2);
+    const Pair<float> xx = cmul_phasor<float>(Pair<float>(vr, vi), c2.x(), s2.x());
+    const Pair<float> zz = cmul_phasor<float>(xx, c2.y(), s2.y());
     const float zr = zz.x(), zi = zz.y();
     float cerr = ((zr > 0 ? 1.0f : -1.0f) * zi) - ((zi > 0 ? 1.0f : -1.0f) * zr);
     cerr = v_clamp(cerr, -1.0f, 1.0f);

@@ -36,8 +36,10 @@ constexpr int kFYS = kFY + kFYM + 1;
 constexpr int kFS = 64;                  // symbol ring per channel
 
 // wave index -> role.  A workgroup's waves are placed on SIMDs cyclically, so waves w and w+4 share a SIMD:
-// the two FLL waves get SIMDs of their own, {A, E} and {C, D} pair up.
-enum { kRoleA = 0, kRoleC = 1, kRoleF0 = 2, kRoleF1 = 3, kRoleE = 4, kRoleD = 5 };
+// the two FLL waves get SIMDs of their own, {E, A} and {D, C} pair up.  The issue arbiter serves the OLDEST wave
+// of a SIMD first (profiles/r02/r02_a_issue_model.md), so the recurrence-bound roles (Costas, timing recovery) take the
+// lower wave index of their pair and the throughput roles (AGC, RRC) fill the slots they leave.
+enum { kRoleE = 0, kRoleD = 1, kRoleF0 = 2, kRoleF1 = 3, kRoleA = 4, kRoleC = 5 };
 
 struct FusedParams {
     const float2* iq;
@@ -81,9 +83,21 @@ struct FusedLds {
     float2 y_ring[kFCh][kFYS];
     float2 s_ring[kFCh][kFS];
     int s_avail[kFCh];
-    __attribute__((aligned(16))) float bank[kInterpPhases * kInterpTaps];
+    // interpolator bank with row 0 repeated in front and row 127 behind: rows max(p-1,0), p, min(p+1,127) of
+    // complex_fd.cpp:102-121 are then the 24 contiguous floats at bank[p * 8]
+    __attribute__((aligned(16))) float bank[(kInterpPhases + 2) * kInterpTaps];
     __attribute__((aligned(16))) float rrc[kRrcExt];       // zero-extended taps, see rrc_direct8
 };
+
+// Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
+// register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
+// ds_read_b128 with offset fields) instead of re-deriving every element's address from the LDS struct offset.
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const vfloat2 lds_cfloat2;
+typedef __attribute__((address_space(3))) const vfloat4 lds_cfloat4;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ unsigned pin_u32(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 
 __device__ __forceinline__ void x_ring_put(FusedLds& L, int c, int i, float2 v) {
     const int s = i & (kFX - 1);
@@ -143,7 +157,11 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
     auto live = [&](int c) { return ch0 + c < p.n_channels; };
 
     // ---- prologue: tables and delay lines into LDS -------------------------------------------------
-    for (int i = tid; i < kInterpPhases * kInterpTaps; i += kFThreads) L.bank[i] = p.bank[i];
+    for (int i = tid; i < (kInterpPhases + 2) * kInterpTaps; i += kFThreads) {
+        int row = i / kInterpTaps - 1;
+        row = row < 0 ? 0 : (row > kInterpPhases - 1 ? kInterpPhases - 1 : row);
+        L.bank[i] = p.bank[row * kInterpTaps + i % kInterpTaps];
+    }
     if (tid < kRrcExt) L.rrc[tid] = p.rrc_ext[tid];
     // rings start at zero: the RRC window may touch slots that were never written (weighted by zero taps)
     for (int i = tid; i < kFCh * kFXS; i += kFThreads) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
@@ -203,9 +221,11 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         }
         R.ph = p.fll_ph[chan(f_c)];
         R.fr = p.fll_fr[chan(f_c)];
+        K1Consts k1 = p.k1;
+        k1.fll_max_freq = v_pin(k1.fll_max_freq);
         {
             FllDeviceIO io{ L, p.hist + (long long)chan(f_c) * kHist, nullptr, f_c, f_pos, 0 };
-            fll8_replay<float, FllDeviceIO>(R, p.k1, io);
+            fll8_replay<float, FllDeviceIO>(R, k1, io);
         }
         __syncthreads();
         FUSED_EPOCHS(
@@ -214,7 +234,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                 const int base = t * kFT;
                 const int cnt = (n - base < kFT) ? (n - base) : kFT;
                 FllDeviceIO io{ L, nullptr, &L.a_buf[t & 1][f_c][0], f_c, f_pos, base };
-                fll8_tile<float, FllDeviceIO, ALPHA0>(R, p.k1, io, cnt);
+                fll8_tile<float, FllDeviceIO, ALPHA0>(R, k1, io, cnt);
             }
         )
         if (f_pos == 0 && live(f_c)) {
@@ -261,6 +281,10 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         st.cph = 0; st.cfr = 0; st.ph2 = 0; st.prev = 0;
         int S = 0;
         const int sym_cap = (int)(p.bits_stride / 2);
+        const unsigned y_base = pin_u32(lds_addr(&L.y_ring[c][0]));
+        const unsigned bank_base = pin_u32(lds_addr(&L.bank[0]));
+        K2Consts k2 = p.k2;
+        k2.tr_max_freq = v_pin(k2.tr_max_freq);
         __syncthreads();
         FUSED_EPOCHS(
             if (e >= 3 && on && !(p.ablate & 8)) {
@@ -268,27 +292,25 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                 const int limit = avail < n ? avail : n;
                 auto one_symbol = [&]() {
                     const int phase = k2_phase(st.mu);
-                    const int pm = phase > 0 ? phase - 1 : 0;
-                    const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
-                    const float2* yw = &L.y_ring[c][(st.offset - (kInterpTaps - 1)) & (kFY - 1)];
+                    // window buffer[offset .. offset+7] (contiguous thanks to the ring's mirror) and bank rows
+                    // max(phase-1,0), phase, min(phase+1,127) = 24 contiguous floats of the padded table
+                    lds_cfloat2* yw = (lds_cfloat2*)(size_t)(y_base + (((st.offset - (kInterpTaps - 1)) & (kFY - 1)) << 3));
+                    lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5));
                     Pair<float> w[kInterpTaps]; float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
                     _Pragma("unroll")
                     for (int j = 0; j < kInterpTaps; j++) {
-                        const float2 wv = yw[j];
+                        const vfloat2 wv = yw[j];
                         w[j] = Pair<float>(wv.x, wv.y);
                     }
-                    const float4* b0 = reinterpret_cast<const float4*>(L.bank + phase * kInterpTaps);
-                    const float4* bm = reinterpret_cast<const float4*>(L.bank + pm * kInterpTaps);
-                    const float4* bp = reinterpret_cast<const float4*>(L.bank + pp * kInterpTaps);
-                    float4 q;
-                    q = b0[0]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
-                    q = b0[1]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
-                    q = bm[0]; tm1[0] = q.x; tm1[1] = q.y; tm1[2] = q.z; tm1[3] = q.w;
-                    q = bm[1]; tm1[4] = q.x; tm1[5] = q.y; tm1[6] = q.z; tm1[7] = q.w;
-                    q = bp[0]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
-                    q = bp[1]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
+                    vfloat4 q;
+                    q = bk[0]; tm1[0] = q.x; tm1[1] = q.y; tm1[2] = q.z; tm1[3] = q.w;
+                    q = bk[1]; tm1[4] = q.x; tm1[5] = q.y; tm1[6] = q.z; tm1[7] = q.w;
+                    q = bk[2]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
+                    q = bk[3]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
+                    q = bk[4]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
+                    q = bk[5]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
                     float vr; float vi;
-                    k2_timing(p.k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
+                    k2_timing(k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
                     L.s_ring[c][S & (kFS - 1)] = make_float2(vr, vi);
                     S++;
                 };
@@ -336,6 +358,8 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
             q.standarderr = p.q_err[chan(c)]; q.sync = p.q_sync[chan(c)];
             qring = p.q_ring + (long long)chan(c) * 4096;
         }
+        K2Consts k2 = p.k2;
+        k2.costas_max_freq = v_pin(k2.costas_max_freq);
         __syncthreads();
         FUSED_EPOCHS(
             if (e >= 4 && on && !(p.ablate & 16)) {
@@ -343,7 +367,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                 while (S < avail) {
                     const float2 v = L.s_ring[c][S & (kFS - 1)];
                     float zr; float zi;
-                    const int d = k2_costas(p.k2, st, v.x, v.y, &zr, &zi);
+                    const int d = k2_costas(k2, st, v.x, v.y, &zr, &zi);
                     if (wr) {
                         // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
                         *reinterpret_cast<unsigned short*>(brow + 2 * S) = (unsigned short)(((d >> 1) & 1) | ((d & 1) << 8));

@@ -722,7 +722,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                 double sum[8] = { 0 };
                 for (size_t w = 0; w < nwg; w++)
                     for (int r = 0; r < 8; r++) sum[r] += (double)host[8 * w + r];
-                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"A\": %.0f, \"C\": %.0f, \"F0\": %.0f, \"F1\": %.0f, \"E\": %.0f, \"D\": %.0f}, \"mean_total_clocks\": %.0f}\n",
+                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"E\": %.0f, \"D\": %.0f, \"F0\": %.0f, \"F1\": %.0f, \"A\": %.0f, \"C\": %.0f}, \"mean_total_clocks\": %.0f}\n",
                              n_samples, nwg, sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg);
                 std::fclose(f);
             }
