@@ -73,7 +73,10 @@ def load_library(rebuild_if_stale=True):
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if rebuild_if_stale and _build.is_stale():
+    override = os.environ.get("TETRA_DEMOD_LIB")     # profiling scripts: an experimental build of the same ABI
+    if override:
+        path = os.path.abspath(override)
+    elif rebuild_if_stale and _build.is_stale():
         path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("HIP library %s is missing; run __graft_entry__.build() (no CPU fallback exists)" % path)

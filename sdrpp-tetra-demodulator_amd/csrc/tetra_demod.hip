@@ -353,7 +353,7 @@ struct tetra_demod {
     bool fused = true;          // pipeline in use
     bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
-    float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 72, RRC zero-extended
+    float *d_be_re84 = nullptr, *d_be_im84 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 84, RRC zero-extended
     // host-path staging
     float* st_iq = nullptr;
     uint8_t* st_bits = nullptr;
@@ -405,17 +405,18 @@ int upload_tables(tetra_demod* h) {
     HIP_TRY(h, hipMemcpy(h->d_rrc, rr.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
-    if (h->design.ntaps <= kF8Pad) {
-        std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rr72(kRrcExt, 0.f);
-        const int o72 = kF8Pad - h->design.ntaps;
+    {
+        std::vector<float> re84(kPadBe, 0.f), im84(kPadBe, 0.f), rrx(kRrcExt, 0.f);
+        const int o84 = kPadBe - h->design.ntaps;
+        const int rpad = (8 - ((h->design.ntaps - 1) & 7)) & 7;     // RRC windows start on a multiple of 8, see kernel_fused.hpp
         for (int k = 0; k < h->design.ntaps; k++) {
-            re72[o72 + k] = h->design.be_re[k];
-            im72[o72 + k] = h->design.be_im[k];
-            rr72[7 + k] = h->design.rrc[k];
+            re84[o84 + k] = h->design.be_re[k];
+            im84[o84 + k] = h->design.be_im[k];
+            rrx[7 + rpad + k] = h->design.rrc[k];
         }
-        HIP_TRY(h, hipMemcpy(h->d_be_re72, re72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_be_im72, im72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rr72.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_re84, re84.data(), sizeof(float) * kPadBe, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_im84, im84.data(), sizeof(float) * kPadBe, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rrx.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
     }
     return TETRA_OK;
 }
@@ -470,7 +471,7 @@ int reset_range(tetra_demod* h, int first, int count) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re84, h->d_be_im84,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -583,7 +584,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     A(dalloc(h, &h->hist, C * kHist));
     A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
     A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
-    h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL) && h->design.ntaps <= kF8Pad;
+    h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL);
     h->keep_y = !h->fused || (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT);
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
@@ -591,7 +592,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_sum, C)); A(dalloc(h, &h->q_ptr, C));
         A(dalloc(h, &h->q_disp, C)); A(dalloc(h, &h->q_sync, C)); A(dalloc(h, &h->q_err, C));
     }
-    A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
+    A(dalloc(h, &h->d_be_re84, (size_t)kPadBe)); A(dalloc(h, &h->d_be_im84, (size_t)kPadBe));
     A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
     A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
     A(dalloc(h, &h->d_rrc, (size_t)kPadTaps)); A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
@@ -682,30 +683,34 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
         pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
         pf.cph = h->cph; pf.cfr = h->cfr; pf.ph2 = h->ph2; pf.prev = h->prev; pf.ybuf = h->ybuf;
-        pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
+        pf.be_re84 = h->d_be_re84; pf.be_im84 = h->d_be_im84; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
         pf.q_ring = h->q_ring; pf.q_sum = h->q_sum; pf.q_ptr = h->q_ptr; pf.q_disp = h->q_disp; pf.q_sync = h->q_sync;
         pf.q_err = h->q_err;
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
-        {
-            const char* ab = std::getenv("TETRA_DEMOD_ABLATE");   // profiling aid, see kernel_fused.hpp
-            pf.ablate = ab ? std::atoi(ab) : 0;
-            // TETRA_DEMOD_PROFILE=<file>: per-role busy clocks of the launch are appended to <file> (synchronises; debug only)
-            pf.prof = nullptr;
-            if (std::getenv("TETRA_DEMOD_PROFILE") && !h->q_ring) {
-                if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * ((size_t)(h->C + kFCh - 1) / kFCh)));
-                HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * ((size_t)(h->C + kFCh - 1) / kFCh), s));
-                pf.prof = h->d_prof;
-            }
-        }
+        pf.prof = nullptr;
         const dim3 gf((h->C + kFCh - 1) / kFCh);
-        HIP_TRY(h, hipEventRecord(ev[0], s));
         const bool a0 = pf.k1.fll_alpha == 0.0f, ql = pf.q_ring != nullptr;
+#ifdef TETRA_DEMOD_DEBUG
+        // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
+        // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
+        const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
+        if (prof_path && !ql) {
+            const size_t nwg = (size_t)gf.x;
+            if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
+            HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
+            pf.prof = h->d_prof;
+        }
+#endif
+        HIP_TRY(h, hipEventRecord(ev[0], s));
+#ifdef TETRA_DEMOD_DEBUG
         if (pf.prof && a0) hipLaunchKernelGGL((k_fused<true, false, true>), gf, dim3(kFThreads), 0, s, pf);
         else if (pf.prof) hipLaunchKernelGGL((k_fused<false, false, true>), gf, dim3(kFThreads), 0, s, pf);
-        else if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
+        else
+#endif
+        if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
         else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
         else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false>), gf, dim3(kFThreads), 0, s, pf);
         else hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
@@ -713,20 +718,22 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         HIP_TRY(h, hipEventRecord(ev[1], s));
         HIP_TRY(h, hipEventRecord(ev[2], s));
         h->n_calls++;
+#ifdef TETRA_DEMOD_DEBUG
         if (pf.prof) {
-            const size_t nwg = (size_t)(h->C + kFCh - 1) / kFCh;
+            const size_t nwg = (size_t)gf.x;
             std::vector<long long> host(8 * nwg);
             HIP_TRY(h, hipStreamSynchronize(s));
             HIP_TRY(h, hipMemcpy(host.data(), h->d_prof, sizeof(long long) * host.size(), hipMemcpyDeviceToHost));
-            if (FILE* f = std::fopen(std::getenv("TETRA_DEMOD_PROFILE"), "a")) {
+            if (FILE* f = std::fopen(prof_path, "a")) {
                 double sum[8] = { 0 };
                 for (size_t w = 0; w < nwg; w++)
                     for (int r = 0; r < 8; r++) sum[r] += (double)host[8 * w + r];
-                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"E\": %.0f, \"D\": %.0f, \"F0\": %.0f, \"F1\": %.0f, \"A\": %.0f, \"C\": %.0f}, \"mean_total_clocks\": %.0f}\n",
-                             n_samples, nwg, sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg);
+                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"L0\": %.0f, \"L1\": %.0f, \"D\": %.0f, \"H\": %.0f, \"A\": %.0f, \"E\": %.0f, \"C\": %.0f}, \"mean_total_clocks\": %.0f}\n",
+                             n_samples, nwg, sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg, sum[7] / nwg);
                 std::fclose(f);
             }
         }
+#endif
         return TETRA_OK;
     }
     HIP_TRY(h, hipEventRecord(ev[0], s));
@@ -812,7 +819,6 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     }
     host::Design nd;
     if (!host::make_design(np, nullptr, nullptr, nullptr, nd)) return TETRA_ERR_UNSUPPORTED;
-    if (h->fused && nd.ntaps > kF8Pad) return TETRA_ERR_UNSUPPORTED;   // fused kernel covers <= 72 taps
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
