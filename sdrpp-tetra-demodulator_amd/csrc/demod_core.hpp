@@ -134,14 +134,6 @@ TD_FN float row_shl2(float old, float src) {
 TD_FN float row_shl2_z(float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x102, 0xf, 0xf, true));
 }
-// Four-lane variants for rows that carry four channels on lanes 4*pos + c (4 positions per channel).
-TD_FN float row_shr4(float old, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
-                                                                 __builtin_bit_cast(int, src), 0x114, 0xf, 0xf, false));
-}
-TD_FN float row_shl4_z(float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x104, 0xf, 0xf, true));
-}
 // row_shl:1 with zero fill (bound_ctrl): lane 15 of each row receives +0.
 TD_FN float row_shl1_z(float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x101, 0xf, 0xf, true));
@@ -223,8 +215,6 @@ TD_FN Row16 v_sqrt_agc(Row16 a) { return v_sqrt(a); }
 TD_FN Row16 row_shr2(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 2 ? old.l[i] : src.l[i - 2]; return r; }
 TD_FN Row16 row_shl2(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 14 ? src.l[i + 2] : old.l[i]; return r; }
 TD_FN Row16 row_shl2_z(Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 14 ? src.l[i + 2] : 0.0f; return r; }
-TD_FN Row16 row_shr4(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 4 ? old.l[i] : src.l[i - 4]; return r; }
-TD_FN Row16 row_shl4_z(Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 12 ? src.l[i + 4] : 0.0f; return r; }
 #endif  // TETRA_HOST_EMUL
 
 template <class V> TD_FN Pair<V> row_shr1(Pair<V> old, Pair<V> src) {
@@ -241,10 +231,6 @@ template <class V> TD_FN Pair<V> row_shl2(Pair<V> old, Pair<V> src) {
     return Pair<V>(row_shl2(old.x(), src.x()), row_shl2(old.y(), src.y()));
 }
 template <class V> TD_FN Pair<V> row_shl2_z(Pair<V> src) { return Pair<V>(row_shl2_z(src.x()), row_shl2_z(src.y())); }
-template <class V> TD_FN Pair<V> row_shr4(Pair<V> old, Pair<V> src) {
-    return Pair<V>(row_shr4(old.x(), src.x()), row_shr4(old.y(), src.y()));
-}
-template <class V> TD_FN Pair<V> row_shl4_z(Pair<V> src) { return Pair<V>(row_shl4_z(src.x()), row_shl4_z(src.y())); }
 
 // ---------------------------------------------------------------------------------------------
 // Run-time phasor (replaces libm cosf/sinf of SDR++ core math::phasor; same function as
@@ -596,83 +582,6 @@ template <class V, class IO, bool ALPHA0> TD_FN void fll8_tile(FllRow8<V>& R, co
     }
 }
 #undef TD_F8_STEP
-
-// ---------------------------------------------------------------------------------------------
-// FLL split in two (round 2): a wavefront issues one instruction of any kind per ~4.7 clocks whatever depends on what
-// (profiles/r02/r02_a_issue_model.md), so the pace of the FLL is the instruction count of the wave that closes the loop.
-// The band-edge FIRs are therefore cut at the 16 newest taps:
-//   * FllFar4  (helper wave): the far part of every sum -- padded taps kp in [0, 4*TH), i.e. samples x_{n-16} and older
-//     -- as a systolic array of 4 positions x TH taps per channel, four channels per 16-lane row (lane = 4*pos + c).
-//     It consumes x_s as the loop wave publishes it and emits, at step s, the partial sums F_{s+16} of output s+16.
-//   * FllNear8 (loop wave): NCO, the 16 newest taps on 8 positions x 2 taps (two channels per row, lane = 2*pos + c),
-//     error, loop filter.  A sum enters the tail position at step n-8 with F_n as its initial value, receives two taps
-//     per step while it hops one position inward per step, and completes in the head lane at step n.
-// Splitting an fmaf chain between two waves does not change a bit: F_n is the chain's accumulator after its first
-// 4*TH links, handed over as a float.  The padded filter has 4*TH + 16 taps (zero taps at the old end).
-// ---------------------------------------------------------------------------------------------
-constexpr int kNearTaps = 16;
-constexpr int kFarLead = 8;     // a far sum F_n is injected into the near row at step n - kFarLead
-
-template <class V> struct FllNear8 {
-    typedef Pair<V> P;
-    V ta[2], tb[2];      // this position's two near taps: slot j <-> padded tap 4*TH + 2*(7-pos) + j
-    P r14, r32;          // the sums that arrived here in the previous step
-    P xs;                // lane (pos, c) holds x_{s-pos}
-    V ph, fr;
-
-    TD_MFN void clear_pipeline() { r14 = P(V(0.0f), V(0.0f)); r32 = r14; xs = r14; }
-
-    // One sample step s.  a = AGC output (a stored x when REPLAY), valid in the head lanes; (f14, f32) = far sums
-    // F_{s+8} = ((S1,S4), (S3,S2)) partials, valid in the tail lanes.
-    template <bool REPLAY, bool ALPHA0> TD_MFN void step(const K1Consts& k, P a, P f14, P f32) {
-        P x;
-        if (REPLAY) {
-            x = a;
-        } else {
-            V s, c;
-            sincos_t<V, true>(-ph, s, c);                             // fll.cpp:137-138
-            x = cmul_phasor<V>(a, c, s);
-        }
-        xs = row_shr2(x, xs);
-        const P c14 = pk_fma(xs, P(ta[1], ta[1]), r14);
-        const P c32 = pk_fma(xs, P(tb[1], tb[1]), r32);
-        r14 = pk_fma(xs, P(ta[0], ta[0]), row_shl2(f14, c14));        // tail lanes have no source: they keep F
-        r32 = pk_fma(xs, P(tb[0], tb[0]), row_shl2(f32, c32));
-        if (!REPLAY) {
-            V err = fll_error<V>(c14, c32);                           // fll.cpp:141-145
-            pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
-        }
-    }
-};
-
-template <class V, int TH> struct FllFar4 {
-    typedef Pair<V> P;
-    static constexpr int kRes = TH - 1;     // resident sums per position = schedule period
-    V ta[TH], tb[TH];    // slot j <-> padded tap TH*(3-pos) + j
-    P r14[kRes], r32[kRes];
-    P xs;                // lane (pos, c) holds x_{s-pos}
-
-    TD_MFN void clear_pipeline() {
-        for (int q = 0; q < kRes; q++) { r14[q] = P(V(0.0f), V(0.0f)); r32[q] = r14[q]; }
-        xs = P(V(0.0f), V(0.0f));
-    }
-    // One step s with PH = s mod (TH-1); x = x_s in the head lanes.  Returns F_{s+16} in the head lanes.
-    template <int PH> TD_MFN void step(P x, P& f14, P& f32) {
-        xs = row_shr4(x, xs);
-        const P c14 = pk_fma(xs, P(ta[TH - 1], ta[TH - 1]), r14[PH]);
-        const P c32 = pk_fma(xs, P(tb[TH - 1], tb[TH - 1]), r32[PH]);
-        r14[PH] = pk_fma(xs, P(ta[0], ta[0]), row_shl4_z(c14));
-        r32[PH] = pk_fma(xs, P(tb[0], tb[0]), row_shl4_z(c32));
-#pragma unroll
-        for (int q = 1; q < TH - 1; q++) {
-            const int i = (PH + q) % kRes;
-            r14[i] = pk_fma(xs, P(ta[TH - 1 - q], ta[TH - 1 - q]), r14[i]);
-            r32[i] = pk_fma(xs, P(tb[TH - 1 - q], tb[TH - 1 - q]), r32[i]);
-        }
-        f14 = c14;
-        f32 = c32;
-    }
-};
 
 // RRC matched filter, direct form, eight consecutive outputs per lane (SDR++ core FIR<complex_t,float>,
 // called at src/dsp/pi4dqpsk.cpp:136).  With nt taps, output i0+m needs x_{i0+m-(nt-1)} .. x_{i0+m}; the

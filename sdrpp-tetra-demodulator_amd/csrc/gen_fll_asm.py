@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
-"""Generator of fll_asm.inc: the two instruction streams that set the pace of the fused kernel, as gfx950 assembly.
+"""Generator of fll_asm.inc: the instruction stream of the FLL waves of the fused kernel, as gfx950 assembly.
 
-Why assembly: a gfx950 wavefront issues one instruction of any kind per ~4.7 clocks (profiles/r02/r02_a_issue_model.md), so
-the FLL loop wave's time IS its instruction count.  hipcc spends 84 instruction slots on the loop wave's sample step
-(scalar bookkeeping, s_nop for the packed-math and DPP hazards, re-materialised constants, one s_waitcnt per LDS load);
-the schedule below needs 55, every hazard gap filled with an instruction that has to be issued anyway.
+Why assembly: a gfx950 wavefront issues one instruction of any kind per ~4.7 clocks whether or not it depends on the
+previous one (profiles/r02/r02_a_issue_model.md), and the FLL wave has a SIMD to itself, so its time IS its instruction
+count.  hipcc spends 71.5 instruction slots on one sample step of FllRow8 (s_nop for the packed-math and DPP hazards,
+a re-materialised constant, one LDS load and one s_waitcnt per sample, sine and cosine polynomials as ten scalar FMAs);
+the schedule below needs 60:
+  * the sine / cosine polynomials of the NCO run as ONE packed Horner chain (the same IEEE operations, two per instruction);
+  * the fourteen band-edge FMAs of a step that are not on the way to the error (the "middle" taps of the systolic row) are
+    issued during the NEXT step, exactly where that step needs an independent instruction between a packed or DPP producer
+    and its consumer -- so no s_nop is left;
+  * AGC samples come two per LDS load, x goes to the ring once per eight samples, constants sit where the constant-bus
+    limit wants them.
+demod_core.hpp is the specification: instruction for instruction the same IEEE operations as
+FllRow8<float>::step<PH, false, true> (and <PH, true, true> for the delay-line replay), which tests/emul compiles for the
+host and checks against the oracle.  kernel_fused.hpp keeps the C++ form for the partial tile at the end of a call.
 
-Two streams are generated (demod_core.hpp is the specification: instruction for instruction the same IEEE operations as
-FllNear8<float>::step<false, true> and FllFar4<float, 17>::step, which tests/emul compiles for the host and checks against
-the oracle; kernel_fused.hpp keeps the C++ form for the partial tile at the end of a call):
-
-  FLL_LOOP_ASM    a loop wave (8 channels): all COMPLETE 32-sample tiles of a call, one s_barrier per tile.  Per sample:
-                  NCO sincos, complex multiply, x shift, the 16 newest band-edge taps (8 positions x 2), band-edge error,
-                  loop filter, x to the ring, progress counter.
-  FLL_HELPER_ASM  the helper wave (16 channels): its whole life -- pipeline rebuild from the stored delay line, then every
-                  tile of the call (68 far taps on 4 positions per channel), barriers included.
+The block covers a wave's whole steady state: rebuild of the in-flight sums from the last 72 stored samples, then every
+COMPLETE 32-sample tile of the call with one s_barrier per tile.
 
 Hazard rules enforced by the emitter (LLVM GCNHazardRecognizer for gfx940/gfx950, cross-checked against hipcc output):
   H1  a VGPR written by a packed-FP32 instruction must not be read by the next instruction (one wait state);
   H2  a VGPR written by a VALU instruction must not be read (or merged into, as `old`) by a DPP instruction within the next
       two instructions;
   H3  VCC written by v_cmp must not be read by v_cndmask within the next two instructions.
-A violated rule gets an s_nop (counted and reported), so a bad schedule costs slots, never correctness.
+A gap is filled from the queue of deferred FMAs, or with an s_nop when that is empty (counted and reported), so a bad
+schedule costs slots, never correctness.
 
 Usage: python gen_fll_asm.py [--check]    (writes fll_asm.inc next to this file; --check only verifies it is current)
 """
@@ -33,9 +37,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "fll_asm.inc")
 
 TILE = 32
-SPIN_LIMIT = 0x40000
-# timing experiments only (results invalid): FLL_ASM_ABLATE=L / H / LH drops the loop waves' / the helper's waits
-ABLATE = os.environ.get("FLL_ASM_ABLATE", "")
+TAPS = 9            # taps per position (kF8Taps); 8 positions x 9 = 72 padded taps
+NRES = TAPS - 1     # resident sums per position = schedule period
 
 
 def f32(x):
@@ -51,7 +54,7 @@ class Emitter:
         self.vcc_write = -100
         self.nops = 0
         self.counts = {}
-        self.mark = None
+        self.pending = []        # deferred independent instructions (the previous step's middle FMAs)
 
     def _slot(self, text, kind):
         self.lines.append(text)
@@ -64,12 +67,7 @@ class Emitter:
     def comment(self, text):
         self.lines.append("; " + text)
 
-    def nop(self, count=1):
-        self._slot("s_nop %d" % (count - 1), "nop")
-        self.nops += 1
-
-    def ins(self, text, kind, writes=(), reads=(), reads_vcc=False, writes_vcc=False):
-        """kind: valu | pk | dpp | lds | salu | wait | br.  writes/reads: VGPR numbers."""
+    def _need(self, kind, writes, reads, reads_vcc):
         need = 0
         for r in reads:
             w = self.last_write.get(r)
@@ -87,13 +85,34 @@ class Emitter:
                     need = max(need, 2 - (self.n - w[0] - 1))
         if reads_vcc:
             need = max(need, 2 - (self.n - self.vcc_write - 1))
-        if need > 0:
-            self.nop(need)
+        return need
+
+    def _emit(self, text, kind, writes, reads, writes_vcc):
         self._slot(text, kind)
         for r in writes:
             self.last_write[r] = (self.n - 1, kind)
         if writes_vcc:
             self.vcc_write = self.n - 1
+
+    def ins(self, text, kind, writes=(), reads=(), reads_vcc=False, writes_vcc=False):
+        """kind: valu | pk | dpp | lds | salu | wait | br.  writes/reads: VGPR numbers.  Hazard gaps are filled from the
+        queue of deferred instructions first, with s_nop only when it is empty."""
+        need = self._need(kind, writes, reads, reads_vcc)
+        while need > 0:
+            if self.pending and self._need(self.pending[0][1], self.pending[0][2], self.pending[0][3], False) == 0:
+                t, k, w, r = self.pending.pop(0)
+                self._emit(t, k, w, r, False)
+            else:
+                self._slot("s_nop 0", "nop")
+                self.nops += 1
+            need = self._need(kind, writes, reads, reads_vcc)
+        self._emit(text, kind, writes, reads, writes_vcc)
+
+    def flush(self, count=None):
+        k = len(self.pending) if count is None else min(count, len(self.pending))
+        for _ in range(k):
+            t, kind, w, r = self.pending.pop(0)
+            self.ins(t, kind, w, r)
 
     def text(self):
         return "\n".join(self.lines)
@@ -109,220 +128,48 @@ def quad(r):
     return "v[%d:%d]" % (r, r + 3)
 
 
-def spin(E, tag, flag_addr, tmp, need_expr_ins, stuck_addr, back):
-    """Slow path of a hand-over wait: spin until `cmp` clears, with the watchdog of kernel_fused.hpp's ho_wait."""
-    E.label(".L%s_%%=:" % tag)
-    E.ins("s_mov_b32 %[spins], 0", "salu")
-    E.label(".L%s_spin_%%=:" % tag)
-    E.ins("ds_read_b32 v%d, v%d" % (tmp, flag_addr), "lds")
-    E.ins("s_waitcnt lgkmcnt(0)", "wait")
-    for t in need_expr_ins(tmp):
-        E.ins(t, "valu")
-    E.ins("s_cbranch_vccz .L%s_%%=" % back, "br")
-    E.ins("s_add_u32 %[spins], %[spins], 1", "salu")
-    E.ins("s_cmp_lt_u32 %%[spins], 0x%x" % SPIN_LIMIT, "salu")
-    E.ins("s_cbranch_scc0 .L%s_giveup_%%=" % tag, "br")
-    E.ins("ds_read_b32 v%d, v%d" % (tmp, stuck_addr), "lds")
-    E.ins("s_waitcnt lgkmcnt(0)", "wait")
-    E.ins("v_cmp_eq_u32 vcc, 0, v%d" % tmp, "valu")
-    E.ins("s_cbranch_vccnz .L%s_spin_%%=" % tag, "br")
-    E.label(".L%s_giveup_%%=:" % tag)
-    E.ins("v_mov_b32 v%d, 1" % tmp, "valu")
-    E.ins("ds_write_b32 v%d, v%d" % (stuck_addr, tmp), "lds")
-    E.ins("s_branch .L%s_%%=" % back, "br")
-
-
 # ----------------------------------------------------------------------------------------------------------------------
-# FLL loop wave
+# fixed registers of the block
 # ----------------------------------------------------------------------------------------------------------------------
-# fixed registers of the loop-wave block
-L_XS = (16, 18)       # x pipeline, alternating by step parity: step s reads L_XS[s&1] and writes L_XS[(s+1)&1]
-L_R14, L_R32 = 20, 22
-L_PH, L_FR = 24, 25
-L_TA, L_TB = 26, 28   # (ta0, ta1), (tb0, tb1)
-L_A = (30, 32)        # AGC output of the step, by parity
-L_F = (36, 40)        # far sums of the step (f14 = +0, f32 = +2), by parity (quad aligned)
-L_K, L_R, L_Z, L_PS, L_PC, L_M = 44, 45, 46, 47, 34, 35
-L_CC, L_SS = 48, 50   # (cos, -), (sin, -): the phasor in the low halves of two aligned pairs
-L_T1, L_T2 = 52, 54
-L_C14, L_C32 = 56, 58
-L_D, L_U = 60, 62
-L_MX, L_MN = 64, 66
-L_E, L_T = 68, 69
-L_FLAG, L_NEED, L_TWO = 70, 71, 72
-L_CS2, L_CC3, L_2PI, L_MAXF = 73, 74, 75, 76     # constants that must sit in vector registers (constant-bus limit)
-L_AADDR, L_FADDR, L_XADDR, L_XDADDR, L_FDADDR, L_STUCK = 77, 78, 79, 80, 81, 82
-L_XBASE, L_HEADMASK = 83, 84
-L_CLOBBER = list(range(16, 85))
+R_TA, R_TB = 16, 25             # ta[0..8] = v16..v24, tb[0..8] = v25..v33 (slot j <-> padded tap 9*(7-pos)+j)
+R_R14, R_R32 = 34, 50           # r14[i] = v[34+2i : 35+2i], r32[i] = v[50+2i : 51+2i], i = 0..7
+R_XS = (66, 68)                 # x pipeline, alternating by step parity: step s reads XS[s&1] and writes XS[(s+1)&1]
+R_PH, R_FR = 70, 71
+R_AQ = (72, 76)                 # AGC samples, two per load: sample s of a tile sits in AQ[(s>>1)&1] + 2*(s&1)
+R_K, R_R = 80, 81
+R_Z = 82                        # (z, -)
+R_Q = 84                        # (S3 constant, first cosine Horner value)
+R_PP = 86                       # (sine, cosine) Horner pair
+R_M = 88
+R_CC, R_SS = 90, 92             # (cos, -), (sin, -): the phasor in the low halves of two aligned pairs
+R_T1, R_T2 = 94, 96
+R_C14, R_C32 = 98, 100
+R_D, R_U = 102, 104
+R_MX, R_MN = 106, 108
+R_E, R_T = 110, 111
+R_CC3, R_2PI, R_MAXF = 112, 113, 114       # constants that must sit in vector registers (constant-bus limit)
+R_AADDR, R_XLANE, R_XROWL, R_TAPADDR, R_HADDR = 115, 116, 117, 118, 119
+CLOBBER = list(range(16, 120))
 
 # sincos_t constants (demod_core.hpp)
 INV_PI_NEG = f32(-0.318309886183790672)
-C1 = 3.140625
 C2N, C3N = -9.67502593994140625e-4, -1.509957990978376432e-7
 S3, S2, S1, S0 = 2.597026877992903e-06, -0.0001980524102691561, 0.008332998491823673, -0.16666656732559204
 C4, C3c, C2c, C1c = -2.604826931928983e-07, 2.476031113474164e-05, -0.0013888374669477344, 0.04166663810610771
 FL_PI = struct.unpack("<f", struct.pack("<f", 3.1415926535))[0]
 
+
+def pk_consts():
+    """The four constant pairs of the packed sine/cosine Horner chain as 64-bit integers (low word = sine side).  The last
+    step multiplies the sine polynomial by z: fma(ps, z, -0.0f) is exactly ps*z (also in the sign of a zero product)."""
+    def u(x):
+        return struct.unpack("<I", struct.pack("<f", x))[0]
+    pairs = [(S2, C2c), (S1, C1c), (S0, -0.5), (-0.0, 1.0)]
+    return [u(a) | (u(b) << 32) for (a, b) in pairs]
+
+
 A_BUF_TOGGLE = 16 * TILE * 8     # bytes between a_buf[0] and a_buf[1] (kFCh x kFT float2)
-
-
-def loop_step(E, s):
-    """Sample step s of a complete tile.  %[..] operands are bound in kernel_fused.hpp."""
-    o, n = L_XS[s & 1], L_XS[(s + 1) & 1]          # old / new x pipeline registers
-    a, F = L_A[s & 1], L_F[s & 1]
-    an, Fn = L_A[(s + 1) & 1], L_F[(s + 1) & 1]
-    f14, f32_ = F, F + 2
-    E.comment("---- step %d" % s)
-    # NCO phasor: sincos_t<float, true>(-ph)
-    E.ins("v_mul_f32 v%d, %s, v%d" % (L_K, INV_PI_NEG, L_PH), "valu", [L_K], [L_PH])
-    E.ins("v_rndne_f32 v%d, v%d" % (L_K, L_K), "valu", [L_K], [L_K])
-    E.ins("v_fma_f32 v%d, v%d, %%[negc1], -v%d" % (L_R, L_K, L_PH), "valu", [L_R], [L_K, L_PH])
-    E.ins("v_fmac_f32 v%d, %s, v%d" % (L_R, f32(C2N), L_K), "valu", [L_R], [L_R, L_K])
-    E.ins("v_fmac_f32 v%d, %s, v%d" % (L_R, f32(C3N), L_K), "valu", [L_R], [L_R, L_K])
-    E.ins("v_mul_f32 v%d, v%d, v%d" % (L_Z, L_R, L_R), "valu", [L_Z], [L_R])
-    E.ins("v_fmamk_f32 v%d, v%d, %s, v%d" % (L_PS, L_Z, f32(S3), L_CS2), "valu", [L_PS], [L_Z, L_CS2])
-    E.ins("v_fmamk_f32 v%d, v%d, %s, v%d" % (L_PC, L_Z, f32(C4), L_CC3), "valu", [L_PC], [L_Z, L_CC3])
-    E.ins("v_fmaak_f32 v%d, v%d, v%d, %s" % (L_PS, L_PS, L_Z, f32(S1)), "valu", [L_PS], [L_PS, L_Z])
-    E.ins("v_fmaak_f32 v%d, v%d, v%d, %s" % (L_PC, L_PC, L_Z, f32(C2c)), "valu", [L_PC], [L_PC, L_Z])
-    E.ins("v_fmaak_f32 v%d, v%d, v%d, %s" % (L_PS, L_PS, L_Z, f32(S0)), "valu", [L_PS], [L_PS, L_Z])
-    E.ins("v_fmaak_f32 v%d, v%d, v%d, %s" % (L_PC, L_PC, L_Z, f32(C1c)), "valu", [L_PC], [L_PC, L_Z])
-    E.ins("v_mul_f32 v%d, v%d, v%d" % (L_PS, L_Z, L_PS), "valu", [L_PS], [L_PS, L_Z])
-    E.ins("v_fma_f32 v%d, v%d, v%d, -0.5" % (L_PC, L_PC, L_Z), "valu", [L_PC], [L_PC, L_Z])
-    E.ins("v_fmac_f32 v%d, v%d, v%d" % (L_R, L_PS, L_R), "valu", [L_R], [L_PS, L_R])                 # sin before the sign
-    E.ins("v_fma_f32 v%d, v%d, v%d, 1.0" % (L_PC, L_PC, L_Z), "valu", [L_PC], [L_PC, L_Z])           # cos before the sign
-    E.ins("v_lshlrev_b32 v%d, 8, v%d" % (L_M, L_K), "valu", [L_M], [L_K])
-    E.ins("v_xor_b32 v%d, v%d, v%d" % (L_SS, L_M, L_R), "valu", [L_SS], [L_M, L_R])
-    E.ins("v_xor_b32 v%d, v%d, v%d" % (L_CC, L_M, L_PC), "valu", [L_CC], [L_M, L_PC])
-    # the loads issued during the previous step (a, F) are due now; everything older has long returned
-    E.ins("s_waitcnt lgkmcnt(0)", "wait")
-    if s % 4 == 2:
-        # the helper's progress counter for the check at the end of this step (as fresh as the schedule allows)
-        E.ins("ds_read_b32 v%d, v%d" % (L_FLAG, L_FDADDR), "lds", [L_FLAG], [L_FDADDR])
-    # x = a * (c + j s): (ar*c, ai*c) + (-(ai*s), ar*s)
-    E.ins("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair(L_T1), pair(a), pair(L_CC)), "pk", [L_T1, L_T1 + 1], [a, a + 1, L_CC])
-    E.ins("v_pk_mul_f32 %s, %s, %s op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[0,1]" % (pair(L_T2), pair(a), pair(L_SS)), "pk",
-          [L_T2, L_T2 + 1], [a, a + 1, L_SS])
-    if s + 1 < TILE:
-        E.ins("ds_read_b64 %s, v%d offset:%d" % (pair(an), L_AADDR, 8 * (s + 1)), "lds", [an, an + 1], [L_AADDR])
-    E.ins("v_pk_add_f32 %s, %s, %s" % (pair(n), pair(L_T1), pair(L_T2)), "pk", [n, n + 1], [L_T1, L_T1 + 1, L_T2, L_T2 + 1])
-    # two instructions between the write of x and the DPP that merges the older samples into its register
-    if s + 1 < TILE:
-        E.ins("ds_read_b128 %s, v%d offset:%d" % (quad(Fn), L_FADDR, 16 * ((s + 1 + 8) & 31)), "lds", list(range(Fn, Fn + 4)), [L_FADDR])
-    if s % 4 == 3:
-        E.ins("v_add_u32 v%d, 4, v%d" % (L_NEED, L_NEED), "valu", [L_NEED], [L_NEED])       # for the next check
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n, o), "dpp", [n], [o])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n + 1, o + 1), "dpp", [n + 1], [o + 1])
-    # newest tap of every position (slot 1) on the resident sums; the head lanes now hold the completed sums
-    E.ins("v_pk_fma_f32 %s, %s, %s, %s op_sel:[0,1,0]" % (pair(L_C14), pair(n), pair(L_TA), pair(L_R14)), "pk",
-          [L_C14, L_C14 + 1], [n, n + 1, L_TA + 1, L_R14, L_R14 + 1])
-    E.ins("v_pk_fma_f32 %s, %s, %s, %s op_sel:[0,1,0]" % (pair(L_C32), pair(n), pair(L_TB), pair(L_R32)), "pk",
-          [L_C32, L_C32 + 1], [n, n + 1, L_TB + 1, L_R32, L_R32 + 1])
-    E.ins("ds_write_b64 v%d, %s offset:%d" % (L_XADDR, pair(n), 8 * s), "lds", [], [L_XADDR, n, n + 1])
-    if s & 1:
-        # x_{s-1}, x_s are in the ring (LDS executes a wave's instructions in order): tell the helper
-        E.ins("ds_add_u32 v%d, v%d" % (L_XDADDR, L_TWO), "lds", [], [L_XDADDR, L_TWO])
-    # fll_error: d = c14 - swap(c32) = (lbe.re, hbe.im), u = c14 + swap(c32) = (hbe.re, lbe.im)
-    E.ins("v_pk_add_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" % (pair(L_D), pair(L_C14), pair(L_C32)),
-          "pk", [L_D, L_D + 1], [L_C14, L_C14 + 1, L_C32, L_C32 + 1])
-    E.ins("v_pk_add_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0]" % (pair(L_U), pair(L_C14), pair(L_C32)),
-          "pk", [L_U, L_U + 1], [L_C14, L_C14 + 1, L_C32, L_C32 + 1])
-    # the sums hop one position inward; the tail lanes (no source lane) keep the far sums F
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:2 row_mask:0xf bank_mask:0xf" % (f14, L_C14), "dpp", [f14], [L_C14])
-    E.ins("v_max_f32 v%d, |v%d|, |v%d|" % (L_MX, L_U, L_D + 1), "valu", [L_MX], [L_U, L_D + 1])
-    E.ins("v_min_f32 v%d, |v%d|, |v%d|" % (L_MN, L_U, L_D + 1), "valu", [L_MN], [L_U, L_D + 1])
-    E.ins("v_max_f32 v%d, |v%d|, |v%d|" % (L_MX + 1, L_D, L_U + 1), "valu", [L_MX + 1], [L_D, L_U + 1])
-    E.ins("v_min_f32 v%d, |v%d|, |v%d|" % (L_MN + 1, L_D, L_U + 1), "valu", [L_MN + 1], [L_D, L_U + 1])
-    E.ins("v_pk_mul_f32 %s, %s, %%[p4] op_sel_hi:[1,0]" % (pair(L_MN), pair(L_MN)), "pk", [L_MN, L_MN + 1], [L_MN, L_MN + 1])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:2 row_mask:0xf bank_mask:0xf" % (f14 + 1, L_C14 + 1), "dpp", [f14 + 1], [L_C14 + 1])
-    E.ins("v_pk_add_f32 %s, %s, %s" % (pair(L_MX), pair(L_MX), pair(L_MN)), "pk", [L_MX, L_MX + 1], [L_MX, L_MX + 1, L_MN, L_MN + 1])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:2 row_mask:0xf bank_mask:0xf" % (f32_, L_C32), "dpp", [f32_], [L_C32])
-    E.ins("v_sub_f32 v%d, v%d, v%d" % (L_E, L_MX, L_MX + 1), "valu", [L_E], [L_MX, L_MX + 1])
-    # PhaseControlLoop::advance with alpha == 0: freq = clamp(freq + beta*err), phase = wrap(phase + freq)
-    E.ins("v_mul_f32 v%d, %%[beta], v%d" % (L_E, L_E), "valu", [L_E], [L_E])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:2 row_mask:0xf bank_mask:0xf" % (f32_ + 1, L_C32 + 1), "dpp", [f32_ + 1], [L_C32 + 1])
-    E.ins("v_add_f32 v%d, v%d, v%d" % (L_E, L_FR, L_E), "valu", [L_E], [L_FR, L_E])
-    E.ins("v_med3_f32 v%d, v%d, %%[minf], v%d" % (L_FR, L_E, L_MAXF), "valu", [L_FR], [L_E, L_MAXF])
-    E.ins("v_add_f32 v%d, v%d, v%d" % (L_PH, L_PH, L_FR), "valu", [L_PH], [L_PH, L_FR])
-    E.ins("v_bfi_b32 v%d, %%[absmask], v%d, v%d" % (L_T, L_2PI, L_PH), "valu", [L_T], [L_2PI, L_PH])
-    E.ins("v_sub_f32 v%d, v%d, v%d" % (L_T, L_PH, L_T), "valu", [L_T], [L_PH, L_T])
-    E.ins("v_cmp_gt_f32 vcc, |v%d|, %%[pi]" % L_PH, "valu", [], [L_PH], writes_vcc=True)
-    # oldest tap of every position (slot 0) on the sums that just arrived
-    E.ins("v_pk_fma_f32 %s, %s, %s, %s op_sel_hi:[1,0,1]" % (pair(L_R14), pair(n), pair(L_TA), pair(f14)), "pk",
-          [L_R14, L_R14 + 1], [n, n + 1, L_TA, f14, f14 + 1])
-    E.ins("v_pk_fma_f32 %s, %s, %s, %s op_sel_hi:[1,0,1]" % (pair(L_R32), pair(n), pair(L_TB), pair(f32_)), "pk",
-          [L_R32, L_R32 + 1], [n, n + 1, L_TB, f32_, f32_ + 1])
-    E.ins("v_cndmask_b32 v%d, v%d, v%d, vcc" % (L_PH, L_PH, L_T), "valu", [L_PH], [L_PH, L_T], reads_vcc=True)
-    if s % 4 == 2:
-        # the F loads of the next four steps fetch F_{s+10} .. F_{s+13}: f_done >= base + s + 14 (L_NEED runs with it)
-        E.ins("s_waitcnt lgkmcnt(0)", "wait")
-        E.ins("v_cmp_lt_i32 vcc, v%d, v%d" % (L_FLAG, L_NEED), "valu", [], [L_FLAG, L_NEED], writes_vcc=True)
-        if "L" not in ABLATE:
-            E.ins("s_cbranch_vccnz .Lslow%d_%%=" % s, "br")
-        E.label(".Lback%d_%%=:" % s)
-
-
-def gen_loop():
-    E = Emitter()
-    # ---- entry: operands -> fixed registers
-    E.comment("state, taps, constants and addresses into the block's fixed registers")
-    for (reg, opnd) in ((L_PH, "ph"), (L_FR, "fr"), (L_NEED, "need"), (L_AADDR, "a_addr"), (L_FADDR, "f_addr"), (L_XBASE, "x_base"),
-                        (L_HEADMASK, "headmask"), (L_XDADDR, "xd_addr"), (L_FDADDR, "fd_addr"), (L_STUCK, "stuck_addr"), (L_MAXF, "maxf")):
-        E.ins("v_mov_b32 v%d, %%[%s]" % (reg, opnd), "valu", [reg])
-    for (reg, opnd) in ((L_XS[0], "xs"), (L_R14, "r14"), (L_R32, "r32"), (L_TA, "ta"), (L_TB, "tb")):
-        E.ins("v_mov_b64 %s, %%[%s]" % (pair(reg), opnd), "valu", [reg, reg + 1])
-    E.ins("v_mov_b32 v%d, %%[two]" % L_TWO, "valu", [L_TWO])      # only lane 0 addresses the counter, the others their own dump word
-    E.ins("v_mov_b32 v%d, %s" % (L_CS2, f32(S2)), "valu", [L_CS2])
-    E.ins("v_mov_b32 v%d, %s" % (L_CC3, f32(C3c)), "valu", [L_CC3])
-    E.ins("v_mov_b32 v%d, %s" % (L_2PI, f32(FL_PI - (-FL_PI))), "valu", [L_2PI])
-    E.label(".Ltile_%=:")
-    # ---- per tile: x ring address of the head lanes ((base & 255) * 8 into the row; the other lanes write to a dump row)
-    E.ins("s_and_b32 %[st], %[base], 0xff", "salu")
-    E.ins("s_lshl_b32 %[st], %[st], 3", "salu")
-    E.ins("v_and_b32 v%d, %%[st], v%d" % (L_T, L_HEADMASK), "valu", [L_T], [L_HEADMASK])
-    E.ins("v_add_u32 v%d, v%d, v%d" % (L_XADDR, L_T, L_XBASE), "valu", [L_XADDR], [L_T, L_XBASE])
-    E.ins("ds_read_b64 %s, v%d" % (pair(L_A[0]), L_AADDR), "lds", [L_A[0], L_A[0] + 1], [L_AADDR])
-    E.ins("ds_read_b128 %s, v%d offset:%d" % (quad(L_F[0]), L_FADDR, 16 * 8), "lds", list(range(L_F[0], L_F[0] + 4)), [L_FADDR])
-    prologue = E.n
-    for s in range(TILE):
-        loop_step(E, s)
-    per_tile = E.n - prologue
-    # ---- tile end: the A wave's other buffer next time, barrier of the epoch, next tile
-    E.ins("v_xor_b32 v%d, 0x%x, v%d" % (L_AADDR, A_BUF_TOGGLE, L_AADDR), "valu", [L_AADDR], [L_AADDR])
-    E.ins("s_add_u32 %[base], %[base], 32", "salu")
-    E.ins("s_sub_u32 %[tiles], %[tiles], 1", "salu")
-    E.ins("s_waitcnt lgkmcnt(0)", "wait")
-    E.ins("s_barrier", "salu")
-    E.ins("s_cmp_lg_u32 %[tiles], 0", "salu")
-    E.ins("s_cbranch_scc1 .Ltile_%=", "br")
-    # ---- exit: state back (the x pipeline ends a tile in the register set it started in)
-    for (reg, opnd) in ((L_PH, "ph"), (L_FR, "fr")):
-        E.ins("v_mov_b32 %%[%s], v%d" % (opnd, reg), "valu")
-    for (reg, opnd) in ((L_XS[0], "xs"), (L_R14, "r14"), (L_R32, "r32")):
-        E.ins("v_mov_b64 %%[%s], %s" % (opnd, pair(reg)), "valu")
-    E.ins("s_branch .Lend_%=", "br")
-    for s in range(TILE):
-        if s % 4 == 2:
-            spin(E, "slow%d" % s, L_FDADDR, L_FLAG,
-                 lambda tmp: ["v_cmp_lt_i32 vcc, v%d, v%d" % (tmp, L_NEED)],
-                 L_STUCK, "back%d" % s)
-    E.label(".Lend_%=:")
-    return E, per_tile
-
-
-# ----------------------------------------------------------------------------------------------------------------------
-# FLL helper wave
-# ----------------------------------------------------------------------------------------------------------------------
-TH = 17
-H_TA, H_TB = 16, 33            # ta[0..16] = v16..v32, tb[0..16] = v33..v49
-H_R14, H_R32 = 50, 82          # r14[i] = v[50+2i : 51+2i], r32[i] = v[82+2i : 83+2i], i = 0..15
-H_XIN = (116, 120)             # the two samples of a pair (4 registers), two pairs in flight; the x pipeline lives in
-                               # the register pair of the sample processed last
-H_C = 124                      # c14 = v[124:125], c32 = v[126:127] (one ds_write_b128)
-H_FLAG = (128, 129)
-H_NEED, H_ONE, H_T = 130, 131, 132
-H_XADDR, H_FADDR, H_XDADDR, H_FDADDR, H_STUCK, H_XROW, H_TAPADDR = 133, 134, 135, 136, 137, 138, 139
-H_CLOBBER = list(range(16, 140))
-BE_IM_OFFSET = 84 * 4          # byte offset of the imaginary taps behind the real ones in FusedLds::be84
+BE_IM_OFFSET = 72 * 4            # byte offset of the imaginary taps behind the real ones in FusedLds::be72
 
 
 def tap_operand(base, j):
@@ -333,156 +180,194 @@ def tap_operand(base, j):
     return pair(r - 1), "op_sel:[0,1,0]"
 
 
-def helper_step(E, s, xr, xs_old, publish_after_write):
-    """One far step, PH = s & 15.  xr = register pair holding x_s in the head lanes; the step shifts the pipeline
-    (xs_old) into it.  Emits F_{s+16} to the ring."""
-    ph = s & 15
-    c14, c32 = H_C, H_C + 2
-    E.comment("---- far step %d" % s)
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:4 row_mask:0xf bank_mask:0xf" % (xr, xs_old), "dpp", [xr], [xs_old])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:4 row_mask:0xf bank_mask:0xf" % (xr + 1, xs_old + 1), "dpp", [xr + 1], [xs_old + 1])
-    xs = xr
+def r14(i):
+    return R_R14 + 2 * (i % NRES)
 
-    def r14(i):
-        return H_R14 + 2 * (i % 16)
 
-    def r32(i):
-        return H_R32 + 2 * (i % 16)
+def r32(i):
+    return R_R32 + 2 * (i % NRES)
 
-    def fma(dst, base, j, acc):
-        op, mod = tap_operand(base, j)
-        E.ins("v_pk_fma_f32 %s, %s, %s, %s %s" % (pair(dst), pair(xs), op, pair(acc), mod), "pk", [dst, dst + 1],
-              [xs, xs + 1, base + j, acc, acc + 1])
 
-    fma(c14, H_TA, TH - 1, r14(ph))
-    fma(c32, H_TB, TH - 1, r32(ph))
-    # middle taps on the other residents: independent of each other, they also fill the hazard gaps
-    mids = []
-    for q in range(1, TH - 1):
-        mids.append((r14(ph + q), H_TA, TH - 1 - q))
-        mids.append((r32(ph + q), H_TB, TH - 1 - q))
-    for (rr, base, j) in mids[:2]:
-        fma(rr, base, j, rr)
-    # completed far sums F_{s+16} of the head lanes -> ring
-    E.ins("ds_write_b128 v%d, %s offset:%d" % (H_FADDR, quad(H_C), 16 * ((s + 16) & 31)), "lds", [], [H_FADDR] + list(range(H_C, H_C + 4)))
-    E.ins("ds_add_u32 v%d, v%d" % (H_FDADDR, H_ONE), "lds", [], [H_FDADDR, H_ONE])
-    if publish_after_write:
-        publish_after_write()
-    # hop: the sums move one position inward (zero fill at the tail), then meet tap 0 of their new position
+def fma_op(dst, xs, base, j, acc):
+    op, mod = tap_operand(base, j)
+    return ("v_pk_fma_f32 %s, %s, %s, %s %s" % (pair(dst), pair(xs), op, pair(acc), mod), "pk", [dst, dst + 1],
+            [xs, xs + 1, base + j, acc, acc + 1])
+
+
+def middle_ops(ph, xs):
+    """The seven middle taps of both sums of a step: r[(ph+q) % 8] += xs * t[8-q], q = 1..7, in the order the next step
+    needs them (it reads r[(ph+1) % 8] first)."""
+    ops = []
+    for q in range(1, TAPS - 1):
+        ops.append(fma_op(r14(ph + q), xs, R_TA, TAPS - 1 - q, r14(ph + q)))
+        ops.append(fma_op(r32(ph + q), xs, R_TB, TAPS - 1 - q, r32(ph + q)))
+    return ops
+
+
+def fir_and_hop(E, s, n, replay):
+    """Newest tap on the oldest residents, error and loop filter (unless replay), hop inward with zero fill, tap 0 on the
+    arrivals.  The middle taps are NOT issued here (see middle_ops)."""
+    ph = s % NRES
+    E.ins(*fma_op(R_C14, n, R_TA, TAPS - 1, r14(ph)))
+    E.ins(*fma_op(R_C32, n, R_TB, TAPS - 1, r32(ph)))
     sh14, sh32 = r14(ph), r32(ph)
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" % (sh14, c14), "dpp", [sh14], [c14])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" % (sh14 + 1, c14 + 1), "dpp", [sh14 + 1], [c14 + 1])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" % (sh32, c32), "dpp", [sh32], [c32])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" % (sh32 + 1, c32 + 1), "dpp", [sh32 + 1], [c32 + 1])
-    for (rr, base, j) in mids[2:]:
-        fma(rr, base, j, rr)
-    fma(sh14, H_TA, 0, sh14)
-    fma(sh32, H_TB, 0, sh32)
+
+    def hop(k):
+        src = (R_C14, R_C14 + 1, R_C32, R_C32 + 1)[k]
+        dst = (sh14, sh14 + 1, sh32, sh32 + 1)[k]
+        E.ins("v_mov_b32_dpp v%d, v%d row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" % (dst, src), "dpp", [dst], [src])
+
+    if replay:
+        for k in range(4):
+            hop(k)
+    else:
+        # fll_error: d = c14 - swap(c32) = (lbe.re, hbe.im), u = c14 + swap(c32) = (hbe.re, lbe.im)
+        E.ins("v_pk_add_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" % (pair(R_D), pair(R_C14), pair(R_C32)),
+              "pk", [R_D, R_D + 1], [R_C14, R_C14 + 1, R_C32, R_C32 + 1])
+        E.ins("v_pk_add_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0]" % (pair(R_U), pair(R_C14), pair(R_C32)),
+              "pk", [R_U, R_U + 1], [R_C14, R_C14 + 1, R_C32, R_C32 + 1])
+        hop(0)
+        E.ins("v_max_f32 v%d, |v%d|, |v%d|" % (R_MX, R_U, R_D + 1), "valu", [R_MX], [R_U, R_D + 1])
+        E.ins("v_min_f32 v%d, |v%d|, |v%d|" % (R_MN, R_U, R_D + 1), "valu", [R_MN], [R_U, R_D + 1])
+        E.ins("v_max_f32 v%d, |v%d|, |v%d|" % (R_MX + 1, R_D, R_U + 1), "valu", [R_MX + 1], [R_D, R_U + 1])
+        E.ins("v_min_f32 v%d, |v%d|, |v%d|" % (R_MN + 1, R_D, R_U + 1), "valu", [R_MN + 1], [R_D, R_U + 1])
+        E.ins("v_pk_mul_f32 %s, %s, %%[p4] op_sel_hi:[1,0]" % (pair(R_MN), pair(R_MN)), "pk", [R_MN, R_MN + 1], [R_MN, R_MN + 1])
+        hop(1)
+        E.ins("v_pk_add_f32 %s, %s, %s" % (pair(R_MX), pair(R_MX), pair(R_MN)), "pk", [R_MX, R_MX + 1], [R_MX, R_MX + 1, R_MN, R_MN + 1])
+        hop(2)
+        E.ins("v_sub_f32 v%d, v%d, v%d" % (R_E, R_MX, R_MX + 1), "valu", [R_E], [R_MX, R_MX + 1])
+        # PhaseControlLoop::advance with alpha == 0: freq = clamp(freq + beta*err), phase = wrap(phase + freq)
+        E.ins("v_mul_f32 v%d, %%[beta], v%d" % (R_E, R_E), "valu", [R_E], [R_E])
+        hop(3)
+        E.ins("v_add_f32 v%d, v%d, v%d" % (R_E, R_FR, R_E), "valu", [R_E], [R_FR, R_E])
+        E.ins("v_med3_f32 v%d, v%d, %%[minf], v%d" % (R_FR, R_E, R_MAXF), "valu", [R_FR], [R_E, R_MAXF])
+        E.ins("v_add_f32 v%d, v%d, v%d" % (R_PH, R_PH, R_FR), "valu", [R_PH], [R_PH, R_FR])
+        E.ins("v_bfi_b32 v%d, %%[absmask], v%d, v%d" % (R_T, R_2PI, R_PH), "valu", [R_T], [R_2PI, R_PH])
+        E.ins("v_sub_f32 v%d, v%d, v%d" % (R_T, R_PH, R_T), "valu", [R_T], [R_PH, R_T])
+        E.ins("v_cmp_gt_f32 vcc, |v%d|, %%[pi]" % R_PH, "valu", [], [R_PH], writes_vcc=True)
+    E.ins(*fma_op(sh14, n, R_TA, 0, sh14))
+    E.ins(*fma_op(sh32, n, R_TB, 0, sh32))
+    if not replay:
+        E.ins("v_cndmask_b32 v%d, v%d, v%d, vcc" % (R_PH, R_PH, R_T), "valu", [R_PH], [R_PH, R_T], reads_vcc=True)
 
 
-def gen_helper():
-    """The helper wave's whole life.  Tile iterations it = 0, 1, 2 rebuild the pipeline from the stored delay line
-    (samples -96 .. -1, zeros before -80 under zero taps) and leave F_0 .. F_15 in the ring; iterations 3 .. ntiles+2 are
-    the tiles of the call.  x of a pair is loaded speculatively together with the loop waves' progress counter while the
-    previous pair is computed, and used only if the counter (loaded FIRST; LDS is in order) says it had been published;
-    otherwise the slow path spins and reloads."""
-    E = Emitter()
-    E.comment("addresses, constants, taps")
-    for (reg, opnd) in ((H_XROW, "x_row"), (H_FADDR, "f_addr"), (H_XDADDR, "xd_addr"), (H_FDADDR, "fd_addr"), (H_STUCK, "stuck_addr"),
-                        (H_TAPADDR, "tap_addr")):
-        E.ins("v_mov_b32 v%d, %%[%s]" % (reg, opnd), "valu", [reg])
-    E.ins("v_mov_b32 v%d, %%[one]" % H_ONE, "valu", [H_ONE])      # only lane 0 addresses the counter, the others their own dump word
-    E.ins("v_mov_b32 v%d, %d" % (H_NEED, -96 + 2), "valu", [H_NEED])
-    for j in range(TH):
-        E.ins("ds_read_b32 v%d, v%d offset:%d" % (H_TA + j, H_TAPADDR, 4 * j), "lds", [H_TA + j])
-        E.ins("ds_read_b32 v%d, v%d offset:%d" % (H_TB + j, H_TAPADDR, BE_IM_OFFSET + 4 * j), "lds", [H_TB + j])
-    for i in range(16):
-        E.ins("v_mov_b64 %s, 0" % pair(H_R14 + 2 * i), "valu", [H_R14 + 2 * i, H_R14 + 2 * i + 1])
-        E.ins("v_mov_b64 %s, 0" % pair(H_R32 + 2 * i), "valu", [H_R32 + 2 * i, H_R32 + 2 * i + 1])
-    final_xs = H_XIN[1] + 2      # where the pipeline sits at the end of a tile = where a tile expects it
-    E.ins("v_mov_b64 %s, 0" % pair(final_xs), "valu", [final_xs, final_xs + 1])
+def real_step(E, s):
+    """Sample step s of a complete tile (FllRow8<float>::step<s & 7, false, true>).  E.pending holds the previous step's
+    middle FMAs (they read the OLD pipeline registers, which the next step's x overwrites: all must be out by the end
+    of this step, and the two on r[ph] before this step's first FMA)."""
+    o, n = R_XS[s & 1], R_XS[(s + 1) & 1]
+    a = R_AQ[(s >> 1) & 1] + 2 * (s & 1)
+    had = len(E.pending)
+    E.comment("---- step %d" % s)
+    # NCO phasor: sincos_t<float, true>(-ph); sine and cosine polynomials as one packed Horner chain
+    E.ins("v_mul_f32 v%d, %s, v%d" % (R_K, INV_PI_NEG, R_PH), "valu", [R_K], [R_PH])
+    E.ins("v_rndne_f32 v%d, v%d" % (R_K, R_K), "valu", [R_K], [R_K])
+    E.ins("v_fma_f32 v%d, v%d, %%[negc1], -v%d" % (R_R, R_K, R_PH), "valu", [R_R], [R_K, R_PH])
+    E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C2N), R_K), "valu", [R_R], [R_R, R_K])
+    E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C3N), R_K), "valu", [R_R], [R_R, R_K])
+    E.ins("v_mul_f32 v%d, v%d, v%d" % (R_Z, R_R, R_R), "valu", [R_Z], [R_R])
+    E.ins("v_fmamk_f32 v%d, v%d, %s, v%d" % (R_Q + 1, R_Z, f32(C4), R_CC3), "valu", [R_Q + 1], [R_Z, R_CC3])        # c4*z + c3
+    E.ins("v_pk_fma_f32 %s, %s, %s, %%[k1] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_Q), pair(R_Z)), "pk", [R_PP, R_PP + 1],
+          [R_Q, R_Q + 1, R_Z])                                                                                        # (s3*z + s2, . *z + c2)
+    for kk in ("k2", "k3", "k4"):                                                                                     # k4: (ps*z - 0, pc*z + 1)
+        E.ins("v_pk_fma_f32 %s, %s, %s, %%[%s] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z), kk), "pk", [R_PP, R_PP + 1],
+              [R_PP, R_PP + 1, R_Z])
+    E.ins("v_lshlrev_b32 v%d, 8, v%d" % (R_M, R_K), "valu", [R_M], [R_K])
+    E.ins("v_fmac_f32 v%d, v%d, v%d" % (R_R, R_PP, R_R), "valu", [R_R], [R_PP, R_R])                                   # sin before the sign
+    E.ins("v_xor_b32 v%d, v%d, v%d" % (R_CC, R_M, R_PP + 1), "valu", [R_CC], [R_M, R_PP + 1])
+    E.ins("v_xor_b32 v%d, v%d, v%d" % (R_SS, R_M, R_R), "valu", [R_SS], [R_M, R_R])
+    if s & 1 == 0:
+        E.ins("s_waitcnt lgkmcnt(0)", "wait")          # this pair of AGC samples (loaded two steps ago)
+    # x = a * (c + j s): (ar*c, ai*c) + (-(ai*s), ar*s)
+    E.ins("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair(R_T1), pair(a), pair(R_CC)), "pk", [R_T1, R_T1 + 1], [a, a + 1, R_CC])
+    E.ins("v_pk_mul_f32 %s, %s, %s op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[0,1]" % (pair(R_T2), pair(a), pair(R_SS)), "pk",
+          [R_T2, R_T2 + 1], [a, a + 1, R_SS])
+    E.ins("v_pk_add_f32 %s, %s, %s" % (pair(n), pair(R_T1), pair(R_T2)), "pk", [n, n + 1], [R_T1, R_T1 + 1, R_T2, R_T2 + 1])
+    if s & 1 == 1 and s + 3 < TILE:
+        # both samples of this pair are consumed: the pair after the next one goes into their registers
+        nq = R_AQ[(s >> 1) & 1]
+        E.ins("ds_read_b128 %s, v%d offset:%d" % (quad(nq), R_AADDR, 8 * (s + 3)), "lds", list(range(nq, nq + 4)), [R_AADDR])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n, o), "dpp", [n], [o])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n + 1, o + 1), "dpp", [n + 1], [o + 1])
+    used = had - len(E.pending)
+    if had and used < 2:
+        E.flush(2 - used)           # the deferred FMAs on r[ph] must precede this step's FMAs on it
+    fir_and_hop(E, s, n, False)
+    E.flush()                       # what is left of the previous step's middle FMAs
+    if s % 8 == 7:
+        # lane (pos) holds x_{s-pos}: eight samples of the tile to the ring
+        E.ins("ds_write_b64 v%d, %s offset:%d" % (R_XLANE, pair(n), 8 * s), "lds", [], [R_XLANE, n, n + 1])
+    E.pending = middle_ops(s % NRES, n)
+
+
+def replay_step(E, g, n_reg, o_reg):
+    """Replay step g (0..7) of a group: x is a stored sample (no NCO, no loop update)."""
+    E.comment("---- replay step %d" % g)
+    E.ins("ds_read_b64 %s, v%d offset:%d" % (pair(n_reg), R_HADDR, 8 * g), "lds", [n_reg, n_reg + 1], [R_HADDR])
+    E.flush()                       # the previous step's middle FMAs (they read o_reg)
     E.ins("s_waitcnt lgkmcnt(0)", "wait")
-    E.ins("s_mov_b32 %[base], -96", "salu")
-    E.ins("s_mov_b32 %[it], 0", "salu")
-    E.label(".Lhtile_%=:")
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n_reg, o_reg), "dpp", [n_reg], [o_reg])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n_reg + 1, o_reg + 1), "dpp", [n_reg + 1], [o_reg + 1])
+    fir_and_hop(E, g, n_reg, True)
+    E.pending = middle_ops(g % NRES, n_reg)
+
+
+def gen():
+    E = Emitter()
+    E.comment("state, constants and addresses into the block's fixed registers; taps from LDS; sums and pipeline start at zero")
+    for (reg, opnd) in ((R_PH, "ph"), (R_FR, "fr"), (R_AADDR, "a_addr"), (R_XROWL, "x_rowlane"), (R_TAPADDR, "tap_addr"),
+                        (R_HADDR, "hist_addr"), (R_MAXF, "maxf")):
+        E.ins("v_mov_b32 v%d, %%[%s]" % (reg, opnd), "valu", [reg])
+    E.ins("v_mov_b32 v%d, %s" % (R_Q, f32(S3)), "valu", [R_Q])
+    E.ins("v_mov_b32 v%d, %s" % (R_CC3, f32(C3c)), "valu", [R_CC3])
+    E.ins("v_mov_b32 v%d, %s" % (R_2PI, f32(FL_PI - (-FL_PI))), "valu", [R_2PI])
+    for j in range(TAPS):
+        E.ins("ds_read_b32 v%d, v%d offset:%d" % (R_TA + j, R_TAPADDR, 4 * j), "lds", [R_TA + j])
+        E.ins("ds_read_b32 v%d, v%d offset:%d" % (R_TB + j, R_TAPADDR, BE_IM_OFFSET + 4 * j), "lds", [R_TB + j])
+    for i in range(NRES):
+        E.ins("v_mov_b64 %s, 0" % pair(R_R14 + 2 * i), "valu", [R_R14 + 2 * i, R_R14 + 2 * i + 1])
+        E.ins("v_mov_b64 %s, 0" % pair(R_R32 + 2 * i), "valu", [R_R32 + 2 * i, R_R32 + 2 * i + 1])
+    E.ins("v_mov_b64 %s, 0" % pair(R_XS[0]), "valu", [R_XS[0], R_XS[0] + 1])
+    E.ins("v_mov_b64 %s, 0" % pair(R_XS[1]), "valu", [R_XS[1], R_XS[1] + 1])
+    E.ins("s_waitcnt lgkmcnt(0)", "wait")
+    # ---- rebuild the in-flight sums: replay of the last 72 stored samples, nine groups of eight steps.  The deferred
+    # middle FMAs carry over the loop's back edge (and into the first real step); the very first batch meets an all-zero
+    # pipeline and all-zero sums, where fma(0, t, 0) changes nothing.
+    E.pending = middle_ops(7, R_XS[0])
+    at_top = [p[0] for p in E.pending]
+    E.ins("s_mov_b32 %[st], 9", "salu")
+    E.label(".Lreplay_%=:")
+    for g in range(8):
+        replay_step(E, g, R_XS[(g + 1) & 1], R_XS[g & 1])
+    assert [p[0] for p in E.pending] == at_top
+    E.ins("v_add_u32 v%d, 64, v%d" % (R_HADDR, R_HADDR), "valu", [R_HADDR], [R_HADDR])
+    E.ins("s_sub_u32 %[st], %[st], 1", "salu")
+    E.ins("s_cmp_lg_u32 %[st], 0", "salu")
+    E.ins("s_cbranch_scc1 .Lreplay_%=", "br")
+    # ---- the tiles
+    E.label(".Ltile_%=:")
+    # x ring address of this lane for the tile: row + 8*(8 + (base & 255) - pos) (front padding of 8 slots, see FusedLds)
     E.ins("s_and_b32 %[st], %[base], 0xff", "salu")
     E.ins("s_lshl_b32 %[st], %[st], 3", "salu")
-    E.ins("v_add_u32 v%d, %%[st], v%d" % (H_XADDR, H_XROW), "valu", [H_XADDR], [H_XROW])
+    E.ins("v_add_u32 v%d, %%[st], v%d" % (R_XLANE, R_XROWL), "valu", [R_XLANE], [R_XROWL])
+    E.ins("ds_read_b128 %s, v%d" % (quad(R_AQ[0]), R_AADDR), "lds", list(range(R_AQ[0], R_AQ[0] + 4)), [R_AADDR])
+    E.ins("ds_read_b128 %s, v%d offset:16" % (quad(R_AQ[1]), R_AADDR), "lds", list(range(R_AQ[1], R_AQ[1] + 4)), [R_AADDR])
     prologue = E.n
-    cur_xs = final_xs
-    for p in range(16):
-        regs = H_XIN[p & 1]
-        nxt = H_XIN[(p + 1) & 1]
-        E.comment("==== pair %d" % p)
-        if p == 0:
-            # first pair of a tile: its samples appear only after the tile's barrier, nothing was prefetched
-            if "H" not in ABLATE:
-                E.ins("s_branch .Lhslow0_%=", "br")
-            E.label(".Lhback0_%=:")
-            if "H" in ABLATE:
-                E.ins("ds_read2_b64 %s, v%d offset0:0 offset1:1" % (quad(regs), H_XADDR), "lds", list(range(regs, regs + 4)), [H_XADDR])
-                E.ins("s_waitcnt lgkmcnt(0)", "wait")
-        for k in range(2):
-            s = 2 * p + k
-            xr = regs + 2 * k
-            helper_step_split(E, s, xr, cur_xs, k == 1, p, nxt)
-            cur_xs = xr
-        if p + 1 < 16:
-            E.ins("v_add_u32 v%d, 2, v%d" % (H_NEED, H_NEED), "valu", [H_NEED], [H_NEED])
-            E.ins("s_waitcnt lgkmcnt(0)", "wait")
-            E.ins("v_cmp_lt_i32 vcc, v%d, v%d" % (H_FLAG[(p + 1) & 1], H_NEED), "valu", [], [H_FLAG[(p + 1) & 1], H_NEED], writes_vcc=True)
-            if "H" not in ABLATE:
-                E.ins("s_cbranch_vccnz .Lhslow%d_%%=" % (p + 1), "br")
-            E.label(".Lhback%d_%%=:" % (p + 1))
-    assert cur_xs == final_xs
+    for s in range(TILE):
+        real_step(E, s)
     per_tile = E.n - prologue
-    # tile end: need of the next tile's first pair, barriers (none during the rebuild, two after it: the end of the
-    # prologue and epoch 0), next tile
-    E.ins("v_add_u32 v%d, 2, v%d" % (H_NEED, H_NEED), "valu", [H_NEED], [H_NEED])
+    assert [p[0] for p in E.pending] == at_top, "deferred FMAs must line up across the loop's back edge"
+    E.ins("v_xor_b32 v%d, 0x%x, v%d" % (R_AADDR, A_BUF_TOGGLE, R_AADDR), "valu", [R_AADDR], [R_AADDR])
     E.ins("s_add_u32 %[base], %[base], 32", "salu")
-    E.ins("s_cmp_lt_u32 %[it], 2", "salu")
-    E.ins("s_cbranch_scc1 .Lhnobar_%=", "br")
+    E.ins("s_sub_u32 %[tiles], %[tiles], 1", "salu")
     E.ins("s_waitcnt lgkmcnt(0)", "wait")
     E.ins("s_barrier", "salu")
-    E.ins("s_cmp_lg_u32 %[it], 2", "salu")
-    E.ins("s_cbranch_scc1 .Lhnobar_%=", "br")
-    E.ins("s_barrier", "salu")
-    E.label(".Lhnobar_%=:")
-    E.ins("s_add_u32 %[it], %[it], 1", "salu")
-    E.ins("s_cmp_lt_u32 %[it], %[iters]", "salu")
-    E.ins("s_cbranch_scc1 .Lhtile_%=", "br")
-    E.ins("s_branch .Lhend_%=", "br")
-    for p in range(16):
-        regs = H_XIN[p & 1]
-        # every iteration loads the counter and THEN the two samples: when the counter is there, so are they
-        E.label(".Lhslow%d_%%=:" % p)
-        E.ins("s_mov_b32 %[spins], 0", "salu")
-        E.label(".Lhspin%d_%%=:" % p)
-        E.ins("ds_read_b32 v%d, v%d" % (H_T, H_XDADDR), "lds")
-        E.ins("ds_read2_b64 %s, v%d offset0:%d offset1:%d" % (quad(regs), H_XADDR, 2 * p, 2 * p + 1), "lds")
-        E.ins("s_waitcnt lgkmcnt(0)", "wait")
-        E.ins("v_cmp_lt_i32 vcc, v%d, v%d" % (H_T, H_NEED), "valu")
-        E.ins("s_cbranch_vccz .Lhback%d_%%=" % p, "br")
-        E.ins("s_add_u32 %[spins], %[spins], 1", "salu")
-        E.ins("s_cmp_lt_u32 %%[spins], 0x%x" % SPIN_LIMIT, "salu")
-        E.ins("s_cbranch_scc1 .Lhspin%d_%%=" % p, "br")
-        E.ins("v_mov_b32 v%d, 1" % H_T, "valu")
-        E.ins("ds_write_b32 v%d, v%d" % (H_STUCK, H_T), "lds")
-        E.ins("s_branch .Lhback%d_%%=" % p, "br")
-    E.label(".Lhend_%=:")
+    E.ins("s_cmp_lg_u32 %[tiles], 0", "salu")
+    E.ins("s_cbranch_scc1 .Ltile_%=", "br")
+    for (reg, opnd) in ((R_PH, "ph"), (R_FR, "fr")):
+        E.ins("v_mov_b32 %%[%s], v%d" % (opnd, reg), "valu")
+    E.pending = []
     return E, per_tile
-
-
-def helper_step_split(E, s, xr, xs_old, second, p, nxt):
-    """helper_step plus the pair-level bookkeeping that has to sit at a fixed point of it: the speculative loads of the
-    next pair (progress counter FIRST, then the two samples) go right behind the second step's ring write -- as late as
-    the LDS latency allows, so that they see as much of the loop waves' progress as possible.  The registers they
-    overwrite were left by the x pipeline during the pair's first step."""
-    def prefetch():
-        E.ins("ds_read_b32 v%d, v%d" % (H_FLAG[(p + 1) & 1], H_XDADDR), "lds", [H_FLAG[(p + 1) & 1]], [H_XDADDR])
-        E.ins("ds_read2_b64 %s, v%d offset0:%d offset1:%d" % (quad(nxt), H_XADDR, 2 * (p + 1), 2 * (p + 1) + 1), "lds",
-              list(range(nxt, nxt + 4)), [H_XADDR])
-    helper_step(E, s, xr, xs_old, prefetch if (second and p + 1 < 16) else None)
 
 
 def c_string(text):
@@ -498,22 +383,20 @@ def c_string(text):
 
 
 def generate():
-    body, l_tile = gen_loop()
-    hbody, h_tile = gen_helper()
+    E, per_tile = gen()
     parts = []
     parts.append("// fll_asm.inc -- GENERATED by gen_fll_asm.py; do not edit.  See that file for the schedule and the hazard rules.\n")
-    parts.append("// loop wave: %d instruction slots per 32-sample tile (%.2f per sample), %d s_nop in the block\n" % (l_tile, l_tile / 32.0, body.nops))
-    parts.append("// helper wave: %d instruction slots per tile (%.2f per sample), %d s_nop in the block\n" % (h_tile, h_tile / 32.0, hbody.nops))
-    parts.append("#define FLL_LOOP_ASM \\\n" + c_string(body.text()).replace("\n", " \\\n") + "\n")
-    parts.append("#define FLL_HELPER_ASM \\\n" + c_string(hbody.text()).replace("\n", " \\\n") + "\n")
-    parts.append("#define FLL_LOOP_CLOBBERS %s\n" % ", ".join('"v%d"' % r for r in L_CLOBBER))
-    parts.append("#define FLL_HELPER_CLOBBERS %s\n" % ", ".join('"v%d"' % r for r in H_CLOBBER))
-    parts.append("#define FLL_ASM_LOOP_SLOTS_PER_TILE %d\n#define FLL_ASM_HELPER_SLOTS_PER_TILE %d\n" % (l_tile, h_tile))
-    return "".join(parts), body, hbody, l_tile, h_tile
+    parts.append("// FLL wave: %d instruction slots per 32-sample tile (%.2f per sample), %d s_nop in the whole block\n" % (per_tile, per_tile / 32.0, E.nops))
+    parts.append("#define FLL_WAVE_ASM \\\n" + c_string(E.text()).replace("\n", " \\\n") + "\n")
+    parts.append("#define FLL_WAVE_CLOBBERS %s\n" % ", ".join('"v%d"' % r for r in CLOBBER))
+    k = pk_consts()
+    parts.append("#define FLL_WAVE_K1 0x%016xull\n#define FLL_WAVE_K2 0x%016xull\n#define FLL_WAVE_K3 0x%016xull\n#define FLL_WAVE_K4 0x%016xull\n" % tuple(k))
+    parts.append("#define FLL_WAVE_SLOTS_PER_TILE %d\n" % per_tile)
+    return "".join(parts), E, per_tile
 
 
 def main():
-    text, body, hbody, l_tile, h_tile = generate()
+    text, E, per_tile = generate()
     if "--check" in sys.argv:
         cur = open(OUT).read() if os.path.exists(OUT) else ""
         if cur != text:
@@ -522,8 +405,7 @@ def main():
         return 0
     with open(OUT, "w") as f:
         f.write(text)
-    print("loop wave  : %d slots / tile = %.2f per sample; block: nops %d, %s" % (l_tile, l_tile / 32.0, body.nops, dict(sorted(body.counts.items()))))
-    print("helper wave: %d slots / tile = %.2f per sample; block: nops %d, %s" % (h_tile, h_tile / 32.0, hbody.nops, dict(sorted(hbody.counts.items()))))
+    print("FLL wave: %d slots / tile = %.2f per sample; block: nops %d, %s" % (per_tile, per_tile / 32.0, E.nops, dict(sorted(E.counts.items()))))
     return 0
 
 

@@ -1,71 +1,52 @@
-// kernel_fused.hpp -- the whole demodulator chain of 16 channels in ONE workgroup of seven specialised
+// kernel_fused.hpp -- the whole demodulator chain of 16 channels in ONE workgroup of six specialised
 // wavefronts (included by tetra_demod.hip; device code only).
 //
-// Why this shape (measured on MI355X, profiles/r02/r02_a_issue_model.md): a gfx950 wavefront issues one instruction
-// of ANY kind (VALU, SALU, s_nop, s_waitcnt, LDS) per ~4.7 clocks whether or not it depends on the previous one, so
-// a role's time is its instruction count, and the chain's pace is the instruction count of its busiest wave.  With
-// 4096 channels there are 16 channels per CU; the loop code (NCO sincos, error functions, loop filters) costs the
-// same whether a wave carries 4 or 64 channels.  A CU's 16 channels are therefore split by STAGE, each stage at the
-// widest lane occupancy its recurrence allows, and the one stage that is too long for one wave -- the FLL, 65-tap
-// complex band-edge FIR pair inside a per-sample feedback loop -- is cut in two at the 16 newest taps:
+// Why this shape (measured on MI355X, profiles/r02/r02_a_issue_model.md, r02_b_*): a gfx950 wavefront issues one
+// instruction of ANY kind (VALU, SALU, s_nop, s_waitcnt, LDS) per ~4.7 clocks whether or not it depends on the previous
+// one, and a SIMD's issue capacity is shared by its waves (a packed-FP32 or DPP instruction occupies it for ~4.4 clocks,
+// a plain VALU one for ~2.3).  A role's time is therefore its instruction count, the chain's pace is the instruction
+// count of its busiest wave, and the sum over the waves of a SIMD must fit too.  With 4096 channels there are 16 channels
+// per CU; the loop code (NCO sincos, error functions, loop filters) costs the same whether a wave carries 4 or 64
+// channels.  A CU's 16 channels are therefore split by STAGE, each stage at the widest lane occupancy its recurrence
+// allows:
 //
-//   wave  role                                              lanes/channel   SIMD
-//   L0,L1 FLL loop: NCO, 16 newest band-edge taps, error,   8 (two channels 0, 1   <- the pace-setters
-//         loop filter (FllNear8)                              per DPP row)
-//   H     FLL helper: the 68 older (zero-padded) taps of     4 (four per     3
-//         both FIRs as a systolic array (FllFar4)             row)
-//   D     ML timing recovery                                 1               2
-//   A     AGC                                                1               0 (with L0)
-//   E     Costas + slicer + diff. decoder + bit unpacker     1               1 (with L1)
-//   C     RRC matched filter (time-parallel)                 4 x 8 outputs   2 (with D)
+//   wave  role                                  lanes/channel   instruction slots / sample     SIMD
+//   F0,F1 FLL: NCO, band-edge FIRs, loop         8 (interleaved) 60 (hand-scheduled, fll_asm.inc) 2, 3: one each, alone
+//   E     Costas + slicer + diff. decoder + out  1               ~45                            0 (older wave)
+//   A     AGC                                    1               ~25                            0
+//   D     ML timing recovery                     1               ~40                            1 (older wave)
+//   C     RRC matched filter (time-parallel)     4 x 8 outputs   ~30                            1
 //
 // The issue arbiter serves the OLDEST wave of a SIMD first, so the recurrence-bound roles take the lower wave index of
-// their SIMD.  Stages are connected by LDS rings (AGC out -> FLL out x -> RRC out y -> symbols) and run as a software
-// pipeline over 32-sample tiles with one workgroup barrier per tile: in epoch e, A works on tile e, L and H on e-1, C
-// on e-2, D consumes y of tiles <= e-3 and E the symbols D published before the epoch.  Inside an epoch L and H hand
-// over through LDS without barriers: H follows L's x by reading a progress counter, and L injects H's partial sums
-// F_n eight samples before output n completes (see FllNear8 / FllFar4 in demod_core.hpp), so H has eight sample
-// periods for its round trip.  No intermediate touches HBM: the kernel reads 8 B and writes 1 B per input sample.
+// their SIMD and the throughput roles fill the slots they leave.  (Cutting the FLL in two -- loop waves plus a helper wave
+// for the far taps -- was built and measured this round: it shortens the longest wave but adds work and a seventh role that
+// does not pack into four SIMDs; profiles/r02/r02_c_fll_split_experiment.md.)
+//
+// Stages are connected by LDS rings (AGC out -> FLL out x -> RRC out y -> symbols) and run as a software pipeline over
+// 32-sample tiles with one workgroup barrier per tile: in epoch e, A works on tile e, F on e-1, C on e-2, D consumes y
+// of tiles <= e-3 and E the symbols D published before the epoch.  No intermediate touches HBM: the kernel reads 8 B
+// and writes 1 B per input sample.
 #pragma once
 
 #include "fll_asm.inc"
-
-#ifndef TETRA_ROLE_MAP
-#define TETRA_ROLE_MAP 3
-#endif
 
 namespace {
 
 constexpr int kFT = 32;                  // samples per tile (pipeline epoch)
 constexpr int kFCh = 16;                 // channels per workgroup
-constexpr int kFWaves = (TETRA_ROLE_MAP == 2 || TETRA_ROLE_MAP == 4) ? 8 : 7;
-constexpr int kFThreads = 64 * kFWaves;
-constexpr int kFX = 256;                 // x ring (FLL output) per channel
-constexpr int kFXS = kFX + 1;            // row stride (odd: spreads channels over LDS banks)
+constexpr int kFThreads = 384;           // 6 waves
+constexpr int kFX = 256;                 // x ring (FLL output) per channel ...
+constexpr int kFXP = 8;                  // ... behind 8 slots of front padding: an FLL lane stores x_{i-pos} at slot i - pos of the
+                                         // tile's window without wrapping (slots -7 .. -1 are never read, see fll_asm.inc)
+constexpr int kFXS = kFXP + kFX + 1;     // row stride (odd: spreads channels over LDS banks)
 constexpr int kFY = 128;                 // y ring (RRC output) per channel ...
 constexpr int kFYM = 8;                  // ... plus a mirror of the first slots so the interpolator window never wraps
 constexpr int kFYS = kFY + kFYM + 1;
 constexpr int kFS = 64;                  // symbol ring per channel
-constexpr int kFF = 32;                  // far-sum ring (F_n) per channel
-constexpr int kFFS = kFF + 1;
-constexpr int kTH = 17;                  // far taps per position of the helper wave: 4 x 17 + 16 = 84 padded taps
-constexpr int kFarTaps = 4 * kTH;
-constexpr int kPadBe = kFarTaps + kNearTaps;
-static_assert(kPadBe >= kHist, "padded band-edge filter must cover the longest supported filter");
-static_assert((kTH - 1) == 16 && kFT % (kTH - 1) == 0, "the helper wave's schedule period must divide the tile");
+static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 
-// wave index -> role; waves w and w+4 share a SIMD (TETRA_ROLE_MAP: placement experiments, profiles/r02)
-#if TETRA_ROLE_MAP == 0
-enum { kRoleL0 = 0, kRoleL1 = 1, kRoleD = 2, kRoleH = 3, kRoleA = 4, kRoleE = 5, kRoleC = 6, kRoleNone = 7 };      // {L0,A} {L1,E} {D,C} {H}
-#elif TETRA_ROLE_MAP == 1
-enum { kRoleL0 = 0, kRoleL1 = 1, kRoleD = 2, kRoleH = 3, kRoleA = 4, kRoleC = 5, kRoleE = 6, kRoleNone = 7 };      // {L0,A} {L1,C} {D,E} {H}
-#elif TETRA_ROLE_MAP == 2
-enum { kRoleL0 = 0, kRoleL1 = 1, kRoleD = 2, kRoleH = 3, kRoleC = 4, kRoleNone = 5, kRoleE = 6, kRoleA = 7 };      // {L0,C} {L1} {D,E} {H,A}
-#elif TETRA_ROLE_MAP == 3
-enum { kRoleL0 = 0, kRoleL1 = 1, kRoleE = 2, kRoleH = 3, kRoleA = 4, kRoleC = 5, kRoleD = 6, kRoleNone = 7 };      // {L0,A} {L1,C} {E,D} {H}
-#elif TETRA_ROLE_MAP == 4
-enum { kRoleL0 = 0, kRoleL1 = 1, kRoleD = 2, kRoleH = 3, kRoleNone = 4, kRoleC = 5, kRoleE = 6, kRoleA = 7 };      // {L0} {L1,C} {D,E} {H,A}
-#endif
+// wave index -> role.  A workgroup's waves are placed on SIMDs cyclically, so waves w and w+4 share a SIMD.
+enum { kRoleE = 0, kRoleD = 1, kRoleF0 = 2, kRoleF1 = 3, kRoleA = 4, kRoleC = 5 };
 
 struct FusedParams {
     const float2* iq;
@@ -80,8 +61,8 @@ struct FusedParams {
     int* prev;
     float2* ybuf;        // [C][7]
     // tables
-    const float* be_re84;   // band-edge taps zero-padded (old end) to kPadBe
-    const float* be_im84;
+    const float* be_re72;   // band-edge taps zero-padded (old end) to 72
+    const float* be_im72;
     const float* rrc_ext;   // [kRrcExt] RRC taps as rrc_direct8 wants them: ext[7 + rrc_pad + k] = h[k], zero elsewhere
     int ntaps;
     const float* bank;
@@ -98,7 +79,7 @@ struct FusedParams {
     float* q_err;
     K1Consts k1;
     K2Consts k2;
-    long long* prof;     // TETRA_DEMOD_DEBUG builds only: [workgroups][8] = busy clocks of waves 0..6 inside their epoch
+    long long* prof;     // TETRA_DEMOD_DEBUG builds only: [workgroups][8] = busy clocks of waves 0..5 inside their epoch
                          // bodies (barrier waits excluded), [7] = clocks from kernel entry to exit of wave 0; null = off
 };
 
@@ -107,21 +88,12 @@ struct FusedLds {
     float2 x_ring[kFCh][kFXS];
     float2 y_ring[kFCh][kFYS];
     float2 s_ring[kFCh][kFS];
-    __attribute__((aligned(16))) float4 f_ring[kFCh][kFFS];
-    // where the lanes that hold nothing worth keeping send their share of a wave-wide ring store (the loop waves' x of
-    // the non-head positions, the helper's partial sums of the non-head positions): lane j writes at 8*j resp. 16*j' plus
-    // the store's immediate offset, so no two lanes of one store ever hit the same address
-    __attribute__((aligned(16))) float4 dump[80];
-    float be84[2][kPadBe];   // band-edge taps (re, im), zero-padded: the helper wave's assembly loads its 34 taps from here
     int s_avail[kFCh];
-    // hand-over counters of the FLL pair: x_i is in x_ring for i < x_done[w] (loop wave w), F_m is in f_ring for m < f_done
-    int x_done[2];
-    int f_done;
-    int stuck;           // set by a wave whose wait ran into the watchdog: every wait gives up (results invalid, no hang)
     // interpolator bank with row 0 repeated in front and row 127 behind: rows max(p-1,0), p, min(p+1,127) of
     // complex_fd.cpp:102-121 are then the 24 contiguous floats at bank[p * 8]
     __attribute__((aligned(16))) float bank[(kInterpPhases + 2) * kInterpTaps];
     __attribute__((aligned(16))) float rrc[kRrcExt];       // zero-extended taps, see rrc_direct8
+    float be72[2][kF8Pad];   // band-edge taps (re, im), zero-padded: the FLL waves' assembly loads its 18 taps from here
 };
 static_assert(sizeof(FusedLds) <= 80 * 1024, "two workgroups must fit one CU's 160 KB of LDS");
 
@@ -132,55 +104,38 @@ typedef float vfloat2 __attribute__((ext_vector_type(2)));
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const vfloat2 lds_cfloat2;
 typedef __attribute__((address_space(3))) const vfloat4 lds_cfloat4;
-typedef __attribute__((address_space(3))) vfloat2 lds_float2;
-typedef __attribute__((address_space(3))) vfloat4 lds_float4;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
 __device__ __forceinline__ unsigned pin_u32(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 
+__device__ __forceinline__ void x_ring_put(FusedLds& L, int c, int i, float2 v) { L.x_ring[c][kFXP + (i & (kFX - 1))] = v; }
+__device__ __forceinline__ float2 x_ring_get(const FusedLds& L, int c, int i) { return L.x_ring[c][kFXP + (i & (kFX - 1))]; }
 __device__ __forceinline__ void y_ring_put(FusedLds& L, int c, int i, float2 v) {
     const int s = i & (kFY - 1);
     L.y_ring[c][s] = v;
     if (s < kFYM) L.y_ring[c][s + kFY] = v;
 }
 
-// Barrier-free hand-over between the FLL loop waves and the helper wave.  LDS executes one wave's instructions in issue
-// order, so "data stores, then counter store" on the producer and "counter load, then data loads" on the consumer need no
-// fence, only that the compiler keeps the order (volatile + memory clobbers).  A wait that spins longer than any healthy
-// run could (the peer is at most a few hundred clocks behind) raises `stuck` and every wait returns: wrong output, no hang.
-// The wait is four instruction slots when the counter is already there (ds_read_b32, s_waitcnt, v_cmp, s_cbranch): hipcc
-// unrolls and if-converts a C++ spin loop into dozens of instructions, so it is written out.  Every lane passes the LDS byte
-// address of the counter IT depends on (the helper wave's upper and lower half follow different loop waves) and the wait
-// ends when no lane is behind.
-// A wave-wide LDS store / atomic to ONE address is executed lane after lane, which would hold up the LDS unit of the whole
-// CU for every publication; so only lane 0 of the publishing wave addresses the counter, the other lanes address their own
-// word of the dump area (ho_pub_addr).
-__device__ __forceinline__ void ho_publish(unsigned pub_addr, int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(pub_addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void ho_wait(unsigned ctr_addr, int need, unsigned stuck_addr) {
-    int got, spins;
-    asm volatile(
-        "s_mov_b32 %1, 0\n"
-        "1:\n"
-        "ds_read_b32 %0, %2\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_cmp_lt_i32 vcc, %0, %3\n"
-        "s_cbranch_vccz 3f\n"
-        "s_add_u32 %1, %1, 1\n"
-        "s_cmp_lt_u32 %1, 0x40000\n"
-        "s_cbranch_scc0 2f\n"
-        "ds_read_b32 %0, %4\n"                 // somebody else gave up: give up too
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_cmp_eq_u32 vcc, 0, %0\n"
-        "s_cbranch_vccnz 1b\n"
-        "2:\n"
-        "v_mov_b32 %0, 1\n"
-        "ds_write_b32 %4, %0\n"
-        "3:\n"
-        : "=&v"(got), "=&s"(spins)
-        : "v"(ctr_addr), "v"(need), "v"(stuck_addr)
-        : "vcc", "scc", "memory");
-}
+// LDS side of one FLL lane in the C++ form of the wave (see fll8_tile / fll8_replay in demod_core.hpp).
+struct FllDeviceIO {
+    FusedLds& L;
+    const float2* a_tile;    // a_buf[parity][ch] of the tile being processed
+    int c;                   // channel within the workgroup
+    int pos;                 // position along the channel's 8 lanes (0 = head)
+    int tile_base;           // first sample index of the tile (replay: index of the first sample to come)
+
+    // the delay line sits in the x ring: the 72 samples in front of tile_base
+    __device__ __forceinline__ Pair<float> load_hist(int g) const {
+        const float2 v = x_ring_get(L, c, tile_base - kF8Pad + g * 8 + pos);
+        return Pair<float>(v.x, v.y);
+    }
+    __device__ __forceinline__ Pair<float> sample(int s) const {
+        const float2 v = a_tile[s];
+        return Pair<float>(v.x, v.y);
+    }
+    __device__ __forceinline__ void xs_store(int iend, int cnt, Pair<float> xs) const {
+        if (pos < cnt) x_ring_put(L, c, tile_base + iend - 1 - pos, make_float2(xs.x(), xs.y()));
+    }
+};
 
 #ifdef TETRA_DEMOD_DEBUG
 #define FUSED_PROF_T0 const long long tb_ = PROF ? __builtin_readcyclecounter() : 0;
@@ -222,17 +177,15 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         L.bank[i] = p.bank[row * kInterpTaps + i % kInterpTaps];
     }
     if (tid < kRrcExt) L.rrc[tid] = p.rrc_ext[tid];
-    if (tid < kPadBe) { L.be84[0][tid] = p.be_re84[tid]; L.be84[1][tid] = p.be_im84[tid]; }
+    if (tid < kF8Pad) { L.be72[0][tid] = p.be_re72[tid]; L.be72[1][tid] = p.be_im72[tid]; }
     // rings start at zero: FIR windows touch slots that were never written (weighted by zero taps, so they must be finite)
     for (int i = tid; i < kFCh * kFXS; i += kFThreads) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < kFCh * kFYS; i += kFThreads) (&L.y_ring[0][0])[i] = make_float2(0.f, 0.f);
     if (tid < kFCh) L.s_avail[tid] = 0;
-    // the helper's counter starts 96 samples back: its pipeline rebuild runs three tiles (samples -96 .. -1)
-    if (tid == 0) { L.x_done[0] = 0; L.x_done[1] = 0; L.f_done = kNearTaps - 96; L.stuck = 0; }
     __syncthreads();
     for (int i = tid; i < kFCh * kHist; i += kFThreads) {
         const int c = i / kHist, m = i % kHist;
-        L.x_ring[c][(m - kHist) & (kFX - 1)] = p.hist[(long long)chan(c) * kHist + m];
+        x_ring_put(L, c, m - kHist, p.hist[(long long)chan(c) * kHist + m]);
     }
     for (int i = tid; i < kFCh * (kInterpTaps - 1); i += kFThreads) {
         const int c = i / (kInterpTaps - 1), m = i % (kInterpTaps - 1);
@@ -281,170 +234,74 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
             }
         )
         if (on && live(c)) p.agc_g[ch0 + c] = g;
-    } else if (wave == kRoleL0 || wave == kRoleL1) {
-        // ---- FLL loop wave: lane -> (row r = lane>>4, pos = (lane&15)>>1, parity = lane&1); tile e-1 in epoch e ---
-        const int fw = wave - kRoleL0;
+    } else if (wave == kRoleF0 || wave == kRoleF1) {
+        // ---- FLL: lane -> (row r = lane>>4, pos = (lane&15)>>1, parity = lane&1); tile e-1 in epoch e ---
+        const int fw = wave - kRoleF0;
         const int f_pos = (lane & 15) >> 1;
         const int f_c = fw * 8 + (lane >> 4) * 2 + (lane & 1);
-        FllNear8<float> R;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int kp = kFarTaps + 2 * (7 - f_pos) + j;
-            R.ta[j] = p.be_re84[kp];
-            R.tb[j] = p.be_im84[kp];
-        }
-        R.ph = p.fll_ph[chan(f_c)];
-        R.fr = p.fll_fr[chan(f_c)];
+        float ph = p.fll_ph[chan(f_c)];
+        float fr = p.fll_fr[chan(f_c)];
         K1Consts k1 = p.k1;
         k1.fll_max_freq = v_pin(k1.fll_max_freq);
-        const unsigned xd = lane == 0 ? lds_addr(&L.x_done[fw]) : lds_addr(&L.dump[0]) + 4u * (unsigned)lane;   // publishing address
-        const unsigned fd = lds_addr(&L.f_done);
-        const unsigned stuck = lds_addr(&L.stuck);
-        lds_cfloat4* const frow = (lds_cfloat4*)(size_t)lds_addr(&L.f_ring[f_c][0]);
-        lds_float2* const xrow = (lds_float2*)(size_t)lds_addr(&L.x_ring[f_c][0]);
-        __syncthreads();      // (the helper wave has rebuilt its pipeline and published F_0 .. F_15)
-        // rebuild the 8 in-flight near sums by replaying the last 16 stored samples
-        R.clear_pipeline();
-        for (int s = -kNearTaps; s < 0; s++) {
-            const vfloat2 xv = xrow[s & (kFX - 1)];
-            vfloat4 f = { 0.f, 0.f, 0.f, 0.f };
-            if (s + kFarLead >= 0) f = frow[(s + kFarLead) & (kFF - 1)];
-            R.template step<true, true>(k1, Pair<float>(xv.x, xv.y), Pair<float>(f.x, f.y), Pair<float>(f.z, f.w));
-        }
+        __syncthreads();
         __syncthreads();      // epoch 0: nothing to do yet
-        // every complete tile of the call: the assembly block of fll_asm.inc (FllNear8<float>::step<false, true> x 32 per
-        // tile, one barrier per tile = epochs 1 .. nfull)
-#ifndef TETRA_FLL_CPP_LOOP
-        const int nfull = n / kFT;
-#else
-        const int nfull = 0;      // verification build: every tile through the C++ form of the step
-#endif
+        // Every COMPLETE tile of the call runs in the assembly block of fll_asm.inc (generated by gen_fll_asm.py from the
+        // schedule of FllRow8<float>::step): rebuild of the in-flight sums from the 72 samples in front of the call, then 32
+        // steps and one barrier per tile = epochs 1 .. nfull.  The alpha != 0 variant of the loop filter (never produced by
+        // the reference's FLL, fll.cpp:25) and the instrumented debug build take the C++ form for every tile.
+        const int nfull = (ALPHA0 && !PROF) ? n / kFT : 0;
         if (nfull > 0) {
-            const bool head = f_pos == 0;
-            const unsigned x_base = head ? lds_addr(&L.x_ring[f_c][0]) : lds_addr(&L.dump[0]) + 8u * (unsigned)lane;
-            const unsigned headmask = head ? 0xffffffffu : 0u;
+            int base_ = 0, tiles_ = nfull, st_;
             const unsigned a_addr = lds_addr(&L.a_buf[0][f_c][0]);
-            const unsigned f_addr = lds_addr(&L.f_ring[f_c][0]);
-            int base_ = 0, tiles_ = nfull, st_, spins_;
-            const int need0 = kNearTaps;          // first check (end of step 2 of tile 0): F_12 .. F_15 <=> f_done >= 16
-            vfloat2 xs_ = { R.xs.x(), R.xs.y() }, r14_ = { R.r14.x(), R.r14.y() }, r32_ = { R.r32.x(), R.r32.y() };
-            const vfloat2 ta_ = { R.ta[0], R.ta[1] }, tb_ = { R.tb[0], R.tb[1] };
-            float ph_ = R.ph, fr_ = R.fr;
+            const unsigned x_rowlane = lds_addr(&L.x_ring[f_c][kFXP]) - 8u * (unsigned)f_pos;
+            const unsigned tap_addr = lds_addr(&L.be72[0][kF8Taps * (kF8Lanes - 1 - f_pos)]);
+            const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - kF8Pad]);
             const unsigned long long p4 = (unsigned long long)__builtin_bit_cast(unsigned, 0.4f);
-            asm volatile(FLL_LOOP_ASM
-                         : [ph] "+v"(ph_), [fr] "+v"(fr_), [r14] "+v"(r14_), [r32] "+v"(r32_), [xs] "+v"(xs_),
-                           [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_), [spins] "=&s"(spins_)
-                         : [ta] "v"(ta_), [tb] "v"(tb_), [need] "v"(need0), [a_addr] "v"(a_addr), [f_addr] "v"(f_addr),
-                           [x_base] "v"(x_base), [headmask] "v"(headmask), [xd_addr] "v"(xd), [fd_addr] "v"(fd),
-                           [stuck_addr] "v"(stuck), [maxf] "v"(k1.fll_max_freq), [two] "v"(2),
+            asm volatile(FLL_WAVE_ASM
+                         : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
+                         : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
+                           [maxf] "v"(k1.fll_max_freq),
                            [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
-                           [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4)
-                         : "vcc", "scc", "memory", FLL_LOOP_CLOBBERS);
-            R.xs = Pair<float>(xs_.x, xs_.y); R.r14 = Pair<float>(r14_.x, r14_.y); R.r32 = Pair<float>(r32_.x, r32_.y);
-            R.ph = ph_; R.fr = fr_;
+                           [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                           [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4)
+                         : "vcc", "scc", "memory", FLL_WAVE_CLOBBERS);
         }
-        // the partial tile at the end of the call (same step, C++ form) and the trailing epochs
-        for (int e = nfull + 1; e < ntiles + 4; e++) {
-            const int t = e - 1;
-            if (t < ntiles) {
-                const int base = t * kFT;
-                const int cnt = (n - base < kFT) ? (n - base) : kFT;
-                lds_cfloat2* a_tile = (lds_cfloat2*)(size_t)lds_addr(&L.a_buf[t & 1][f_c][0]);
-                for (int s = 0; s < cnt; s++) {
-                    if ((s & 3) == 0) ho_wait(fd, base + s + kFarLead + 4, stuck);      // F_{s+8} .. F_{s+11}
-                    const vfloat2 av = a_tile[s];
-                    const vfloat4 f = frow[(base + s + kFarLead) & (kFF - 1)];
-                    R.template step<false, ALPHA0>(k1, Pair<float>(av.x, av.y), Pair<float>(f.x, f.y), Pair<float>(f.z, f.w));
-                    // lane (pos) holds x_{base+s-pos}: every position rewrites its sample (the older ones unchanged)
-                    xrow[(base + s - f_pos) & (kFX - 1)] = vfloat2{ R.xs.x(), R.xs.y() };
-                    if ((s & 1) == 1) ho_publish(xd, base + s + 1);
-                }
-                ho_publish(xd, base + kFT);      // lets the helper wave run its tile to the end
+        // the tiles the block did not take (the partial tile at the end of the call) and the trailing epochs
+        if (nfull < ntiles) {
+            FllRow8<float> R;
+#pragma unroll
+            for (int j = 0; j < kF8Taps; j++) {
+                const int kp = kF8Taps * (kF8Lanes - 1 - f_pos) + j;
+                R.ta[j] = p.be_re72[kp];
+                R.tb[j] = p.be_im72[kp];
             }
-            __syncthreads();
+            R.ph = ph;
+            R.fr = fr;
+            {
+                FllDeviceIO io{ L, nullptr, f_c, f_pos, nfull * kFT };
+                fll8_replay<float, FllDeviceIO>(R, k1, io);
+            }
+            for (int e = nfull + 1; e < ntiles + 4; e++) {
+                FUSED_PROF_T0
+                const int t = e - 1;
+                if (t < ntiles) {
+                    const int base = t * kFT;
+                    const int cnt = (n - base < kFT) ? (n - base) : kFT;
+                    FllDeviceIO io{ L, &L.a_buf[t & 1][f_c][0], f_c, f_pos, base };
+                    fll8_tile<float, FllDeviceIO, ALPHA0>(R, k1, io, cnt);
+                }
+                FUSED_PROF_T1
+                __syncthreads();
+            }
+            ph = R.ph;
+            fr = R.fr;
+        } else {
+            for (int e = nfull + 1; e < ntiles + 4; e++) __syncthreads();
         }
         if (f_pos == 0 && live(f_c)) {
-            p.fll_ph[ch0 + f_c] = R.ph;
-            p.fll_fr[ch0 + f_c] = R.fr;
+            p.fll_ph[ch0 + f_c] = ph;
+            p.fll_fr[ch0 + f_c] = fr;
         }
-    } else if (wave == kRoleH) {
-        // ---- FLL helper wave: lane -> (row r = lane>>4, pos = (lane&15)>>2, c4 = lane&3), channel 4r + c4 -------
-        // Its whole life is one assembly block (fll_asm.inc, generated by gen_fll_asm.py from the schedule of
-        // FllFar4<float, 17>::step): three tiles that rebuild the in-flight far sums from the stored delay line (samples
-        // -96 .. -1; x_i = 0 before -80, under zero taps) and leave F_0 .. F_15 in the ring, the barrier that ends the
-        // prologue, epoch 0's barrier, then one tile + barrier per epoch.  A tile is always run to its 32nd sample (the loop
-        // waves publish the whole tile at the end of a call's partial one; what the helper computes beyond is never used).
-        const int h_pos = (lane & 15) >> 2;
-        const int h_c = (lane >> 4) * 4 + (lane & 3);
-        const unsigned x_row = lds_addr(&L.x_ring[h_c][0]);
-        // only the head lanes hold completed far sums; the others' share of the ring store goes to the dump area
-        const unsigned f_addr = h_pos == 0 ? lds_addr(&L.f_ring[h_c][0])
-                                           : lds_addr(&L.dump[0]) + 16u * (unsigned)((lane >> 4) * 12 + (lane & 15) - 4);
-        const unsigned xd_addr = lds_addr(&L.x_done[lane >> 5]);      // rows 0,1 follow loop wave 0, rows 2,3 loop wave 1
-        const unsigned fd_addr = lane == 0 ? lds_addr(&L.f_done) : lds_addr(&L.dump[0]) + 4u * (unsigned)lane;          // publishing address
-        const unsigned stuck_addr = lds_addr(&L.stuck);
-        const unsigned tap_addr = lds_addr(&L.be84[0][kTH * (3 - h_pos)]);
-#ifndef TETRA_FLL_CPP_HELPER
-        {
-            int base_, it_, st_, spins_;
-            asm volatile(FLL_HELPER_ASM
-                         : [base] "=&s"(base_), [it] "=&s"(it_), [st] "=&s"(st_), [spins] "=&s"(spins_)
-                         : [iters] "s"(ntiles + 3), [x_row] "v"(x_row), [f_addr] "v"(f_addr), [xd_addr] "v"(xd_addr),
-                           [fd_addr] "v"(fd_addr), [stuck_addr] "v"(stuck_addr), [tap_addr] "v"(tap_addr),
-                           [one] "v"(1)
-                         : "vcc", "scc", "memory", FLL_HELPER_CLOBBERS);
-        }
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-#else
-        // Verification build (-DTETRA_FLL_CPP_HELPER): the same role from the C++ source that tests/emul compiles for the host.
-        (void)tap_addr;
-        FllFar4<float, kTH> F;
-#pragma unroll
-        for (int j = 0; j < kTH; j++) {
-            const int kp = kTH * (3 - h_pos) + j;
-            F.ta[j] = p.be_re84[kp];
-            F.tb[j] = p.be_im84[kp];
-        }
-        lds_cfloat2* const xrow = (lds_cfloat2*)(size_t)x_row;
-        lds_float4* const frow = (lds_float4*)(size_t)f_addr;
-        F.clear_pipeline();
-#define FUSED_H_STEP(S, I)                                                                         \
-        {                                                                                          \
-            const vfloat2 xv = xrow[(I) & (kFX - 1)];                                              \
-            Pair<float> f14; Pair<float> f32;                                                      \
-            F.template step<(S) & 15>(Pair<float>(xv.x, xv.y), f14, f32);                          \
-            frow[((I) + kNearTaps) & (kFF - 1)] = vfloat4{ f14.x(), f14.y(), f32.x(), f32.y() };   \
-        }
-        for (int i0 = -kHist; i0 < 0; i0 += 16) {
-            FUSED_H_STEP(0, i0) FUSED_H_STEP(1, i0 + 1) FUSED_H_STEP(2, i0 + 2) FUSED_H_STEP(3, i0 + 3)
-            FUSED_H_STEP(4, i0 + 4) FUSED_H_STEP(5, i0 + 5) FUSED_H_STEP(6, i0 + 6) FUSED_H_STEP(7, i0 + 7)
-            FUSED_H_STEP(8, i0 + 8) FUSED_H_STEP(9, i0 + 9) FUSED_H_STEP(10, i0 + 10) FUSED_H_STEP(11, i0 + 11)
-            FUSED_H_STEP(12, i0 + 12) FUSED_H_STEP(13, i0 + 13) FUSED_H_STEP(14, i0 + 14) FUSED_H_STEP(15, i0 + 15)
-        }
-        ho_publish(fd_addr, kNearTaps);
-        __syncthreads();
-#define FUSED_H_PAIR(S)                                                                            \
-        {                                                                                          \
-            ho_wait(xd_addr, base + s0 + (S) + 2, stuck_addr);                                     \
-            FUSED_H_STEP(S, base + s0 + (S))                                                       \
-            FUSED_H_STEP((S) + 1, base + s0 + (S) + 1)                                             \
-            ho_publish(fd_addr, base + s0 + (S) + 2 + kNearTaps);                                  \
-        }
-        FUSED_EPOCHS(
-            const int t = e - 1;
-            if (t >= 0 && t < ntiles) {
-                const int base = t * kFT;
-                for (int s0 = 0; s0 < kFT; s0 += 16) {
-                    FUSED_H_PAIR(0) FUSED_H_PAIR(2) FUSED_H_PAIR(4) FUSED_H_PAIR(6)
-                    FUSED_H_PAIR(8) FUSED_H_PAIR(10) FUSED_H_PAIR(12) FUSED_H_PAIR(14)
-                }
-            }
-        )
-#undef FUSED_H_PAIR
-#undef FUSED_H_STEP
-#endif
     } else if (wave == kRoleC) {
         // ---- RRC: lane -> (channel c = lane & 15, j = lane >> 4), outputs base + 8j + m; tile e-2 -------
         // The window of eight consecutive outputs starts at x_{i0-(nt-1)}; it is widened at the old end (under zero
@@ -452,7 +309,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         const int c = lane & 15;
         const int rrc_pad = (8 - ((p.ntaps - 1) & 7)) & 7;
         const int rrc_chunks = (p.ntaps - 1 + rrc_pad) / 8 + 1;
-        const unsigned x_base = pin_u32(lds_addr(&L.x_ring[c][0]));
+        const unsigned x_base = pin_u32(lds_addr(&L.x_ring[c][kFXP]));
         __syncthreads();
         FUSED_EPOCHS(
             const int t = e - 2;
@@ -545,9 +402,6 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
             p.omega[ch0 + c] = st.omega;
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
         }
-    } else if (wave == kRoleNone) {
-        __syncthreads();
-        FUSED_EPOCHS()
     } else {
         // ---- kRoleE: Costas + slicer + differential decoder + bit unpacker; symbols published before e ----
         const bool on = lane < kFCh;
@@ -614,7 +468,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
     // delay lines: last 80 FLL outputs, last 7 RRC outputs (both rings still hold them; the loops end on a barrier)
     for (int i = tid; i < kFCh * kHist; i += kFThreads) {
         const int c = i / kHist, m = i % kHist;
-        if (live(c)) p.hist[(long long)(ch0 + c) * kHist + m] = L.x_ring[c][(n - kHist + m) & (kFX - 1)];
+        if (live(c)) p.hist[(long long)(ch0 + c) * kHist + m] = x_ring_get(L, c, n - kHist + m);
     }
     for (int i = tid; i < kFCh * (kInterpTaps - 1); i += kFThreads) {
         const int c = i / (kInterpTaps - 1), m = i % (kInterpTaps - 1);

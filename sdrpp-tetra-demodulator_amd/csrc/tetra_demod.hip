@@ -353,7 +353,7 @@ struct tetra_demod {
     bool fused = true;          // pipeline in use
     bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
-    float *d_be_re84 = nullptr, *d_be_im84 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 84, RRC zero-extended
+    float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 72, RRC zero-extended
     // host-path staging
     float* st_iq = nullptr;
     uint8_t* st_bits = nullptr;
@@ -405,17 +405,17 @@ int upload_tables(tetra_demod* h) {
     HIP_TRY(h, hipMemcpy(h->d_rrc, rr.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
-    {
-        std::vector<float> re84(kPadBe, 0.f), im84(kPadBe, 0.f), rrx(kRrcExt, 0.f);
-        const int o84 = kPadBe - h->design.ntaps;
+    if (h->design.ntaps <= kF8Pad) {
+        std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rrx(kRrcExt, 0.f);
+        const int o72 = kF8Pad - h->design.ntaps;
         const int rpad = (8 - ((h->design.ntaps - 1) & 7)) & 7;     // RRC windows start on a multiple of 8, see kernel_fused.hpp
         for (int k = 0; k < h->design.ntaps; k++) {
-            re84[o84 + k] = h->design.be_re[k];
-            im84[o84 + k] = h->design.be_im[k];
+            re72[o72 + k] = h->design.be_re[k];
+            im72[o72 + k] = h->design.be_im[k];
             rrx[7 + rpad + k] = h->design.rrc[k];
         }
-        HIP_TRY(h, hipMemcpy(h->d_be_re84, re84.data(), sizeof(float) * kPadBe, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_be_im84, im84.data(), sizeof(float) * kPadBe, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_re72, re72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_im72, im72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rrx.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
     }
     return TETRA_OK;
@@ -471,7 +471,7 @@ int reset_range(tetra_demod* h, int first, int count) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re84, h->d_be_im84,
+                     h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -584,7 +584,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     A(dalloc(h, &h->hist, C * kHist));
     A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
     A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
-    h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL);
+    h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL) && h->design.ntaps <= kF8Pad;
     h->keep_y = !h->fused || (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT);
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
@@ -592,7 +592,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_sum, C)); A(dalloc(h, &h->q_ptr, C));
         A(dalloc(h, &h->q_disp, C)); A(dalloc(h, &h->q_sync, C)); A(dalloc(h, &h->q_err, C));
     }
-    A(dalloc(h, &h->d_be_re84, (size_t)kPadBe)); A(dalloc(h, &h->d_be_im84, (size_t)kPadBe));
+    A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
     A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
     A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
     A(dalloc(h, &h->d_rrc, (size_t)kPadTaps)); A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
@@ -683,7 +683,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
         pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
         pf.cph = h->cph; pf.cfr = h->cfr; pf.ph2 = h->ph2; pf.prev = h->prev; pf.ybuf = h->ybuf;
-        pf.be_re84 = h->d_be_re84; pf.be_im84 = h->d_be_im84; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
+        pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
@@ -728,8 +728,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                 double sum[8] = { 0 };
                 for (size_t w = 0; w < nwg; w++)
                     for (int r = 0; r < 8; r++) sum[r] += (double)host[8 * w + r];
-                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"L0\": %.0f, \"L1\": %.0f, \"D\": %.0f, \"H\": %.0f, \"A\": %.0f, \"E\": %.0f, \"C\": %.0f}, \"mean_total_clocks\": %.0f}\n",
-                             n_samples, nwg, sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg, sum[7] / nwg);
+                std::fprintf(f, "{\"n\": %d, \"workgroups\": %zu, \"mean_busy_clocks\": {\"E\": %.0f, \"D\": %.0f, \"F0\": %.0f, \"F1\": %.0f, \"A\": %.0f, \"C\": %.0f}, \"mean_total_clocks\": %.0f}\n",
+                             n_samples, nwg, sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[7] / nwg);
                 std::fclose(f);
             }
         }
@@ -819,6 +819,7 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     }
     host::Design nd;
     if (!host::make_design(np, nullptr, nullptr, nullptr, nd)) return TETRA_ERR_UNSUPPORTED;
+    if (h->fused && nd.ntaps > kF8Pad) return TETRA_ERR_UNSUPPORTED;   // fused kernel covers <= 72 taps
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());

@@ -209,40 +209,61 @@ int emul_k2(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n,
 
 
 // ---------------------------------------------------------------------------------------------------
-// Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllNear8 + FllFar4, rrc_direct8, k2_timing,
-// k2_costas) run stage after stage over linear arrays -- a valid serialisation of the device's software pipeline.  The
-// near/far FLL pair is stepped in the order the device's hand-over allows: the far row runs exactly 8 samples behind the
-// near row (far step s-8 produces F_{s+8}, which near step s injects).  The LDS rings, epochs and the flag hand-over
-// between the two waves are device-only.
+// Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllRow8 + fll8_replay/fll8_tile,
+// rrc_direct8, k2_timing, k2_costas) run stage after stage over linear arrays -- a valid serialisation of the
+// device's barrier-synchronised software pipeline.  (The LDS ring/epoch bookkeeping itself is device-only.)
 // ---------------------------------------------------------------------------------------------------
-}  // extern "C"
 namespace {
-constexpr int kTH = 17;                       // far taps per position
-constexpr int kFarTaps = 4 * kTH;             // 68
-constexpr int kPad84 = kFarTaps + kNearTaps;  // 84 padded band-edge taps
+struct Fll8EmulIO {
+    const float* hist[2];   // per parity: stored delay line [80][2]
+    const float* a[2];      // per parity: AGC output of the whole chunk [n][2]
+    float* x[2];            // per parity: FLL output [n][2]
+    int tile_base = 0;
+    int n = 0;
 
-template <int PH> void far_step_ph(FllFar4<Row16, kTH>& F, Pair<Row16> x, Pair<Row16>& f14, Pair<Row16>& f32) {
-    F.template step<PH>(x, f14, f32);
-}
-void far_step(FllFar4<Row16, kTH>& F, int s, Pair<Row16> x, Pair<Row16>& f14, Pair<Row16>& f32) {
-    switch (((s % 16) + 16) % 16) {
-#define FS(N) case N: far_step_ph<N>(F, x, f14, f32); break;
-        FS(0) FS(1) FS(2) FS(3) FS(4) FS(5) FS(6) FS(7) FS(8) FS(9) FS(10) FS(11) FS(12) FS(13) FS(14) FS(15)
-#undef FS
+    Pair<Row16> load_hist(int g) const {
+        Row16 re, im;
+        for (int l = 0; l < 16; l++) {
+            const int pos = l >> 1, par = l & 1;
+            const int m = (kHist - kF8Pad) + g * 8 + pos;
+            re.l[l] = hist[par][2 * m];
+            im.l[l] = hist[par][2 * m + 1];
+        }
+        return Pair<Row16>(re, im);
     }
-}
+    Pair<Row16> sample(int s) const {
+        Row16 re, im;
+        const int i = tile_base + s;
+        for (int l = 0; l < 16; l++) {
+            const int par = l & 1;
+            re.l[l] = i < n ? a[par][2 * i] : 0.f;
+            im.l[l] = i < n ? a[par][2 * i + 1] : 0.f;
+        }
+        return Pair<Row16>(re, im);
+    }
+    void xs_store(int iend, int cnt, Pair<Row16> xs) {
+        for (int l = 0; l < 16; l++) {
+            const int pos = l >> 1, par = l & 1;
+            if (pos < cnt) {
+                const int i = tile_base + iend - 1 - pos;
+                x[par][2 * i] = xs.x().l[l];
+                x[par][2 * i + 1] = xs.y().l[l];
+            }
+        }
+    }
+};
 }  // namespace
-extern "C" {
 
 // C <= 64 channels (processed in rows of two).  iq [C][n] channel-major.  Outputs like emul_k2, plus y_out [C][n].
 int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
                uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym) {
-    if (C < 1 || C > 64 || t->ntaps > kHist) return -1;
-    float re84[kPad84] = { 0 }, im84[kPad84] = { 0 };
+    if (C < 1 || C > 64 || t->ntaps > kF8Pad) return -1;
+    const int tile = 32;
+    float re72[kF8Pad] = { 0 }, im72[kF8Pad] = { 0 };
     float rrc_ext[kRrcExt] = { 0 };
-    const int o84 = kPad84 - t->ntaps;
+    const int o72 = kF8Pad - t->ntaps;
     const int rpad = (8 - ((t->ntaps - 1) & 7)) & 7;      // RRC windows start on a multiple of 8 (see kernel_fused.hpp)
-    for (int k = 0; k < t->ntaps; k++) { re84[o84 + k] = t->be_re[k]; im84[o84 + k] = t->be_im[k]; rrc_ext[7 + rpad + k] = t->rrc[k]; }
+    for (int k = 0; k < t->ntaps; k++) { re72[o72 + k] = t->be_re[k]; im72[o72 + k] = t->be_im[k]; rrc_ext[7 + rpad + k] = t->rrc[k]; }
     const int rrc_chunks = (t->ntaps - 1 + rpad) / 8 + 1;
     std::vector<float> a((size_t)C * n * 2), x((size_t)C * n * 2);
     // A: AGC
@@ -255,91 +276,38 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
         }
         st[c].agc_gain = g;
     }
-    // L + H: near rows of two interleaved channels, each fed by a far row that carries the same two channels
-    std::vector<float> zhist(2 * kHist, 0.f);
+    // F: FLL rows of two interleaved channels
+    std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kHist, 0.f), dump((size_t)std::max(n, 1) * 2);
     for (int c0 = 0; c0 < C; c0 += 2) {
         const bool two = c0 + 1 < C;
-        const float* hist[2] = { st[c0].hist, two ? st[c0 + 1].hist : zhist.data() };
-        FllNear8<Row16> R;
-        FllFar4<Row16, kTH> F;
+        FllRow8<Row16> R;
+        for (int j = 0; j < kF8Taps; j++) {
+            Row16 ta, tb;
+            for (int l = 0; l < 16; l++) {
+                const int pos = l >> 1;
+                const int kp = kF8Taps * (kF8Lanes - 1 - pos) + j;
+                ta.l[l] = re72[kp];
+                tb.l[l] = im72[kp];
+            }
+            R.ta[j] = ta;
+            R.tb[j] = tb;
+        }
         for (int l = 0; l < 16; l++) {
-            const int pos = l >> 1;
-            for (int j = 0; j < 2; j++) {
-                const int kp = kFarTaps + 2 * (7 - pos) + j;
-                R.ta[j].l[l] = re84[kp];
-                R.tb[j].l[l] = im84[kp];
-            }
-            const int fpos = l >> 2;
-            for (int j = 0; j < kTH; j++) {
-                const int kp = kTH * (3 - fpos) + j;
-                F.ta[j].l[l] = re84[kp];
-                F.tb[j].l[l] = im84[kp];
-            }
             const int c = (l & 1) && two ? c0 + 1 : c0;
             R.ph.l[l] = st[c].fll_phase;
             R.fr.l[l] = st[c].fll_freq;
         }
-        // sample x_i of channel parity par: history for i < 0 (zero before it), this call's FLL output otherwise
-        auto xval = [&](int par, int i, int comp) -> float {
-            if (i >= 0) return x[((size_t)(c0 + (par && two ? 1 : 0)) * n + i) * 2 + comp];
-            if (i < -kHist) return 0.f;
-            return hist[par][2 * (kHist + i) + comp];
-        };
-        auto far_in = [&](int i) {       // far row lane 4*pos + c4: head lanes (pos 0) take x_i of channel c4 & 1
-            Row16 re, im;
-            for (int l = 0; l < 16; l++) { re.l[l] = xval(l & 1, i, 0); im.l[l] = xval(l & 1, i, 1); }
-            return Pair<Row16>(re, im);
-        };
-        std::vector<float> Fq((size_t)(n + 16) * 8, 0.f);     // F_m, m >= 0: [m][parity][4]
-        auto far_run = [&](int s) {
-            Pair<Row16> f14, f32;
-            far_step(F, s, far_in(s), f14, f32);
-            const int m = s + 16;
-            if (m >= 0 && m < n + 16)
-                for (int par = 0; par < 2; par++) {
-                    float* q = &Fq[((size_t)m * 2 + par) * 4];
-                    q[0] = f14.x().l[par]; q[1] = f14.y().l[par]; q[2] = f32.x().l[par]; q[3] = f32.y().l[par];
-                }
-        };
-        F.clear_pipeline();
-        for (int s = -kHist; s < 0; s++) far_run(s);          // rebuilds the in-flight far sums, yields F_0 .. F_15
-        auto near_f = [&](int s, Pair<Row16>& f14, Pair<Row16>& f32) {
-            Row16 a0(0.f), a1(0.f), a2(0.f), a3(0.f);
-            const int m = s + kFarLead;
-            if (m >= 0)
-                for (int l = 0; l < 16; l++) {
-                    const float* q = &Fq[((size_t)m * 2 + (l & 1)) * 4];
-                    a0.l[l] = q[0]; a1.l[l] = q[1]; a2.l[l] = q[2]; a3.l[l] = q[3];
-                }
-            f14 = Pair<Row16>(a0, a1);
-            f32 = Pair<Row16>(a2, a3);
-        };
-        R.clear_pipeline();
-        for (int s = -kNearTaps; s < 0; s++) {
-            Row16 re, im;
-            for (int l = 0; l < 16; l++) { re.l[l] = xval(l & 1, s, 0); im.l[l] = xval(l & 1, s, 1); }
-            Pair<Row16> f14, f32;
-            near_f(s, f14, f32);
-            R.template step<true, true>(t->k1, Pair<Row16>(re, im), f14, f32);
-        }
-        for (int s = 0; s < n; s++) {
-            if (s >= kFarLead) far_run(s - kFarLead);
-            Row16 re, im;
-            for (int l = 0; l < 16; l++) {
-                const int c = (l & 1) && two ? c0 + 1 : c0;
-                re.l[l] = a[((size_t)c * n + s) * 2];
-                im.l[l] = a[((size_t)c * n + s) * 2 + 1];
-            }
-            Pair<Row16> f14, f32;
-            near_f(s, f14, f32);
-            if (t->k1.fll_alpha == 0.0f) R.template step<false, true>(t->k1, Pair<Row16>(re, im), f14, f32);
-            else R.template step<false, false>(t->k1, Pair<Row16>(re, im), f14, f32);
-            x[((size_t)c0 * n + s) * 2] = R.xs.x().l[0];
-            x[((size_t)c0 * n + s) * 2 + 1] = R.xs.y().l[0];
-            if (two) {
-                x[((size_t)(c0 + 1) * n + s) * 2] = R.xs.x().l[1];
-                x[((size_t)(c0 + 1) * n + s) * 2 + 1] = R.xs.y().l[1];
-            }
+        Fll8EmulIO io;
+        io.hist[0] = st[c0].hist; io.hist[1] = two ? st[c0 + 1].hist : zhist.data();
+        io.a[0] = &a[(size_t)c0 * n * 2]; io.a[1] = two ? &a[(size_t)(c0 + 1) * n * 2] : zeros.data();
+        io.x[0] = &x[(size_t)c0 * n * 2]; io.x[1] = two ? &x[(size_t)(c0 + 1) * n * 2] : dump.data();
+        io.n = n;
+        fll8_replay<Row16, Fll8EmulIO>(R, t->k1, io);
+        for (int base = 0; base < n; base += tile) {
+            io.tile_base = base;
+            const int cnt = n - base < tile ? n - base : tile;
+            if (t->k1.fll_alpha == 0.0f) fll8_tile<Row16, Fll8EmulIO, true>(R, t->k1, io, cnt);
+            else fll8_tile<Row16, Fll8EmulIO, false>(R, t->k1, io, cnt);
         }
         st[c0].fll_phase = R.ph.l[0]; st[c0].fll_freq = R.fr.l[0];
         if (two) { st[c0 + 1].fll_phase = R.ph.l[1]; st[c0 + 1].fll_freq = R.fr.l[1]; }
