@@ -44,7 +44,16 @@ enum {
     TETRA_FLAG_TWO_KERNEL = 1,   /* run the two-kernel pipeline (AGC+FLL+RRC kernel -> HBM scratch -> timing/Costas kernel)
                                     instead of the fused single-kernel pipeline */
     TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
-    TETRA_FLAG_QUALITY = 4       /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
+    TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
+    TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
+                                    the dsp::block sets it):
+                                      - tetra_demod_reset keeps ph2 (src/dsp/pi4dqpsk_costas.h:32 is never reset by
+                                        PI4DQPSK::reset, pi4dqpsk.cpp:120-130), COMPLEX_FD's delay buffer (complex_fd.cpp:78-87
+                                        does not clear it) and the slicer's previous symbol (another block);
+                                      - TETRA_PARAM_RRC_TAP_COUNT re-designs only the RRC and leaves the FLL's band-edge filters
+                                        at their construction-time length (pi4dqpsk.cpp:56-70);
+                                      - TETRA_PARAM_RRC_BETA truncates its value to an integer like setRRCBeta(int)
+                                        (src/dsp/pi4dqpsk.h:56, pi4dqpsk.cpp:72). */
 };
 
 /* Input sample layout of process(): element (channel c, sample n) of the complex64 stream. */
@@ -72,7 +81,7 @@ typedef struct tetra_demod_config {
     double fll_bandwidth;    /* 0.006 */
     double omega_gain;       /* timing loop beta, src/main.cpp:82 */
     double mu_gain;          /* timing loop alpha, src/main.cpp:81 */
-    double omega_rel_limit;  /* 0.02 */
+    double omega_rel_limit;  /* 0.02; 0 .. 0.05 accepted (the output rows are sized for omega >= 2 x 0.95) */
     /* Optional caller-supplied tables (NULL = design them like the reference does).  In an SDR++
      * build the host may pass SDR++'s own tap generators' output here. */
     const float* rrc_taps;        /* [rrc_tap_count]                 taps::rootRaisedCosine, pi4dqpsk.cpp:18 */
@@ -97,10 +106,10 @@ typedef struct tetra_demod_channel_state {
 enum {
     TETRA_PARAM_SYMBOLRATE = 0,       /* setSymbolrate      pi4dqpsk.cpp:32-42  (also resets timing recovery, complex_fd.cpp:30-41) */
     TETRA_PARAM_SAMPLERATE = 1,       /* setSamplerate      pi4dqpsk.cpp:44-54 */
-    TETRA_PARAM_RRC_TAP_COUNT = 2,    /* setRRCTapCount     pi4dqpsk.cpp:68-70.  Deviation: a NEW count also re-designs the FLL's band-edge filters
-                                       * to that length (the kernels share one delay line of taps-1 samples between the three FIRs); the
-                                       * reference re-designs only the RRC here and keeps the FLL at its construction-time length */
-    TETRA_PARAM_RRC_BETA = 3,         /* setRRCParams beta  pi4dqpsk.cpp:56-66 (double; the reference's setRRCBeta(int) truncation quirk is NOT reproduced) */
+    TETRA_PARAM_RRC_TAP_COUNT = 2,    /* setRRCTapCount     pi4dqpsk.cpp:68-70.  Without TETRA_FLAG_REFERENCE_QUIRKS a NEW count also re-designs the
+                                       * FLL's band-edge filters to that length (what a fresh init with that count gives); with the flag only
+                                       * the RRC changes, like the reference */
+    TETRA_PARAM_RRC_BETA = 3,         /* setRRCParams beta  pi4dqpsk.cpp:56-66 (a double; truncated like setRRCBeta(int) only with the quirks flag) */
     TETRA_PARAM_AGC_RATE = 4,         /* setAGCRate         pi4dqpsk.cpp:76-80 */
     TETRA_PARAM_COSTAS_BANDWIDTH = 5, /* setCostasBandwidth pi4dqpsk.cpp:82-86 */
     TETRA_PARAM_FLL_BANDWIDTH = 6,    /* setFllBandwidth    pi4dqpsk.cpp:88-92 */
@@ -148,20 +157,31 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
 int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
                         int32_t* n_bits, float* sym);
 
-/* PI4DQPSK::reset (src/dsp/pi4dqpsk.cpp:120-130) + slicer state; channel = -1 resets all. */
+/* PI4DQPSK::reset (src/dsp/pi4dqpsk.cpp:120-130); channel = -1 resets all.  Resets the AGC gain, the FLL and PLL loop states,
+ * the timing loop and the FIR delay line.  Without TETRA_FLAG_REFERENCE_QUIRKS it also zeroes ph2, COMPLEX_FD's delay buffer,
+ * the slicer's previous symbol and the quality statistic (= a fresh chain); with the flag those keep their values like in the
+ * reference.  One deviation remains in both modes: the reference's FLL::reset (fll.cpp:120-127) leaves the delay lines of its two
+ * band-edge FIRs alone and only FIR::reset of the RRC clears one; the kernels keep ONE delay line for the three FIRs and clear
+ * it, so the FLL error of the first taps-1 samples after a reset is computed over zeros. */
 int tetra_demod_reset(tetra_demod_t* h, int channel);
 
-/* The twelve PI4DQPSK setters collapse to one call (IDs above).  Like the reference, changing a
- * rate or the RRC design re-designs the taps and keeps loop state; TETRA_PARAM_SYMBOLRATE /
- * _SAMPLERATE additionally reset the timing loop (COMPLEX_FD::setOmega, complex_fd.cpp:30-41). */
+/* The twelve PI4DQPSK setters collapse to one call (IDs above).  Like the reference: the loop setters (AGC rate, Costas / FLL
+ * bandwidth, timing gains and limit) change loop constants and nothing else; changing a rate or the RRC design re-designs the
+ * RRC taps only and keeps loop state -- no setter re-designs the FLL's band-edge filters (pi4dqpsk.cpp:32-118; the tap-count
+ * exception without the quirks flag is described at TETRA_PARAM_RRC_TAP_COUNT); TETRA_PARAM_SYMBOLRATE / _SAMPLERATE
+ * additionally reset the timing loop (COMPLEX_FD::setOmega, complex_fd.cpp:30-41).  Caller-supplied tables (cfg.rrc_taps,
+ * cfg.bandedge_taps, cfg.interp_bank) survive every setter that does not have to re-design them; a setter that would
+ * (a rate / RRC setter with cfg.rrc_taps, a tap count with either FIR table) returns TETRA_ERR_UNSUPPORTED and changes nothing. */
 int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value);
 
 int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out);
 int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in);
 
-/* Copies of the designed tables (any pointer may be NULL): rrc[taps], be_re[taps], be_im[taps]
- * (lower band-edge filter), bank[128*8]; *taps receives the tap count. */
+/* Copies of the designed tables (any pointer may be NULL): rrc[taps], be_re[be_taps], be_im[be_taps] (lower band-edge
+ * filter), bank[128*8]; *taps receives the RRC tap count.  be_taps = tetra_demod_bandedge_tap_count(h) equals taps except
+ * after a TETRA_PARAM_RRC_TAP_COUNT under TETRA_FLAG_REFERENCE_QUIRKS; 80 entries always suffice. */
 int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank);
+int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
 
 /* DQPSKSymbolExtractor's public `standarderr` / `sync` members (src/dsp/dqpsk_sym_extr.h:36-37; computed at
  * dqpsk_sym_extr.cpp:8-31, read by the GUI at src/main.cpp:211,215) for every channel: the mean angular distance of

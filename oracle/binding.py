@@ -49,6 +49,7 @@ class Tables(C.Structure):
     _fields_ = [
         ("cfg", Cfg),
         ("ntaps", C.c_int),
+        ("ntaps_be", C.c_int),
         ("rrc", C.c_float * MAX_TAPS),
         ("be_a", C.c_float * MAX_TAPS),
         ("be_b", C.c_float * MAX_TAPS),
@@ -88,6 +89,12 @@ def lib():
         L.tetra_oracle_design.restype = C.c_int
         L.tetra_oracle_reset.argtypes = [C.POINTER(Tables), C.POINTER(State)]
         L.tetra_oracle_reset.restype = None
+        L.tetra_oracle_reset_reference.argtypes = [C.POINTER(Tables), C.POINTER(State)]
+        L.tetra_oracle_reset_reference.restype = None
+        L.tetra_oracle_reset_timing.argtypes = [C.POINTER(Tables), C.POINTER(State)]
+        L.tetra_oracle_reset_timing.restype = None
+        L.tetra_oracle_set_param.argtypes = [C.POINTER(Tables), C.c_int, C.c_double, C.c_int]
+        L.tetra_oracle_set_param.restype = C.c_int
         L.tetra_oracle_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.tetra_oracle_sincosf.restype = None
         vp = C.c_void_p
@@ -126,6 +133,18 @@ class Oracle:
     def reset(self):
         lib().tetra_oracle_reset(C.byref(self.tab), C.byref(self.st))
 
+    def reset_reference(self):
+        """PI4DQPSK::reset as the reference does it (ph2, COMPLEX_FD's delay buffer and the slicer keep their values)."""
+        lib().tetra_oracle_reset_reference(C.byref(self.tab), C.byref(self.st))
+
+    def set_param(self, param_id, value, quirks=False):
+        """A PI4DQPSK setter (ids = TETRA_PARAM_*); rate setters also reset this channel's timing loop."""
+        rc = lib().tetra_oracle_set_param(C.byref(self.tab), int(param_id), float(value), 1 if quirks else 0)
+        if rc != 0:
+            raise ValueError("tetra_oracle_set_param failed: %d" % rc)
+        if param_id in (0, 1):
+            lib().tetra_oracle_reset_timing(C.byref(self.tab), C.byref(self.st))
+
     # tables as numpy (copies)
     @property
     def ntaps(self):
@@ -135,8 +154,9 @@ class Oracle:
         return np.ctypeslib.as_array(self.tab.rrc)[: self.ntaps].copy()
 
     def bandedge_taps(self):
-        a = np.ctypeslib.as_array(self.tab.be_a)[: self.ntaps].copy()
-        b = np.ctypeslib.as_array(self.tab.be_b)[: self.ntaps].copy()
+        nb = int(self.tab.ntaps_be)
+        a = np.ctypeslib.as_array(self.tab.be_a)[:nb].copy()
+        b = np.ctypeslib.as_array(self.tab.be_b)[:nb].copy()
         return a, b
 
     def interp_bank(self):

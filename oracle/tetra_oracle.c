@@ -169,6 +169,7 @@ int tetra_oracle_design(const tetra_oracle_cfg_t* cfg, tetra_oracle_tables_t* ta
     memset(tab, 0, sizeof(*tab));
     tab->cfg = *cfg;
     tab->ntaps = cfg->rrc_tap_count;
+    tab->ntaps_be = cfg->rrc_tap_count;
 
     /* PI4DQPSK::init pi4dqpsk.cpp:17: FLL::init(NULL, fllBandwidth, (int)sym, (int)samp, taps,
      * (float)beta, 0, -pi/2, +pi/2); rates pass through int parameters (fll.h:33). */
@@ -201,6 +202,72 @@ int tetra_oracle_design(const tetra_oracle_cfg_t* cfg, tetra_oracle_tables_t* ta
     return 0;
 }
 
+static void design_timing_limits(tetra_oracle_tables_t* tab) {
+    double omega = tab->cfg.samplerate / tab->cfg.symbolrate;
+    tab->tr_omega = (float)omega;
+    tab->tr_min_freq = (float)(omega * (1.0 - tab->cfg.omega_rel_limit));
+    tab->tr_max_freq = (float)(omega * (1.0 + tab->cfg.omega_rel_limit));
+}
+
+int tetra_oracle_set_param(tetra_oracle_tables_t* tab, int param_id, double value, int quirks) {
+    if (!tab) return -1;
+    tetra_oracle_cfg_t* c = &tab->cfg;
+    float unused;
+    switch (param_id) {
+    case 0: /* setSymbolrate pi4dqpsk.cpp:32-42 */
+    case 1: /* setSamplerate pi4dqpsk.cpp:44-54 */
+        if (!(value > 0)) return -3;
+        if (param_id == 0) c->symbolrate = value; else c->samplerate = value;
+        design_rrc(tab->ntaps, c->rrc_beta, c->symbolrate, c->samplerate, tab->rrc);
+        design_timing_limits(tab);          /* recov.setOmega: complex_fd.cpp:30-41 */
+        return 0;
+    case 2: { /* setRRCTapCount -> setRRCParams pi4dqpsk.cpp:56-70 */
+        int n = (int)value;
+        if (n < 2 || n > TETRA_ORACLE_MAX_TAPS) return -2;
+        c->rrc_tap_count = n;
+        tab->ntaps = n;
+        memset(tab->rrc, 0, sizeof(tab->rrc));
+        design_rrc(n, c->rrc_beta, c->symbolrate, c->samplerate, tab->rrc);
+        if (!quirks && n != tab->ntaps_be) {
+            tab->ntaps_be = n;
+            memset(tab->be_a, 0, sizeof(tab->be_a));
+            memset(tab->be_b, 0, sizeof(tab->be_b));
+            design_bandedge(n, (float)c->rrc_beta, (double)(int)c->symbolrate, (double)(int)c->samplerate, tab->be_a, tab->be_b);
+        }
+        return 0;
+    }
+    case 3: /* setRRCBeta(int) pi4dqpsk.cpp:72-74 */
+        c->rrc_beta = quirks ? (double)(int)value : value;
+        design_rrc(tab->ntaps, c->rrc_beta, c->symbolrate, c->samplerate, tab->rrc);
+        return 0;
+    case 4: c->agc_rate = value; tab->agc_rate = (float)value; return 0;                       /* pi4dqpsk.cpp:76-80 */
+    case 5: c->costas_bandwidth = value;                                                      /* pi4dqpsk.cpp:82-86 */
+        critically_damped((float)value, &tab->costas_alpha, &tab->costas_beta); return 0;
+    case 6: c->fll_bandwidth = value; critically_damped((float)value, &unused, &tab->fll_beta); /* fll.cpp:63-72 */
+        tab->fll_alpha = 0.0f; return 0;
+    case 7: c->omega_gain = value; tab->tr_beta = (float)value; return 0;                      /* complex_fd.cpp:43-48 */
+    case 8: c->mu_gain = value; tab->tr_alpha = (float)value; return 0;                        /* complex_fd.cpp:50-55 */
+    case 9: c->omega_rel_limit = value; design_timing_limits(tab); return 0;                   /* complex_fd.cpp:57-62 */
+    default: return -1;
+    }
+}
+
+void tetra_oracle_reset_timing(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st) {
+    st->mu = 0.0f;                  /* complex_fd.cpp:35-38 */
+    st->omega = tab->tr_omega;
+    st->offset = 0;
+}
+
+void tetra_oracle_reset_reference(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st) {
+    st->agc_gain = 1.0f;            /* FastAGC::reset -> initGain */
+    st->fll_phase = 0.0f;           /* FLL::reset fll.cpp:120-127 */
+    st->fll_freq = 0.0f;
+    memset(st->hist, 0, sizeof(st->hist));   /* FIR::reset (one delay line here, see the header) */
+    st->costas_phase = 0.0f;        /* PLL::reset */
+    st->costas_freq = 0.0f;
+    tetra_oracle_reset_timing(tab, st);      /* COMPLEX_FD::reset complex_fd.cpp:78-87 */
+}
+
 void tetra_oracle_reset(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st) {
     memset(st, 0, sizeof(*st));
     st->agc_gain = 1.0f;            /* FastAGC initGain (SDR++ core) */
@@ -229,8 +296,11 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
                          int count, const float* iq,
                          float* x_out, float* y_out, float* sym_out,
                          uint8_t* dibits, uint8_t* bits) {
-    const int nt = tab->ntaps;
-    const int H = nt - 1;
+    const int nt = tab->ntaps;                 /* RRC FIR length */
+    const int nb = tab->ntaps_be;              /* band-edge FIR length (== nt unless a quirks-mode setRRCTapCount changed nt) */
+    const int H = TETRA_ORACLE_MAX_TAPS - 1;   /* one delay line serves the three FIRs; the state always keeps the last
+                                                * H = 128 FLL outputs (newest last), whatever the filter lengths */
+    (void)nb;
     if (count <= 0) return 0;
 
     /* delay line + new samples, split re/im: w[0..H-1] = history, w[H+i] = x_i */
@@ -260,9 +330,9 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
         wi[H + i] = xi;
         /* two band-edge FIRs over the same delay line, fll.cpp:141-142 */
         float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
-        const float* pr = wr + i;
-        const float* pi = wi + i;
-        for (int k = 0; k < nt; k++) {
+        const float* pr = wr + i + (H - (nb - 1));
+        const float* pi = wi + i + (H - (nb - 1));
+        for (int k = 0; k < nb; k++) {
             s1 = fmaf(pr[k], tab->be_a[k], s1);
             s2 = fmaf(pi[k], tab->be_b[k], s2);
             s3 = fmaf(pr[k], tab->be_b[k], s3);
@@ -288,8 +358,8 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
     for (int k = 0; k < 7; k++) { yr[k] = st->ybuf[2 * k]; yi[k] = st->ybuf[2 * k + 1]; }
     for (int i = 0; i < count; i++) {
         float ar = 0.0f, ai = 0.0f;
-        const float* pr = wr + i;
-        const float* pi = wi + i;
+        const float* pr = wr + i + (H - (nt - 1));
+        const float* pi = wi + i + (H - (nt - 1));
         for (int k = 0; k < nt; k++) {
             ar = fmaf(pr[k], tab->rrc[k], ar);
             ai = fmaf(pi[k], tab->rrc[k], ai);

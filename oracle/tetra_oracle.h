@@ -68,7 +68,8 @@ typedef struct {
 typedef struct {
     float agc_gain;                 /* FastAGC _gain */
     float fll_phase, fll_freq;      /* FLL pcl.phase / pcl.freq (fll.h:58) */
-    float hist[2 * (TETRA_ORACLE_MAX_TAPS - 1)]; /* last taps-1 FLL outputs (re,im): FIR delay lines */
+    float hist[2 * (TETRA_ORACLE_MAX_TAPS - 1)]; /* the last 128 FLL outputs (re,im), newest last: delay line of the three FIRs
+                                                  * (each uses its own last taps-1 samples) */
     float mu, omega;                /* COMPLEX_FD pcl.phase / pcl.freq (complex_fd.h:57) */
     int32_t offset;                 /* COMPLEX_FD offset (complex_fd.h:72) */
     float ybuf[2 * (TETRA_ORACLE_INTERP_TAPS - 1)]; /* COMPLEX_FD delay buffer */
@@ -86,7 +87,10 @@ typedef struct {
 /* Derived constants + tables, shared by all channels. */
 typedef struct {
     tetra_oracle_cfg_t cfg;
-    int   ntaps;                              /* rrc_tap_count */
+    int   ntaps;                              /* rrc_tap_count = length of the RRC FIR */
+    int   ntaps_be;                           /* length of the FLL's band-edge FIRs: the tap count PI4DQPSK::init was called with;
+                                               * PI4DQPSK's setters never touch the FLL's filters (pi4dqpsk.cpp:32-74), so with
+                                               * reference quirks it stays at that value when setRRCTapCount changes ntaps */
     float rrc[TETRA_ORACLE_MAX_TAPS];         /* taps::rootRaisedCosine */
     float be_a[TETRA_ORACLE_MAX_TAPS];        /* band-edge tap real part (tL.re == tH.re) */
     float be_b[TETRA_ORACLE_MAX_TAPS];        /* band-edge tap imag part of tL (tH.im = -b) */
@@ -101,6 +105,27 @@ void tetra_oracle_default_cfg(tetra_oracle_cfg_t* cfg);
 /* 0 on success, <0 on bad parameters. */
 int  tetra_oracle_design(const tetra_oracle_cfg_t* cfg, tetra_oracle_tables_t* tab);
 void tetra_oracle_reset(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st);
+
+/*
+ * The setters of PI4DQPSK (pi4dqpsk.h:52-63, pi4dqpsk.cpp:32-118) on an existing design; ids as in the product's
+ * include/tetra_demod.h (TETRA_PARAM_*: 0 symbolrate, 1 samplerate, 2 rrc tap count, 3 rrc beta, 4 agc rate, 5 costas
+ * bandwidth, 6 fll bandwidth, 7 omega gain, 8 mu gain, 9 omega rel limit).  Loop setters change loop constants only;
+ * the rate and RRC setters re-design only the RRC taps (and the timing loop's nominal omega / limits); the band-edge
+ * filters are never re-designed from here, except that WITHOUT quirks a new tap count re-designs them to the new length
+ * (the product's kernels then keep one length for all three FIRs).  With quirks != 0 the reference is followed to the
+ * letter: a new tap count leaves the FLL alone (pi4dqpsk.cpp:56-66) and setRRCBeta(int) truncates its argument
+ * (pi4dqpsk.h:56, pi4dqpsk.cpp:72).  Rate setters also reset the timing loop of every state the caller owns
+ * (tetra_oracle_reset_timing), like COMPLEX_FD::setOmega (complex_fd.cpp:30-41).  Returns 0, <0 on a bad value.
+ */
+int  tetra_oracle_set_param(tetra_oracle_tables_t* tab, int param_id, double value, int quirks);
+void tetra_oracle_reset_timing(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st);
+/*
+ * PI4DQPSK::reset (pi4dqpsk.cpp:120-130) as the reference does it: AGC gain, FLL phase/freq, the FIR delay line, PLL
+ * phase/freq and the timing loop are reset; ph2 (pi4dqpsk_costas.h:32), COMPLEX_FD's delay buffer and the symbol
+ * extractor (another block) keep their values.  (The reference clears only the RRC's delay line and leaves the
+ * band-edge FIRs' -- this restatement, like the product, keeps ONE delay line for the three FIRs and clears it.)
+ */
+void tetra_oracle_reset_reference(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st);
 
 void tetra_oracle_sincosf(float x, float* s, float* c);
 

@@ -18,6 +18,7 @@ LAYOUT_TIME_MAJOR = 1
 FLAG_TWO_KERNEL = 1
 FLAG_KEEP_RRC_OUT = 2
 FLAG_QUALITY = 4
+FLAG_REFERENCE_QUIRKS = 8
 
 PARAMS = dict(symbolrate=0, samplerate=1, rrc_tap_count=2, rrc_beta=3, agc_rate=4, costas_bandwidth=5,
               fll_bandwidth=6, omega_gain=7, mu_gain=8, omega_rel_limit=9)
@@ -28,6 +29,7 @@ EXPORTS = [
     "tetra_demod_set_param", "tetra_demod_get_state", "tetra_demod_set_state", "tetra_demod_get_tables",
     "tetra_demod_debug_read_rrc_out", "tetra_demod_last_kernel_ms", "tetra_demod_strerror",
     "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history", "tetra_demod_get_quality",
+    "tetra_demod_bandedge_tap_count",
 ]
 
 
@@ -94,6 +96,7 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_get_state.argtypes = [vp, i32, C.POINTER(ChannelState)]
     L.tetra_demod_set_state.argtypes = [vp, i32, C.POINTER(ChannelState)]
     L.tetra_demod_get_tables.argtypes = [vp, C.POINTER(i32), vp, vp, vp, vp]
+    L.tetra_demod_bandedge_tap_count.argtypes = [vp]
     L.tetra_demod_debug_read_rrc_out.argtypes = [vp, vp, i32]
     L.tetra_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.tetra_demod_strerror.argtypes = [i32]
@@ -235,13 +238,14 @@ class Demodulator:
         nt = C.c_int(0)
         self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), None, None, None, None), "tetra_demod_get_tables")
         n = nt.value
+        nb = self._lib.tetra_demod_bandedge_tap_count(self._h)
         rrc = np.zeros(n, np.float32)
-        re = np.zeros(n, np.float32)
-        im = np.zeros(n, np.float32)
+        re = np.zeros(80, np.float32)
+        im = np.zeros(80, np.float32)
         bank = np.zeros((128, 8), np.float32)
         self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), _np_ptr(rrc), _np_ptr(re), _np_ptr(im),
                                                      _np_ptr(bank)), "tetra_demod_get_tables")
-        return dict(rrc=rrc, be_re=re, be_im=im, bank=bank)
+        return dict(rrc=rrc, be_re=re[:nb].copy(), be_im=im[:nb].copy(), bank=bank)
 
     def read_rrc_out(self, n_samples):
         y = np.zeros((self.n_channels, n_samples), np.complex64)

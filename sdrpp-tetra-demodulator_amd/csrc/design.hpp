@@ -30,8 +30,10 @@ struct DesignParams {
 };
 
 struct Design {
-    int ntaps = 0;
-    std::vector<float> rrc, be_re, be_im;   // [ntaps]; be_* = lower band-edge filter, upper = conj
+    int ntaps = 0;                          // RRC FIR length
+    int ntaps_be = 0;                       // band-edge FIR length (== ntaps unless TETRA_FLAG_REFERENCE_QUIRKS kept the FLL's
+                                            // construction-time filters across a setRRCTapCount, pi4dqpsk.cpp:56-70)
+    std::vector<float> rrc, be_re, be_im;   // [ntaps] / [ntaps_be]; be_* = lower band-edge filter, upper = conj
     std::vector<float> bank;                // [128*8]
     K1Consts k1;
     K2Consts k2;
@@ -119,29 +121,10 @@ inline void interp_bank(float* bank /* [128][8] */) {
     }
 }
 
-// Full design.  user_* may be null.  Returns false on unsupported parameters.
-inline bool make_design(const DesignParams& p, const float* user_rrc, const float* user_be, const float* user_bank,
-                        Design& d) {
-    if (p.rrc_tap_count < 2 || p.rrc_tap_count > kPadTaps) return false;
-    if (!(p.symbolrate > 0) || !(p.samplerate > 0)) return false;
-    d.ntaps = p.rrc_tap_count;
-    d.rrc.assign(d.ntaps, 0.f);
-    d.be_re.assign(d.ntaps, 0.f);
-    d.be_im.assign(d.ntaps, 0.f);
-    d.bank.assign(kInterpPhases * kInterpTaps, 0.f);
-    if (user_be) {
-        std::memcpy(d.be_re.data(), user_be, sizeof(float) * d.ntaps);
-        std::memcpy(d.be_im.data(), user_be + d.ntaps, sizeof(float) * d.ntaps);
-    } else {
-        // FLL::init takes the rates through int parameters (src/dsp/fll.h:33)
-        bandedge_filters(d.ntaps, (float)p.rrc_beta, (double)(int)p.symbolrate, (double)(int)p.samplerate,
-                         d.be_re.data(), d.be_im.data());
-    }
-    if (user_rrc) std::memcpy(d.rrc.data(), user_rrc, sizeof(float) * d.ntaps);
-    else root_raised_cosine(d.ntaps, p.rrc_beta, p.symbolrate, p.samplerate, d.rrc.data());
-    if (user_bank) std::memcpy(d.bank.data(), user_bank, sizeof(float) * d.bank.size());
-    else interp_bank(d.bank.data());
-
+// The pieces of the design, one per group of PI4DQPSK setters (src/dsp/pi4dqpsk.cpp:32-118): the loop setters change
+// loop constants only, the rate / RRC setters re-design only the RRC taps (and the timing loop's nominal omega and limits);
+// nothing but init ever designs the FLL's band-edge filters.
+inline void design_loops(const DesignParams& p, Design& d) {
     float unused;
     loop_gains((float)p.fll_bandwidth, unused, d.k1.fll_beta);
     d.k1.fll_alpha = 0.0f;  // fll.cpp:25
@@ -150,16 +133,55 @@ inline bool make_design(const DesignParams& p, const float* user_rrc, const floa
     d.k1.agc_set_point = (float)1.0;
     d.k1.agc_max_gain = (float)10e6;
     d.k1.agc_rate = (float)p.agc_rate;
-
     loop_gains((float)p.costas_bandwidth, d.k2.costas_alpha, d.k2.costas_beta);
     d.k2.costas_min_freq = (float)(double)(-kFlPi / 10.0f);
     d.k2.costas_max_freq = (float)(double)(kFlPi / 10.0f);
-    const double omega = p.samplerate / p.symbolrate;
-    d.tr_omega = (float)omega;
     d.k2.tr_alpha = (float)p.mu_gain;
     d.k2.tr_beta = (float)p.omega_gain;
+}
+inline void design_timing_limits(const DesignParams& p, Design& d) {
+    const double omega = p.samplerate / p.symbolrate;
+    d.tr_omega = (float)omega;
     d.k2.tr_min_freq = (float)(omega * (1.0 - p.omega_rel_limit));
     d.k2.tr_max_freq = (float)(omega * (1.0 + p.omega_rel_limit));
+}
+inline void design_rrc(const DesignParams& p, Design& d) {
+    d.ntaps = p.rrc_tap_count;
+    d.rrc.assign(d.ntaps, 0.f);
+    root_raised_cosine(d.ntaps, p.rrc_beta, p.symbolrate, p.samplerate, d.rrc.data());
+}
+inline void design_bandedge(const DesignParams& p, Design& d, int count) {
+    d.ntaps_be = count;
+    d.be_re.assign(count, 0.f);
+    d.be_im.assign(count, 0.f);
+    // FLL::init takes the rates through int parameters (src/dsp/fll.h:33)
+    bandedge_filters(count, (float)p.rrc_beta, (double)(int)p.symbolrate, (double)(int)p.samplerate, d.be_re.data(), d.be_im.data());
+}
+// The kernels size an output row for omega >= 2 * 0.95 (tetra_demod_bits_stride) and their forward-progress clamp is
+// neutral only while omega_min > 1 + |alpha|: limits outside [0, 0.05] are refused.
+inline bool params_ok(const DesignParams& p) {
+    if (p.rrc_tap_count < 2 || p.rrc_tap_count > kPadTaps) return false;
+    if (!(p.symbolrate > 0) || !(p.samplerate > 0)) return false;
+    if (!(p.omega_rel_limit >= 0.0) || !(p.omega_rel_limit <= 0.05)) return false;
+    return true;
+}
+
+// Full design (PI4DQPSK::init).  user_* may be null.  Returns false on unsupported parameters.
+inline bool make_design(const DesignParams& p, const float* user_rrc, const float* user_be, const float* user_bank,
+                        Design& d) {
+    if (!params_ok(p)) return false;
+    design_rrc(p, d);
+    design_bandedge(p, d, p.rrc_tap_count);
+    d.bank.assign(kInterpPhases * kInterpTaps, 0.f);
+    if (user_be) {
+        std::memcpy(d.be_re.data(), user_be, sizeof(float) * d.ntaps);
+        std::memcpy(d.be_im.data(), user_be + d.ntaps, sizeof(float) * d.ntaps);
+    }
+    if (user_rrc) std::memcpy(d.rrc.data(), user_rrc, sizeof(float) * d.ntaps);
+    if (user_bank) std::memcpy(d.bank.data(), user_bank, sizeof(float) * d.bank.size());
+    else interp_bank(d.bank.data());
+    design_loops(p, d);
+    design_timing_limits(p, d);
     return true;
 }
 

@@ -248,8 +248,8 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         // Every COMPLETE tile of the call runs in the assembly block of fll_asm.inc (generated by gen_fll_asm.py from the
         // schedule of FllRow8<float>::step): rebuild of the in-flight sums from the 72 samples in front of the call, then 32
         // steps and one barrier per tile = epochs 1 .. nfull.  The alpha != 0 variant of the loop filter (never produced by
-        // the reference's FLL, fll.cpp:25) and the instrumented debug build take the C++ form for every tile.
-        const int nfull = (ALPHA0 && !PROF) ? n / kFT : 0;
+        // the reference's FLL, fll.cpp:25) takes the C++ form for every tile; the debug build does not instrument the block.
+        const int nfull = ALPHA0 ? n / kFT : 0;
         if (nfull > 0) {
             int base_ = 0, tiles_ = nfull, st_;
             const unsigned a_addr = lds_addr(&L.a_buf[0][f_c][0]);

@@ -350,6 +350,8 @@ struct tetra_demod {
     double* q_sum = nullptr;
     int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
     float* q_err = nullptr;
+    bool user_rrc = false, user_be = false;   // caller-supplied FIR tables (cfg.rrc_taps / cfg.bandedge_taps)
+    bool quirks = false;        // TETRA_FLAG_REFERENCE_QUIRKS
     bool fused = true;          // pipeline in use
     bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
@@ -394,26 +396,26 @@ struct DeviceGuard {
 int upload_tables(tetra_demod* h) {
     // zero-pad the FIR taps at the old end to kPadTaps
     std::vector<float> re(kPadTaps, 0.f), im(kPadTaps, 0.f), rr(kPadTaps, 0.f);
-    const int off = kPadTaps - h->design.ntaps;
-    for (int k = 0; k < h->design.ntaps; k++) {
-        re[off + k] = h->design.be_re[k];
-        im[off + k] = h->design.be_im[k];
-        rr[off + k] = h->design.rrc[k];
+    const int off = kPadTaps - h->design.ntaps, off_be = kPadTaps - h->design.ntaps_be;
+    for (int k = 0; k < h->design.ntaps_be; k++) {
+        re[off_be + k] = h->design.be_re[k];
+        im[off_be + k] = h->design.be_im[k];
     }
+    for (int k = 0; k < h->design.ntaps; k++) rr[off + k] = h->design.rrc[k];
     HIP_TRY(h, hipMemcpy(h->d_be_re, re.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_be_im, im.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_rrc, rr.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
-    if (h->design.ntaps <= kF8Pad) {
+    if (h->design.ntaps <= kF8Pad && h->design.ntaps_be <= kF8Pad) {
         std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rrx(kRrcExt, 0.f);
-        const int o72 = kF8Pad - h->design.ntaps;
+        const int o72 = kF8Pad - h->design.ntaps_be;
         const int rpad = (8 - ((h->design.ntaps - 1) & 7)) & 7;     // RRC windows start on a multiple of 8, see kernel_fused.hpp
-        for (int k = 0; k < h->design.ntaps; k++) {
+        for (int k = 0; k < h->design.ntaps_be; k++) {
             re72[o72 + k] = h->design.be_re[k];
             im72[o72 + k] = h->design.be_im[k];
-            rrx[7 + rpad + k] = h->design.rrc[k];
         }
+        for (int k = 0; k < h->design.ntaps; k++) rrx[7 + rpad + k] = h->design.rrc[k];
         HIP_TRY(h, hipMemcpy(h->d_be_re72, re72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_be_im72, im72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rrx.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
@@ -437,12 +439,12 @@ int reset_timing(tetra_demod* h, int first, int count) {
     return TETRA_OK;
 }
 
-int reset_range(tetra_demod* h, int first, int count) {
+// PI4DQPSK::reset (pi4dqpsk.cpp:120-130) for channels [first, first+count); `fresh` = also everything the reference's
+// reset leaves alone (a new handle, and every reset without TETRA_FLAG_REFERENCE_QUIRKS).
+int reset_range(tetra_demod* h, int first, int count, bool fresh) {
     int rc;
-    // FastAGC::reset -> initGain 1.0; FLL::reset fll.cpp:120-127; FIR::reset clears the delay line;
-    // PLL::reset; COMPLEX_FD::reset complex_fd.cpp:78-87 (its delay buffer is NOT cleared by the reference's
-    // reset(); a fresh handle starts with zeros either way); slicer prev = 0; ph2 is a plain member that the
-    // reference never resets -- a fresh chain has 0, and so does a reset here.
+    // FastAGC::reset -> initGain 1.0; FLL::reset fll.cpp:120-127; FIR::reset clears the delay line (ONE delay line for the
+    // three FIRs here, see tetra_demod.h); PLL::reset; COMPLEX_FD::reset complex_fd.cpp:78-87
     if ((rc = fill(h, h->agc_g, 1.0f, first, count))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->fll_ph + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->fll_fr + first, 0, sizeof(float) * count, 0));
@@ -450,21 +452,25 @@ int reset_range(tetra_demod* h, int first, int count) {
     if ((rc = reset_timing(h, first, count))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->cph + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->cfr + first, 0, sizeof(float) * count, 0));
-    HIP_TRY(h, hipMemsetAsync(h->ph2 + first, 0, sizeof(float) * count, 0));
-    HIP_TRY(h, hipMemsetAsync(h->prev + first, 0, sizeof(int) * count, 0));
-    if (h->q_ring) {   // DQPSKSymbolExtractor's statistic: ring and counters back to a fresh block's (zeros)
-        HIP_TRY(h, hipMemsetAsync(h->q_ring + (size_t)first * 4096, 0, sizeof(float) * 4096 * (size_t)count, 0));
-        HIP_TRY(h, hipMemsetAsync(h->q_sum + first, 0, sizeof(double) * count, 0));
-        HIP_TRY(h, hipMemsetAsync(h->q_ptr + first, 0, sizeof(int) * count, 0));
-        HIP_TRY(h, hipMemsetAsync(h->q_disp + first, 0, sizeof(int) * count, 0));
-        HIP_TRY(h, hipMemsetAsync(h->q_sync + first, 0, sizeof(int) * count, 0));
-        HIP_TRY(h, hipMemsetAsync(h->q_err + first, 0, sizeof(float) * count, 0));
+    if (fresh) {
+        // not touched by the reference's reset: ph2 (a plain member, pi4dqpsk_costas.h:32), the slicer's previous symbol
+        // and statistic (DQPSKSymbolExtractor is another block), COMPLEX_FD's delay buffer
+        HIP_TRY(h, hipMemsetAsync(h->ph2 + first, 0, sizeof(float) * count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->prev + first, 0, sizeof(int) * count, 0));
+        if (h->q_ring) {
+            HIP_TRY(h, hipMemsetAsync(h->q_ring + (size_t)first * 4096, 0, sizeof(float) * 4096 * (size_t)count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->q_sum + first, 0, sizeof(double) * count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->q_ptr + first, 0, sizeof(int) * count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->q_disp + first, 0, sizeof(int) * count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->q_sync + first, 0, sizeof(int) * count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->q_err + first, 0, sizeof(float) * count, 0));
+        }
+        // fused pipeline keeps the delay buffer in ybuf, the two-kernel pipeline in the first kYHist rows of the time-major y
+        // scratch (columns [first, first+count))
+        HIP_TRY(h, hipMemsetAsync(h->ybuf + (size_t)first * kYHist, 0, sizeof(float2) * kYHist * (size_t)count, 0));
+        if (h->y)
+            HIP_TRY(h, hipMemset2DAsync(h->y + first, sizeof(float2) * (size_t)h->C, 0, sizeof(float2) * (size_t)count, kYHist, 0));
     }
-    // COMPLEX_FD delay buffer: fused pipeline keeps it in ybuf, the two-kernel pipeline in the first kYHist
-    // rows of the time-major y scratch (columns [first, first+count))
-    HIP_TRY(h, hipMemsetAsync(h->ybuf + (size_t)first * kYHist, 0, sizeof(float2) * kYHist * (size_t)count, 0));
-    if (h->y)
-        HIP_TRY(h, hipMemset2DAsync(h->y + first, sizeof(float2) * (size_t)h->C, 0, sizeof(float2) * (size_t)count, kYHist, 0));
     HIP_TRY(h, hipStreamSynchronize(0));
     return TETRA_OK;
 }
@@ -584,6 +590,9 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     A(dalloc(h, &h->hist, C * kHist));
     A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
     A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
+    h->user_rrc = cfg->rrc_taps != nullptr;
+    h->user_be = cfg->bandedge_taps != nullptr;
+    h->quirks = (cfg->flags & TETRA_FLAG_REFERENCE_QUIRKS) != 0;
     h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL) && h->design.ntaps <= kF8Pad;
     h->keep_y = !h->fused || (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT);
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
@@ -600,7 +609,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         for (auto& e : slot)
             if (rc == TETRA_OK && hipEventCreate(&e) != hipSuccess) rc = TETRA_ERR_HIP;
     if (rc == TETRA_OK) rc = upload_tables(h);
-    if (rc == TETRA_OK) rc = reset_range(h, 0, h->C);
+    if (rc == TETRA_OK) rc = reset_range(h, 0, h->C, true);
     if (rc != TETRA_OK) {
         int st = (h->last_hip == (int)hipErrorOutOfMemory) ? TETRA_ERR_NOMEM : rc;
         free_all(h);
@@ -797,48 +806,56 @@ int tetra_demod_reset(tetra_demod_t* h, int channel) {
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
-    return channel < 0 ? reset_range(h, 0, h->C) : reset_range(h, channel, 1);
+    return channel < 0 ? reset_range(h, 0, h->C, !h->quirks) : reset_range(h, channel, 1, !h->quirks);
 }
 
 int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     if (!h) return TETRA_ERR_ARG;
     host::DesignParams np = h->dp;
-    bool timing_reset = false;
+    host::Design nd = h->design;          // caller-supplied tables and everything a setter does not own are carried over
+    bool timing_reset = false, tables = false;
     switch (param_id) {
-    case TETRA_PARAM_SYMBOLRATE: np.symbolrate = value; timing_reset = true; break;
-    case TETRA_PARAM_SAMPLERATE: np.samplerate = value; timing_reset = true; break;
-    case TETRA_PARAM_RRC_TAP_COUNT: np.rrc_tap_count = (int)value; break;
-    case TETRA_PARAM_RRC_BETA: np.rrc_beta = value; break;
+    // loop setters (pi4dqpsk.cpp:76-118): loop constants only
     case TETRA_PARAM_AGC_RATE: np.agc_rate = value; break;
     case TETRA_PARAM_COSTAS_BANDWIDTH: np.costas_bandwidth = value; break;
     case TETRA_PARAM_FLL_BANDWIDTH: np.fll_bandwidth = value; break;
     case TETRA_PARAM_OMEGA_GAIN: np.omega_gain = value; break;
     case TETRA_PARAM_MU_GAIN: np.mu_gain = value; break;
     case TETRA_PARAM_OMEGA_REL_LIMIT: np.omega_rel_limit = value; break;
+    // rate setters (pi4dqpsk.cpp:32-54): RRC taps + COMPLEX_FD::setOmega; the FLL's filters are not touched
+    case TETRA_PARAM_SYMBOLRATE:
+    case TETRA_PARAM_SAMPLERATE:
+        if (param_id == TETRA_PARAM_SYMBOLRATE) np.symbolrate = value; else np.samplerate = value;
+        timing_reset = tables = true;
+        break;
+    // setRRCParams (pi4dqpsk.cpp:56-74)
+    case TETRA_PARAM_RRC_TAP_COUNT: np.rrc_tap_count = (int)value; tables = true; break;
+    case TETRA_PARAM_RRC_BETA: np.rrc_beta = h->quirks ? (double)(int)value : value; tables = true; break;   // setRRCBeta(int), pi4dqpsk.h:56
     default: return TETRA_ERR_ARG;
     }
-    host::Design nd;
-    if (!host::make_design(np, nullptr, nullptr, nullptr, nd)) return TETRA_ERR_UNSUPPORTED;
-    if (h->fused && nd.ntaps > kF8Pad) return TETRA_ERR_UNSUPPORTED;   // fused kernel covers <= 72 taps
+    if (!host::params_ok(np)) return TETRA_ERR_UNSUPPORTED;
+    if (tables) {
+        if (h->user_rrc) return TETRA_ERR_UNSUPPORTED;                 // would have to re-design a caller-supplied table
+        host::design_rrc(np, nd);
+        if (param_id == TETRA_PARAM_RRC_TAP_COUNT && !h->quirks && np.rrc_tap_count != nd.ntaps_be) {
+            if (h->user_be) return TETRA_ERR_UNSUPPORTED;
+            host::design_bandedge(np, nd, np.rrc_tap_count);           // documented deviation: one length for the three FIRs
+        }
+        if (h->fused && (nd.ntaps > kF8Pad || nd.ntaps_be > kF8Pad)) return TETRA_ERR_UNSUPPORTED;   // fused kernel covers <= 72 taps
+    }
+    host::design_loops(np, nd);
+    host::design_timing_limits(np, nd);
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
-    // Reference quirks kept: the FLL band-edge taps are only re-designed by setSymbolrate/setSamplerate
-    // (FLL::setSymbolrate/setSamplerate are never called by PI4DQPSK's setters -- pi4dqpsk.cpp:32-54 touch
-    // only rrc and recov), and setRRCParams re-designs only the RRC (pi4dqpsk.cpp:56-66).
-    if (param_id == TETRA_PARAM_SYMBOLRATE || param_id == TETRA_PARAM_SAMPLERATE ||
-        param_id == TETRA_PARAM_RRC_TAP_COUNT || param_id == TETRA_PARAM_RRC_BETA) {
-        if (nd.ntaps == h->design.ntaps) {
-            nd.be_re = h->design.be_re;
-            nd.be_im = h->design.be_im;
-        }
-    }
     h->dp = np;
     h->design = nd;
-    int rc = upload_tables(h);
-    if (rc != TETRA_OK) return rc;
+    if (tables) {
+        int rc = upload_tables(h);
+        if (rc != TETRA_OK) return rc;
+    }
     if (timing_reset) {
-        rc = reset_timing(h, 0, h->C);
+        int rc = reset_timing(h, 0, h->C);
         if (rc != TETRA_OK) return rc;
         HIP_TRY(h, hipStreamSynchronize(0));
     }
@@ -889,11 +906,13 @@ int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re
     const int nt = h->design.ntaps;
     if (taps) *taps = nt;
     if (rrc) std::memcpy(rrc, h->design.rrc.data(), sizeof(float) * nt);
-    if (be_re) std::memcpy(be_re, h->design.be_re.data(), sizeof(float) * nt);
-    if (be_im) std::memcpy(be_im, h->design.be_im.data(), sizeof(float) * nt);
+    if (be_re) std::memcpy(be_re, h->design.be_re.data(), sizeof(float) * h->design.ntaps_be);
+    if (be_im) std::memcpy(be_im, h->design.be_im.data(), sizeof(float) * h->design.ntaps_be);
     if (bank) std::memcpy(bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps);
     return TETRA_OK;
 }
+
+int tetra_demod_bandedge_tap_count(tetra_demod_t* h) { return h ? h->design.ntaps_be : TETRA_ERR_ARG; }
 
 int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples) {
     if (!h || !y || n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_ARG;

@@ -29,6 +29,7 @@ void PI4DQPSK::init(stream<complex_t>* in, double symbolrate, double samplerate,
     cfg.omega_gain = omegaGain;
     cfg.mu_gain = muGain;
     cfg.omega_rel_limit = omegaRelLimit;
+    cfg.flags |= TETRA_FLAG_REFERENCE_QUIRKS;   // this class IS the reference's block: reset() and the RRC setters behave like pi4dqpsk.cpp
     if (h_) { tetra_demod_destroy(h_); h_ = nullptr; }
     status_ = tetra_demod_create(&cfg, &h_);
     const int stride = tetra_demod_bits_stride(STREAM_BUFFER_SIZE);

@@ -106,7 +106,7 @@ def _compare(tag, pkg, oracle, iq, chunks, want_state=True, flags=2):
                 if getattr(st, f) != getattr(o, g):
                     problems.append(dict(tag=tag, ch=c, what="state." + f, gpu=getattr(st, f), ref=getattr(o, g)))
             hg = np.array(st.hist[:], np.float32)[2 * 16:]
-            ho = np.array(o.hist[:128], np.float32)
+            ho = np.array(o.hist[:], np.float32)[-128:]
             if not np.array_equal(_u32(hg), _u32(ho)):
                 problems.append(dict(tag=tag, ch=c, what="state.hist"))
             if not np.array_equal(_u32(np.array(st.ybuf[:], np.float32)), _u32(np.array(o.ybuf[:], np.float32))):
@@ -257,6 +257,94 @@ def test_setters_match_oracle_with_same_parameters(pkg, oracle, synth, pipeline)
     with pytest.raises(pkg.TetraDemodError):
         d.set_param("rrc_tap_count", 500)
     d.close()
+
+
+def _run_vs_oracles(d, orcs, blk):
+    bits, nb, sym = d.process(blk, want_sym=True)
+    for c, o in enumerate(orcs):
+        r = o.process(blk[c])
+        assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), c
+        assert np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])), c
+
+
+def test_setter_sequences_keep_what_they_do_not_own(pkg, oracle, synth):
+    """a rate setter followed by a loop setter must not re-design the FLL's band-edge filters (the reference's
+    setters never do, pi4dqpsk.cpp:32-118); every step compared with the oracle driven through the same setters."""
+    Cn, N = 3, 6000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=83)
+    d = pkg.Demodulator(Cn, 2000)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    be0 = d.tables()["be_re"].copy()
+    _run_vs_oracles(d, orcs, iq[:, :2000])
+    for name, val in (("samplerate", 40000.0), ("agc_rate", 0.03), ("fll_bandwidth", 0.004), ("rrc_beta", 0.4), ("mu_gain", 0.02)):
+        d.set_param(name, val)
+        for o in orcs:
+            o.set_param(pkg.binding.PARAMS[name], val)
+    assert np.array_equal(d.tables()["be_re"], be0)                 # untouched by all of them
+    assert np.array_equal(d.tables()["rrc"], orcs[0].rrc_taps())    # re-designed for 40 ksps / beta 0.4
+    _run_vs_oracles(d, orcs, iq[:, 2000:4000])
+    # a new tap count WITHOUT the quirks flag re-designs all three FIRs to that length, as documented
+    d.set_param("rrc_tap_count", 49)
+    for o in orcs:
+        o.set_param(2, 49)
+    assert d.tables()["be_re"].size == 49 and np.array_equal(d.tables()["be_re"], orcs[0].bandedge_taps()[0])
+    _run_vs_oracles(d, orcs, iq[:, 4000:])
+    with pytest.raises(pkg.TetraDemodError):
+        d.set_param("omega_rel_limit", 0.2)                           # rows are sized for omega >= 2 x 0.95
+    d.close()
+
+
+def test_caller_tables_survive_setters(pkg, oracle, synth):
+    """Caller-supplied tables stay in force across every setter that does not have to re-design them; one that would is
+    refused and changes nothing."""
+    o = oracle.Oracle()
+    a, b = o.bandedge_taps()
+    rrc = (o.rrc_taps() * np.float32(1.25)).astype(np.float32)
+    be = np.concatenate([a * np.float32(0.5), b * np.float32(0.5)]).astype(np.float32)
+    d = pkg.Demodulator(2, 1000, rrc_taps=rrc, bandedge_taps=be)
+    for name, val in (("agc_rate", 0.05), ("costas_bandwidth", 0.02), ("fll_bandwidth", 0.003), ("omega_gain", 1e-4), ("omega_rel_limit", 0.01)):
+        d.set_param(name, val)
+        t = d.tables()
+        assert np.array_equal(t["rrc"], rrc) and np.array_equal(t["be_re"], be[:65]) and np.array_equal(t["be_im"], be[65:]), name
+    for name, val in (("symbolrate", 17000.0), ("rrc_beta", 0.5), ("rrc_tap_count", 33)):
+        with pytest.raises(pkg.TetraDemodError):
+            d.set_param(name, val)
+        assert np.array_equal(d.tables()["rrc"], rrc)
+    d.close()
+
+
+def test_reference_quirks_flag(pkg, oracle, synth):
+    """TETRA_FLAG_REFERENCE_QUIRKS: reset() keeps ph2 / COMPLEX_FD's buffer / the slicer like PI4DQPSK::reset
+    (pi4dqpsk.cpp:120-130), setRRCTapCount leaves the FLL's filters alone (pi4dqpsk.cpp:56-70), setRRCBeta(int) truncates
+    (pi4dqpsk.cpp:72); each against the oracle's restatement of the same rule, mid-stream."""
+    Cn, N = 4, 8000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=87)
+    d = pkg.Demodulator(Cn, 2048, flags=pkg.binding.FLAG_REFERENCE_QUIRKS)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    _run_vs_oracles(d, orcs, iq[:, :1999])              # odd count: ph2 is mid-cycle
+    d.reset()
+    for o in orcs:
+        o.reset_reference()
+    assert d.get_state(1).ph2 == orcs[1].st.ph2 != 0.0
+    _run_vs_oracles(d, orcs, iq[:, 1999:4000])
+    d.set_param("rrc_tap_count", 33)                       # RRC only; the band-edge filters keep their 65 taps
+    for o in orcs:
+        o.set_param(2, 33, quirks=True)
+    t = d.tables()
+    assert t["rrc"].size == 33 and t["be_re"].size == 65
+    _run_vs_oracles(d, orcs, iq[:, 4000:6000])
+    d.set_param("rrc_beta", 1.7)                           # setRRCBeta(int): 1
+    for o in orcs:
+        o.set_param(3, 1.7, quirks=True)
+    assert np.array_equal(d.tables()["rrc"], orcs[0].rrc_taps())
+    _run_vs_oracles(d, orcs, iq[:, 6000:])
+    d.close()
+    # without the flag the same reset gives a fresh chain
+    d2 = pkg.Demodulator(Cn, 2000)
+    d2.process(iq[:, :1999])
+    d2.reset()
+    assert d2.get_state(1).ph2 == 0.0
+    d2.close()
 
 
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
