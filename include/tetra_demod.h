@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TETRA_DEMOD_ABI_VERSION 1
+#define TETRA_DEMOD_ABI_VERSION 2
 
 enum {
     TETRA_OK = 0,
@@ -49,7 +49,8 @@ enum {
                                     the dsp::block sets it):
                                       - tetra_demod_reset keeps ph2 (src/dsp/pi4dqpsk_costas.h:32 is never reset by
                                         PI4DQPSK::reset, pi4dqpsk.cpp:120-130), COMPLEX_FD's delay buffer (complex_fd.cpp:78-87
-                                        does not clear it) and the slicer's previous symbol (another block);
+                                        does not clear it) and the slicer's previous symbol (another block); it clears the
+                                        delay line for the RRC only -- the FLL's band-edge FIRs keep theirs (fll.cpp:120-127);
                                       - TETRA_PARAM_RRC_TAP_COUNT re-designs only the RRC and leaves the FLL's band-edge filters
                                         at their construction-time length (pi4dqpsk.cpp:56-70);
                                       - TETRA_PARAM_RRC_BETA truncates its value to an integer like setRRCBeta(int)
@@ -100,6 +101,10 @@ typedef struct tetra_demod_channel_state {
     int32_t prev;                    /* DQPSKSymbolExtractor prev (src/dsp/dqpsk_sym_extr.h:42) */
     float hist[2 * 80];              /* last 80 FLL outputs (re,im), newest last: FIR delay lines (only the last taps-1 matter) */
     float ybuf[2 * 7];               /* COMPLEX_FD delay buffer: last 7 RRC outputs */
+    int32_t rrc_valid;               /* how many of the newest hist[] samples the RRC FIR may see, 0..80 (80 = all; older ones are
+                                      * zeros to it).  The reference keeps a delay line per FIR object; rrc.reset()
+                                      * (pi4dqpsk.cpp:125) and a growing FIR::setTaps clear/zero-fill the RRC's only.  Below 80
+                                      * only after a TETRA_FLAG_REFERENCE_QUIRKS reset or tap-count growth. */
 } tetra_demod_channel_state_t;
 
 /* IDs for tetra_demod_set_param: the setters of PI4DQPSK (src/dsp/pi4dqpsk.h:52-63). */
@@ -160,9 +165,10 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
 /* PI4DQPSK::reset (src/dsp/pi4dqpsk.cpp:120-130); channel = -1 resets all.  Resets the AGC gain, the FLL and PLL loop states,
  * the timing loop and the FIR delay line.  Without TETRA_FLAG_REFERENCE_QUIRKS it also zeroes ph2, COMPLEX_FD's delay buffer,
  * the slicer's previous symbol and the quality statistic (= a fresh chain); with the flag those keep their values like in the
- * reference.  One deviation remains in both modes: the reference's FLL::reset (fll.cpp:120-127) leaves the delay lines of its two
- * band-edge FIRs alone and only FIR::reset of the RRC clears one; the kernels keep ONE delay line for the three FIRs and clear
- * it, so the FLL error of the first taps-1 samples after a reset is computed over zeros. */
+ * reference.  The delay line: the reference has one per FIR object and its reset clears the RRC's only (rrc.reset(),
+ * pi4dqpsk.cpp:125; FLL::reset, fll.cpp:120-127, leaves the two band-edge FIRs' lines alone).  The kernels keep ONE line for the
+ * three FIRs: without the flag it is cleared (fresh chain); with the flag it is kept and channel_state.rrc_valid = 0 hides it
+ * from the RRC, which is the reference's behaviour to the letter (fused pipeline; the two-kernel pipeline always clears it). */
 int tetra_demod_reset(tetra_demod_t* h, int channel);
 
 /* The twelve PI4DQPSK setters collapse to one call (IDs above).  Like the reference: the loop setters (AGC rate, Costas / FLL

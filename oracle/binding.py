@@ -42,6 +42,7 @@ class State(C.Structure):
         ("errorbuf", C.c_float * 4096),
         ("errorptr", C.c_int32), ("errordisplayptr", C.c_int32),
         ("standarderr", C.c_float), ("sync", C.c_int32),
+        ("rrc_valid", C.c_int32),
     ]
 
 
@@ -139,9 +140,12 @@ class Oracle:
 
     def set_param(self, param_id, value, quirks=False):
         """A PI4DQPSK setter (ids = TETRA_PARAM_*); rate setters also reset this channel's timing loop."""
+        old_ntaps = int(self.tab.ntaps)
         rc = lib().tetra_oracle_set_param(C.byref(self.tab), int(param_id), float(value), 1 if quirks else 0)
         if rc != 0:
             raise ValueError("tetra_oracle_set_param failed: %d" % rc)
+        if quirks and int(self.tab.ntaps) > old_ntaps:
+            lib().tetra_oracle_rrc_taps_grown(C.byref(self.st), old_ntaps)
         if param_id in (0, 1):
             lib().tetra_oracle_reset_timing(C.byref(self.tab), C.byref(self.st))
 

@@ -258,11 +258,19 @@ void tetra_oracle_reset_timing(const tetra_oracle_tables_t* tab, tetra_oracle_st
     st->offset = 0;
 }
 
+/* FIR::setTaps with MORE taps (SDR++ core, as restated in SURVEY.md Appendix A / tests/refshim): the RRC's delay line keeps
+ * its old taps-1 samples and the newly visible older part is zero-filled.  Reference-quirks mode only; without the quirks
+ * the single shared delay line simply becomes visible further back. */
+void tetra_oracle_rrc_taps_grown(tetra_oracle_state_t* st, int old_ntaps) {
+    if (st->rrc_valid > old_ntaps - 1) st->rrc_valid = old_ntaps - 1;
+}
+
 void tetra_oracle_reset_reference(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st) {
     st->agc_gain = 1.0f;            /* FastAGC::reset -> initGain */
     st->fll_phase = 0.0f;           /* FLL::reset fll.cpp:120-127 */
     st->fll_freq = 0.0f;
-    memset(st->hist, 0, sizeof(st->hist));   /* FIR::reset (one delay line here, see the header) */
+    st->rrc_valid = 0;              /* rrc.reset() pi4dqpsk.cpp:125: the RRC's delay line is cleared; the band-edge FIRs'
+                                     * lines are NOT (FLL::reset touches only the loop) -- the shared line stays */
     st->costas_phase = 0.0f;        /* PLL::reset */
     st->costas_freq = 0.0f;
     tetra_oracle_reset_timing(tab, st);      /* COMPLEX_FD::reset complex_fd.cpp:78-87 */
@@ -280,6 +288,7 @@ void tetra_oracle_reset(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* 
     st->costas_freq = 0.0f;
     st->ph2 = 0.0f;
     st->prev = 0;
+    st->rrc_valid = TETRA_ORACLE_MAX_TAPS - 1;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -356,11 +365,16 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
 
     /* --- FIR<complex_t,float>::process (SDR++ core; pi4dqpsk.cpp:136): RRC --- */
     for (int k = 0; k < 7; k++) { yr[k] = st->ybuf[2 * k]; yi[k] = st->ybuf[2 * k + 1]; }
+    const int valid0 = st->rrc_valid;          /* delay-line samples the RRC may see (all of them unless a reference-style
+                                                * reset or a tap-count growth happened less than nt-1 samples ago) */
     for (int i = 0; i < count; i++) {
         float ar = 0.0f, ai = 0.0f;
         const float* pr = wr + i + (H - (nt - 1));
         const float* pi = wi + i + (H - (nt - 1));
-        for (int k = 0; k < nt; k++) {
+        const long long have = (long long)valid0 + i + 1;   /* window samples that exist for this filter, newest first */
+        const int k0 = have >= nt ? 0 : (int)(nt - have);   /* older ones are zeros in the reference's RRC delay line;
+                                                             * fmaf(0, tap, acc) == acc, so they are skipped */
+        for (int k = k0; k < nt; k++) {
             ar = fmaf(pr[k], tab->rrc[k], ar);
             ai = fmaf(pi[k], tab->rrc[k], ai);
         }
@@ -370,6 +384,7 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
     if (y_out) for (int i = 0; i < count; i++) { y_out[2 * i] = yr[7 + i]; y_out[2 * i + 1] = yi[7 + i]; }
     /* FIR delay line update (memmove in SDR++ core FIR::process) */
     for (int k = 0; k < H; k++) { st->hist[2 * k] = wr[count + k]; st->hist[2 * k + 1] = wi[count + k]; }
+    st->rrc_valid = (long long)valid0 + count >= H ? H : valid0 + count;
 
     /* --- COMPLEX_FD::process complex_fd.cpp:89-151, PI4DQPSK_COSTAS::process
      * --- pi4dqpsk_costas.cpp:5-21, DQPSKSymbolExtractor::process dqpsk_sym_extr.cpp:4-55

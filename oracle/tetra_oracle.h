@@ -82,6 +82,11 @@ typedef struct {
     int32_t errorptr, errordisplayptr;
     float standarderr;
     int32_t sync;
+    /* How many of the newest delay-line samples the RRC FIR may see (saturates at 128).  The reference keeps three FIR
+     * objects with a delay line each; PI4DQPSK::reset clears only the RRC's (rrc.reset(), pi4dqpsk.cpp:125 -- FLL::reset,
+     * fll.cpp:120-127, resets the loop and leaves its two band-edge FIRs' lines alone).  With ONE shared line here, the
+     * reference's reset is "keep the line, RRC sees none of it": rrc_valid = 0.  Found by tests/test_reference_shim.py. */
+    int32_t rrc_valid;
 } tetra_oracle_state_t;
 
 /* Derived constants + tables, shared by all channels. */
@@ -122,10 +127,12 @@ void tetra_oracle_reset_timing(const tetra_oracle_tables_t* tab, tetra_oracle_st
 /*
  * PI4DQPSK::reset (pi4dqpsk.cpp:120-130) as the reference does it: AGC gain, FLL phase/freq, the FIR delay line, PLL
  * phase/freq and the timing loop are reset; ph2 (pi4dqpsk_costas.h:32), COMPLEX_FD's delay buffer and the symbol
- * extractor (another block) keep their values.  (The reference clears only the RRC's delay line and leaves the
- * band-edge FIRs' -- this restatement, like the product, keeps ONE delay line for the three FIRs and clears it.)
+ * extractor (another block) keep their values.  The reference clears only the RRC's delay line and leaves the
+ * band-edge FIRs' own: with ONE shared line here that is "keep the line, rrc_valid = 0" (see the state struct).
  */
 void tetra_oracle_reset_reference(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st);
+/* After a quirks-mode setRRCTapCount that made the RRC longer: see the .c file. */
+void tetra_oracle_rrc_taps_grown(tetra_oracle_state_t* st, int old_ntaps);
 
 void tetra_oracle_sincosf(float x, float* s, float* c);
 

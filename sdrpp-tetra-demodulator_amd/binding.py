@@ -50,7 +50,7 @@ class ChannelState(C.Structure):
         ("agc_gain", C.c_float), ("fll_phase", C.c_float), ("fll_freq", C.c_float),
         ("mu", C.c_float), ("omega", C.c_float), ("offset", C.c_int32),
         ("costas_phase", C.c_float), ("costas_freq", C.c_float), ("ph2", C.c_float), ("prev", C.c_int32),
-        ("hist", C.c_float * 160), ("ybuf", C.c_float * 14),
+        ("hist", C.c_float * 160), ("ybuf", C.c_float * 14), ("rrc_valid", C.c_int32),
     ]
 
 

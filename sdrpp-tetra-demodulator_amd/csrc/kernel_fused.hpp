@@ -55,6 +55,7 @@ struct FusedParams {
     // state
     float *agc_g, *fll_ph, *fll_fr;
     float2* hist;        // [C][kHist]
+    int* rrc_valid;      // [C] how many of the newest delay-line samples the RRC may see (kHist = all; tetra_demod.h)
     float *mu, *omega;
     int* offset;
     float *cph, *cfr, *ph2;
@@ -310,6 +311,11 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         const int rrc_pad = (8 - ((p.ntaps - 1) & 7)) & 7;
         const int rrc_chunks = (p.ntaps - 1 + rrc_pad) / 8 + 1;
         const unsigned x_base = pin_u32(lds_addr(&L.x_ring[c][kFXP]));
+        // Reference-style reset / tap-count growth (tetra_demod.h, rrc_valid): delay-line samples older than the newest
+        // valid0 are zeros to the RRC (and only to it).  Rare, and only the tiles whose windows reach into the delay
+        // line are affected: they take the masked copy of the loop, wave-uniformly.
+        const int valid0 = p.rrc_valid[chan(c)];
+        const bool blanked = __builtin_amdgcn_readfirstlane(__any(valid0 < kHist) ? 1 : 0) != 0;
         __syncthreads();
         FUSED_EPOCHS(
             const int t = e - 2;
@@ -318,13 +324,22 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                 if (i0 < n) {
                     const int start = i0 - (p.ntaps - 1) - rrc_pad;
                     Pair<float> out[kRrcOut];
+                    auto tap4 = [&](int q) { const float4 t4 = reinterpret_cast<const float4*>(L.rrc)[q];
+                                             Tap4 r; r.v[0] = t4.x; r.v[1] = t4.y; r.v[2] = t4.z; r.v[3] = t4.w; return r; };
+                    if (blanked && t * kFT < p.ntaps - 1 + rrc_pad) {
+                        rrc_direct8(rrc_chunks,
+                                    [&](int q) {
+                                        const float2 v = x_ring_get(L, c, start + q);
+                                        const bool seen = start + q >= -valid0;
+                                        return Pair<float>(seen ? v.x : 0.0f, seen ? v.y : 0.0f); },
+                                    tap4, out);
+                    } else
                     rrc_direct8(rrc_chunks,
                                 [&](int q) {      // q = 8*ck + j: chunk base wrapped, j added as an immediate offset
                                     lds_cfloat2* xw = (lds_cfloat2*)(size_t)(x_base + (((start + (q & ~7)) & (kFX - 1)) << 3));
                                     const vfloat2 v = xw[q & 7];
                                     return Pair<float>(v.x, v.y); },
-                                [&](int q) { const float4 t4 = reinterpret_cast<const float4*>(L.rrc)[q];
-                                             Tap4 r; r.v[0] = t4.x; r.v[1] = t4.y; r.v[2] = t4.z; r.v[3] = t4.w; return r; }, out);
+                                tap4, out);
                     _Pragma("unroll")
                     for (int m = 0; m < kRrcOut; m++) {
                         if (i0 + m < n) {
@@ -337,6 +352,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                 }
             }
         )
+        if (lane < kFCh && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
     } else if (wave == kRoleD) {
         // ---- timing recovery: lane c < 16 owns channel c; consumes y of tiles <= e-3 ---------------------
         const bool on = lane < kFCh;

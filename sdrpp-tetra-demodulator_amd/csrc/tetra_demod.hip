@@ -325,6 +325,14 @@ __global__ void k_fill_f32(float* p, float v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void k_fill_i32(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_min_i32(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && p[i] > v) p[i] = v;
+}
 
 }  // namespace
 
@@ -344,6 +352,7 @@ struct tetra_demod {
     float2* hist = nullptr;
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
+    int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
     float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state
@@ -448,7 +457,15 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
     if ((rc = fill(h, h->agc_g, 1.0f, first, count))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->fll_ph + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->fll_fr + first, 0, sizeof(float) * count, 0));
-    HIP_TRY(h, hipMemsetAsync(h->hist + (size_t)first * kHist, 0, sizeof(float2) * kHist * (size_t)count, 0));
+    // FIR::reset: the reference clears the RRC's delay line only; FLL::reset leaves the band-edge FIRs' lines alone.  To the
+    // letter (quirks, fused pipeline) the shared line therefore stays and the RRC is told to see none of it.
+    if (fresh || !h->fused) {
+        HIP_TRY(h, hipMemsetAsync(h->hist + (size_t)first * kHist, 0, sizeof(float2) * kHist * (size_t)count, 0));
+        hipLaunchKernelGGL(k_fill_i32, dim3((count + 255) / 256), dim3(256), 0, 0, h->rrc_valid + first, (int)kHist, count);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        HIP_TRY(h, hipMemsetAsync(h->rrc_valid + first, 0, sizeof(int) * count, 0));
+    }
     if ((rc = reset_timing(h, first, count))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->cph + first, 0, sizeof(float) * count, 0));
     HIP_TRY(h, hipMemsetAsync(h->cfr + first, 0, sizeof(float) * count, 0));
@@ -477,7 +494,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -590,6 +607,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     A(dalloc(h, &h->hist, C * kHist));
     A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
     A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
+    A(dalloc(h, &h->rrc_valid, C));
     h->user_rrc = cfg->rrc_taps != nullptr;
     h->user_be = cfg->bandedge_taps != nullptr;
     h->quirks = (cfg->flags & TETRA_FLAG_REFERENCE_QUIRKS) != 0;
@@ -690,6 +708,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.iq = p1.iq; pf.in_ch_stride = p1.in_ch_stride; pf.in_t_stride = p1.in_t_stride;
         pf.n = n_samples; pf.n_channels = h->C;
         pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
+        pf.rrc_valid = h->rrc_valid;
         pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
         pf.cph = h->cph; pf.cfr = h->cfr; pf.ph2 = h->ph2; pf.prev = h->prev; pf.ybuf = h->ybuf;
         pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
@@ -848,11 +867,18 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
+    const int old_ntaps = h->design.ntaps;
     h->dp = np;
     h->design = nd;
     if (tables) {
         int rc = upload_tables(h);
         if (rc != TETRA_OK) return rc;
+        if (h->quirks && h->fused && nd.ntaps > old_ntaps) {
+            // FIR::setTaps with more taps keeps the RRC's old taps-1 history samples and zero-fills the newly visible part
+            hipLaunchKernelGGL(k_min_i32, dim3((h->C + 255) / 256), dim3(256), 0, 0, h->rrc_valid, old_ntaps - 1, h->C);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipStreamSynchronize(0));
+        }
     }
     if (timing_reset) {
         int rc = reset_timing(h, 0, h->C);
@@ -872,6 +898,7 @@ int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_sta
     GET1(out->agc_gain, h->agc_g); GET1(out->fll_phase, h->fll_ph); GET1(out->fll_freq, h->fll_fr);
     GET1(out->mu, h->mu); GET1(out->omega, h->omega); GET1(out->offset, h->offset);
     GET1(out->costas_phase, h->cph); GET1(out->costas_freq, h->cfr); GET1(out->ph2, h->ph2); GET1(out->prev, h->prev);
+    GET1(out->rrc_valid, h->rrc_valid);
 #undef GET1
     HIP_TRY(h, hipMemcpy(out->hist, h->hist + (size_t)c * kHist, sizeof(float2) * kHist, hipMemcpyDeviceToHost));
     if (h->fused)
@@ -892,6 +919,8 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     SET1(h->agc_g, in->agc_gain); SET1(h->fll_ph, in->fll_phase); SET1(h->fll_fr, in->fll_freq);
     SET1(h->mu, in->mu); SET1(h->omega, in->omega); SET1(h->offset, in->offset);
     SET1(h->cph, in->costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
+    const int rv = !h->fused ? (int)kHist : in->rrc_valid < 0 ? 0 : in->rrc_valid > (int)kHist ? (int)kHist : in->rrc_valid;
+    SET1(h->rrc_valid, rv);
 #undef SET1
     HIP_TRY(h, hipMemcpy(h->hist + (size_t)c * kHist, in->hist, sizeof(float2) * kHist, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->ybuf + (size_t)c * kYHist, in->ybuf, sizeof(float2) * kYHist, hipMemcpyHostToDevice));

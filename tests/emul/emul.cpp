@@ -110,6 +110,7 @@ void emul_reset_state(const emul_tables* t, tetra_demod_channel_state_t* st) {
     std::memset(st, 0, sizeof(*st));
     st->agc_gain = 1.0f;
     st->omega = t->tr_omega;
+    st->rrc_valid = kHist;
 }
 
 // Kernel 1 for one channel: iq[n] -> y[n]; updates agc/fll/hist in st.
@@ -322,8 +323,11 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
         struct { float* p; float* data() { return p; } } xf{ xfp };
         for (int i0 = 0; i0 < n; i0 += 8) {
             Pair<float> out[kRrcOut];
-            const float* w = xf.data() + 2 * (kHist + i0 - (t->ntaps - 1) - rpad);
-            rrc_direct8(rrc_chunks, [&](int q) { return Pair<float>(w[2 * q], w[2 * q + 1]); },
+            const int start = i0 - (t->ntaps - 1) - rpad;
+            const float* w = xf.data() + 2 * (kHist + start);
+            const int valid0 = st[c].rrc_valid;           // delay-line samples the RRC may see (tetra_demod.h)
+            rrc_direct8(rrc_chunks, [&](int q) { const bool seen = start + q >= -valid0;
+                                                 return Pair<float>(seen ? w[2 * q] : 0.0f, seen ? w[2 * q + 1] : 0.0f); },
                         [&](int q) { Tap4 r; for (int z = 0; z < 4; z++) r.v[z] = rrc_ext[4 * q + z]; return r; }, out);
             for (int m = 0; m < kRrcOut && i0 + m < n; m++) {
                 y[((size_t)c * n + i0 + m) * 2] = out[m].x();
@@ -334,6 +338,7 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
         std::vector<float> nh(2 * kHist);
         std::memcpy(nh.data(), xf.data() + 2 * n, sizeof(float) * 2 * kHist);
         std::memcpy(st[c].hist, nh.data(), sizeof(float) * 2 * kHist);
+        st[c].rrc_valid = st[c].rrc_valid + n >= kHist ? kHist : st[c].rrc_valid + n;
     }
     if (y_out && n) std::memcpy(y_out, y.data(), sizeof(float) * y.size());
     // D + E

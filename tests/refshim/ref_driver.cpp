@@ -1,0 +1,70 @@
+// C entry points around the REFERENCE's own PI4DQPSK -> DQPSKSymbolExtractor -> BitUnpacker objects, for
+// tests/test_reference_shim.py.  The reference sources are compiled where they lie (-I /root/reference/src) against the
+// stand-in core headers in this directory; see README.md.  Chain order as the reference wires it (main.cpp:84-92).
+#include <dsp/pi4dqpsk.h>
+#include <dsp/dqpsk_sym_extr.h>
+#include <dsp/bit_unpacker.h>
+
+#include <memory>
+
+namespace {
+struct Chain {
+    dsp::demod::PI4DQPSK demod;
+    dsp::DQPSKSymbolExtractor extractor;
+    dsp::BitUnpacker unpacker;
+    std::vector<dsp::complex_t> sym;
+    std::vector<uint8_t> dibits;
+};
+}
+
+extern "C" {
+
+void* ref_create(double symbolrate, double samplerate, int rrc_taps, double rrc_beta, double agc_rate, double costas_bw,
+                 double fll_bw, double omega_gain, double mu_gain, double omega_rel_limit) {
+    Chain* c = new Chain();
+    c->demod.init(nullptr, symbolrate, samplerate, rrc_taps, rrc_beta, agc_rate, costas_bw, fll_bw, omega_gain, mu_gain,
+                  omega_rel_limit);
+    c->extractor.init(nullptr);
+    c->unpacker.init(nullptr);
+    c->sym.resize(STREAM_BUFFER_SIZE);
+    c->dibits.resize(STREAM_BUFFER_SIZE);
+    return c;
+}
+
+void ref_destroy(void* h) { delete (Chain*)h; }
+
+// count <= STREAM_BUFFER_SIZE interleaved complex samples in; symbols (interleaved re,im), one bit per byte out.
+// Returns the number of symbols produced (bits = 2 x symbols).
+int ref_process(void* h, int count, const float* iq, float* symbols, uint8_t* bits) {
+    Chain* c = (Chain*)h;
+    if (count < 0 || count > STREAM_BUFFER_SIZE) { return -1; }
+    const int ns = c->demod.process(count, (const dsp::complex_t*)iq, c->sym.data());
+    memcpy(symbols, c->sym.data(), (size_t)ns * sizeof(dsp::complex_t));
+    const int nd = c->extractor.process(ns, c->sym.data(), c->dibits.data());
+    c->unpacker.process(nd, c->dibits.data(), bits);
+    return ns;
+}
+
+// id follows include/tetra_demod.h's TETRA_PARAM_* numbering.
+int ref_set_param(void* h, int id, double v) {
+    Chain* c = (Chain*)h;
+    switch (id) {
+    case 0: c->demod.setSymbolrate(v); break;
+    case 1: c->demod.setSamplerate(v); break;
+    case 2: c->demod.setRRCTapCount((int)v); break;
+    case 3: c->demod.setRRCBeta(v); break;  // int parameter in the reference: truncates
+    case 4: c->demod.setAGCRate(v); break;
+    case 5: c->demod.setCostasBandwidth(v); break;
+    case 6: c->demod.setFllBandwidth(v); break;
+    case 7: c->demod.setOmegaGain(v); break;
+    case 8: c->demod.setMuGain(v); break;
+    case 9: c->demod.setOmegaRelLimit(v); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+void ref_reset(void* h) { ((Chain*)h)->demod.reset(); }
+
+int ref_sync(void* h) { return ((Chain*)h)->extractor.sync ? 1 : 0; }
+}

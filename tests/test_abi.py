@@ -22,7 +22,7 @@ def test_header_symbols_all_exported(pkg):
     for n in names:
         assert hasattr(L, n), "declared in include/tetra_demod.h but not exported: " + n
     assert set(pkg.binding.EXPORTS) == set(names)
-    assert L.tetra_demod_abi_version() == 1
+    assert L.tetra_demod_abi_version() == 2
 
 
 def test_channeliser_header_symbols_all_exported(pkg):
@@ -171,4 +171,4 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), lib, "-Wl,-rpath," + os.path.dirname(lib),
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["65", "800", "1"]
+    assert out == ["65", "800", "2"]

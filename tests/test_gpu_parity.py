@@ -111,6 +111,8 @@ def _compare(tag, pkg, oracle, iq, chunks, want_state=True, flags=2):
                 problems.append(dict(tag=tag, ch=c, what="state.hist"))
             if not np.array_equal(_u32(np.array(st.ybuf[:], np.float32)), _u32(np.array(o.ybuf[:], np.float32))):
                 problems.append(dict(tag=tag, ch=c, what="state.ybuf"))
+            if st.rrc_valid != min(o.rrc_valid, 80):
+                problems.append(dict(tag=tag, ch=c, what="state.rrc_valid", gpu=st.rrc_valid, ref=o.rrc_valid))
     d.close()
     return problems
 
@@ -326,13 +328,26 @@ def test_reference_quirks_flag(pkg, oracle, synth):
     for o in orcs:
         o.reset_reference()
     assert d.get_state(1).ph2 == orcs[1].st.ph2 != 0.0
-    _run_vs_oracles(d, orcs, iq[:, 1999:4000])
+    # the delay line survives the reset for the FLL's band-edge filters and is hidden from the RRC (rrc_valid = 0):
+    # rrc.reset() pi4dqpsk.cpp:125 versus FLL::reset fll.cpp:120-127; tests/test_reference_shim.py checks the oracle's
+    # version of this rule against the reference's own code
+    st = d.get_state(1)
+    assert st.rrc_valid == 0 and np.any(np.array(st.hist[:]) != 0.0)
+    _run_vs_oracles(d, orcs, iq[:, 1999:2030])             # a call shorter than the filter: still partly hidden afterwards
+    assert d.get_state(1).rrc_valid == 31 == orcs[1].st.rrc_valid
+    _run_vs_oracles(d, orcs, iq[:, 2030:4000])
     d.set_param("rrc_tap_count", 33)                       # RRC only; the band-edge filters keep their 65 taps
     for o in orcs:
         o.set_param(2, 33, quirks=True)
     t = d.tables()
     assert t["rrc"].size == 33 and t["be_re"].size == 65
-    _run_vs_oracles(d, orcs, iq[:, 4000:6000])
+    _run_vs_oracles(d, orcs, iq[:, 4000:4500])
+    d.set_param("rrc_tap_count", 49)                       # growing: FIR::setTaps zero-fills what the longer RRC newly sees
+    for o in orcs:
+        o.set_param(2, 49, quirks=True)
+    assert d.get_state(2).rrc_valid == 32 == orcs[2].st.rrc_valid
+    _run_vs_oracles(d, orcs, iq[:, 4500:4517])
+    _run_vs_oracles(d, orcs, iq[:, 4517:6000])
     d.set_param("rrc_beta", 1.7)                           # setRRCBeta(int): 1
     for o in orcs:
         o.set_param(3, 1.7, quirks=True)
