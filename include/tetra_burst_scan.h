@@ -11,7 +11,8 @@
  * its look-ahead quirk: the 22-bit pre-filter is seeded from in[0..19] and then fed in[cur+21], so in[20] is never
  * shifted in and the first 21 positions see a misaligned filter (a sequence starting there can be missed) -- reproduced.
  * Like the reference, the scan reads up to in[end_of_in + 20]; every row must have those bytes readable
- * (end_of_in[c] + 21 <= bits_stride).
+ * (end_of_in[c] + 21 <= bits_stride; a larger end_of_in is cut back to bits_stride - 21 inside the kernel, so a bad count
+ * can never read into the next channel's row).
  * Parity for this entry point is PINNED: tests compare it with the reference function itself, built from the reference's
  * own source file into oracle/_ref (oracle/build_ref.sh).
  */

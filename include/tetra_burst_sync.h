@@ -64,8 +64,9 @@ int tetra_bsync_reset(tetra_bsync_t* h);
 /* Frame slots per channel a process call needs: (4096 + max_bits) / 510 + 2. */
 int tetra_bsync_max_frames(tetra_bsync_t* h);
 /*
- * d_bits        [C][bits_stride] uint8, one bit per byte (device pointer, 4-byte aligned, bits_stride % 4 == 0)
- * d_n_bits      [C] int32: new bits per channel (e.g. the demodulator's n_bits); values above max_bits are clamped
+ * d_bits        [C][bits_stride] uint8, one bit per byte (device pointer, 4-byte aligned, bits_stride % 4 == 0,
+ *               bits_stride >= max_bits or TETRA_ERR_SIZE)
+ * d_n_bits      [C] int32: new bits per channel (e.g. the demodulator's n_bits); values above max_bits (or the row) are clamped
  * d_frames      [C][max_frames][512] uint8 out: the consumed frames, one bit per byte
  * d_frame_type  [C][max_frames] int32 out: see above; unused slots = TETRA_FRAME_NONE
  * d_frame_bitnum[C][max_frames] uint32 out: bitbuf_start_bitnum of the frame (absolute bit number of its first bit)

@@ -82,6 +82,115 @@ def build_sync_burst(sb, bb, bkn):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The reference's synchroniser RUN: tetra_burst_sync_in() (phy/tetra_burst_sync.c:54-155) -> tetra_burst_rx_cb()
+# (phy/tetra_burst.c:343-393) -> tp_sap_udata_ind(), the last being the test-side recorder tests/refrec/tp_sap_recorder.c
+# (oracle/_ref/libtetra_tpsap_recorder.so).  The recorder library is loaded RTLD_GLOBAL so that the reference library's lazy
+# reference to tp_sap_udata_ind binds to it.
+# ---------------------------------------------------------------------------------------------------------------------
+RECORDER_LIB_PATH = os.path.join(_HERE, "_ref", "libtetra_tpsap_recorder.so")
+_rec = None
+
+
+class RecEvent(C.Structure):
+    _fields_ = [("type", C.c_int32), ("blk_num", C.c_int32), ("len", C.c_int32), ("frame_bitnum", C.c_uint32),
+                ("tn", C.c_uint32), ("fn", C.c_uint32), ("mn", C.c_uint32), ("bits", C.c_uint8 * 432)]
+
+
+def sync_run_available():
+    if not available():
+        return False
+    if not os.path.exists(RECORDER_LIB_PATH):
+        try:
+            build()
+        except Exception:
+            return False
+    if not os.path.exists(RECORDER_LIB_PATH):
+        return False
+    try:
+        lib().tetra_tdma_time_add_tn      # libraries built before tetra_tdma.c was added cannot run the state machine
+    except AttributeError:
+        return False
+    return True
+
+
+def _rec_lib():
+    global _rec
+    if _rec is None:
+        if not sync_run_available():
+            raise RuntimeError("oracle/_ref recorder not built and /root/reference not present")
+        R = C.CDLL(RECORDER_LIB_PATH, mode=os.RTLD_GLOBAL | os.RTLD_LAZY)
+        vp = C.c_void_p
+        R.rec_new.argtypes = [vp]
+        R.rec_new.restype = vp
+        R.rec_free.argtypes = [vp]
+        R.rec_set_traffic.argtypes = [vp, C.c_int]
+        R.rec_feed.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+        R.rec_rx_state.argtypes = [vp, vp, vp]
+        R.rec_event_count.argtypes = [vp]
+        R.rec_event_count.restype = C.c_int
+        R.rec_event_size.restype = C.c_int
+        R.rec_events.argtypes = [vp, C.c_int, C.c_int, vp]
+        R.rec_clear_events.argtypes = [vp]
+        assert R.rec_event_size() == C.sizeof(RecEvent)
+        _rec = R
+    return _rec
+
+
+class ReferenceBurstSync:
+    """One tetra_rx_state driven through the REFERENCE's tetra_burst_sync_in.  feed() returns the tp_sap_udata_ind calls
+    the reference made during it: list of (type, blk_num, bits uint8[len], frame_bitnum).  NOTE the reference keeps the
+    slot counter in a global (t_phy_state): instances share it, exactly like the plugin's single decoder."""
+
+    def __init__(self, is_traffic=0):
+        R, L = _rec_lib(), lib()
+        phy = C.addressof(C.c_char.in_dll(L, "t_phy_state"))
+        self._h = R.rec_new(phy)
+        R.rec_set_traffic(self._h, int(is_traffic))
+        self._sync_in = C.cast(L.tetra_burst_sync_in, C.c_void_p)
+
+    def close(self):
+        if self._h:
+            _rec_lib().rec_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def feed(self, bits, chunk=1):
+        R = _rec_lib()
+        b = np.ascontiguousarray(bits, np.uint8)
+        R.rec_clear_events(self._h)
+        R.rec_feed(self._h, self._sync_in, b.ctypes.data_as(C.c_void_p), int(b.size), int(chunk))
+        n = R.rec_event_count(self._h)
+        ev = (RecEvent * max(n, 1))()
+        if n:
+            R.rec_events(self._h, 0, n, ev)
+        return [(int(e.type), int(e.blk_num), np.frombuffer(bytes(e.bits), np.uint8)[: e.len].copy(), int(e.frame_bitnum),
+                 (int(e.tn), int(e.fn), int(e.mn))) for e in ev[:n]]
+
+    @property
+    def state(self):
+        """(state, bits_in_buf, bitbuf_start_bitnum, next_frame_start_bitnum) like oracle.BurstSyncOracle.state"""
+        w = (C.c_uint32 * 4)()
+        _rec_lib().rec_rx_state(self._h, w, None)
+        return int(w[0]), int(w[1]), int(w[2]), int(w[3])
+
+    def bitbuf(self):
+        w = (C.c_uint32 * 4)()
+        buf = np.zeros(4096, np.uint8)
+        _rec_lib().rec_rx_state(self._h, w, buf.ctypes.data_as(C.c_void_p))
+        return buf[: int(w[1])].copy()
+
+
+# what tetra_burst_rx_cb hands downstream per burst type, in its call order (tetra_burst.c:353-384): (tp_sap type, blk_num)
+RX_CB_BLOCKS = {
+    TRAIN_SYNC: ((0, 1), (3, 0), (1, 2)),       # SB1/BLK_1, BBK/0, SB2/BLK_2
+    TRAIN_NORM_2: ((3, 0), (2, 1), (2, 2)),     # BBK/0, NDB/BLK_1, NDB/BLK_2
+    TRAIN_NORM_1: ((3, 0), (5, 0)),             # BBK/0, SCH_F/0
+}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Lower-MAC channel coding (SURVEY.md 8(f) #3): oracle/_ref/libtetra_lmac_ref.so = the reference's own
 # lower_mac/{tetra_scramb,tetra_interleave,tetra_conv_enc,crc_simple,viterbi,viterbi_cch,osmo_conv}.c
 # ---------------------------------------------------------------------------------------------------------------------

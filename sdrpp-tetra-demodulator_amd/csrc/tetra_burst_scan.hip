@@ -59,7 +59,10 @@ __global__ __launch_bounds__(kThreads) void k_find_train_seq(const uint8_t* bits
     __shared__ unsigned heads[5];
     const int ch = blockIdx.x;
     const uint8_t* in = bits + (long long)ch * bits_stride;
-    const int end = end_of_in[ch];
+    // the search reads in[cur + 21] for every cur < end (tetra_burst.c:296): a count that would take that look-ahead out of
+    // the row is cut back to what the row holds (documented in tetra_burst_scan.h: rows extend 21 bytes past end_of_in)
+    int end = end_of_in[ch];
+    end = end > bits_stride - 21 ? bits_stride - 21 : end;
     if (threadIdx.x == 0) best = 0xffffffffu;
     if (threadIdx.x < 5) heads[threadIdx.x] = head22(threadIdx.x);
     __syncthreads();

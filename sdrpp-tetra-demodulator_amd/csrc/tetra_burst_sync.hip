@@ -48,6 +48,7 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
     State st = states[ch];
     int n_new = n_bits[ch];
     n_new = n_new < 0 ? 0 : (n_new > max_bits ? max_bits : n_new);
+    n_new = n_new > bits_stride ? bits_stride : n_new;         // a poisoned count never reads into the next channel's row
     const int x0 = kOff - (int)st.bits_in_buf, xe = kOff + n_new;
 
     // 1. pack the stream
@@ -241,6 +242,7 @@ int tetra_bsync_process_device(tetra_bsync_t* h, const uint8_t* d_bits, int bits
                                int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames, void* hip_stream) {
     if (!h || !d_bits || !d_n_bits || !d_frames || !d_frame_type || !d_frame_bitnum || !d_n_frames) return TETRA_ERR_ARG;
     if (bits_stride < 4) return TETRA_ERR_ARG;
+    if (bits_stride < h->max_bits) return TETRA_ERR_SIZE;      // rows must be able to hold the max_bits the handle was sized for
     if ((bits_stride & 3) || ((uintptr_t)d_bits & 3) || ((uintptr_t)d_frames & 3)) return TETRA_ERR_ALIGN;
     hipLaunchKernelGGL(k_burst_sync, dim3(h->n_channels), dim3(kLanes), lds_bytes(h->max_bits, h->max_frames),
                        static_cast<hipStream_t>(hip_stream), d_bits, bits_stride, d_n_bits, h->max_bits, h->max_frames, h->d_state,

@@ -100,7 +100,8 @@ struct tetra_chan {
     int device = 0, last_hip = 0;
     int M = 0, P = 0, D = 0, L = 0, N1 = 0, N2 = 0, max_in = 0;
     std::vector<float> proto;
-    float2* xbuf = nullptr;     // [L-1 + max_in]
+    float2* xbuf = nullptr;     // [L-1 + max_in]: [history | new samples] of the call in flight
+    float2* xalt = nullptr;     // same size: receives the next call's history (one copy, then the two swap roles)
     float* d_h = nullptr;
     float2 *d_w1 = nullptr, *d_w2 = nullptr, *d_wm = nullptr;
     float2* st_out = nullptr;   // host-path staging
@@ -186,7 +187,7 @@ int upload_twiddles(tetra_chan* h) {
 }
 
 void free_all(tetra_chan* h) {
-    void* ptrs[] = { h->xbuf, h->d_h, h->d_w1, h->d_w2, h->d_wm, h->st_out };
+    void* ptrs[] = { h->xbuf, h->xalt, h->d_h, h->d_w1, h->d_w2, h->d_wm, h->st_out };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
 }
@@ -232,6 +233,7 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
     Guard g(dev);
     if (!g.ok) { delete h; return TETRA_ERR_NO_DEVICE; }
     bool ok = hipMalloc((void**)&h->xbuf, sizeof(float2) * ((size_t)h->L - 1 + h->max_in)) == hipSuccess &&
+              hipMalloc((void**)&h->xalt, sizeof(float2) * ((size_t)h->L - 1 + h->max_in)) == hipSuccess &&
               hipMalloc((void**)&h->d_h, sizeof(float) * h->L) == hipSuccess &&
               hipMalloc((void**)&h->d_w1, sizeof(float2) * h->N1) == hipSuccess &&
               hipMalloc((void**)&h->d_w2, sizeof(float2) * h->N2) == hipSuccess &&
@@ -280,18 +282,12 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     }
     CH_TRY(h, hipEventRecord(h->ev[1], s));
     h->ev_valid = true;
-    // carry: the last L-1 samples of [history | new] move to the front (regions may overlap: go through the tail)
+    // carry: the last L-1 samples of [history | new] become the next call's history -- ONE copy into the other buffer
+    // (whatever n_in is; an in-place move would overlap for n_in < L-1), then the buffers swap roles.  Stream order keeps the
+    // kernel above ahead of the copy and the copy ahead of the next call's writes.
     if (n_in > 0) {
-        if ((size_t)n_in >= hist) {
-            CH_TRY(h, hipMemcpyAsync(h->xbuf, h->xbuf + n_in, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
-        } else {
-            // overlapping move by n_in (< L-1): copy forward in chunks of n_in (each chunk's source and destination
-            // are disjoint, and stream order makes every chunk see the original data)
-            for (size_t off = 0; off < hist; off += (size_t)n_in) {
-                const size_t len = (hist - off < (size_t)n_in) ? hist - off : (size_t)n_in;
-                CH_TRY(h, hipMemcpyAsync(h->xbuf + off, h->xbuf + off + n_in, sizeof(float2) * len, hipMemcpyDeviceToDevice, s));
-            }
-        }
+        CH_TRY(h, hipMemcpyAsync(h->xalt, h->xbuf + n_in, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
+        float2* t = h->xbuf; h->xbuf = h->xalt; h->xalt = t;
     }
     h->phase = (h->phase + n_in) % h->D;
     h->consumed += n_in;
@@ -310,22 +306,22 @@ int tetra_chan_process(tetra_chan_t* h, const float* x, int n_in, float* out, in
         CH_TRY(h, hipMalloc((void**)&h->st_out, sizeof(float2) * frames * (size_t)h->M));
         h->st_out_frames = frames;
     }
-    float2* d_x = nullptr;
+    struct Tmp {                      // freed on every return path
+        float2* p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } d_x, d_dummy;
     if (n_in > 0) {
-        CH_TRY(h, hipMalloc((void**)&d_x, sizeof(float2) * (size_t)n_in));
-        CH_TRY(h, hipMemcpy(d_x, x, sizeof(float2) * (size_t)n_in, hipMemcpyHostToDevice));
+        CH_TRY(h, hipMalloc((void**)&d_x.p, sizeof(float2) * (size_t)n_in));
+        CH_TRY(h, hipMemcpy(d_x.p, x, sizeof(float2) * (size_t)n_in, hipMemcpyHostToDevice));
     }
-    float2* d_dummy = nullptr;
-    if (!h->st_out) CH_TRY(h, hipMalloc((void**)&d_dummy, sizeof(float2)));
-    int rc = tetra_chan_process_device(h, reinterpret_cast<const float*>(d_x), n_in,
-                                       reinterpret_cast<float*>(h->st_out ? h->st_out : d_dummy), n_frames, nullptr);
+    if (!h->st_out) CH_TRY(h, hipMalloc((void**)&d_dummy.p, sizeof(float2)));
+    int rc = tetra_chan_process_device(h, reinterpret_cast<const float*>(d_x.p), n_in,
+                                       reinterpret_cast<float*>(h->st_out ? h->st_out : d_dummy.p), n_frames, nullptr);
     if (rc == TETRA_OK) {
         hipError_t e = hipStreamSynchronize(0);
         if (e == hipSuccess && frames) e = hipMemcpy(out, h->st_out, sizeof(float2) * frames * (size_t)h->M, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { h->last_hip = (int)e; rc = TETRA_ERR_HIP; }
     }
-    if (d_x) (void)hipFree(d_x);
-    if (d_dummy) (void)hipFree(d_dummy);
     return rc;
 }
 

@@ -1001,15 +1001,16 @@ int tetra_demod_debug_selftest(tetra_demod_t* h, const float* in128, float* out3
     if (!h || !in128 || !out320) return TETRA_ERR_ARG;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
-    float *din = nullptr, *dout = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&din, sizeof(float) * 128));
-    HIP_TRY(h, hipMalloc((void**)&dout, sizeof(float) * 320));
-    HIP_TRY(h, hipMemcpy(din, in128, sizeof(float) * 128, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, din, dout);
+    struct Tmp {                      // freed on every return path
+        float* p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } din, dout;
+    HIP_TRY(h, hipMalloc((void**)&din.p, sizeof(float) * 128));
+    HIP_TRY(h, hipMalloc((void**)&dout.p, sizeof(float) * 320));
+    HIP_TRY(h, hipMemcpy(din.p, in128, sizeof(float) * 128, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, din.p, dout.p);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpy(out320, dout, sizeof(float) * 320, hipMemcpyDeviceToHost));
-    (void)hipFree(din);
-    (void)hipFree(dout);
+    HIP_TRY(h, hipMemcpy(out320, dout.p, sizeof(float) * 320, hipMemcpyDeviceToHost));
     return TETRA_OK;
 }
 

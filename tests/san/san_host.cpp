@@ -1,0 +1,163 @@
+// Sanitizer run of the host-side glue (sdrpp-tetra-demodulator_amd/host/: dsp_compat.h's stream / block / Processor and
+// the PI4DQPSK / PI4DQPSKBank classes), built by tests/test_sanitizers.py under -fsanitize=address,undefined.
+//   san_host            no GPU needed: the stream/worker-thread machinery with a pass-through block (start, temp-stop while
+//                       data flows, stop with a blocked writer and a blocked reader), and the GPU classes' error paths
+//                       (un-initialised use, bad parameters)
+//   san_host gpu        additionally streams chunks through a real PI4DQPSK and a PI4DQPSKBank (run by the -m gpu test)
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "san_host: check failed line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+
+namespace {
+class PassThrough : public dsp::Processor<dsp::complex_t, dsp::complex_t> {
+public:
+    int run() override {
+        int count = _in->read();
+        if (count < 0) return -1;
+        std::memcpy(out.writeBuf, _in->readBuf, sizeof(dsp::complex_t) * (size_t)count);
+        _in->flush();
+        if (!out.swap(count)) return -1;
+        return count;
+    }
+};
+
+int stream_machinery() {
+    dsp::stream<dsp::complex_t> src;
+    PassThrough blk;
+    blk.init(&src);
+    blk.start();
+    std::atomic<long> sum_in{ 0 }, sum_out{ 0 };
+    std::thread feeder([&] {
+        for (int k = 0; k < 200; k++) {
+            const int n = 1 + (k * 37) % 1000;
+            for (int i = 0; i < n; i++) src.writeBuf[i] = dsp::complex_t{ (float)(k + i), -(float)i };
+            sum_in += n;
+            if (!src.swap(n)) return;
+        }
+    });
+    // temp-stops while data flows: like in the reference, a chunk the worker had already taken when it was stopped is dropped
+    // (run() returns -1 from swap() after flush()), so at most one chunk per pause may go missing -- never more, never garbage
+    std::thread pauser([&] { for (int k = 0; k < 20; k++) { blk.tempStop(); blk.tempStart(); } });
+    std::atomic<int> got{ 0 };
+    std::thread sink([&] {
+        for (;;) {
+            const int c = blk.out.read();
+            if (c < 0) return;
+            sum_out += c;
+            blk.out.flush();
+            got++;
+        }
+    });
+    feeder.join();
+    pauser.join();
+    for (int spin = 0; spin < 200 && got < 180; spin++) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    blk.out.stopReader();
+    sink.join();
+    blk.out.clearStops();
+    CHECK(got >= 180 && got <= 200 && sum_out <= sum_in);
+    // stop with the worker blocked in read(), then with a writer blocked in swap()
+    blk.stop();
+    blk.start();
+    std::thread w([&] { src.writeBuf[0] = dsp::complex_t{ 1, 2 }; (void)src.swap(1); (void)src.swap(1); (void)src.swap(1); });
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    blk.stop();
+    src.stopWriter();
+    w.join();
+    return 0;
+}
+
+int error_paths(bool have_gpu) {
+    dsp::demod::PI4DQPSK dem;                         // never initialised
+    std::vector<dsp::complex_t> buf(64);
+    CHECK(dem.lastStatus() != TETRA_OK);
+    CHECK(dem.process(64, buf.data(), buf.data()) < 0);
+    if (!have_gpu) {                                  // init() whose GPU set-up fails: the block exists, every call reports failure
+        tetra_demod_config_t c0;
+        tetra_demod_default_config(&c0);
+        dsp::stream<dsp::complex_t> src;
+        dem.init(&src, c0.symbolrate, c0.samplerate, c0.rrc_tap_count, c0.rrc_beta, c0.agc_rate, c0.costas_bandwidth,
+                 c0.fll_bandwidth, c0.omega_gain, c0.mu_gain, c0.omega_rel_limit);
+        CHECK(dem.lastStatus() != TETRA_OK);
+        dem.setAGCRate(0.1);
+        dem.setRRCParams(33, 0.4);
+        dem.reset();
+        CHECK(dem.lastStatus() != TETRA_OK && dem.process(64, buf.data(), buf.data()) < 0);
+    }
+    dsp::demod::PI4DQPSKBank bank;
+    tetra_demod_config_t cfg;
+    tetra_demod_default_config(&cfg);
+    cfg.n_channels = 0;                               // invalid
+    CHECK(bank.init(cfg) != TETRA_OK);
+    CHECK(bank.process(10, buf.data(), nullptr, nullptr) != TETRA_OK);
+    CHECK(bank.reset() != TETRA_OK && bank.setParam(4, 0.1) != TETRA_OK);
+    if (!have_gpu) {
+        tetra_demod_default_config(&cfg);
+        cfg.n_channels = 4; cfg.max_samples = 256;
+        cfg.device = 12345;                           // no such device
+        CHECK(bank.init(cfg) != TETRA_OK);
+    }
+    return 0;
+}
+
+int gpu_paths() {
+    tetra_demod_config_t cfg;
+    tetra_demod_default_config(&cfg);
+    // the single-channel drop-in, driven from its worker thread, chunks that yield at least one symbol each
+    dsp::stream<dsp::complex_t> src;
+    dsp::demod::PI4DQPSK dem(&src, cfg.symbolrate, cfg.samplerate, cfg.rrc_tap_count, cfg.rrc_beta, cfg.agc_rate,
+                             cfg.costas_bandwidth, cfg.fll_bandwidth, cfg.omega_gain, cfg.mu_gain, cfg.omega_rel_limit);
+    CHECK(dem.lastStatus() == TETRA_OK);
+    dem.start();
+    std::thread feeder([&] {
+        for (int k = 0; k < 40; k++) {
+            const int n = 2 + (k * 97) % 3000;
+            for (int i = 0; i < n; i++) src.writeBuf[i] = dsp::complex_t{ 0.3f * (float)((i >> 1) & 1) - 0.15f, 0.2f * (float)(i & 1) - 0.1f };
+            if (!src.swap(n)) return;
+        }
+    });
+    long syms = 0;
+    for (int k = 0; k < 40; k++) {
+        const int c = dem.out.read();
+        if (c < 0) break;
+        syms += c;
+        dem.out.flush();
+        if (k == 10) { dem.setCostasBandwidth(0.02); dem.setRRCTapCount(33); }
+        if (k == 20) dem.reset();
+    }
+    feeder.join();
+    dem.stop();
+    CHECK(syms > 1000);
+    // the bank with exactly-sized rows
+    dsp::demod::PI4DQPSKBank bank;
+    cfg.n_channels = 19; cfg.max_samples = 1000;
+    CHECK(bank.init(cfg) == TETRA_OK);
+    for (int count : { 1, 63, 1000 }) {
+        std::vector<dsp::complex_t> iq((size_t)19 * count, dsp::complex_t{ 0.1f, -0.2f });
+        const int stride = bank.bitsStride(count);
+        std::vector<uint8_t> bits((size_t)19 * stride);
+        std::vector<int32_t> nb(19);
+        std::vector<dsp::complex_t> sym((size_t)19 * (stride / 2));
+        CHECK(bank.process(count, iq.data(), bits.data(), nb.data(), sym.data()) == TETRA_OK);
+        for (int c = 0; c < 19; c++) CHECK(nb[c] >= 0 && nb[c] <= stride);
+    }
+    CHECK(bank.process(1001, nullptr, nullptr, nullptr) != TETRA_OK);
+    return 0;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
+    if (stream_machinery()) return 1;
+    if (error_paths(gpu)) return 2;
+    if (gpu && gpu_paths()) return 3;
+    std::puts("san_host: ok");
+    return 0;
+}

@@ -2,8 +2,9 @@
 
 Anchors: the restated training-sequence search (oracle/burst_sync_oracle.c) is pinned against the reference's own
 tetra_find_train_seq built into oracle/_ref; the burst layouts are pinned by round trip through the reference's own burst
-builders.  The state machine (tetra_burst_sync_in, which cannot be run from oracle/_ref -- its callback chain ends in
-tetra_lower_mac.c, which needs the ETSI codec sources) is checked against the literal restatement fed one bit per call."""
+builders; and the state machine + demultiplexer are pinned against the reference's own tetra_burst_sync_in() ->
+tetra_burst_rx_cb() RUN from oracle/_ref, with a test-side recorder (tests/refrec/tp_sap_recorder.c) standing where
+tp_sap_udata_ind() -- the lower MAC, which needs the ETSI codec sources -- would be."""
 import json
 import os
 
@@ -122,6 +123,53 @@ def test_literal_state_machine_locks_and_is_chunking_independent_for_small_chunk
         assert all(np.array_equal(a, b) for a, b in zip(res[1][:3], res[chunk][:3])) and res[chunk][3] == st
 
 
+def _expected_tp_sap_calls(oracle, ref, frames, types, bitnums):
+    """What tetra_burst_rx_cb would hand downstream for the frames the restated state machine reported."""
+    out = []
+    for f, t, b in zip(frames, types, bitnums):
+        for tp, blk in ref.RX_CB_BLOCKS.get(int(t), ()):
+            out.append((tp, blk, oracle.bsync_demux(f, int(t), tp, blk), int(b)))
+    return out
+
+
+def _same_calls(got, want):
+    return len(got) == len(want) and all(g[0] == w[0] and g[1] == w[1] and g[3] == w[3] and np.array_equal(g[2], w[2])
+                                         for g, w in zip(got, want))
+
+
+def test_reference_state_machine_run_equals_restatement(ref, oracle):
+    """THE PIN of oracle/burst_sync_oracle.c: the reference's unmodified tetra_burst_sync_in (tetra_burst_sync.c:54-155) and
+    tetra_burst_rx_cb (tetra_burst.c:343-393) run on 80 adversarial streams with the same call pattern as the restatement
+    (1 to 510 bits per call: LOCKED consumes one frame per call, so longer calls overrun the reference's own 4096-bit
+    buffer, tetra_burst_sync.c:38-51,98-101 -- the plugin feeds it a few hundred bits at a time): every tp_sap_udata_ind call
+    -- block kind, block number, the block's bits, the frame's bit number -- and the whole tetra_rx_state after every
+    block of calls are equal."""
+    if not ref.sync_run_available():
+        pytest.skip("oracle/_ref recorder library not available")
+    rng = np.random.default_rng(321)
+    n_calls, kinds = 0, {}
+    for seed in range(80):
+        tx = make_stream(ref, seed)
+        r, o = ref.ReferenceBurstSync(), oracle.BurstSyncOracle()
+        pos = 0
+        while pos < tx.size:
+            n = int(rng.choice([1, 37, 510, 3000, 9000]))
+            chunk = int(rng.choice([1, 1, 2, 7, 100, 509, 510]))
+            blk = tx[pos:pos + n]
+            pos += n
+            got = r.feed(blk, chunk)
+            fo = o.feed(blk, chunk)
+            want = _expected_tp_sap_calls(oracle, ref, *fo)
+            assert _same_calls(got, want), (seed, pos, chunk)
+            assert r.state == o.state, (seed, pos, chunk)
+            assert np.array_equal(r.bitbuf(), o._st[16:16 + o.state[1]]), (seed, pos)
+            n_calls += len(got)
+            for g in got:
+                kinds[(g[0], g[1])] = kinds.get((g[0], g[1]), 0) + 1
+        r.close()
+    assert n_calls > 3000 and all(kinds.get(k, 0) > 100 for k in ((0, 1), (1, 2), (2, 1), (2, 2), (3, 0), (5, 0)))
+
+
 def test_kernel_logic_equals_literal_state_machine(ref, oracle):
     """csrc/bsync_core.hpp built for the host (event-driven, bitmaps, literal fallback) == the literal restatement fed one
     bit per call: frames, types, bit numbers and the carried state after every call, for arbitrary call sizes."""
@@ -179,6 +227,64 @@ def test_gpu_burst_sync_equals_literal_state_machine(pkg, ref, oracle):
                 seen[int(t)] = seen.get(int(t), 0) + 1
     bs.close()
     assert min(seen.get(k, 0) for k in (-1, 0, 1, 3)) > 20
+
+
+@pytest.mark.gpu
+def test_gpu_burst_sync_and_demux_equal_the_reference_run(pkg, ref):
+    """k_burst_sync + k_burst_demux against the REFERENCE's own tetra_burst_sync_in -> tetra_burst_rx_cb run (prebuilt
+    oracle/_ref libraries + the tp_sap_udata_ind recorder), no restatement in between: per channel, the blocks the device
+    demultiplexer produces for each (kind, block number) are the reference's tp_sap_udata_ind calls, in order, and the
+    synchroniser state after every call equals the reference's tetra_rx_state."""
+    import torch
+    if not ref.sync_run_available():
+        pytest.skip("oracle/_ref recorder library not available")
+    bb = pkg.bsync_binding
+    rng = np.random.default_rng(78)
+    Cn, max_bits = 32, 9000
+    streams = [make_stream(ref, 2000 + c) for c in range(Cn)]
+    bs = bb.BurstSync(Cn, max_bits)
+    F = bs.max_frames
+    refs = [ref.ReferenceBurstSync() for _ in range(Cn)]
+    pos = np.zeros(Cn, np.int64)
+    dev = torch.device("cuda", 0)
+    total = 0
+    for call in range(6):
+        stride = (max_bits + 15) & ~15
+        rows = rng.integers(0, 2, (Cn, stride), dtype=np.uint8)
+        nb = np.zeros(Cn, np.int32)
+        for c in range(Cn):
+            n = int(min(rng.choice([1, 300, 4000, 9000]), streams[c].size - pos[c]))
+            rows[c, :n] = streams[c][pos[c]:pos[c] + n]
+            nb[c] = n
+        frames, ft, fb, nf = bs.process(rows, nb)
+        st = bs.states()
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames.reshape(Cn * F, 512))).to(dev)
+        d_types = torch.from_numpy(np.ascontiguousarray(ft.reshape(Cn * F))).to(dev)
+        blocks = {}
+        for tp, blk, width in ((0, 1, 120), (1, 2, 216), (2, 1, 216), (2, 2, 216), (3, 0, 30), (5, 0, 432)):
+            row_stride = (width + 7) & ~7
+            d_rows = torch.zeros((Cn * F, row_stride), dtype=torch.uint8, device=dev)
+            d_valid = torch.zeros((Cn * F,), dtype=torch.int32, device=dev)
+            bb.demux_device(d_frames, d_types, Cn * F, tp, blk, d_rows, row_stride, d_valid)
+            torch.cuda.synchronize()
+            blocks[(tp, blk)] = (d_rows.cpu().numpy().reshape(Cn, F, row_stride)[:, :, :width],
+                                 d_valid.cpu().numpy().reshape(Cn, F))
+        for c in range(Cn):
+            got = refs[c].feed(streams[c][pos[c]:pos[c] + nb[c]], 1)      # the reference, one bit per call
+            pos[c] += nb[c]
+            assert st[c] == refs[c].state, (call, c)
+            dev_calls = []
+            for k in range(nf[c]):
+                for tp, blk in ref.RX_CB_BLOCKS.get(int(ft[c, k]), ()):
+                    rowsk, valid = blocks[(tp, blk)]
+                    assert valid[c, k] == 1
+                    dev_calls.append((tp, blk, rowsk[c, k], int(fb[c, k])))
+            assert _same_calls(got, dev_calls), (call, c)
+            total += len(got)
+    bs.close()
+    for r in refs:
+        r.close()
+    assert total > 1500
 
 
 @pytest.mark.gpu
