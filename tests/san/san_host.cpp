@@ -123,17 +123,26 @@ int gpu_paths() {
             if (!src.swap(n)) return;
         }
     });
-    long syms = 0;
-    for (int k = 0; k < 40; k++) {
-        const int c = dem.out.read();
-        if (c < 0) break;
-        syms += c;
-        dem.out.flush();
-        if (k == 10) { dem.setCostasBandwidth(0.02); dem.setRRCTapCount(33); }
-        if (k == 20) dem.reset();
-    }
+    std::atomic<long> syms{ 0 };
+    std::thread sink([&] {
+        for (;;) {
+            const int c = dem.out.read();
+            if (c < 0) return;
+            syms += c;
+            dem.out.flush();
+        }
+    });
+    // setters and reset() from the control thread while chunks flow (each temp-stops the worker, pi4dqpsk.cpp:32-42)
+    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    dem.setCostasBandwidth(0.02);
+    dem.setRRCTapCount(33);
+    dem.reset();
+    CHECK(dem.lastStatus() == TETRA_OK);
     feeder.join();
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
     dem.stop();
+    dem.out.stopReader();
+    sink.join();
     CHECK(syms > 1000);
     // the bank with exactly-sized rows
     dsp::demod::PI4DQPSKBank bank;

@@ -54,5 +54,5 @@ def test_host_glue_streams_through_the_gpu_under_asan_and_ubsan(pkg):
     sanitizer's reach (and its exit-time leaks are not ours): leak detection is off for this run only."""
     exe = _build_host(pkg)
     env = dict(ENV, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0")
-    r = subprocess.run([exe, "gpu"], env=env, capture_output=True, text=True, timeout=240)
+    r = subprocess.run([exe, "gpu"], env=env, capture_output=True, text=True, timeout=90)
     assert r.returncode == 0 and "san_host: ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
