@@ -34,6 +34,12 @@ SAMPLES = 36000
 BASE_CHANNELS = 64
 ALGO_BYTES_PER_SAMPLE = 9.0
 HBM_PEAK_GBS = 8000.0
+# Useful arithmetic of the chain per input sample at 2 samples/symbol and 65 taps, an fma counted as 2 (DESIGN.md section 4
+# itemises it): AGC 9 + rotation (sine/cosine polynomial + complex multiply) 36 + two band-edge FIRs as four 65-tap real sums
+# 520 + error/loop 12 + RRC 260 + per symbol (3 x 8-tap complex interpolator sums 96, timing loop 12, two rotations 72,
+# Costas loop + slicer 16) / 2 = 98  ->  935 flop per sample.
+FLOP_PER_SAMPLE = 935.0
+VALU_PEAK_TFLOPS = 157.3          # MI355X FP32 vector peak (MI355X_MICROARCH.md)
 
 
 def make_input(torch, synth, device, n_channels, n_samples, seed):
@@ -58,38 +64,69 @@ def make_input(torch, synth, device, n_channels, n_samples, seed):
     return out, txb
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources the dominant kernel is built from: a counter measurement is only as current as this."""
+    import hashlib
+    csrc = os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc")
+    hsh = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".inc", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                hsh.update(name.encode() + b"\0" + f.read())
+    return hsh.hexdigest()
+
+
 def pmc_traffic(pipeline, channels, samples):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/run_rocprof.sh:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md
-    prescribes).  Counters cannot be collected from inside this process, so the committed measurement for
-    the same workload is reported; None if there is none."""
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/run_rocprof.sh: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be
+    collected from inside this process, so the committed measurement for the same workload is reported -- but ONLY if it
+    was taken on the kernel sources of this build (run_rocprof.sh stores kernel_source_hash() in the file); a measurement
+    of other sources is refused: (None, None, reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic_%s_%dx%d.json" % (pipeline, channels, samples))
     try:
         with open(path) as f:
             d = json.load(f)
-            return float(d["traffic_bytes_per_launch"]), d.get("issue")
+        if d.get("kernel_source_sha256") != kernel_source_hash():
+            return None, None, "stale: %s was measured on other kernel sources (re-run profiles/run_rocprof.sh)" % os.path.basename(path)
+        return float(d["traffic_bytes_per_launch"]), d.get("issue"), "bytes per launch (rocprofv3 PMC, %s)" % os.path.basename(path)
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, None, "no counter measurement for this workload under profiles/"
 
 
-def cpu_baseline(synth, n_samples, budget_s=12.0):
-    """Time the CPU oracle (OpenMP over channels, all host threads) on a bounded sample of the same workload:
-    batches of 4 channels per thread x n_samples, streamed back to back (state carried) for ~budget_s seconds."""
+def cpu_baseline(synth, n_samples, budget_s=8.0):
+    """Time the CPU legs on a bounded sample of the same workload: batches of 4 channels per thread x n_samples, streamed
+    back to back (state carried) for ~budget_s seconds each, OpenMP over channels on all host threads.
+      port       oracle/tetra_oracle.c -- the bit-exact checker (-O2, one serial fmaf chain per FIR: built for parity)
+      port-fast  oracle/tetra_fast.c   -- the same chain built for speed (-O3 -march=native -ffast-math, FIR sums over
+                 independent accumulators, blocked RRC); its bits after lock equal the oracle's (tests/test_oracle.py)
+    `threads` = OpenMP threads used, `cores` = physical cores of this host."""
     from oracle import binding as ob
     threads = ob.max_threads()
+    cores = ob.physical_cores()
     n_ch = min(4096, max(8, 4 * threads))
     base, _, _ = synth.gen_batch(min(n_ch, 32), n_samples, base_seed=999)
     iq = np.ascontiguousarray(np.tile(base, ((n_ch + base.shape[0] - 1) // base.shape[0], 1))[:n_ch])
-    _, _, _, states = ob.process_batch(iq, threads=threads)          # warm-up (also locks the loops)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        _, _, _, states = ob.process_batch(iq, threads=threads, states=states)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 400:
-            break
-    return dict(value=round(reps * n_ch * n_samples / el / 1e6, 3), unit="Msamples/s", cores=threads, kind="port",
-                sample="%d x (%d channels x %d samples), %d OpenMP threads, %.1f s" % (reps, n_ch, n_samples, threads, el))
+
+    def leg(kind, call):
+        states = call(None)                                            # warm-up (also locks the loops)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            states = call(states)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or reps >= 400:
+                break
+        return dict(value=round(reps * n_ch * n_samples / el / 1e6, 3), unit="Msamples/s", cores=cores, threads=threads,
+                    kind=kind, per_thread_msamples_s=round(reps * n_ch * n_samples / el / 1e6 / threads, 3),
+                    sample="%d x (%d channels x %d samples), %d OpenMP threads on %d physical cores, %.1f s"
+                           % (reps, n_ch, n_samples, threads, cores, el))
+
+    port = leg("port", lambda st: ob.process_batch(iq, threads=threads, states=st)[3])
+    try:
+        fast = leg("port-fast", lambda st: ob.fast_process_batch(iq, threads=threads, states=st)[2])
+    except Exception as e:          # the baseline must never take the bench line down
+        fast = dict(error=str(e)[:200], kind="port-fast")
+    return port, fast
 
 
 def wideband_config5(args, torch, pkg, device, local_rank):
@@ -145,9 +182,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--config5", action="store_true",
                     help="run BASELINE config 5 instead (wideband -> channeliser -> 800-channel demod); informational")
-    ap.add_argument("--host-path", action="store_true",
-                    help="also time tetra_demod_process (host buffers: H2D + kernel + D2H) and report it as "
-                         "host_path_msamples_s (informational; never the metric value)")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the PCIe-inclusive host-path legs (tetra_demod_process / tetra_demod_process_async on page-locked "
+                         "buffers; informational fields host_path_*, never the metric value)")
+    ap.add_argument("--host-path", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--chain", action="store_true",
                     help="also run the device-resident receive chain behind the demodulator (burst synchroniser -> demultiplexer "
                          "-> lower-MAC decoder; profiles/measure_pipeline*.py) and attach its timings as \"chain\" (informational)")
@@ -230,43 +268,67 @@ def main():
         if errs > 1e-3 * ncmp:
             raise SystemExit("known-answer check failed: %d bit errors in %d bits after lock" % (errs, ncmp))
 
-    host_path = None
-    host_path_pinned = None
-    if args.host_path and rank == 0:
-        h_iq = iq.cpu().numpy()
-        dem.reset()
-        dem.process(h_iq)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            dem.process(h_iq)
-        host_path = 3.0 * C * N / (time.perf_counter() - t1) / 1e6
-        # same entry point with page-locked caller buffers (what a host integration should hand over): the copies inside
-        # tetra_demod_process then run as DMA at PCIe rate instead of through the runtime's pageable staging
+    # End-to-end host path (beside the metric, never the metric): host buffers in, host buffers out, PCIe
+    # included.  Page-locked caller buffers throughout.  sync = tetra_demod_process (copy, kernel, copy);
+    # async = tetra_demod_process_async (time chunks double-buffered, two calls in flight), float and int16 input.
+    host = {}
+    if not args.no_host_path and rank == 0 and world == 1:
         import ctypes
-        stride = pkg.binding.bits_stride(N)
-        p_iq = torch.from_numpy(h_iq).pin_memory()
-        p_bits = torch.zeros((C, stride), dtype=torch.uint8).pin_memory()
-        p_nb = torch.zeros(C, dtype=torch.int32).pin_memory()
-        lib = pkg.binding.load_library()
+        B = pkg.binding
+        lib = B.load_library()
         vp = ctypes.c_void_p
+        h_iq = iq.cpu()
+        p_iq = h_iq.pin_memory()
+        p_bits = [torch.zeros((C, stride), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        p_nb = [torch.zeros(C, dtype=torch.int32).pin_memory() for _ in range(2)]
+        p_q = (torch.view_as_real(h_iq) * 32768.0).round().clamp(-32768, 32767).to(torch.int16).pin_memory()
+        del h_iq
 
-        def pinned_call():
-            rc = lib.tetra_demod_process(dem._h, vp(p_iq.data_ptr()), N, vp(p_bits.data_ptr()), stride, vp(p_nb.data_ptr()), None)
+        def sync_call():
+            rc = lib.tetra_demod_process(dem._h, vp(p_iq.data_ptr()), N, vp(p_bits[0].data_ptr()), stride, vp(p_nb[0].data_ptr()), None)
             if rc:
                 raise SystemExit("tetra_demod_process failed: %d" % rc)
-        dem.reset()
-        pinned_call()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            pinned_call()
-        host_path_pinned = 3.0 * C * N / (time.perf_counter() - t1) / 1e6
+
+        def timed(fn, reps, finish=None):
+            dem.reset()
+            fn(0)
+            if finish:
+                finish()
+            t1 = time.perf_counter()
+            for r in range(reps):
+                fn(r)
+            if finish:
+                finish()
+            return reps * C * N / (time.perf_counter() - t1) / 1e6
+
+        host["host_path_pinned_msamples_s"] = round(timed(lambda r: sync_call(), 3), 1)
+        host["host_path_async_msamples_s"] = round(timed(
+            lambda r: dem.process_async(p_iq.data_ptr(), B.IQ_CF32, N, p_bits[r & 1].data_ptr(), stride, p_nb[r & 1].data_ptr()),
+            6, dem.wait), 1)
+        host["host_path_async_cs16_msamples_s"] = round(timed(
+            lambda r: dem.process_async(p_q.data_ptr(), B.IQ_CS16, N, p_bits[r & 1].data_ptr(), stride, p_nb[r & 1].data_ptr()),
+            6, dem.wait), 1)
+        host["host_path_note"] = ("PCIe-inclusive, page-locked host buffers, informational: sync = tetra_demod_process; async = "
+                                  "tetra_demod_process_async with two calls in flight; cs16 = int16 IQ converted on the GPU")
+        del p_iq, p_q, p_bits, p_nb
 
     if rank == 0:
         total_samples = float(world) * C * N * args.steps
         value = total_samples / elapsed / 1e6
         algo_bytes = ALGO_BYTES_PER_SAMPLE * C * N
-        traffic, issue = pmc_traffic("two_kernel" if args.two_kernel else "fused", C, N)
+        traffic, issue, traffic_unit = pmc_traffic("two_kernel" if args.two_kernel else "fused", C, N)
         achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
+        # the bound that actually binds: FP32 vector issue.  Useful flops / launch time against the vector peak, and the shader
+        # clocks one workgroup (16 channels, one CU) spends per sample of its channels
+        clk_khz, cus = pkg.binding.device_info(local_rank)
+        clk_hz = clk_khz * 1e3
+        valu_tflops = FLOP_PER_SAMPLE * C * N / (k1_ms * 1e-3) / 1e12
+        waves = (C + 15) // 16
+        rounds = max(1, -(-waves // cus))          # workgroups per CU, executed one after the other at this LDS footprint
+        valu = {"achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "flop_per_sample": FLOP_PER_SAMPLE,
+                "cycles_per_sample": round(k1_ms * 1e-3 * clk_hz / N / rounds, 1),
+                "cycles_note": "launch time x %.0f MHz / samples per channel / %d workgroup round(s) per CU" % (clk_hz / 1e6, rounds)}
         out = {
             "metric": "IQ Msamples/s demodulated to bits, batched TETRA channels",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -281,7 +343,8 @@ def main():
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
+                         "traffic_unit": traffic_unit,
+                         "valu": valu,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(k1_ms, 4), "second_kernel_ms": round(k2_ms, 4),
                          "note": "HBM is the roofline BASELINE.json names; the kernel itself is VALU-issue bound "
@@ -289,11 +352,12 @@ def main():
                          "issue_counters": issue},
             "check": check,
         }
-        if host_path is not None:
-            out["host_path_msamples_s"] = round(host_path, 1)
-            out["host_path_pinned_msamples_s"] = round(host_path_pinned, 1)
+        out.update(host)
+        if dist is not None:
+            out["rccl_world_size"] = dist.get_world_size() if args.backend == "nccl" else None
+            out["dist_backend"] = args.backend
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg.synth, N)
+            out["cpu_baseline"], out["cpu_baseline_fast"] = cpu_baseline(pkg.synth, N)
         if args.chain and world == 1:
             dem.close()
             dem = None

@@ -20,6 +20,7 @@
 #ifndef TETRA_DEMOD_H
 #define TETRA_DEMOD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -162,6 +163,30 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
 int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
                         int32_t* n_bits, float* sym);
 
+/*
+ * Asynchronous host entry point: the same call as tetra_demod_process (host buffers in, host buffers out, state carried),
+ * enqueued and pipelined instead of copy -> kernel -> copy.  The call is cut along the time axis into up to eight chunks;
+ * while chunk k is demodulated, chunk k+1 crosses PCIe into the other half of a double buffer, and the call's bits go back on
+ * a third stream -- so up to two calls may be in flight and the steady state is bounded by the input copy alone.  The bits
+ * are exactly those of tetra_demod_process on the same samples (chunks carry state like calls do).
+ *   iq         host memory, in cfg.layout.  PAGE-LOCKED memory (tetra_demod_host_alloc, hipHostMalloc, hipHostRegister)
+ *              is what makes the copies asynchronous; pageable memory works but serialises.
+ *   iq_format  TETRA_IQ_CF32: complex float like the reference's complex_t stream;
+ *              TETRA_IQ_CS16: interleaved int16 (re, im) as SDR hardware delivers it -- converted on the GPU as x / 32768
+ *              (exact in binary32, the scaling SDR++'s sources apply on the host), half the PCIe bytes.
+ *   bits / n_bits   host memory, [n_channels][bits_stride] / [n_channels]; valid after tetra_demod_wait().
+ * The input and output buffers must stay untouched until tetra_demod_wait() returns.  Do not mix with other calls on the
+ * same handle before waiting, except further tetra_demod_process_async calls.  No symbol output on this path.
+ */
+enum { TETRA_IQ_CF32 = 0, TETRA_IQ_CS16 = 1 };
+int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride,
+                              int32_t* n_bits);
+/* Blocks until every tetra_demod_process_async call enqueued on this handle has delivered its output. */
+int tetra_demod_wait(tetra_demod_t* h);
+/* Page-locked host memory for the two calls above, for callers that do not link HIP themselves (NULL on failure). */
+void* tetra_demod_host_alloc(size_t bytes);
+void tetra_demod_host_free(void* p);
+
 /* PI4DQPSK::reset (src/dsp/pi4dqpsk.cpp:120-130); channel = -1 resets all.  Resets the AGC gain, the FLL and PLL loop states,
  * the timing loop and the FIR delay line.  Without TETRA_FLAG_REFERENCE_QUIRKS it also zeroes ph2, COMPLEX_FD's delay buffer,
  * the slicer's previous symbol and the quality statistic (= a fresh chain); with the flag those keep their values like in the
@@ -220,6 +245,8 @@ const char* tetra_demod_strerror(int status);
 /* hipError_t of the last failing HIP call on this handle (0 if none). */
 int tetra_demod_last_hip_error(tetra_demod_t* h);
 int tetra_demod_abi_version(void);
+/* Shader clock (kHz) and compute-unit count of a device, for callers that price a launch in clocks (either may be NULL). */
+int tetra_demod_device_info(int device, int* clock_khz, int* compute_units);
 
 #ifdef __cplusplus
 }

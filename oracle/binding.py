@@ -209,6 +209,73 @@ def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None)
     return bits, nb, sym, states
 
 
+_FAST_LIB_PATH = os.path.join(_HERE, "libtetra_fast.so")
+_fast = None
+
+
+def fast_lib():
+    """oracle/tetra_fast.c: the speed-oriented CPU port (bench.py's "port-fast" baseline leg).  Built -march=native ON THE HOST
+    THAT RUNS IT (a prebuilt file from another machine is rebuilt: its instruction set may not match)."""
+    global _fast
+    if _fast is None:
+        src = os.path.join(_HERE, "tetra_fast.c")
+        stamp = _FAST_LIB_PATH + ".host"
+        host = open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0] if os.path.exists("/proc/cpuinfo") else ""
+        fresh = (os.path.exists(_FAST_LIB_PATH) and os.path.getmtime(src) <= os.path.getmtime(_FAST_LIB_PATH) and
+                 os.path.exists(stamp) and open(stamp).read() == host)
+        if not fresh:
+            subprocess.run(["make", "-C", _HERE, "-B", "libtetra_fast.so"], check=True, stdout=subprocess.DEVNULL)
+            with open(stamp, "w") as f:
+                f.write(host)
+        L = C.CDLL(_FAST_LIB_PATH)
+        vp = C.c_void_p
+        L.tetra_fast_process_batch.argtypes = [C.POINTER(Tables), C.POINTER(State), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                               C.c_int, vp]
+        L.tetra_fast_process_batch.restype = C.c_int
+        _fast = L
+    return _fast
+
+
+def fast_process_batch(iq, cfg=None, chunk=0, threads=0, states=None):
+    """Like process_batch, through the speed-oriented port.  Returns (bits, n_bits, states)."""
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    Cn, N = iq.shape
+    cfg = cfg if cfg is not None else default_cfg()
+    tab = Tables()
+    if lib().tetra_oracle_design(C.byref(cfg), C.byref(tab)) != 0:
+        raise ValueError("tetra_oracle_design failed")
+    if states is None:
+        states = (State * Cn)()
+        for c in range(Cn):
+            lib().tetra_oracle_reset(C.byref(tab), C.byref(states[c]))
+    stride = bits_stride(N)
+    bits = np.zeros((Cn, stride), np.uint8)
+    nb = np.zeros(Cn, np.int32)
+    if fast_lib().tetra_fast_process_batch(C.byref(tab), states, Cn, N, chunk, threads, _ptr(iq), _ptr(bits), stride, _ptr(nb)) != 0:
+        raise RuntimeError("fast port: output row overflow")
+    return bits, nb, states
+
+
+def physical_cores():
+    """Distinct (package, core) pairs of this host; falls back to the logical count."""
+    try:
+        ids, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    ids.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            ids.add((phys, core))
+        return len(ids) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def bits_stride(n_samples):
     """Output row stride used by the tests: >= 2*(N/1.94+1) bits, multiple of 16."""
     s = int(n_samples / 0.95) + 16

@@ -1,15 +1,18 @@
+# rocprofv3 evidence for the bench line (run on the GPU box through gpurun): one --kernel-trace --stats pass and the counter
+# passes, each --pmc run on its own (never combined with other trace domains), then profiles/pmc_summary.py condenses them.
+#   gpurun --timeout 1500 -- 'sh profiles/run_rocprof.sh r02_x'
+# Results land in gpurun_out/prof_out/ ; copy the ones to keep into profiles/.
 set -x
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof
-cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-check"
+TAG=${1:-r02}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof
-rocprofv3 -L > $O/counters_list.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r01 -- $B > $O/trace.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o r01 -- $B > $O/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o r01 -- $B > $O/pmc_write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq -o r01 -- $B > $O/pmc_sq.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o r01 -- $B > $O/pmc_sq2.log 2>&1
-ls -R $O | head -40
-# neighbouring stages: kernel trace of the device-resident chain and of the decoder / scan micro-benchmarks
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe -o pipe -- python $GRAFT_REPO_ROOT/profiles/measure_pipeline.py > $O/pipe.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lmac -o lmac -- python $GRAFT_REPO_ROOT/profiles/measure_lmac.py > $O/lmac.log 2>&1
+rm -rf $O && mkdir -p $O $GRAFT_REPO_ROOT/gpurun_out/prof_out
+cd /tmp && export TMPDIR=/tmp
+B="python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-check --no-host-path"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r02 -- $B > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o r02 -- $B > $O/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o r02 -- $B > $O/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq -o r02 -- $B > $O/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o r02 -- $B > $O/pmc_sq2.log 2>&1
+cd $GRAFT_REPO_ROOT && python profiles/pmc_summary.py $O gpurun_out/prof_out $TAG
+tail -3 $O/trace.log
+cat gpurun_out/prof_out/${TAG}_rocprof_summary.md

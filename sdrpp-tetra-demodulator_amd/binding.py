@@ -29,8 +29,10 @@ EXPORTS = [
     "tetra_demod_set_param", "tetra_demod_get_state", "tetra_demod_set_state", "tetra_demod_get_tables",
     "tetra_demod_debug_read_rrc_out", "tetra_demod_last_kernel_ms", "tetra_demod_strerror",
     "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history", "tetra_demod_get_quality",
-    "tetra_demod_bandedge_tap_count",
+    "tetra_demod_bandedge_tap_count", "tetra_demod_process_async", "tetra_demod_wait", "tetra_demod_host_alloc",
+    "tetra_demod_host_free", "tetra_demod_device_info",
 ]
+IQ_CF32, IQ_CS16 = 0, 1
 
 
 class Config(C.Structure):
@@ -106,9 +108,16 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_debug_selftest.argtypes = [vp, vp, vp]
     L.tetra_demod_kernel_ms_history.argtypes = [vp, i32, vp, vp]
     L.tetra_demod_get_quality.argtypes = [vp, vp, vp]
+    L.tetra_demod_process_async.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    L.tetra_demod_wait.argtypes = [vp]
+    L.tetra_demod_device_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+    L.tetra_demod_host_alloc.argtypes = [C.c_size_t]
+    L.tetra_demod_host_free.argtypes = [vp]
     for name in EXPORTS:
-        if name != "tetra_demod_strerror":
+        if name not in ("tetra_demod_strerror", "tetra_demod_host_alloc", "tetra_demod_host_free"):
             getattr(L, name).restype = i32
+    L.tetra_demod_host_alloc.restype = vp
+    L.tetra_demod_host_free.restype = None
     _lib = L
     return L
 
@@ -118,6 +127,15 @@ def _strerror(status):
         return load_library(False).tetra_demod_strerror(status).decode()
     except Exception:  # pragma: no cover
         return "?"
+
+
+def device_info(device=0):
+    """(shader clock in kHz, compute units) of a device."""
+    clk, cus = C.c_int32(0), C.c_int32(0)
+    rc = load_library().tetra_demod_device_info(int(device), C.byref(clk), C.byref(cus))
+    if rc != 0:
+        raise TetraDemodError(rc, "tetra_demod_device_info")
+    return int(clk.value), int(cus.value)
 
 
 def default_config():
@@ -205,6 +223,16 @@ class Demodulator:
         rc = self._lib.tetra_demod_process(self._h, _np_ptr(iq), n, _np_ptr(bits), stride, _np_ptr(nb), _np_ptr(sym))
         self._check(rc, "tetra_demod_process")
         return bits, nb, sym
+
+    def process_async(self, iq_ptr, iq_format, n_samples, bits_ptr, bits_stride_, n_bits_ptr):
+        """tetra_demod_process_async on raw host addresses (page-locked buffers, e.g. torch pinned tensors' data_ptr() or
+        host_alloc()); the buffers must stay alive and untouched until wait()."""
+        rc = self._lib.tetra_demod_process_async(self._h, C.c_void_p(int(iq_ptr)), int(iq_format), int(n_samples),
+                                                 C.c_void_p(int(bits_ptr)), int(bits_stride_), C.c_void_p(int(n_bits_ptr)))
+        self._check(rc, "tetra_demod_process_async")
+
+    def wait(self):
+        self._check(self._lib.tetra_demod_wait(self._h), "tetra_demod_wait")
 
     def process_device(self, d_iq, n_samples, d_bits, bits_stride_, d_n_bits, d_sym=None, stream=None):
         """Device path: arguments are objects with .data_ptr() (torch tensors on this GPU) or ints."""

@@ -329,6 +329,28 @@ __global__ void k_fill_i32(int* p, int v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// Host-path helpers (tetra_demod_process_async).
+// int16 IQ as most SDR hardware delivers it -> the complex float the chain computes on; x / 32768 is exact in binary32.
+__global__ void k_cs16_to_cf32(const short2* __restrict__ in, float2* __restrict__ out, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const short2 v = in[i];
+        out[i] = make_float2((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
+    }
+}
+// One time chunk's bits appended to the call's output rows: out[c][out_n[c] ..] = chunk[c][0 .. chunk_n[c]).
+__global__ void k_append_bits(const uint8_t* __restrict__ chunk, int chunk_stride, const int* __restrict__ chunk_n,
+                              uint8_t* __restrict__ out, int out_stride, int* __restrict__ out_n) {
+    const int c = blockIdx.x;
+    const int at = out_n[c];
+    int n = chunk_n[c];
+    n = at + n > out_stride ? out_stride - at : n;
+    const uint8_t* src = chunk + (size_t)c * chunk_stride;
+    uint8_t* dst = out + (size_t)c * out_stride + at;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) out_n[c] = at + n;
+}
 __global__ void k_min_i32(int* p, int v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && p[i] > v) p[i] = v;
@@ -377,6 +399,20 @@ struct tetra_demod {
     long long n_calls = 0;      // process calls that launched kernels
     long long* d_prof = nullptr;   // TETRA_DEMOD_PROFILE scratch
     int last_n = 0;
+    // tetra_demod_process_async: three streams, time chunks double-buffered in HBM (see the function)
+    struct Async {
+        bool ready = false;
+        hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+        hipEvent_t ev_in[2] = {}, ev_free[2] = {}, ev_done[2] = {}, ev_out[2] = {};
+        void* d_raw[2] = {};        // int16 input only: the chunk as it came
+        float* d_iq[2] = {};        // the chunk as complex float [C][chunk] (or [chunk][C])
+        uint8_t* d_cbits[2] = {};   // the chunk's bits [C][chunk_stride]
+        int* d_cnb[2] = {};
+        uint8_t* d_out[2] = {};     // a call's bits [C][bits_stride]; two calls may be in flight
+        int* d_onb[2] = {};
+        size_t raw_bytes = 0, iq_bytes = 0, cbits_bytes = 0, out_bytes = 0;
+        long long chunks = 0, calls = 0;
+    } as;
 };
 
 #define HIP_TRY(h, expr)                                  \
@@ -501,6 +537,18 @@ void free_all(tetra_demod* h) {
     for (auto& slot : h->ev)
         for (auto& e : slot)
             if (e) (void)hipEventDestroy(e);
+    auto& a = h->as;
+    for (int i = 0; i < 2; i++) {
+        void* bufs[] = { a.d_raw[i], a.d_iq[i], a.d_cbits[i], a.d_cnb[i], a.d_out[i], a.d_onb[i] };
+        for (void* p : bufs)
+            if (p) (void)hipFree(p);
+        hipEvent_t evs[] = { a.ev_in[i], a.ev_free[i], a.ev_done[i], a.ev_out[i] };
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+    }
+    hipStream_t ss[] = { a.s_in, a.s_k, a.s_out };
+    for (hipStream_t st : ss)
+        if (st) (void)hipStreamDestroy(st);
 }
 
 template <class T> int dalloc(tetra_demod* h, T** p, size_t count) {
@@ -513,6 +561,21 @@ template <class T> int dalloc(tetra_demod* h, T** p, size_t count) {
 extern "C" {
 
 int tetra_demod_abi_version(void) { return TETRA_DEMOD_ABI_VERSION; }
+
+int tetra_demod_device_info(int device, int* clock_khz, int* compute_units) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TETRA_ERR_NO_DEVICE;
+    int v = 0;
+    if (clock_khz) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, device) != hipSuccess) return TETRA_ERR_HIP;
+        *clock_khz = v;
+    }
+    if (compute_units) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return TETRA_ERR_HIP;
+        *compute_units = v;
+    }
+    return TETRA_OK;
+}
 
 const char* tetra_demod_strerror(int status) {
     switch (status) {
@@ -817,6 +880,137 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
     HIP_TRY(h, hipMemcpy(n_bits, h->st_nbits, sizeof(int) * C, hipMemcpyDeviceToHost));
     if (sym) HIP_TRY(h, hipMemcpy(sym, h->st_sym, sym_bytes, hipMemcpyDeviceToHost));
     return TETRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Asynchronous host entry point.  The call is cut along the TIME axis into chunks (state carries from chunk to chunk like
+// from call to call, so the bits are those of one call); chunk k+1 crosses PCIe while chunk k is demodulated:
+//   s_in : H2D of chunk k into slot k%2                      (waits until the kernel that last read that slot is done)
+//   s_k  : [int16 -> float] -> k_fused -> k_append_bits        (waits for the copy)
+//   s_out: D2H of the call's bits and counts                   (waits for the last append)
+// Two calls may be in flight (two output slots), so call j+1's input copy overlaps call j's output copy.
+// ------------------------------------------------------------------------------------------------
+namespace {
+int grow(tetra_demod* h, void** p, size_t* have, size_t want) {
+    if (want <= *have && *p) return TETRA_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    HIP_TRY(h, hipMalloc(p, want));
+    return TETRA_OK;
+}
+
+int async_chunk_len(int n_samples) {
+    int k = n_samples / 4096;
+    k = k < 1 ? 1 : (k > 8 ? 8 : k);
+    const int len = (n_samples + k - 1) / k;
+    return (len + 31) & ~31;
+}
+}  // namespace
+
+int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride,
+                              int32_t* n_bits) {
+    if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
+    if (iq_format != TETRA_IQ_CF32 && iq_format != TETRA_IQ_CS16) return TETRA_ERR_ARG;
+    if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
+    if (bits_stride < tetra_demod_bits_stride(n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    auto& a = h->as;
+    const size_t C = (size_t)h->C;
+    if (!a.ready) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&a.s_in, hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithFlags(&a.s_k, hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithFlags(&a.s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_in[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_free[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_done[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_out[i], hipEventDisableTiming));
+            HIP_TRY(h, hipMalloc((void**)&a.d_cnb[i], sizeof(int) * C));
+            HIP_TRY(h, hipMalloc((void**)&a.d_onb[i], sizeof(int) * C));
+        }
+        a.ready = true;
+    }
+    const int chunk = async_chunk_len(n_samples);
+    const int cstride = tetra_demod_bits_stride(chunk);
+    const size_t in_elem = iq_format == TETRA_IQ_CS16 ? sizeof(short) * 2 : sizeof(float) * 2;
+    const size_t want_iq = sizeof(float) * 2 * C * (size_t)chunk, want_raw = iq_format == TETRA_IQ_CS16 ? in_elem * C * (size_t)chunk : 0;
+    const size_t want_cbits = C * (size_t)cstride, want_out = C * (size_t)bits_stride;
+    if (want_iq > a.iq_bytes || want_raw > a.raw_bytes || want_cbits > a.cbits_bytes || want_out > a.out_bytes) {
+        HIP_TRY(h, hipDeviceSynchronize());          // buffers may be in use by calls still in flight
+        for (int i = 0; i < 2; i++) {
+            int rc;
+            size_t t;
+            t = a.iq_bytes; if ((rc = grow(h, (void**)&a.d_iq[i], &t, want_iq))) return rc;
+            if (want_raw) { t = a.raw_bytes; if ((rc = grow(h, &a.d_raw[i], &t, want_raw))) return rc; }
+            t = a.cbits_bytes; if ((rc = grow(h, (void**)&a.d_cbits[i], &t, want_cbits))) return rc;
+            t = a.out_bytes; if ((rc = grow(h, (void**)&a.d_out[i], &t, want_out))) return rc;
+        }
+        a.iq_bytes = a.iq_bytes > want_iq ? a.iq_bytes : want_iq;
+        if (want_raw) a.raw_bytes = a.raw_bytes > want_raw ? a.raw_bytes : want_raw;
+        a.cbits_bytes = a.cbits_bytes > want_cbits ? a.cbits_bytes : want_cbits;
+        a.out_bytes = a.out_bytes > want_out ? a.out_bytes : want_out;
+    }
+    const int os = (int)(a.calls & 1);               // output slot of this call
+    if (a.calls >= 2) HIP_TRY(h, hipStreamWaitEvent(a.s_k, a.ev_out[os], 0));     // its previous user's D2H is done
+    HIP_TRY(h, hipMemsetAsync(a.d_out[os], 0, want_out, a.s_k));
+    HIP_TRY(h, hipMemsetAsync(a.d_onb[os], 0, sizeof(int) * C, a.s_k));
+    const bool time_major = h->cfg.layout == TETRA_LAYOUT_TIME_MAJOR;
+    const uint8_t* src = static_cast<const uint8_t*>(iq);
+    for (int pos = 0; pos < n_samples; pos += chunk) {
+        const int len = n_samples - pos < chunk ? n_samples - pos : chunk;
+        const int sl = (int)(a.chunks & 1);
+        if (a.chunks >= 2) HIP_TRY(h, hipStreamWaitEvent(a.s_in, a.ev_free[sl], 0));
+        void* dst = iq_format == TETRA_IQ_CS16 ? a.d_raw[sl] : (void*)a.d_iq[sl];
+        if (time_major) {      // iq[n][c]: a time chunk is contiguous
+            HIP_TRY(h, hipMemcpyAsync(dst, src + in_elem * C * (size_t)pos, in_elem * C * (size_t)len, hipMemcpyHostToDevice, a.s_in));
+        } else {               // iq[c][n]: one row piece per channel, packed to [C][len] on the device
+            HIP_TRY(h, hipMemcpy2DAsync(dst, in_elem * (size_t)len, src + in_elem * (size_t)pos, in_elem * (size_t)n_samples,
+                                        in_elem * (size_t)len, C, hipMemcpyHostToDevice, a.s_in));
+        }
+        HIP_TRY(h, hipEventRecord(a.ev_in[sl], a.s_in));
+        HIP_TRY(h, hipStreamWaitEvent(a.s_k, a.ev_in[sl], 0));
+        if (iq_format == TETRA_IQ_CS16) {
+            const long long n = (long long)C * len;
+            hipLaunchKernelGGL(k_cs16_to_cf32, dim3(2048), dim3(256), 0, a.s_k, static_cast<const short2*>(a.d_raw[sl]),
+                               reinterpret_cast<float2*>(a.d_iq[sl]), n);
+            HIP_TRY(h, hipGetLastError());
+        }
+        const int rc = tetra_demod_process_device(h, a.d_iq[sl], len, a.d_cbits[sl], cstride, a.d_cnb[sl], nullptr, a.s_k);
+        if (rc != TETRA_OK) return rc;
+        hipLaunchKernelGGL(k_append_bits, dim3((unsigned)C), dim3(64), 0, a.s_k, a.d_cbits[sl], cstride, a.d_cnb[sl], a.d_out[os],
+                           bits_stride, a.d_onb[os]);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(a.ev_free[sl], a.s_k));
+        a.chunks++;
+    }
+    HIP_TRY(h, hipEventRecord(a.ev_done[os], a.s_k));
+    HIP_TRY(h, hipStreamWaitEvent(a.s_out, a.ev_done[os], 0));
+    HIP_TRY(h, hipMemcpyAsync(bits, a.d_out[os], want_out, hipMemcpyDeviceToHost, a.s_out));
+    HIP_TRY(h, hipMemcpyAsync(n_bits, a.d_onb[os], sizeof(int) * C, hipMemcpyDeviceToHost, a.s_out));
+    HIP_TRY(h, hipEventRecord(a.ev_out[os], a.s_out));
+    a.calls++;
+    return TETRA_OK;
+}
+
+int tetra_demod_wait(tetra_demod_t* h) {
+    if (!h) return TETRA_ERR_ARG;
+    if (!h->as.ready) return TETRA_OK;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipStreamSynchronize(h->as.s_in));
+    HIP_TRY(h, hipStreamSynchronize(h->as.s_k));
+    HIP_TRY(h, hipStreamSynchronize(h->as.s_out));
+    return TETRA_OK;
+}
+
+void* tetra_demod_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void tetra_demod_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int tetra_demod_reset(tetra_demod_t* h, int channel) {

@@ -489,3 +489,47 @@ def test_soak_twelve_seconds_of_signal_with_carried_state(pkg, oracle, synth):
         assert np.float32(st.mu).tobytes() == np.float32(o.mu).tobytes() and st.offset == o.offset
     d.close()
     assert total > Cn * SEC * 35000
+
+
+def _pinned(torch, arr):
+    t = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
+    return t
+
+
+@pytest.mark.parametrize("layout", ["channel_major", "time_major"])
+def test_async_host_path_equals_the_synchronous_one(pkg, oracle, synth, layout):
+    """tetra_demod_process_async (time-axis chunks double-buffered over three streams, up to two calls in flight) returns the
+    bits of tetra_demod_process / the oracle on the same samples, for float input and for int16 input (converted on the GPU as
+    x / 32768), in both layouts, with ragged call sizes (one chunk, several chunks, a last partial chunk)."""
+    import torch
+    B = pkg.binding
+    Cn = 21
+    sizes = [36000, 5000, 9001, 36000]
+    iq, _, _ = synth.gen_batch(Cn, sum(sizes), base_seed=555, amp=0.5)
+    q = np.clip(np.round(iq.view(np.float32) * 32768.0), -32768, 32767).astype(np.int16)      # [Cn][2N] interleaved
+    iq_q = (q.astype(np.float32) / np.float32(32768.0)).view(np.complex64)
+    tm = layout == "time_major"
+    lay = B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR
+    for fmt, data, raw in ((B.IQ_CF32, iq, iq), (B.IQ_CS16, iq_q, q.reshape(Cn, -1, 2))):
+        d = pkg.Demodulator(Cn, max(sizes), layout=lay)
+        orcs = [oracle.Oracle() for _ in range(Cn)]
+        keep, pos = [], 0
+        for n in sizes:
+            blk = raw[:, pos:pos + n]
+            host_in = _pinned(torch, np.swapaxes(blk, 0, 1) if tm else blk)
+            stride = B.bits_stride(n)
+            bits = torch.full((Cn, stride), 7, dtype=torch.uint8).pin_memory()
+            nb = torch.full((Cn,), -1, dtype=torch.int32).pin_memory()
+            d.process_async(host_in.data_ptr(), fmt, n, bits.data_ptr(), stride, nb.data_ptr())
+            keep.append((host_in, bits, nb, pos, n))
+            pos += n
+            if len(keep) % 2 == 0:
+                d.wait()                       # two calls were in flight
+        d.wait()
+        for host_in, bits, nb, p0, n in keep:
+            bits, nb = bits.numpy(), nb.numpy()
+            for c in range(Cn):
+                r = orcs[c].process(data[c, p0:p0 + n])
+                assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (fmt, c, p0)
+                assert not bits[c][nb[c]:].any()
+        d.close()

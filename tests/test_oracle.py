@@ -175,3 +175,18 @@ def test_golden_fixture(oracle, name):
         assert np.array_equal(r["sym"].view(np.uint32), g["sym"][c][:nb // 2].view(np.uint32))
         assert np.float32(o.st.fll_freq).view(np.uint32) == g["fll_freq"][c].view(np.uint32)
         assert np.float32(o.st.omega).view(np.uint32) == g["omega"][c].view(np.uint32)
+
+
+def test_fast_port_decides_like_the_oracle(oracle, synth):
+    """oracle/tetra_fast.c (bench.py's "port-fast" CPU baseline: -O3 -march=native -ffast-math, independent accumulators) is
+    the same chain: same symbol counts, and once the loops have locked every bit equals the oracle's and the transmitted one."""
+    iq, txb, _ = synth.gen_batch(6, 24000, base_seed=4242)
+    b0, n0, _, st0 = oracle.process_batch(iq, threads=2)
+    b1, n1, st1 = oracle.fast_process_batch(iq, chunk=5000, threads=2)
+    assert np.array_equal(n0, n1)
+    for c in range(6):
+        h = n0[c] // 2
+        assert np.array_equal(b0[c][h:n0[c]], b1[c][h:n1[c]]), c
+        lag, err, n = synth.align_and_count_errors(b1[c][:n1[c]], txb[c], skip=h)
+        assert err == 0 and n > 11000
+        assert abs(st0[c].agc_gain - st1[c].agc_gain) < 1e-3 * st0[c].agc_gain and st0[c].offset == st1[c].offset
