@@ -15,6 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 KERNEL = "k_fused"
+STEPS = 6            # --steps of the profiled command: the last STEPS launches are its timed region
 
 
 def counters(path):
@@ -26,8 +27,8 @@ def counters(path):
         for row in csv.DictReader(f):
             if KERNEL in row["Kernel_Name"]:
                 acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    # the first launch of a run is the warm-up step (cold caches): drop it when there are others
-    return {k: sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0] for k, v in acc.items()}
+    # the timed region = the last STEPS launches (before them: clock-ramp and warm-up passes)
+    return {k: sum(v[-STEPS:]) / len(v[-STEPS:]) for k, v in acc.items()}
 
 
 def main(prof, out, tag, C=4096, N=36000):
@@ -43,6 +44,14 @@ def main(prof, out, tag, C=4096, N=36000):
         w.writeheader()
         for row in stats_rows[:12]:
             w.writerow(row)
+    # per-launch durations in launch order: the first launches after idle run on a ramping clock (bench.py RAMP_STEPS)
+    durs = []
+    with open(os.path.join(prof, "trace", "r02_kernel_trace.csv"), newline="") as f:
+        for row in csv.DictReader(f):
+            if KERNEL in row["Kernel_Name"]:
+                durs.append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6))
+    durs = [d for _, d in sorted(durs)]
+    timed = durs[-STEPS:]
     c = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         c.update(counters(os.path.join(prof, sub, "r02_counter_collection.csv")))
@@ -70,6 +79,7 @@ def main(prof, out, tag, C=4096, N=36000):
     import bench
     d = {"kernel": KERNEL, "workload": "%dx%d" % (C, N), "kernel_source_sha256": bench.kernel_source_hash(),
          "kernel_trace_avg_ms": round(avg_ms, 4), "kernel_trace_calls": int(kern["Calls"]),
+         "kernel_trace_timed_region_avg_ms": round(sum(timed) / len(timed), 4), "kernel_trace_launch_ms": [round(d, 4) for d in durs],
          "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "traffic_bytes_per_launch": traffic,
          "algorithmic_bytes_per_launch": algo,
          "correction": "FETCH_SIZE KiB*1024*2 (gfx950 half-count of wide coalesced reads) + WRITE_SIZE KiB*1024",
@@ -82,8 +92,12 @@ def main(prof, out, tag, C=4096, N=36000):
         f.write("## --kernel-trace --stats (top rows; full table in %s_kernel_stats.csv)\n\n| kernel | calls | avg ms | %% |\n|---|---|---|---|\n" % tag)
         for row in stats_rows[:6]:
             f.write("| `%s` | %s | %.4f | %s |\n" % (row["Name"][:100], row["Calls"], float(row["AverageNs"]) / 1e6, row["Percentage"]))
-        f.write("\n**%s: %.4f ms average over %s launches** -> 9 B x %d x %d = %.3f GB / launch -> %.1f GB/s = %.2f %% of 8 TB/s\n\n"
+        f.write("\n%s, --stats row: %.4f ms average over ALL %s launches -> 9 B x %d x %d = %.3f GB / launch -> %.1f GB/s = %.2f %% of 8 TB/s\n\n"
                 % (KERNEL, avg_ms, kern["Calls"], C, N, algo / 1e9, algo / avg_ms / 1e6, algo / avg_ms / 1e6 / 80.0))
+        f.write("launch by launch (ms): %s\n\n**timed region (last %d launches, what bench.py's HIP events cover): %.4f ms average** -> %.1f GB/s = "
+                "%.2f %% of 8 TB/s; the launches before it are bench.py's clock-ramp and warm-up passes\n\n"
+                % (", ".join("%.3f" % d for d in durs), len(timed), sum(timed) / len(timed), algo / (sum(timed) / len(timed)) / 1e6,
+                   algo / (sum(timed) / len(timed)) / 1e6 / 80.0))
         f.write("## counters per launch (separate --pmc passes)\n\n| counter | per launch |\n|---|---|\n")
         for k in sorted(c):
             f.write("| %s | %.4g |\n" % (k, c[k]))
