@@ -97,5 +97,101 @@ int PI4DQPSKBank::process(int count, const complex_t* in, uint8_t* bits, int32_t
 int PI4DQPSKBank::reset(int channel) { return h_ ? tetra_demod_reset(h_, channel) : TETRA_ERR_ARG; }
 int PI4DQPSKBank::setParam(int id, double v) { return h_ ? tetra_demod_set_param(h_, id, v) : TETRA_ERR_ARG; }
 
+PI4DQPSKMultiBank::~PI4DQPSKMultiBank() { shutdown(); }
+
+void PI4DQPSKMultiBank::shutdown() {
+    {
+        std::lock_guard<std::mutex> l(m_);
+        quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto& s : shards_)
+        if (s->worker.joinable()) s->worker.join();
+    for (auto& s : shards_)
+        if (s->h) tetra_demod_destroy(s->h);
+    shards_.clear();
+    quit_ = false;
+    epoch_ = 0;
+    pending_ = 0;
+}
+
+int PI4DQPSKMultiBank::init(const tetra_demod_config_t& cfg, const std::vector<int>& devices) {
+    shutdown();
+    const int G = (int)devices.size();
+    if (G < 1 || cfg.n_channels < G) return TETRA_ERR_ARG;
+    if (cfg.layout != TETRA_LAYOUT_CHANNEL_MAJOR) return TETRA_ERR_UNSUPPORTED;   // a shard's rows must be one contiguous block
+    channels_ = cfg.n_channels;
+    const int q = channels_ / G, r = channels_ % G;
+    for (int g = 0; g < G; g++) {
+        std::unique_ptr<Shard> s(new Shard());
+        s->device = devices[g];
+        s->first = g * q + (g < r ? g : r);
+        s->count = q + (g < r ? 1 : 0);
+        tetra_demod_config_t c = cfg;
+        c.n_channels = s->count;
+        c.device = s->device;
+        const int rc = tetra_demod_create(&c, &s->h);
+        if (rc != TETRA_OK) { shutdown(); return rc; }
+        shards_.push_back(std::move(s));
+    }
+    for (auto& s : shards_) s->worker = std::thread([this, p = s.get()] { workerLoop(p); });
+    return TETRA_OK;
+}
+
+void PI4DQPSKMultiBank::workerLoop(Shard* s) {
+    long long seen = 0;
+    for (;;) {
+        Job j;
+        {
+            std::unique_lock<std::mutex> l(m_);
+            cv_.wait(l, [&] { return quit_ || epoch_ != seen; });
+            if (quit_) return;
+            seen = epoch_;
+            j = job_;
+        }
+        // this shard's rows of the caller's buffers; its own handle, device and streams
+        const size_t stride = (size_t)tetra_demod_bits_stride(j.count);
+        int rc = tetra_demod_process_async(s->h, j.in + (size_t)s->first * (size_t)j.count, TETRA_IQ_CF32, j.count,
+                                           j.bits + (size_t)s->first * stride, (int)stride, j.nBits + s->first);
+        if (rc == TETRA_OK) rc = tetra_demod_wait(s->h);
+        {
+            std::lock_guard<std::mutex> l(m_);
+            s->status = rc;
+            pending_--;
+        }
+        cv_.notify_all();
+    }
+}
+
+int PI4DQPSKMultiBank::process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits) {
+    if (shards_.empty() || !in || !bits || !nBits) return TETRA_ERR_ARG;
+    std::unique_lock<std::mutex> l(m_);
+    job_.count = count; job_.in = in; job_.bits = bits; job_.nBits = nBits;
+    pending_ = (int)shards_.size();
+    epoch_++;
+    cv_.notify_all();
+    cv_.wait(l, [&] { return pending_ == 0; });
+    for (auto& s : shards_)
+        if (s->status != TETRA_OK) return s->status;
+    return TETRA_OK;
+}
+
+int PI4DQPSKMultiBank::reset() {
+    if (shards_.empty()) return TETRA_ERR_ARG;
+    for (auto& s : shards_) { const int rc = tetra_demod_reset(s->h, -1); if (rc != TETRA_OK) return rc; }
+    return TETRA_OK;
+}
+
+int PI4DQPSKMultiBank::setParam(int id, double v) {
+    if (shards_.empty()) return TETRA_ERR_ARG;
+    for (auto& s : shards_) { const int rc = tetra_demod_set_param(s->h, id, v); if (rc != TETRA_OK) return rc; }
+    return TETRA_OK;
+}
+
+void PI4DQPSKMultiBank::shardInfo(int shard, int& first, int& count, int& device) const {
+    const Shard& s = *shards_.at((size_t)shard);
+    first = s.first; count = s.count; device = s.device;
+}
+
 }  // namespace demod
 }  // namespace dsp

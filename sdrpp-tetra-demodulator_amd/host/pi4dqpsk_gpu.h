@@ -10,8 +10,14 @@
 // dsp::demod::PI4DQPSKBank    the batched form the GPU is built for: C channels per call, returns the unpacked
 //                             bit streams tetra_burst_sync_in() eats (src/decoder/src/phy/tetra_burst_sync.c:54),
 //                             i.e. PI4DQPSK + DQPSKSymbolExtractor + BitUnpacker for every channel at once.
+// dsp::demod::PI4DQPSKMultiBank  a bank spread over the GPUs of one node from ONE process: one handle, host thread and
+//                             stream set per device, channel ranges, nothing exchanged.
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/tetra_demod.h"
@@ -100,6 +106,51 @@ public:
 private:
     tetra_demod_t* h_ = nullptr;
     int channels_ = 0;
+};
+
+// One node, G GPUs, one process: the channel axis cut into G contiguous ranges (sizes differ by at most one, the rule of
+// shard.channel_range), each range a tetra_demod handle on its own device driven by its own host thread and its own HIP
+// streams (tetra_demod_process_async).  Channels are independent chains, so nothing is exchanged between the shards -- the
+// in-process counterpart of bench.py's one-rank-per-GPU launch.  `devices` may name a device more than once (two shards on
+// one GPU: how the single-GPU test exercises two handles concurrently from two threads).
+class PI4DQPSKMultiBank {
+public:
+    PI4DQPSKMultiBank() {}
+    ~PI4DQPSKMultiBank();
+    PI4DQPSKMultiBank(const PI4DQPSKMultiBank&) = delete;
+    PI4DQPSKMultiBank& operator=(const PI4DQPSKMultiBank&) = delete;
+
+    // cfg.n_channels = ALL channels (>= devices.size()); cfg.device is ignored; channel-major layout only.
+    int init(const tetra_demod_config_t& cfg, const std::vector<int>& devices);
+    // in: [n_channels][count] (page-locked memory makes the shards' copies overlap); bits: [n_channels][bitsStride(count)];
+    // nBits: [n_channels].  Runs every shard concurrently and returns when all are done: TETRA_OK or the first failure.
+    int process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits);
+    int bitsStride(int count) const { return tetra_demod_bits_stride(count); }
+    int reset();
+    int setParam(int paramId, double value);
+    int channels() const { return channels_; }
+    int shards() const { return (int)shards_.size(); }
+    // channel range [first, first + count) and device of a shard
+    void shardInfo(int shard, int& first, int& count, int& device) const;
+
+private:
+    struct Shard {
+        tetra_demod_t* h = nullptr;
+        int device = 0, first = 0, count = 0;
+        std::thread worker;
+        int status = TETRA_OK;
+    };
+    struct Job { int count = 0; const complex_t* in = nullptr; uint8_t* bits = nullptr; int32_t* nBits = nullptr; };
+    void workerLoop(Shard* s);
+    void shutdown();
+    std::vector<std::unique_ptr<Shard>> shards_;
+    int channels_ = 0;
+    std::mutex m_;
+    std::condition_variable cv_;
+    Job job_;
+    long long epoch_ = 0;      // bumped per process() call; each worker runs every epoch once
+    int pending_ = 0;
+    bool quit_ = false;
 };
 
 }  // namespace demod

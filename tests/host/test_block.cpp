@@ -5,12 +5,62 @@
 // Without arguments: only constructs the classes (compile/link check; needs no GPU).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
 #include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
 
+// test_block multibank <iq.f32 [C][n]> <C> <n> <calls> <out_bits.u8> <out_nbits.i32> [dev0 dev1 ...]
+// PI4DQPSKMultiBank over the given devices (default: 0 0 = two shards, two host threads, two handles on ONE GPU), the
+// stream cut into `calls` equal calls; writes every call's bit rows [calls][C][stride] and counts [calls][C].
+static int multibank_main(int argc, char** argv) {
+    const int C = std::atoi(argv[3]), n = std::atoi(argv[4]), calls = std::atoi(argv[5]);
+    std::vector<int> devs;
+    for (int i = 8; i < argc; i++) devs.push_back(std::atoi(argv[i]));
+    if (devs.empty()) devs = { 0, 0 };
+    std::vector<float> iq((size_t)C * n * 2);
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f || std::fread(iq.data(), sizeof(float), iq.size(), f) != iq.size()) return 2;
+    std::fclose(f);
+    const int per = n / calls;
+    tetra_demod_config_t cfg;
+    tetra_demod_default_config(&cfg);
+    cfg.n_channels = C;
+    cfg.max_samples = per;
+    dsp::demod::PI4DQPSKMultiBank mb;
+    int rc = mb.init(cfg, devs);
+    if (rc != TETRA_OK) { std::fprintf(stderr, "init failed: %s\n", tetra_demod_strerror(rc)); return 3; }
+    const int stride = mb.bitsStride(per);
+    // page-locked buffers: the shards' copies then really run side by side
+    dsp::complex_t* in = (dsp::complex_t*)tetra_demod_host_alloc(sizeof(dsp::complex_t) * (size_t)C * per);
+    uint8_t* bits = (uint8_t*)tetra_demod_host_alloc((size_t)C * stride);
+    int32_t* nb = (int32_t*)tetra_demod_host_alloc(sizeof(int32_t) * C);
+    if (!in || !bits || !nb) return 4;
+    FILE* fb = std::fopen(argv[6], "wb");
+    FILE* fn = std::fopen(argv[7], "wb");
+    for (int k = 0; k < calls; k++) {
+        for (int c = 0; c < C; c++)
+            std::memcpy(in + (size_t)c * per, iq.data() + 2 * ((size_t)c * n + (size_t)k * per), sizeof(dsp::complex_t) * per);
+        rc = mb.process(per, in, bits, nb);
+        if (rc != TETRA_OK) { std::fprintf(stderr, "process failed: %s\n", tetra_demod_strerror(rc)); return 5; }
+        std::fwrite(bits, 1, (size_t)C * stride, fb);
+        std::fwrite(nb, sizeof(int32_t), C, fn);
+        if (k == calls / 2 && mb.setParam(TETRA_PARAM_AGC_RATE, 0.02) != TETRA_OK) return 6;   // a setter reaches every shard
+    }
+    std::fclose(fb);
+    std::fclose(fn);
+    for (int g = 0; g < mb.shards(); g++) {
+        int first, count, dev;
+        mb.shardInfo(g, first, count, dev);
+        std::printf("shard %d: channels [%d, %d) on device %d\n", g, first, first + count, dev);
+    }
+    tetra_demod_host_free(in); tetra_demod_host_free(bits); tetra_demod_host_free(nb);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 8 && !std::strcmp(argv[1], "multibank")) return multibank_main(argc, argv);
     tetra_demod_config_t cfg;
     tetra_demod_default_config(&cfg);
     if (argc < 5) {

@@ -158,6 +158,19 @@ int gpu_paths() {
         for (int c = 0; c < 19; c++) CHECK(nb[c] >= 0 && nb[c] <= stride);
     }
     CHECK(bank.process(1001, nullptr, nullptr, nullptr) != TETRA_OK);
+    // two shards on one device: two worker threads, two handles, exactly-sized pageable rows
+    dsp::demod::PI4DQPSKMultiBank mb;
+    cfg.n_channels = 9; cfg.max_samples = 6000;
+    CHECK(mb.init(cfg, { 0, 0 }) == TETRA_OK && mb.shards() == 2);
+    for (int count : { 6000, 33, 4097 }) {
+        std::vector<dsp::complex_t> iq((size_t)9 * count, dsp::complex_t{ 0.2f, 0.1f });
+        const int stride = mb.bitsStride(count);
+        std::vector<uint8_t> bits((size_t)9 * stride);
+        std::vector<int32_t> nb(9);
+        CHECK(mb.process(count, iq.data(), bits.data(), nb.data()) == TETRA_OK);
+        for (int c = 0; c < 9; c++) CHECK(nb[c] >= 0 && nb[c] <= stride);
+    }
+    CHECK(mb.reset() == TETRA_OK && mb.setParam(TETRA_PARAM_FLL_BANDWIDTH, 0.004) == TETRA_OK);
     return 0;
 }
 }  // namespace

@@ -44,3 +44,33 @@ def test_block_mirror_streams_like_the_plugin(pkg, oracle, synth, tmp_path):
     r = oracle.Oracle().process(iq)
     assert np.array_equal(sym.view(np.uint32), r["sym"].view(np.uint32))
     assert np.array_equal(bits, r["bits"])
+
+
+@pytest.mark.gpu
+def test_multibank_two_shards_two_threads_one_device(pkg, oracle, synth, tmp_path):
+    """PI4DQPSKMultiBank with devices {0, 0}: two handles on ONE GPU, each driven by its own host thread through its own
+    HIP streams at the same time (the "one handle per thread, no global state" claim of include/tetra_demod.h), over five
+    calls with a setter in the middle.  Every channel's bits equal the oracle's; the split follows shard.channel_range."""
+    exe = _build(pkg)
+    Cn, n, calls = 37, 20000, 5
+    iq, _, _ = synth.gen_batch(Cn, n, base_seed=4100)
+    f_in = tmp_path / "iq.f32"
+    np.ascontiguousarray(iq).view(np.float32).tofile(f_in)
+    f_bits, f_nb = tmp_path / "bits.u8", tmp_path / "nb.i32"
+    r = subprocess.run([exe, "multibank", str(f_in), str(Cn), str(n), str(calls), str(f_bits), str(f_nb), "0", "0"],
+                       check=True, timeout=300, capture_output=True, text=True)
+    lo0, hi0 = pkg.shard.channel_range(Cn, 2, 0)
+    lo1, hi1 = pkg.shard.channel_range(Cn, 2, 1)
+    assert "shard 0: channels [%d, %d) on device 0" % (lo0, hi0) in r.stdout
+    assert "shard 1: channels [%d, %d) on device 0" % (lo1, hi1) in r.stdout
+    per = n // calls
+    stride = pkg.binding.bits_stride(per)
+    bits = np.fromfile(f_bits, np.uint8).reshape(calls, Cn, stride)
+    nb = np.fromfile(f_nb, np.int32).reshape(calls, Cn)
+    for c in range(Cn):
+        o = oracle.Oracle()
+        for k in range(calls):
+            want = o.process(iq[c, k * per:(k + 1) * per])["bits"]
+            assert nb[k, c] == want.size and np.array_equal(bits[k, c, :want.size], want), (c, k)
+            if k == calls // 2:
+                o.set_param(4, 0.02)
