@@ -10,7 +10,7 @@ range -- channels are independent, so there is no data-path collective; RCCL is 
 barrier and the max-over-ranks of the elapsed time ("weak" scaling).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel (k_fused, the whole chain in one launch; k1_agc_fll_rrc with --two-kernel):
+  roofline      dominant kernel (k_fused, the whole chain in one launch):
                 algorithmic bytes (9 B per input sample: 8 B IQ read + 1 B bit written, SURVEY.md section
                 8(d)) / its mean launch duration from HIP events recorded on the launch stream inside the
                 timed region, against 8 TB/s HBM peak;
@@ -179,7 +179,6 @@ def main():
     ap.add_argument("--samples", type=int, default=SAMPLES, help="samples per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--two-kernel", action="store_true", help="run the two-kernel pipeline instead of the fused kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--config5", action="store_true",
                     help="run BASELINE config 5 instead (wideband -> channeliser -> 800-channel demod); informational")
@@ -224,7 +223,7 @@ def main():
     stride = pkg.binding.bits_stride(N)
     bits = torch.zeros((C, stride), dtype=torch.uint8, device=device)
     nbits = torch.zeros(C, dtype=torch.int32, device=device)
-    dem = pkg.Demodulator(C, N, device=local_rank, flags=1 if args.two_kernel else 0)
+    dem = pkg.Demodulator(C, N, device=local_rank, flags=0)
     stream = torch.cuda.current_stream(device)
 
     def step():
@@ -325,7 +324,7 @@ def main():
         total_samples = float(world) * C * N * args.steps
         value = total_samples / elapsed / 1e6
         algo_bytes = ALGO_BYTES_PER_SAMPLE * C * N
-        traffic, issue, traffic_unit = pmc_traffic("two_kernel" if args.two_kernel else "fused", C, N)
+        traffic, issue, traffic_unit = pmc_traffic("fused", C, N)
         achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
         # the bound that actually binds: FP32 vector issue.  Useful flops / launch time against the vector peak, and the shader
         # clocks one workgroup (16 channels, one CU) spends per sample of its channels
@@ -347,8 +346,8 @@ def main():
             "config": {"workload": "%d channels/GPU x %d complex64 samples (1 s @ 36 ksps), 65-tap RRC, "
                                    "pi/4-DQPSK Es/N0 25 dB, state carried" % (C, N),
                        "channels_per_gpu": C, "samples_per_channel": N, "sharding": "channel ranges, no collective",
-                       "pipeline": "two_kernel" if args.two_kernel else "fused"},
-            "roofline": {"bound": "hbm", "kernel": "k1_agc_fll_rrc" if args.two_kernel else "k_fused",
+                       "pipeline": "fused"},
+            "roofline": {"bound": "hbm", "kernel": "k_fused",
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic,

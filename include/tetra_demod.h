@@ -32,7 +32,7 @@ extern "C" {
 enum {
     TETRA_OK = 0,
     TETRA_ERR_ARG = -1,         /* NULL / out-of-range argument */
-    TETRA_ERR_UNSUPPORTED = -2, /* parameter outside what the kernels implement (e.g. > 80 RRC taps) */
+    TETRA_ERR_UNSUPPORTED = -2, /* parameter outside what the kernel implements (e.g. > 72 RRC taps) */
     TETRA_ERR_NO_DEVICE = -3,   /* no HIP device / bad ordinal */
     TETRA_ERR_HIP = -4,         /* a HIP runtime call failed (see tetra_demod_last_hip_error) */
     TETRA_ERR_NOMEM = -5,
@@ -42,8 +42,8 @@ enum {
 
 /* tetra_demod_config_t.flags */
 enum {
-    TETRA_FLAG_TWO_KERNEL = 1,   /* run the two-kernel pipeline (AGC+FLL+RRC kernel -> HBM scratch -> timing/Costas kernel)
-                                    instead of the fused single-kernel pipeline */
+    TETRA_FLAG_RETIRED_TWO_KERNEL = 1, /* ABI 1's two-kernel pipeline was retired in ABI 2: tetra_demod_create refuses the flag
+                                    (TETRA_ERR_UNSUPPORTED).  With it went tap counts 73..80: rrc_tap_count is 2..72. */
     TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
     TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
     TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
@@ -75,7 +75,7 @@ typedef struct tetra_demod_config {
     int32_t device;          /* HIP device ordinal; -1 = current device */
     double symbolrate;       /* 18000 */
     double samplerate;       /* 36000 */
-    int32_t rrc_tap_count;   /* 65; 2..80 supported (the fused kernel covers <= 72, longer filters run the two-kernel pipeline) */
+    int32_t rrc_tap_count;   /* 65; 2..72 supported (the reference builds with RRC_TAP_COUNT 65, src/main.cpp:36) */
     int32_t flags;           /* TETRA_FLAG_* */
     double rrc_beta;         /* 0.35 */
     double agc_rate;         /* 0.02 */
@@ -223,13 +223,12 @@ int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
 int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync);
 
 /* Debug/verification tap: RRC output (timing-recovery input) of the last process call,
- * y[n_channels][n_samples] complex64 channel-major, copied to host memory.  Needs TETRA_FLAG_TWO_KERNEL or
+ * y[n_channels][n_samples] complex64 channel-major, copied to host memory.  Needs
  * TETRA_FLAG_KEEP_RRC_OUT (TETRA_ERR_UNSUPPORTED otherwise). */
 int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples);
 
 /* GPU time of the kernels of the most recent process call, from HIP events recorded on the call's stream
- * (synchronises on them).  Fused pipeline: k1 = the fused kernel, k2 = 0.  Two-kernel pipeline:
- * k1 = AGC+FLL+RRC, k2 = timing+Costas+slicer. */
+ * (synchronises on them): k1 = k_fused; k2 = 0 (the slot of ABI 1's second kernel, kept for the signature). */
 int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms);
 /* Same for the n (1..64) most recent kernel-launching process calls, oldest first: k1_ms[n], k2_ms[n]
  * (either may be NULL).  The events are recorded on each call's own stream, so a benchmark can read the

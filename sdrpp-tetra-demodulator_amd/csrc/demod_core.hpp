@@ -38,9 +38,7 @@
 namespace tdm {
 
 constexpr float kFlPi = 3.1415926535f;       // SDR++ core FL_M_PI
-constexpr int kLanes = 16;                    // lanes per channel row (one DPP row)
-constexpr int kTapsPerLane = 5;               // taps applied per lane visit
-constexpr int kPadTaps = kLanes * kTapsPerLane;  // 80: max FIR length of the systolic array
+constexpr int kPadTaps = 80;                  // table capacity of the C ABI (get_tables, channel_state.hist); filters are <= 72 taps
 constexpr int kHist = kPadTaps;               // stored delay-line samples per channel
 constexpr int kInterpPhases = 128;
 constexpr int kInterpTaps = 8;
@@ -339,17 +337,7 @@ template <class V, bool CLAMP, bool ALPHA0 = false> TD_FN void pcl_advance(V err
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel 1 row program: AGC -> FLL -> RRC for one channel on a 16-lane row.
-//
-// The three 65-tap FIRs (two conjugate band-edge filters evaluated as four real sums, one RRC) run
-// as ONE systolic array along the row.  Taps are zero-padded at the old end to 80 = 16 lanes x 5;
-// padded tap kp lives in lane 15 - kp/5, slot kp%5, so lane 0 owns the five newest taps.  The
-// derotated sample x_i is produced in lane 0 and travels outward one lane per step (row_shr:1);
-// partial sums are created in lane 15 and travel inward one lane per four steps (row_shl:1, zero fill),
-// receiving their taps in ascending tap order -- bit-identical to a direct-form fmaf chain
-// `for k: acc = fmaf(hist[k], tap[k], acc)` -- and complete in lane 0 in the very step that
-// produces x_i, where the FLL error needs them.  Only the newest tap sits on the per-sample
-// critical path.  Lanes 1..15 execute the scalar loop code on don't-care data.
+// AGC and FLL constants + the AGC step (sample rate side of the chain).
 // ---------------------------------------------------------------------------------------------
 struct K1Consts {
     float agc_set_point, agc_rate, agc_max_gain;
@@ -365,123 +353,6 @@ template <class V> TD_FN Pair<V> agc_step(const K1Consts& k, Pair<V> in, V& g) {
     return Pair<V>(ar, ai);
 }
 
-template <class V> struct K1Row {
-    typedef Pair<V> P;
-    // per-lane tap blocks (slot j = padded tap 5*(15-lane)+j): band-edge re / im (lower filter), RRC
-    V ta[kTapsPerLane], tb[kTapsPerLane], th[kTapsPerLane];
-    // resident partial sums (4 per lane per group): (S1,S4) = x*(a,a), (S3,S2) = x*(b,b), (y.re,y.im) = x*(h,h)
-    P r14[4], r32[4], ry[4];
-    P xs;          // x pipeline register: lane l holds x_{i-l}
-    V g, ph, fr;   // AGC gain, FLL phase, FLL freq (meaningful in lane 0)
-
-    TD_MFN void clear_pipeline() {
-        for (int q = 0; q < 4; q++) { r14[q] = P(V(0.0f), V(0.0f)); r32[q] = P(V(0.0f), V(0.0f)); ry[q] = P(V(0.0f), V(0.0f)); }
-        xs = P(V(0.0f), V(0.0f));
-    }
-
-    // One sample step.  PH = step index mod 4 (selects which resident register is oldest).
-    // REPLAY: `in` is a stored delay-line sample x (no AGC/FLL, loop state untouched).
-    // ALPHA0: the FLL loop's alpha is exactly 0 (fll.cpp:25 forces it), so `freq + alpha*err` is `freq`.
-    // Returns the completed RRC output y_i (valid in lane 0; don't-care when REPLAY).
-    template <int PH, bool REPLAY, bool ALPHA0> TD_MFN P step(const K1Consts& k, P in) {
-        P x;
-        if (REPLAY) {
-            x = in;
-        } else {
-            P a = agc_step<V>(k, in, g);
-            // fll.cpp:137-138  x = in * phasor(-phase)
-            V s, c;
-            sincos_t<V, true>(-ph, s, c);
-            x = cmul_phasor<V>(a, c, s);
-        }
-        xs = row_shr1(x, xs);
-        // newest tap of this lane's block on the oldest resident sums
-        P c14 = pk_fma(xs, P(ta[4], ta[4]), r14[PH]);
-        P c32 = pk_fma(xs, P(tb[4], tb[4]), r32[PH]);
-        P cy = pk_fma(xs, P(th[4], th[4]), ry[PH]);
-        // hop one lane inward; lane 15 starts fresh sums at +0
-        r14[PH] = pk_fma(xs, P(ta[0], ta[0]), row_shl1_z(c14));
-        r32[PH] = pk_fma(xs, P(tb[0], tb[0]), row_shl1_z(c32));
-        ry[PH] = pk_fma(xs, P(th[0], th[0]), row_shl1_z(cy));
-        r14[(PH + 1) & 3] = pk_fma(xs, P(ta[3], ta[3]), r14[(PH + 1) & 3]);
-        r32[(PH + 1) & 3] = pk_fma(xs, P(tb[3], tb[3]), r32[(PH + 1) & 3]);
-        ry[(PH + 1) & 3] = pk_fma(xs, P(th[3], th[3]), ry[(PH + 1) & 3]);
-        r14[(PH + 2) & 3] = pk_fma(xs, P(ta[2], ta[2]), r14[(PH + 2) & 3]);
-        r32[(PH + 2) & 3] = pk_fma(xs, P(tb[2], tb[2]), r32[(PH + 2) & 3]);
-        ry[(PH + 2) & 3] = pk_fma(xs, P(th[2], th[2]), ry[(PH + 2) & 3]);
-        r14[(PH + 3) & 3] = pk_fma(xs, P(ta[1], ta[1]), r14[(PH + 3) & 3]);
-        r32[(PH + 3) & 3] = pk_fma(xs, P(tb[1], tb[1]), r32[(PH + 3) & 3]);
-        ry[(PH + 3) & 3] = pk_fma(xs, P(th[1], th[1]), ry[(PH + 3) & 3]);
-        if (!REPLAY) {
-            // fll.cpp:141-145: band-edge outputs from the four real sums, error, loop advance
-            V err = fll_error<V>(c14, c32);
-            pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
-        }
-        return cy;
-    }
-};
-
-// Row driver of kernel 1: delay-line replay, 16-sample tiles, state save.
-// IO supplies the memory side (device: global/LDS accesses of one lane; host emulation: arrays):
-//   P    load_hist(int t)                      lane l <- stored delay-line sample t*16 + l
-//   void stage_tile(int t, int n)              make input samples t*16 .. t*16+15 available
-//   P    sample(int s)                         input sample s of the staged tile, broadcast to the row
-//   void emit(int s, P y)                      lane 0 holds RRC output s of the tile
-//   void flush_tile(int base, int cnt)         write the tile's cnt outputs out
-//   void ring_store(int iend, int cnt, P xs)   lane l < cnt holds x_{iend-1-l}
-//   void save(const K1Row<V>&, int n)          loop state + new delay line (samples n-80..n-1)
-#define TD_K1_REPLAY(S)                                               \
-    {                                                                 \
-        (void)R.template step<(S)&3, true, true>(k, cur);             \
-        cur = row_shl1(cur, cur);                                     \
-    }
-#define TD_K1_STEP(S)                                                 \
-    {                                                                 \
-        P yy = ALPHA0 ? R.template step<(S)&3, false, true>(k, io.sample(S)) \
-                      : R.template step<(S)&3, false, false>(k, io.sample(S)); \
-        io.emit(S, yy);                                               \
-    }
-#define TD_K1_STEP_G(S) \
-    if ((S) < cnt) TD_K1_STEP(S)
-
-template <class V, class IO, bool ALPHA0> TD_FN void k1_run(K1Row<V>& R, const K1Consts& k, IO& io, int n) {
-    typedef Pair<V> P;
-    P cur(V(0.0f), V(0.0f));
-    R.clear_pipeline();
-    // Rebuild the in-flight partial sums by replaying the stored delay line (steps -80..-1).
-    for (int t = 0; t < kHist / kLanes; t++) {
-        cur = io.load_hist(t);
-        TD_K1_REPLAY(0) TD_K1_REPLAY(1) TD_K1_REPLAY(2) TD_K1_REPLAY(3)
-        TD_K1_REPLAY(4) TD_K1_REPLAY(5) TD_K1_REPLAY(6) TD_K1_REPLAY(7)
-        TD_K1_REPLAY(8) TD_K1_REPLAY(9) TD_K1_REPLAY(10) TD_K1_REPLAY(11)
-        TD_K1_REPLAY(12) TD_K1_REPLAY(13) TD_K1_REPLAY(14) TD_K1_REPLAY(15)
-        io.ring_store(-kHist + kLanes * (t + 1), kLanes, R.xs);
-    }
-    const int ntiles = (n + kLanes - 1) / kLanes;
-    for (int t = 0; t < ntiles; t++) {
-        io.stage_tile(t, n);
-        const int base = t * kLanes;
-        const int cnt = (n - base < kLanes) ? (n - base) : kLanes;
-        if (cnt == kLanes) {
-            TD_K1_STEP(0) TD_K1_STEP(1) TD_K1_STEP(2) TD_K1_STEP(3)
-            TD_K1_STEP(4) TD_K1_STEP(5) TD_K1_STEP(6) TD_K1_STEP(7)
-            TD_K1_STEP(8) TD_K1_STEP(9) TD_K1_STEP(10) TD_K1_STEP(11)
-            TD_K1_STEP(12) TD_K1_STEP(13) TD_K1_STEP(14) TD_K1_STEP(15)
-        } else {
-            TD_K1_STEP_G(0) TD_K1_STEP_G(1) TD_K1_STEP_G(2) TD_K1_STEP_G(3)
-            TD_K1_STEP_G(4) TD_K1_STEP_G(5) TD_K1_STEP_G(6) TD_K1_STEP_G(7)
-            TD_K1_STEP_G(8) TD_K1_STEP_G(9) TD_K1_STEP_G(10) TD_K1_STEP_G(11)
-            TD_K1_STEP_G(12) TD_K1_STEP_G(13) TD_K1_STEP_G(14) TD_K1_STEP_G(15)
-        }
-        io.flush_tile(base, cnt);
-        io.ring_store(base + cnt, cnt, R.xs);
-    }
-    io.save(R, n);
-}
-#undef TD_K1_REPLAY
-#undef TD_K1_STEP
-#undef TD_K1_STEP_G
-
 // ---------------------------------------------------------------------------------------------
 // Fused kernel building blocks.
 //
@@ -489,9 +360,11 @@ template <class V, class IO, bool ALPHA0> TD_FN void k1_run(K1Row<V>& R, const K
 // lanes, so every cross-lane move is a two-lane DPP shift and both channels' heads (lanes 0,1) and
 // tails (lanes 14,15) fall on the row boundary where DPP's keep-old / zero-fill do the right thing.
 // Band-edge taps are zero-padded at the old end to 72 = 8 positions x 9; padded tap kp lives at
-// position 7 - kp/9 (lane 2*pos + parity), slot kp%9.  Same schedule as K1Row otherwise: x travels
-// outward one position per step, partial sums travel inward one position per eight steps, ascending
-// tap order, newest tap applied in the head lane in the step that produces x.
+// position 7 - kp/9 (lane 2*pos + parity), slot kp%9.  The FIRs run as ONE systolic array along the
+// row: the derotated sample x_i is produced in the head lane and travels outward one position per step,
+// partial sums are created at the tail and travel inward one position per eight steps, receiving their
+// taps in ascending tap order -- bit-identical to a direct-form `for k: acc = fmaf(hist[k], tap[k], acc)`
+// -- and complete in the head lane in the very step that produces x_i, where the FLL error needs them.
 // ---------------------------------------------------------------------------------------------
 constexpr int kF8Lanes = 8;
 constexpr int kF8Taps = 9;
@@ -750,14 +623,6 @@ TD_FN void quality_step(QualityState& q, float* ring, float zr, float zi) {
         q.sync = q.standarderr >= 0.35f ? 0 : 1;
         q.disp = 0;
     }
-}
-
-// Both halves for one symbol (kernel 2 of the two-kernel pipeline).
-TD_FN int k2_symbol(const K2Consts& k, K2State& st, int phase, const Pair<float>* w,
-                    const float* tm1, const float* t0, const float* tp1, float* sym_re, float* sym_im) {
-    float vr, vi;
-    k2_timing(k, st, phase, w, tm1, t0, tp1, &vr, &vi);
-    return k2_costas(k, st, vr, vi, sym_re, sym_im);
 }
 
 }  // namespace tdm

@@ -1,12 +1,9 @@
 // tetra_demod.hip -- HIP kernels (gfx950) + C ABI of the batched TETRA pi/4-DQPSK demodulator.
 //
-// Kernel 1  k1_agc_fll_rrc   AGC -> band-edge FLL -> RRC matched filter, one 16-lane DPP row per
-//                            channel (4 channels per wavefront), FIRs as a systolic array along the
-//                            row (see demod_core.hpp K1Row).  Reads iq, writes the matched-filter
-//                            output y time-major into an HBM scratch.
-// Kernel 2  k2_sync_slice    ML timing recovery -> pi/4 Costas -> slicer -> differential decoder ->
-//                            bit unpacker, one lane per channel (64 channels per wavefront), y window
-//                            and the 128x8 interpolator bank staged in LDS.
+// The whole chain runs in ONE kernel, k_fused (kernel_fused.hpp): AGC -> band-edge FLL -> RRC matched filter -> ML timing
+// recovery -> pi/4 Costas -> slicer -> differential decoder -> bit unpacker, sixteen channels per workgroup, six specialised
+// waves, all intermediate streams in LDS rings.  (The two-kernel pipeline of round 1 -- k1_agc_fll_rrc / k2_sync_slice with an
+// HBM scratch in between -- was retired in ABI 2; `git log` has it.)
 // Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
 // src/dsp/bit_unpacker.cpp:4-10 (see include/tetra_demod.h).
 //
@@ -27,277 +24,11 @@ using namespace tdm;
 
 namespace {
 
-constexpr int kK1Threads = 256;                 // 4 waves = 16 channel rows
-constexpr int kK1RowsPerBlock = kK1Threads / kLanes;
-constexpr int kRing = 128;                      // per-row LDS ring of recent FLL outputs
-constexpr int kK2Threads = 64;                  // 1 wave = 64 channels
-constexpr int kK2TileRows = 128;                // y rows staged in LDS per tile
-constexpr int kYHist = kInterpTaps - 1;         // 7 delay-buffer rows in front of the new y rows
-
-struct K1Params {
-    const float2* iq;
-    long long in_ch_stride, in_t_stride;  // in complex samples
-    int n, n_channels;
-    float2* y;                            // [(kYHist + n)][n_channels], row kYHist + i = y_i
-    float* agc_g;
-    float* fll_ph;
-    float* fll_fr;
-    float2* hist;                         // [n_channels][kHist]
-    const float* be_re;                   // [kPadTaps] zero-padded at the old end
-    const float* be_im;
-    const float* rrc;
-    K1Consts k;
-};
-
-struct K2Params {
-    float2* y;
-    int n, n_channels;
-    float* mu;
-    float* omega;
-    int* offset;
-    float* cph;
-    float* cfr;
-    float* ph2;
-    int* prev;
-    const float* bank;                    // [128*8]
-    uint8_t* bits;
-    long long bits_stride;
-    int* n_bits;
-    float2* sym;                          // optional [n_channels][bits_stride/2]
-    float* q_ring;                        // optional sync/quality statistic (see FusedParams)
-    double* q_sum;
-    int *q_ptr, *q_disp, *q_sync;
-    float* q_err;
-    K2Consts k;
-};
+constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
 
 __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
     float2 v = *p;
     return Pair<float>(v.x, v.y);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Kernel 1
-// ------------------------------------------------------------------------------------------------
-// Memory side of one lane of a channel row (see k1_run in demod_core.hpp).  Input samples and RRC outputs
-// move through small LDS tiles so that the per-sample work costs no VALU instructions: the tile is written
-// once per 16 samples, each step reads its sample as an LDS broadcast and drops its output with one ds_write.
-struct K1DeviceIO {
-    const K1Params& p;
-    float2* ring;            // this row's LDS ring [kRing] of recent FLL outputs
-    float2* in_tile;         // this row's LDS input tile [kLanes]
-    float2* y_tile;          // this row's LDS output tile [kLanes]
-    float2* y_sink;          // where this lane's emit() lands: y_tile for lane 0, a dump area for the others
-    const float2* hp;        // this channel's stored delay line
-    const float2* ip;        // this channel's input
-    int lane, ch;
-    bool active;
-    Pair<float> nxt;         // prefetched next input tile (lane l: sample t*16 + l)
-
-    __device__ __forceinline__ Pair<float> load_hist(int t) const { return ld_pair(hp + t * kLanes + lane); }
-    __device__ __forceinline__ Pair<float> load_in(int t, int n) const {
-        const int i = t * kLanes + lane;
-        if (i < n) return ld_pair(ip + (long long)i * p.in_t_stride);
-        return Pair<float>(0.f, 0.f);
-    }
-    __device__ __forceinline__ void stage_tile(int t, int n) {
-        if (t == 0) nxt = load_in(0, n);
-        in_tile[lane] = make_float2(nxt.x(), nxt.y());
-        nxt = load_in(t + 1, n);
-    }
-    __device__ __forceinline__ Pair<float> sample(int s) const {
-        const float2 v = in_tile[s];
-        return Pair<float>(v.x, v.y);
-    }
-    __device__ __forceinline__ void emit(int s, Pair<float> y) const { y_sink[s] = make_float2(y.x(), y.y()); }
-    __device__ __forceinline__ void flush_tile(int base, int cnt) const {
-        if (active && lane < cnt) p.y[(long long)(kYHist + base + lane) * p.n_channels + ch] = y_tile[lane];
-    }
-    __device__ __forceinline__ void ring_store(int iend, int cnt, Pair<float> xs) const {
-        if (lane < cnt) ring[(iend - 1 - lane) & (kRing - 1)] = make_float2(xs.x(), xs.y());
-    }
-    __device__ __forceinline__ void save(const K1Row<float>& R, int n) const {
-        if (!active) return;
-        if (lane == 0) {
-            p.agc_g[ch] = R.g;
-            p.fll_ph[ch] = R.ph;
-            p.fll_fr[ch] = R.fr;
-        }
-        // new delay line = samples n-80 .. n-1 (the replayed history is in the ring too)
-        float2* ho = p.hist + (long long)ch * kHist;
-#pragma unroll
-        for (int q = 0; q < kHist / kLanes; q++) {
-            const int m = q * kLanes + lane;
-            ho[m] = ring[(n - kHist + m) & (kRing - 1)];
-        }
-    }
-};
-
-template <bool ALPHA0> __global__ __launch_bounds__(kK1Threads) void k1_agc_fll_rrc(K1Params p) {
-    __shared__ float2 ring[kK1RowsPerBlock][kRing];
-    __shared__ float2 in_tile[kK1RowsPerBlock][kLanes];
-    __shared__ float2 y_tile[kK1RowsPerBlock][kLanes];
-    __shared__ float2 dump[kK1Threads + kLanes];
-
-    const int lane = threadIdx.x & (kLanes - 1);
-    const int row = threadIdx.x >> 4;
-    const int ch = blockIdx.x * kK1RowsPerBlock + row;
-    const bool active = ch < p.n_channels;
-    const int chl = active ? ch : p.n_channels - 1;
-
-    K1Row<float> R;
-    // taps: padded index kp = 5*(15-lane) + j
-#pragma unroll
-    for (int j = 0; j < kTapsPerLane; j++) {
-        const int kp = kTapsPerLane * (kLanes - 1 - lane) + j;
-        R.ta[j] = p.be_re[kp];
-        R.tb[j] = p.be_im[kp];
-        R.th[j] = p.rrc[kp];
-    }
-    R.g = p.agc_g[chl];
-    R.ph = p.fll_ph[chl];
-    R.fr = p.fll_fr[chl];
-
-    K1DeviceIO io{ p, &ring[row][0], &in_tile[row][0], &y_tile[row][0],
-                   lane == 0 ? &y_tile[row][0] : &dump[threadIdx.x],
-                   p.hist + (long long)chl * kHist, p.iq + (long long)chl * p.in_ch_stride, lane, ch, active,
-                   Pair<float>(0.f, 0.f) };
-    k1_run<float, K1DeviceIO, ALPHA0>(R, p.k, io, p.n);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Kernel 2
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        int o = __shfl_xor(v, m, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__global__ __launch_bounds__(kK2Threads) void k2_sync_slice(K2Params p) {
-    __shared__ float2 tile[kK2TileRows][kK2Threads];
-    __shared__ __attribute__((aligned(16))) float bank[kInterpPhases * kInterpTaps];
-
-    const int lane = threadIdx.x;
-    const int ch = blockIdx.x * kK2Threads + lane;
-    const bool active = ch < p.n_channels;
-    const int chl = active ? ch : p.n_channels - 1;
-
-    for (int i = lane; i < kInterpPhases * kInterpTaps; i += kK2Threads) bank[i] = p.bank[i];
-
-    K2State st;
-    st.mu = p.mu[chl];
-    st.omega = p.omega[chl];
-    st.offset = p.offset[chl];
-    st.cph = p.cph[chl];
-    st.cfr = p.cfr[chl];
-    st.ph2 = p.ph2[chl];
-    st.prev = p.prev[chl];
-
-    const int n = p.n;
-    const int nrows = n + kYHist;  // valid y rows
-    int S = 0;                     // symbols emitted by this lane
-    unsigned long long pack = 0;   // up to 4 symbols = 8 bit-bytes
-    uint8_t* brow = p.bits + (long long)chl * p.bits_stride;
-    float2* srow = p.sym ? p.sym + (long long)chl * (p.bits_stride / 2) : nullptr;
-    const bool qon = p.q_ring != nullptr;
-    QualityState qs;
-    qs.sum = 0.0; qs.ptr = 0; qs.disp = 0; qs.standarderr = 0.0f; qs.sync = 0;
-    float* qring = nullptr;
-    if (qon) {
-        qs.sum = p.q_sum[chl]; qs.ptr = p.q_ptr[chl]; qs.disp = p.q_disp[chl]; qs.standarderr = p.q_err[chl]; qs.sync = p.q_sync[chl];
-        qring = p.q_ring + (long long)chl * 4096;
-    }
-    __syncthreads();
-
-    while (true) {
-        const bool pending = active && st.offset < n;
-        if (!__any(pending)) break;
-        const int base = wave_min_i32(pending ? st.offset : 0x7fffffff);
-        // stage rows [base, base + kK2TileRows) of this wave's 64 channels
-        __syncthreads();
-        for (int r0 = 0; r0 < kK2TileRows; r0 += 16) {
-            float2 v[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {      // 16 independent loads in flight
-                const int rr = base + r0 + j;
-                v[j] = make_float2(0.f, 0.f);
-                if (rr < nrows) v[j] = p.y[(long long)rr * p.n_channels + chl];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) tile[r0 + j][lane] = v[j];
-        }
-        __syncthreads();
-        while (true) {
-            const int rel = st.offset - base;
-            // output capacity guard (see kernel_fused.hpp): never reached by a finite stream
-            if (S >= (int)(p.bits_stride / 2) && st.offset < n) st.offset = n;
-            const bool can = active && st.offset < n && (rel + kInterpTaps <= kK2TileRows);
-            if (!__any(can)) break;
-            if (can) {
-                // complex_fd.cpp:101
-                int phase = (int)v_floor(st.mu * (float)kInterpPhases);
-                phase = phase < 0 ? 0 : phase;
-                phase = phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
-                const int pm = phase > 0 ? phase - 1 : 0;
-                const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
-                Pair<float> w[kInterpTaps];
-                float t0[kInterpTaps], tm1[kInterpTaps], tp1[kInterpTaps];
-#pragma unroll
-                for (int j = 0; j < kInterpTaps; j++) {
-                    const float2 wv = tile[rel + j][lane];
-                    w[j] = Pair<float>(wv.x, wv.y);
-                }
-                const float4* b0 = reinterpret_cast<const float4*>(bank + phase * kInterpTaps);
-                const float4* bm = reinterpret_cast<const float4*>(bank + pm * kInterpTaps);
-                const float4* bp = reinterpret_cast<const float4*>(bank + pp * kInterpTaps);
-                float4 q;
-                q = b0[0]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
-                q = b0[1]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
-                q = bm[0]; tm1[0] = q.x; tm1[1] = q.y; tm1[2] = q.z; tm1[3] = q.w;
-                q = bm[1]; tm1[4] = q.x; tm1[5] = q.y; tm1[6] = q.z; tm1[7] = q.w;
-                q = bp[0]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
-                q = bp[1]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
-                float zr, zi;
-                const int d = k2_symbol(p.k, st, phase, w, tm1, t0, tp1, &zr, &zi);
-                if (srow) srow[S] = make_float2(zr, zi);
-                if (qon) quality_step(qs, qring, zr, zi);
-                // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
-                const unsigned long long two = (unsigned long long)((d >> 1) & 1) | ((unsigned long long)(d & 1) << 8);
-                pack |= two << (16 * (S & 3));
-                S++;
-                if ((S & 3) == 0) {
-                    *reinterpret_cast<unsigned long long*>(brow + 2 * (S - 4)) = pack;
-                    pack = 0;
-                }
-            }
-        }
-    }
-
-    if (active) {
-        const int rem = S & 3;
-        for (int q = 0; q < 2 * rem; q++) brow[2 * (S - rem) + q] = (uint8_t)((pack >> (8 * q)) & 0xff);
-        p.n_bits[ch] = 2 * S;
-        p.mu[ch] = st.mu;
-        p.omega[ch] = st.omega;
-        p.offset[ch] = st.offset - n;   // complex_fd.cpp:145
-        p.cph[ch] = st.cph;
-        p.cfr[ch] = st.cfr;
-        p.ph2[ch] = st.ph2;
-        p.prev[ch] = st.prev;
-        if (qon) {
-            p.q_sum[ch] = qs.sum; p.q_ptr[ch] = qs.ptr; p.q_disp[ch] = qs.disp; p.q_err[ch] = qs.standarderr; p.q_sync[ch] = qs.sync;
-        }
-        // delay buffer update, complex_fd.cpp:148: rows n..n+6 become rows 0..6
-        float2 tmp[kYHist];
-#pragma unroll
-        for (int k = 0; k < kYHist; k++) tmp[k] = p.y[(long long)(n + k) * p.n_channels + ch];
-#pragma unroll
-        for (int k = 0; k < kYHist; k++) p.y[(long long)k * p.n_channels + ch] = tmp[k];
-    }
 }
 
 }  // namespace
@@ -383,7 +114,6 @@ struct tetra_demod {
     float* q_err = nullptr;
     bool user_rrc = false, user_be = false;   // caller-supplied FIR tables (cfg.rrc_taps / cfg.bandedge_taps)
     bool quirks = false;        // TETRA_FLAG_REFERENCE_QUIRKS
-    bool fused = true;          // pipeline in use
     bool keep_y = false;        // y scratch allocated
     float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
     float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 72, RRC zero-extended
@@ -495,7 +225,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
     HIP_TRY(h, hipMemsetAsync(h->fll_fr + first, 0, sizeof(float) * count, 0));
     // FIR::reset: the reference clears the RRC's delay line only; FLL::reset leaves the band-edge FIRs' lines alone.  To the
     // letter (quirks, fused pipeline) the shared line therefore stays and the RRC is told to see none of it.
-    if (fresh || !h->fused) {
+    if (fresh) {
         HIP_TRY(h, hipMemsetAsync(h->hist + (size_t)first * kHist, 0, sizeof(float2) * kHist * (size_t)count, 0));
         hipLaunchKernelGGL(k_fill_i32, dim3((count + 255) / 256), dim3(256), 0, 0, h->rrc_valid + first, (int)kHist, count);
         HIP_TRY(h, hipGetLastError());
@@ -518,11 +248,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
             HIP_TRY(h, hipMemsetAsync(h->q_sync + first, 0, sizeof(int) * count, 0));
             HIP_TRY(h, hipMemsetAsync(h->q_err + first, 0, sizeof(float) * count, 0));
         }
-        // fused pipeline keeps the delay buffer in ybuf, the two-kernel pipeline in the first kYHist rows of the time-major y
-        // scratch (columns [first, first+count))
         HIP_TRY(h, hipMemsetAsync(h->ybuf + (size_t)first * kYHist, 0, sizeof(float2) * kYHist * (size_t)count, 0));
-        if (h->y)
-            HIP_TRY(h, hipMemset2DAsync(h->y + first, sizeof(float2) * (size_t)h->C, 0, sizeof(float2) * (size_t)count, kYHist, 0));
     }
     HIP_TRY(h, hipStreamSynchronize(0));
     return TETRA_OK;
@@ -654,7 +380,8 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     h->dp.omega_gain = cfg->omega_gain;
     h->dp.mu_gain = cfg->mu_gain;
     h->dp.omega_rel_limit = cfg->omega_rel_limit;
-    if (!host::make_design(h->dp, cfg->rrc_taps, cfg->bandedge_taps, cfg->interp_bank, h->design)) {
+    if (!host::make_design(h->dp, cfg->rrc_taps, cfg->bandedge_taps, cfg->interp_bank, h->design) ||
+        h->design.ntaps > kF8Pad || (cfg->flags & TETRA_FLAG_RETIRED_TWO_KERNEL)) {      // the kernel covers 2..72 taps
         delete h;
         return TETRA_ERR_UNSUPPORTED;
     }
@@ -674,8 +401,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     h->user_rrc = cfg->rrc_taps != nullptr;
     h->user_be = cfg->bandedge_taps != nullptr;
     h->quirks = (cfg->flags & TETRA_FLAG_REFERENCE_QUIRKS) != 0;
-    h->fused = !(cfg->flags & TETRA_FLAG_TWO_KERNEL) && h->design.ntaps <= kF8Pad;
-    h->keep_y = !h->fused || (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT);
+    h->keep_y = (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT) != 0;
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
     if (cfg->flags & TETRA_FLAG_QUALITY) {
@@ -725,50 +451,12 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         HIP_TRY(h, hipMemsetAsync(d_n_bits, 0, sizeof(int32_t) * (size_t)h->C, s));
         return TETRA_OK;
     }
-    K1Params p1;
-    p1.iq = reinterpret_cast<const float2*>(d_iq);
-    if (h->cfg.layout == TETRA_LAYOUT_CHANNEL_MAJOR) {
-        p1.in_ch_stride = n_samples;
-        p1.in_t_stride = 1;
-    } else {
-        p1.in_ch_stride = 1;
-        p1.in_t_stride = h->C;
-    }
-    p1.n = n_samples;
-    p1.n_channels = h->C;
-    p1.y = h->y;
-    p1.agc_g = h->agc_g;
-    p1.fll_ph = h->fll_ph;
-    p1.fll_fr = h->fll_fr;
-    p1.hist = h->hist;
-    p1.be_re = h->d_be_re;
-    p1.be_im = h->d_be_im;
-    p1.rrc = h->d_rrc;
-    p1.k = h->design.k1;
-    K2Params p2;
-    p2.y = h->y;
-    p2.n = n_samples;
-    p2.n_channels = h->C;
-    p2.mu = h->mu;
-    p2.omega = h->omega;
-    p2.offset = h->offset;
-    p2.cph = h->cph;
-    p2.cfr = h->cfr;
-    p2.ph2 = h->ph2;
-    p2.prev = h->prev;
-    p2.bank = h->d_bank;
-    p2.bits = d_bits;
-    p2.bits_stride = bits_stride;
-    p2.n_bits = d_n_bits;
-    p2.sym = reinterpret_cast<float2*>(d_sym);
-    p2.q_ring = h->q_ring; p2.q_sum = h->q_sum; p2.q_ptr = h->q_ptr; p2.q_disp = h->q_disp; p2.q_sync = h->q_sync;
-    p2.q_err = h->q_err;
-    p2.k = h->design.k2;
-
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
-    if (h->fused) {
+    {
         FusedParams pf;
-        pf.iq = p1.iq; pf.in_ch_stride = p1.in_ch_stride; pf.in_t_stride = p1.in_t_stride;
+        pf.iq = reinterpret_cast<const float2*>(d_iq);
+        if (h->cfg.layout == TETRA_LAYOUT_CHANNEL_MAJOR) { pf.in_ch_stride = n_samples; pf.in_t_stride = 1; }
+        else { pf.in_ch_stride = 1; pf.in_t_stride = h->C; }
         pf.n = n_samples; pf.n_channels = h->C;
         pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
         pf.rrc_valid = h->rrc_valid;
@@ -827,17 +515,6 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
 #endif
         return TETRA_OK;
     }
-    HIP_TRY(h, hipEventRecord(ev[0], s));
-    const dim3 g1((h->C + kK1RowsPerBlock - 1) / kK1RowsPerBlock);
-    if (p1.k.fll_alpha == 0.0f) hipLaunchKernelGGL(k1_agc_fll_rrc<true>, g1, dim3(kK1Threads), 0, s, p1);
-    else hipLaunchKernelGGL(k1_agc_fll_rrc<false>, g1, dim3(kK1Threads), 0, s, p1);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(k2_sync_slice, dim3((h->C + kK2Threads - 1) / kK2Threads), dim3(kK2Threads), 0, s, p2);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(ev[2], s));
-    h->n_calls++;
-    return TETRA_OK;
 }
 
 int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
@@ -1054,7 +731,7 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
             if (h->user_be) return TETRA_ERR_UNSUPPORTED;
             host::design_bandedge(np, nd, np.rrc_tap_count);           // documented deviation: one length for the three FIRs
         }
-        if (h->fused && (nd.ntaps > kF8Pad || nd.ntaps_be > kF8Pad)) return TETRA_ERR_UNSUPPORTED;   // fused kernel covers <= 72 taps
+        if (nd.ntaps > kF8Pad || nd.ntaps_be > kF8Pad) return TETRA_ERR_UNSUPPORTED;   // the kernel covers <= 72 taps
     }
     host::design_loops(np, nd);
     host::design_timing_limits(np, nd);
@@ -1067,7 +744,7 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     if (tables) {
         int rc = upload_tables(h);
         if (rc != TETRA_OK) return rc;
-        if (h->quirks && h->fused && nd.ntaps > old_ntaps) {
+        if (h->quirks && nd.ntaps > old_ntaps) {
             // FIR::setTaps with more taps keeps the RRC's old taps-1 history samples and zero-fills the newly visible part
             hipLaunchKernelGGL(k_min_i32, dim3((h->C + 255) / 256), dim3(256), 0, 0, h->rrc_valid, old_ntaps - 1, h->C);
             HIP_TRY(h, hipGetLastError());
@@ -1095,11 +772,7 @@ int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_sta
     GET1(out->rrc_valid, h->rrc_valid);
 #undef GET1
     HIP_TRY(h, hipMemcpy(out->hist, h->hist + (size_t)c * kHist, sizeof(float2) * kHist, hipMemcpyDeviceToHost));
-    if (h->fused)
-        HIP_TRY(h, hipMemcpy(out->ybuf, h->ybuf + (size_t)c * kYHist, sizeof(float2) * kYHist, hipMemcpyDeviceToHost));
-    else
-        HIP_TRY(h, hipMemcpy2D(out->ybuf, sizeof(float2), h->y + c, sizeof(float2) * (size_t)h->C, sizeof(float2), kYHist,
-                               hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out->ybuf, h->ybuf + (size_t)c * kYHist, sizeof(float2) * kYHist, hipMemcpyDeviceToHost));
     return TETRA_OK;
 }
 
@@ -1113,14 +786,11 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     SET1(h->agc_g, in->agc_gain); SET1(h->fll_ph, in->fll_phase); SET1(h->fll_fr, in->fll_freq);
     SET1(h->mu, in->mu); SET1(h->omega, in->omega); SET1(h->offset, in->offset);
     SET1(h->cph, in->costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
-    const int rv = !h->fused ? (int)kHist : in->rrc_valid < 0 ? 0 : in->rrc_valid > (int)kHist ? (int)kHist : in->rrc_valid;
+    const int rv = in->rrc_valid < 0 ? 0 : in->rrc_valid > (int)kHist ? (int)kHist : in->rrc_valid;
     SET1(h->rrc_valid, rv);
 #undef SET1
     HIP_TRY(h, hipMemcpy(h->hist + (size_t)c * kHist, in->hist, sizeof(float2) * kHist, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->ybuf + (size_t)c * kYHist, in->ybuf, sizeof(float2) * kYHist, hipMemcpyHostToDevice));
-    if (h->y)
-        HIP_TRY(h, hipMemcpy2D(h->y + c, sizeof(float2) * (size_t)h->C, in->ybuf, sizeof(float2), sizeof(float2), kYHist,
-                               hipMemcpyHostToDevice));
     return TETRA_OK;
 }
 

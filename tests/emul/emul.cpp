@@ -1,12 +1,10 @@
-// emul.cpp -- host emulation of the two GPU kernels' lane-level algorithms (TEST TOOL).
+// emul.cpp -- host emulation of the GPU kernel's lane-level algorithms (TEST TOOL).
 //
-// Compiles the product's shared kernel source (sdrpp-tetra-demodulator_amd/csrc/demod_core.hpp)
-// with -DTETRA_HOST_EMUL: kernel 1's row program runs on a 16-lane Row16 with emulated DPP
-// moves through the very same k1_run<> driver the device uses; kernel 2's wave-level tile logic
-// is transcribed for up to 64 lock-stepped lanes around the shared k2_symbol().  The tests
-// compare this against the CPU oracle so that the systolic schedule, the replay of the delay
-// line and the tile bookkeeping are verified without a GPU.  It also exposes the product's
-// host-side filter design (design.hpp) for comparison with the oracle's.
+// Compiles the product's shared kernel source (sdrpp-tetra-demodulator_amd/csrc/demod_core.hpp) with -DTETRA_HOST_EMUL:
+// the building blocks of k_fused (agc_step, the FLL row FllRow8 with fll8_replay / fll8_tile on a 16-lane Row16 with
+// emulated DPP moves, rrc_direct8, k2_timing, k2_costas) run stage after stage over linear arrays.  The tests compare this
+// against the CPU oracle so that the systolic schedule, the replay of the delay line and the tile bookkeeping are verified
+// without a GPU.  It also exposes the product's host-side filter design (design.hpp) for comparison with the oracle's.
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -mfma -mavx2 -DTETRA_HOST_EMUL -shared -fPIC
 #include <cstdint>
@@ -22,48 +20,7 @@ using namespace tdm;
 
 namespace {
 
-constexpr int kRing = 128;
 constexpr int kYHist = kInterpTaps - 1;
-constexpr int kK2TileRows = 128;
-
-struct K1EmulIO {
-    const float* hist;   // [80][2]
-    const float* iq;     // [n][2]
-    float* y;            // [n][2]
-    float ring[kRing][2];
-    tetra_demod_channel_state_t* st;
-    int tile = 0, nn = 0;
-
-    Pair<Row16> load_hist(int t) const {
-        Row16 a, b;
-        for (int l = 0; l < 16; l++) { a.l[l] = hist[2 * (t * 16 + l)]; b.l[l] = hist[2 * (t * 16 + l) + 1]; }
-        return Pair<Row16>(a, b);
-    }
-    void stage_tile(int t, int n) { tile = t; nn = n; }
-    Pair<Row16> sample(int s) const {
-        const int i = tile * 16 + s;
-        if (i < nn) return Pair<Row16>(Row16(iq[2 * i]), Row16(iq[2 * i + 1]));
-        return Pair<Row16>(Row16(0.f), Row16(0.f));
-    }
-    void emit(int s, Pair<Row16> yy) {
-        const int i = tile * 16 + s;
-        y[2 * i] = yy.x().l[0];
-        y[2 * i + 1] = yy.y().l[0];
-    }
-    void flush_tile(int, int) {}
-    void ring_store(int iend, int cnt, Pair<Row16> xs) {
-        for (int l = 0; l < 16; l++)
-            if (l < cnt) { int k = (iend - 1 - l) & (kRing - 1); ring[k][0] = xs.x().l[l]; ring[k][1] = xs.y().l[l]; }
-    }
-    void save(const K1Row<Row16>& R, int n) {
-        st->agc_gain = R.g.l[0];
-        st->fll_phase = R.ph.l[0];
-        st->fll_freq = R.fr.l[0];
-        float nh[2 * kHist];
-        for (int m = 0; m < kHist; m++) { int k = (n - kHist + m) & (kRing - 1); nh[2 * m] = ring[k][0]; nh[2 * m + 1] = ring[k][1]; }
-        std::memcpy(st->hist, nh, sizeof(nh));
-    }
-};
 
 }  // namespace
 
@@ -113,103 +70,6 @@ void emul_reset_state(const emul_tables* t, tetra_demod_channel_state_t* st) {
     st->rrc_valid = kHist;
 }
 
-// Kernel 1 for one channel: iq[n] -> y[n]; updates agc/fll/hist in st.
-void emul_k1(const emul_tables* t, tetra_demod_channel_state_t* st, int n, const float* iq, float* y) {
-    float re[kPadTaps] = { 0 }, im[kPadTaps] = { 0 }, rr[kPadTaps] = { 0 };
-    const int off = kPadTaps - t->ntaps;
-    for (int k = 0; k < t->ntaps; k++) { re[off + k] = t->be_re[k]; im[off + k] = t->be_im[k]; rr[off + k] = t->rrc[k]; }
-    K1Row<Row16> R;
-    for (int j = 0; j < kTapsPerLane; j++) {
-        Row16 a, b, h;
-        for (int l = 0; l < 16; l++) {
-            const int kp = kTapsPerLane * (kLanes - 1 - l) + j;
-            a.l[l] = re[kp]; b.l[l] = im[kp]; h.l[l] = rr[kp];
-        }
-        R.ta[j] = a;
-        R.tb[j] = b;
-        R.th[j] = h;
-    }
-    R.g = Row16(st->agc_gain);
-    R.ph = Row16(st->fll_phase);
-    R.fr = Row16(st->fll_freq);
-    K1EmulIO io;
-    std::vector<float> hist(st->hist, st->hist + 2 * kHist);
-    io.hist = hist.data(); io.iq = iq; io.y = y; io.st = st;
-    std::memset(io.ring, 0, sizeof(io.ring));
-    if (t->k1.fll_alpha == 0.0f) k1_run<Row16, K1EmulIO, true>(R, t->k1, io, n);
-    else k1_run<Row16, K1EmulIO, false>(R, t->k1, io, n);
-}
-
-// Kernel 2 for C <= 64 channels in one emulated wave.  y: [C][n] channel-major input (this call's
-// RRC output), st[c].ybuf supplies / receives the 7 delay rows.  bits [C][stride], sym optional.
-int emul_k2(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* y, uint8_t* bits,
-            int bits_stride, int32_t* n_bits, float* sym) {
-    if (C < 1 || C > 64) return -1;
-    const int nrows = n + kYHist;
-    // time-major scratch like the device's: row r, channel c
-    std::vector<float> ys((size_t)nrows * C * 2);
-    for (int c = 0; c < C; c++) {
-        for (int k = 0; k < kYHist; k++) { ys[((size_t)k * C + c) * 2] = st[c].ybuf[2 * k]; ys[((size_t)k * C + c) * 2 + 1] = st[c].ybuf[2 * k + 1]; }
-        for (int i = 0; i < n; i++) { ys[((size_t)(kYHist + i) * C + c) * 2] = y[((size_t)c * n + i) * 2]; ys[((size_t)(kYHist + i) * C + c) * 2 + 1] = y[((size_t)c * n + i) * 2 + 1]; }
-    }
-    K2State ks[64];
-    int S[64];
-    for (int c = 0; c < C; c++) {
-        ks[c].mu = st[c].mu; ks[c].omega = st[c].omega; ks[c].offset = st[c].offset;
-        ks[c].cph = st[c].costas_phase; ks[c].cfr = st[c].costas_freq; ks[c].ph2 = st[c].ph2; ks[c].prev = st[c].prev;
-        S[c] = 0;
-    }
-    std::vector<float> tile((size_t)kK2TileRows * C * 2);
-    while (true) {
-        bool any = false;
-        int base = 0x7fffffff;
-        for (int c = 0; c < C; c++)
-            if (ks[c].offset < n) { any = true; if (ks[c].offset < base) base = ks[c].offset; }
-        if (!any) break;
-        for (int r = 0; r < kK2TileRows; r++)
-            for (int c = 0; c < C; c++) {
-                const int rr = base + r;
-                float a = 0.f, b = 0.f;
-                if (rr < nrows) { a = ys[((size_t)rr * C + c) * 2]; b = ys[((size_t)rr * C + c) * 2 + 1]; }
-                tile[((size_t)r * C + c) * 2] = a; tile[((size_t)r * C + c) * 2 + 1] = b;
-            }
-        while (true) {
-            bool anycan = false;
-            for (int c = 0; c < C; c++) {
-                const int rel = ks[c].offset - base;
-                const bool can = ks[c].offset < n && (rel + kInterpTaps <= kK2TileRows);
-                if (!can) continue;
-                anycan = true;
-                int phase = (int)v_floor(ks[c].mu * (float)kInterpPhases);
-                phase = phase < 0 ? 0 : phase;
-                phase = phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
-                const int pm = phase > 0 ? phase - 1 : 0;
-                const int pp = phase < kInterpPhases - 1 ? phase + 1 : kInterpPhases - 1;
-                Pair<float> w[kInterpTaps];
-                for (int j = 0; j < kInterpTaps; j++) w[j] = Pair<float>(tile[((size_t)(rel + j) * C + c) * 2], tile[((size_t)(rel + j) * C + c) * 2 + 1]);
-                float zr, zi;
-                const int d = k2_symbol(t->k2, ks[c], phase, w, t->bank + pm * kInterpTaps, t->bank + phase * kInterpTaps,
-                                        t->bank + pp * kInterpTaps, &zr, &zi);
-                if (2 * S[c] + 2 > bits_stride) return -2;
-                if (sym) { sym[((size_t)c * (bits_stride / 2) + S[c]) * 2] = zr; sym[((size_t)c * (bits_stride / 2) + S[c]) * 2 + 1] = zi; }
-                bits[(size_t)c * bits_stride + 2 * S[c]] = (uint8_t)((d >> 1) & 1);
-                bits[(size_t)c * bits_stride + 2 * S[c] + 1] = (uint8_t)(d & 1);
-                S[c]++;
-            }
-            if (!anycan) break;
-        }
-    }
-    for (int c = 0; c < C; c++) {
-        n_bits[c] = 2 * S[c];
-        st[c].mu = ks[c].mu; st[c].omega = ks[c].omega; st[c].offset = ks[c].offset - n;
-        st[c].costas_phase = ks[c].cph; st[c].costas_freq = ks[c].cfr; st[c].ph2 = ks[c].ph2; st[c].prev = ks[c].prev;
-        for (int k = 0; k < kYHist; k++) { st[c].ybuf[2 * k] = ys[((size_t)(n + k) * C + c) * 2]; st[c].ybuf[2 * k + 1] = ys[((size_t)(n + k) * C + c) * 2 + 1]; }
-    }
-    return 0;
-}
-
-
-// ---------------------------------------------------------------------------------------------------
 // Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllRow8 + fll8_replay/fll8_tile,
 // rrc_direct8, k2_timing, k2_costas) run stage after stage over linear arrays -- a valid serialisation of the
 // device's barrier-synchronised software pipeline.  (The LDS ring/epoch bookkeeping itself is device-only.)

@@ -59,10 +59,6 @@ def lib():
         L.emul_default_cfg.restype = None
         L.emul_reset_state.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState)]
         L.emul_reset_state.restype = None
-        L.emul_k1.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState), C.c_int, vp, vp]
-        L.emul_k1.restype = None
-        L.emul_k2.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState), C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
-        L.emul_k2.restype = C.c_int
         L.emul_fused.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState), C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]
         L.emul_fused.restype = C.c_int
         _lib = L
@@ -96,8 +92,8 @@ def bits_stride(n):
 class EmulDemod:
     """C <= 64 channels through the emulated kernels, with carried state."""
 
-    def __init__(self, n_channels=1, cfg=None, fused=False):
-        self.fused = fused
+    def __init__(self, n_channels=1, cfg=None, fused=True):
+        self.fused = True
         self.C = n_channels
         self.tab = design(cfg)
         self.st = (ChannelState * n_channels)()
@@ -112,18 +108,9 @@ class EmulDemod:
         assert Cn == self.C
         y = np.zeros((Cn, n), np.complex64)
         stride = bits_stride(n)
-        if self.fused:
-            bits = np.zeros((Cn, stride), np.uint8)
-            nb = np.zeros(Cn, np.int32)
-            sym = np.zeros((Cn, stride // 2), np.complex64) if want_sym else None
-            rc = lib().emul_fused(C.byref(self.tab), self.st, Cn, n, _p(iq), _p(y), _p(bits), stride, _p(nb), _p(sym))
-            assert rc == 0, rc
-            return dict(y=y, bits=bits, n_bits=nb, sym=sym)
-        for c in range(Cn):
-            lib().emul_k1(C.byref(self.tab), C.byref(self.st[c]), n, _p(iq[c]), _p(y[c]))
         bits = np.zeros((Cn, stride), np.uint8)
         nb = np.zeros(Cn, np.int32)
         sym = np.zeros((Cn, stride // 2), np.complex64) if want_sym else None
-        rc = lib().emul_k2(C.byref(self.tab), self.st, Cn, n, _p(y), _p(bits), stride, _p(nb), _p(sym))
+        rc = lib().emul_fused(C.byref(self.tab), self.st, Cn, n, _p(iq), _p(y), _p(bits), stride, _p(nb), _p(sym))
         assert rc == 0, rc
         return dict(y=y, bits=bits, n_bits=nb, sym=sym)

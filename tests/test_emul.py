@@ -1,9 +1,9 @@
 """CPU tests of the kernels' lane-level code through the host emulation (tests/emul/emul.cpp).
 
-The emulation compiles the SAME source the GPU runs (csrc/demod_core.hpp: K1Row, k1_run, k2_symbol,
-sincos, pcl_advance) with a 16-lane Row16 standing in for one DPP row, so the systolic FIR schedule,
-the delay-line replay and the tile bookkeeping are checked bit-for-bit against the oracle without a
-GPU.  It is a test tool, not a product path.
+The emulation compiles the SAME source the GPU runs (csrc/demod_core.hpp: agc_step, FllRow8 with fll8_replay /
+fll8_tile, rrc_direct8, k2_timing, k2_costas, sincos, pcl_advance) with a 16-lane Row16 standing in for one DPP row,
+so the systolic FIR schedule, the delay-line replay and the tile bookkeeping are checked bit-for-bit against the
+oracle without a GPU.  It is a test tool, not a product path.
 """
 import numpy as np
 import pytest
@@ -48,7 +48,7 @@ def test_emulated_kernels_match_oracle(emul, oracle, synth, N, chunks):
         q = e.process(iq[pos:pos + ch], want_sym=True)
         pos += ch
         nb = int(q["n_bits"][0])
-        assert np.array_equal(_u32(q["y"][0]), _u32(r["y"]))            # kernel 1: RRC output
+        assert np.array_equal(_u32(q["y"][0]), _u32(r["y"]))            # RRC output
         assert nb == r["bits"].size and np.array_equal(q["bits"][0][:nb], r["bits"])
         assert np.array_equal(_u32(q["sym"][0][:nb // 2]), _u32(r["sym"]))
     st, os_ = e.st[0], o.st
@@ -59,7 +59,7 @@ def test_emulated_kernels_match_oracle(emul, oracle, synth, N, chunks):
 
 
 def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth):
-    """64 lanes in one emulated kernel-2 wave, including a noise-only and an all-zero channel (their timing
+    """64 channels through the emulated stages, including a noise-only and an all-zero channel (their timing
     loops wander, so per-lane offsets diverge inside a tile)."""
     Cn, N = 64, 6000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=99)
@@ -72,26 +72,6 @@ def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth
     assert np.array_equal(q["n_bits"], nb)
     for c in range(Cn):
         assert np.array_equal(q["bits"][c][:nb[c]], bits[c][:nb[c]]), c
-
-
-def test_other_tap_counts(emul, oracle, synth):
-    """RRC tap count is a PI4DQPSK parameter (setRRCTapCount, pi4dqpsk.cpp:68-70): 33 and 79 taps map onto the
-    80-tap systolic array by zero padding at the old end."""
-    N = 3000
-    iq, _, _ = synth.gen_channel(N, 12)
-    for nt in (33, 79, 80):
-        ocfg = oracle.default_cfg()
-        ocfg.rrc_tap_count = nt
-        o = oracle.Oracle(ocfg)
-        ecfg = emul.default_cfg()
-        ecfg.rrc_tap_count = nt
-        e = emul.EmulDemod(1, ecfg)
-        for pos in (0, 1500):
-            r = o.process(iq[pos:pos + 1500], stages=True)
-            q = e.process(iq[pos:pos + 1500])
-            assert np.array_equal(_u32(q["y"][0]), _u32(r["y"])), nt
-            nb = int(q["n_bits"][0])
-            assert np.array_equal(q["bits"][0][:nb], r["bits"]), nt
 
 
 def test_fused_stage_code_equals_oracle(emul, oracle, synth, lanes=True):

@@ -64,7 +64,7 @@ def test_tables_match_oracle(pkg, oracle):
     assert np.array_equal(t["bank"], o.interp_bank())
 
 
-PIPELINES = {"fused": 2, "two_kernel": 1}   # flags: fused + keep RRC output for the stage check / two-kernel
+PIPELINES = {"fused": 2}   # flags: keep the RRC output for the stage check (ABI 1's second pipeline was retired in ABI 2)
 
 
 def _compare(tag, pkg, oracle, iq, chunks, want_state=True, flags=2):
@@ -212,9 +212,22 @@ def test_time_major_layout(pkg, oracle, synth, pipeline):
     d.close()
 
 
-@pytest.mark.parametrize("pipeline,nt", [("fused", 33), ("fused", 72), ("two_kernel", 33), ("two_kernel", 79), ("fused", 79)])
+def test_retired_pipeline_and_tap_counts_above_72_are_refused(pkg):
+    with pytest.raises(pkg.TetraDemodError) as e:
+        pkg.Demodulator(4, 1000, flags=1)                      # TETRA_FLAG_RETIRED_TWO_KERNEL
+    assert e.value.status == -2                                # TETRA_ERR_UNSUPPORTED
+    with pytest.raises(pkg.TetraDemodError):
+        pkg.Demodulator(4, 1000, rrc_tap_count=73)
+    d = pkg.Demodulator(4, 1000)
+    with pytest.raises(pkg.TetraDemodError):
+        d.set_param("rrc_tap_count", 79)
+    assert d.tables()["rrc"].size == 65                        # refused setters change nothing
+    d.close()
+
+
+@pytest.mark.parametrize("pipeline,nt", [("fused", 2), ("fused", 33), ("fused", 72)])
 def test_other_tap_counts(pkg, oracle, synth, pipeline, nt):
-    """rrcTapCount is a PI4DQPSK parameter; > 72 taps silently uses the two-kernel pipeline."""
+    """rrcTapCount is a PI4DQPSK parameter (2..72 here; the reference builds with 65)."""
     Cn, N = 6, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=71)
     d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & 1, rrc_tap_count=nt)
