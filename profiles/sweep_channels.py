@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Channel-count sweep of the hot path on ONE GPU: launch time of k_fused for C channels x 36000 samples,
+input resident in HBM, steady clocks (same ramp as bench.py).  One JSON line per C.
+    python profiles/sweep_channels.py [--channels 256 800 4096 8192 16384 32768] [--steps 6]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--channels", type=int, nargs="+", default=[256, 800, 4096, 8192, 16384, 32768])
+    ap.add_argument("--samples", type=int, default=36000)
+    ap.add_argument("--steps", type=int, default=6)
+    a = ap.parse_args()
+    import torch
+    import tetra_amd
+    import bench
+    pkg = tetra_amd.pkg
+    dev = torch.device("cuda", 0)
+    clk_khz, cus = pkg.binding.device_info(0)
+    N = a.samples
+    stride = pkg.binding.bits_stride(N)
+    base = None
+    for C in a.channels:
+        iq, _ = bench.make_input(torch, pkg.synth, dev, C, N, seed=20260000)
+        bits = torch.zeros((C, stride), dtype=torch.uint8, device=dev)
+        nb = torch.zeros(C, dtype=torch.int32, device=dev)
+        dem = pkg.Demodulator(C, N)
+        st = torch.cuda.current_stream(dev)
+        for _ in range(bench.RAMP_STEPS + 2):
+            dem.process_device(iq, N, bits, stride, nb, None, st)
+        torch.cuda.synchronize()
+        for _ in range(a.steps):
+            dem.process_device(iq, N, bits, stride, nb, None, st)
+        torch.cuda.synchronize()
+        k1, _ = dem.kernel_ms_history(a.steps)
+        ms = float(k1.mean())
+        wgs = (C + 15) // 16
+        if C == 4096:
+            base = ms
+        print(json.dumps({"channels": C, "samples": N, "kernel_ms": round(ms, 4), "workgroups": wgs, "cus": cus,
+                          "workgroups_per_cu": round(wgs / cus, 2), "msamples_s": round(C * N / ms / 1e3, 1),
+                          "ms_per_4096_channels": round(ms * 4096 / C, 4),
+                          "vs_4096": round(ms / base, 3) if base else None}), flush=True)
+        dem.close()
+        del iq, bits, nb
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
