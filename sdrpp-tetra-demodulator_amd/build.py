@@ -32,6 +32,9 @@ def is_stale():
 def build(force=False, verbose=False):
     """Compile the library if missing or older than its sources.  Returns the .so path."""
     if force or is_stale():
+        # fll_asm.inc is generated (and committed): refuse to build from one that is not what the generator emits
+        import sys
+        subprocess.run([sys.executable, os.path.join(CSRC, "gen_fll_asm.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
         cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
         if verbose:
             print(" ".join(cmd))

@@ -172,3 +172,12 @@ int main(void) {
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out == ["65", "800", "2"]
+
+
+def test_generated_fll_assembly_is_current():
+    """csrc/fll_asm.inc is generated by csrc/gen_fll_asm.py and committed: the committed file is what the generator emits."""
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "gen_fll_asm.py")
+    r = subprocess.run([sys.executable, gen, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

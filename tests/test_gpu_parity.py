@@ -375,6 +375,27 @@ def test_reference_quirks_flag(pkg, oracle, synth):
     d2.close()
 
 
+def test_parity_8192_channels_two_workgroup_rounds(pkg, oracle, synth):
+    """More workgroups than CUs (512 > 256: every CU runs two workgroups one after the other) and a channel count that is
+    not a multiple of 16 on top (8192 + 5): every output bit of two consecutive calls equals the oracle's."""
+    Cb, Cn, N = 128, 8197, 3000
+    base, _, _ = synth.gen_batch(Cb, 2 * N, base_seed=778)
+    rng = np.random.default_rng(6)
+    amp = rng.uniform(0.1, 2.0, (Cn, 1)).astype(np.float32)
+    rot = np.exp(1j * rng.uniform(-np.pi, np.pi, (Cn, 1))).astype(np.complex64)
+    iq = (base[np.arange(Cn) % Cb] * (amp * rot)).astype(np.complex64)
+    d = pkg.Demodulator(Cn, N)
+    states = None
+    for k in range(2):
+        blk = np.ascontiguousarray(iq[:, k * N:(k + 1) * N])
+        bits, nb, _ = d.process(blk)
+        rb, rnb, _, states = oracle.process_batch(blk, states=states)
+        assert np.array_equal(nb, rnb), k
+        bad = [c for c in range(Cn) if not np.array_equal(bits[c][:nb[c]], rb[c][:nb[c]])]
+        assert not bad, (k, bad[:10])
+    d.close()
+
+
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 def test_non_finite_input_cannot_hang_or_overrun(pkg, synth, pipeline):
     """NaN/Inf in one channel poisons that channel's loops (as it would the reference's) but the call returns,
