@@ -200,6 +200,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the demodulator has no CPU path")
+    local_rank %= max(1, torch.cuda.device_count())     # more ranks than GPUs (functional test of the N > 1 path on one GPU, --backend gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
