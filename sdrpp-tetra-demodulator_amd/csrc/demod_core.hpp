@@ -146,8 +146,9 @@ TD_FN float v_sqrt_agc(float x) {
     float yu = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
     float rd = __builtin_fmaf(-yd, y, x);
     float ru = __builtin_fmaf(-yu, y, x);
-    y = (rd <= 0.0f) ? yd : y;
-    y = (ru > 0.0f) ? yu : y;
+    const bool down = rd <= 0.0f, up = ru > 0.0f;     // never both: both compares first, then both selects (hazard slots overlap)
+    y = down ? yd : y;
+    y = up ? yu : y;
     return y;
 }
 #else
@@ -557,9 +558,11 @@ TD_FN int k2_phase(float mu) {
 // Costas loop + slicer + differential decoder for one symbol (pi4dqpsk_costas.cpp:7-28,
 // dqpsk_sym_extr.cpp:6-7,32-52).  Returns the dibit; (*zr, *zi) = PI4DQPSK::process output.
 TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
-    float ph2 = st.ph2 + (-kFlPi / 4.0f);
-    if (ph2 >= 2 * kFlPi) ph2 -= 2 * kFlPi;
-    else if (ph2 <= -2 * kFlPi) ph2 += 2 * kFlPi;
+    // pi4dqpsk_costas.cpp:10-15 as two selects (same values as the if / else-if, no divergent branch in the wave)
+    const float t2 = st.ph2 + (-kFlPi / 4.0f);
+    const float dn2 = t2 - 2 * kFlPi, up2 = t2 + 2 * kFlPi;
+    float ph2 = v_sel(t2 <= -2 * kFlPi, up2, t2);
+    ph2 = v_sel(t2 >= 2 * kFlPi, dn2, ph2);
     st.ph2 = ph2;
     Pair<float> s2, c2;                                   // (loop phasor, pi/4-rotation phasor) in one packed evaluation
     sincos_pair(Pair<float>(-st.cph, ph2), s2, c2);
