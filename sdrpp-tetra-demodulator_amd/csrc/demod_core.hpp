@@ -469,30 +469,46 @@ constexpr int kRrcMaxTaps = 80;
 constexpr int kRrcOut = 8;
 constexpr int kRrcExt = 104;   // >= 7 + 7 (alignment pad) + kRrcMaxTaps - 1 + 16, a multiple of 4
 struct Tap4 { float v[4]; };
-template <class LD, class LT> TD_FN void rrc_direct8(int nchunks, LD ld, LT tap4, Pair<float>* out) {
+// One chunk of the walk.  ENDS: 0 = every product; 1 = the FIRST chunk of a window whose taps start exactly at ext[7]
+// (no alignment pad): sample j meets tap kk = j - m of output m, which exists only for j >= m; 2 = the LAST chunk of
+// a window whose newest tap sits at its first sample (nt - 1 a multiple of 8): kk = nt - 1 + j - m exists only for j <= m.
+// The skipped products are the ones against zero taps, which leave the chain untouched bit for bit (above).
+template <int ENDS, class LD, class LT> TD_FN void rrc_chunk8(int ck, LD& ld, LT& tap4, Pair<float>* acc) {
+    const int p0 = ck * 8;
+    Pair<float> x[8];
+    float h[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = ld(p0 + j);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {            // ext[p0 .. p0+15]: tap index kk = p0 - 7 + q'
+        if ((ENDS == 1 && q == 0) || (ENDS == 2 && q >= 2)) continue;      // those taps meet no kept product
+        const Tap4 t = tap4(2 * ck + q);
+        h[4 * q] = t.v[0]; h[4 * q + 1] = t.v[1]; h[4 * q + 2] = t.v[2]; h[4 * q + 3] = t.v[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int m = 0; m < kRrcOut; m++) {
+            if ((ENDS == 1 && j < m) || (ENDS == 2 && j > m)) continue;
+            // sample p0+j meets tap kk = p0 + j - m of output m  ->  ext index kk + 7 = p0 + (j - m + 7)
+            acc[m] = pk_fma(x[j], Pair<float>(h[j - m + 7], h[j - m + 7]), acc[m]);
+        }
+    }
+}
+// TRI: the caller guarantees an unpadded window with nt = 8 (nchunks - 1) + 1 taps (65 taps: 9 chunks): the two end
+// chunks are triangular, 36 products instead of 64 each.
+template <bool TRI, class LD, class LT> TD_FN void rrc_direct8(int nchunks, LD ld, LT tap4, Pair<float>* out) {
     Pair<float> acc[kRrcOut];
 #pragma unroll
     for (int m = 0; m < kRrcOut; m++) acc[m] = Pair<float>(0.0f, 0.0f);
+    if (TRI) {
+        rrc_chunk8<1>(0, ld, tap4, acc);
 #pragma unroll 1
-    for (int ck = 0; ck < nchunks; ck++) {
-        const int p0 = ck * 8;
-        Pair<float> x[8];
-        float h[16];
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = ld(p0 + j);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {            // ext[p0 .. p0+15]: tap index kk = p0 - 7 + q'
-            const Tap4 t = tap4(2 * ck + q);
-            h[4 * q] = t.v[0]; h[4 * q + 1] = t.v[1]; h[4 * q + 2] = t.v[2]; h[4 * q + 3] = t.v[3];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-#pragma unroll
-            for (int m = 0; m < kRrcOut; m++) {
-                // sample p0+j meets tap kk = p0 + j - m of output m  ->  ext index kk + 7 = p0 + (j - m + 7)
-                acc[m] = pk_fma(x[j], Pair<float>(h[j - m + 7], h[j - m + 7]), acc[m]);
-            }
-        }
+        for (int ck = 1; ck < nchunks - 1; ck++) rrc_chunk8<0>(ck, ld, tap4, acc);
+        rrc_chunk8<2>(nchunks - 1, ld, tap4, acc);
+    } else {
+#pragma unroll 1
+        for (int ck = 0; ck < nchunks; ck++) rrc_chunk8<0>(ck, ld, tap4, acc);
     }
 #pragma unroll
     for (int m = 0; m < kRrcOut; m++) out[m] = acc[m];

@@ -46,7 +46,17 @@ constexpr int kFS = 64;                  // symbol ring per channel
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 
 // wave index -> role.  A workgroup's waves are placed on SIMDs cyclically, so waves w and w+4 share a SIMD.
-enum { kRoleE = 0, kRoleD = 1, kRoleF0 = 2, kRoleF1 = 3, kRoleA = 4, kRoleC = 5 };
+// Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
+// the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
+//   SIMD0 {E (wave 0), C (wave 4)}   SIMD1 {D (wave 1), A (wave 5)}   SIMD2 {F0}   SIMD3 {F1}
+// The symbol-rate recurrences (E, D) keep priority; the packed-FP32-heavy RRC wave sits beside the lighter of the two.
+// Measured A/B on one box (profiles/r02/r02_j_role_placement.md): this placement 4.41 ms; {E,A}{D,C} 4.49; the same pairs with
+// priorities flipped 5.23; {E,D}{A,C} 5.02.
+#ifndef TETRA_ROLE_IDS
+#define TETRA_ROLE_IDS 0, 1, 2, 3, 5, 4
+#endif
+namespace role_ids { constexpr int v[6] = { TETRA_ROLE_IDS }; }
+enum { kRoleE = role_ids::v[0], kRoleD = role_ids::v[1], kRoleF0 = role_ids::v[2], kRoleF1 = role_ids::v[3], kRoleA = role_ids::v[4], kRoleC = role_ids::v[5] };
 
 struct FusedParams {
     const float2* iq;
@@ -310,6 +320,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         const int c = lane & 15;
         const int rrc_pad = (8 - ((p.ntaps - 1) & 7)) & 7;
         const int rrc_chunks = (p.ntaps - 1 + rrc_pad) / 8 + 1;
+        const bool rrc_tri = rrc_pad == 0 && rrc_chunks >= 2;      // nt = 8k + 1 taps (the reference's 65): no alignment pad
         const unsigned x_base = pin_u32(lds_addr(&L.x_ring[c][kFXP]));
         // Reference-style reset / tap-count growth (tetra_demod.h, rrc_valid): delay-line samples older than the newest
         // valid0 are zeros to the RRC (and only to it).  Rare, and only the tiles whose windows reach into the delay
@@ -326,20 +337,22 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                     Pair<float> out[kRrcOut];
                     auto tap4 = [&](int q) { const float4 t4 = reinterpret_cast<const float4*>(L.rrc)[q];
                                              Tap4 r; r.v[0] = t4.x; r.v[1] = t4.y; r.v[2] = t4.z; r.v[3] = t4.w; return r; };
+                    auto ldx = [&](int q) {      // q = 8*ck + j: chunk base wrapped, j added as an immediate offset
+                        lds_cfloat2* xw = (lds_cfloat2*)(size_t)(x_base + (((start + (q & ~7)) & (kFX - 1)) << 3));
+                        const vfloat2 v = xw[q & 7];
+                        return Pair<float>(v.x, v.y); };
                     if (blanked && t * kFT < p.ntaps - 1 + rrc_pad) {
-                        rrc_direct8(rrc_chunks,
+                        rrc_direct8<false>(rrc_chunks,
                                     [&](int q) {
                                         const float2 v = x_ring_get(L, c, start + q);
                                         const bool seen = start + q >= -valid0;
                                         return Pair<float>(seen ? v.x : 0.0f, seen ? v.y : 0.0f); },
                                     tap4, out);
-                    } else
-                    rrc_direct8(rrc_chunks,
-                                [&](int q) {      // q = 8*ck + j: chunk base wrapped, j added as an immediate offset
-                                    lds_cfloat2* xw = (lds_cfloat2*)(size_t)(x_base + (((start + (q & ~7)) & (kFX - 1)) << 3));
-                                    const vfloat2 v = xw[q & 7];
-                                    return Pair<float>(v.x, v.y); },
-                                tap4, out);
+                    } else if (rrc_tri) {
+                        rrc_direct8<true>(rrc_chunks, ldx, tap4, out);      // 65 taps: triangular first and last chunk
+                    } else {
+                        rrc_direct8<false>(rrc_chunks, ldx, tap4, out);
+                    }
                     _Pragma("unroll")
                     for (int m = 0; m < kRrcOut; m++) {
                         if (i0 + m < n) {
@@ -475,7 +488,9 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
     }
 #ifdef TETRA_DEMOD_DEBUG
     if (PROF && lane == 0) {
-        p.prof[(long long)blockIdx.x * 8 + wave] = busy_;
+        int slot = 0;          // report in role order E, D, F0, F1, A, C whatever the wave indices are
+        for (int r = 0; r < 6; r++) slot = role_ids::v[r] == wave ? r : slot;
+        p.prof[(long long)blockIdx.x * 8 + slot] = busy_;
         if (wave == 0) p.prof[(long long)blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - t_entry_;
     }
 #else

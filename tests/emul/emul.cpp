@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tetra_demod.h"
@@ -186,9 +187,12 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
             const int start = i0 - (t->ntaps - 1) - rpad;
             const float* w = xf.data() + 2 * (kHist + start);
             const int valid0 = st[c].rrc_valid;           // delay-line samples the RRC may see (tetra_demod.h)
-            rrc_direct8(rrc_chunks, [&](int q) { const bool seen = start + q >= -valid0;
+            const bool tri = rpad == 0 && rrc_chunks >= 2 && st[c].rrc_valid >= kHist;
+            auto run = [&](auto T) { rrc_direct8<decltype(T)::value>(rrc_chunks, [&](int q) { const bool seen = start + q >= -valid0;
                                                  return Pair<float>(seen ? w[2 * q] : 0.0f, seen ? w[2 * q + 1] : 0.0f); },
-                        [&](int q) { Tap4 r; for (int z = 0; z < 4; z++) r.v[z] = rrc_ext[4 * q + z]; return r; }, out);
+                        [&](int q) { Tap4 r; for (int z = 0; z < 4; z++) r.v[z] = rrc_ext[4 * q + z]; return r; }, out); };
+            // like the kernel: 8k+1 taps without hidden delay-line samples take the triangular end chunks
+            if (tri) run(std::true_type{}); else run(std::false_type{});
             for (int m = 0; m < kRrcOut && i0 + m < n; m++) {
                 y[((size_t)c * n + i0 + m) * 2] = out[m].x();
                 y[((size_t)c * n + i0 + m) * 2 + 1] = out[m].y();
