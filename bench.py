@@ -65,15 +65,19 @@ def make_input(torch, synth, device, n_channels, n_samples, seed):
     return out, txb
 
 
+KERNEL_SOURCES = ("kernel_fused.hpp", "demod_core.hpp", "fll_asm.inc")      # what k_fused is compiled from (+ the flags below)
+
+
 def kernel_source_hash():
-    """sha256 over the kernel sources the dominant kernel is built from: a counter measurement is only as current as this."""
+    """sha256 over the sources the dominant kernel is built from (and its arithmetic-relevant compile flags): a counter
+    measurement is only as current as this.  Host-side files (the C ABI around the launch) do not enter."""
     import hashlib
     csrc = os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc")
     hsh = hashlib.sha256()
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".hpp", ".inc", ".h")):
-            with open(os.path.join(csrc, name), "rb") as f:
-                hsh.update(name.encode() + b"\0" + f.read())
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(csrc, name), "rb") as f:
+            hsh.update(name.encode() + b"\0" + f.read())
+    hsh.update(b"-O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950")
     return hsh.hexdigest()
 
 

@@ -524,6 +524,11 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
     if (bits_stride < tetra_demod_bits_stride(n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    if (h->as.ready) {      // asynchronous calls still in flight run on their own streams: let them finish first (state order)
+        HIP_TRY(h, hipStreamSynchronize(h->as.s_in));
+        HIP_TRY(h, hipStreamSynchronize(h->as.s_k));
+        HIP_TRY(h, hipStreamSynchronize(h->as.s_out));
+    }
     const size_t C = (size_t)h->C;
     const size_t iq_bytes = sizeof(float) * 2 * C * (size_t)n_samples;
     const size_t bits_bytes = C * (size_t)bits_stride;

@@ -567,3 +567,26 @@ def test_async_host_path_equals_the_synchronous_one(pkg, oracle, synth, layout):
                 assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (fmt, c, p0)
                 assert not bits[c][nb[c]:].any()
         d.close()
+
+
+def test_sync_call_after_an_async_one_without_wait(pkg, oracle, synth):
+    """tetra_demod_process right behind tetra_demod_process_async with no wait in between: the synchronous entry point lets
+    the call in flight finish first, so the state order (and every bit) is that of two consecutive calls."""
+    import torch
+    B = pkg.binding
+    Cn, n = 9, 12000
+    iq, _, _ = synth.gen_batch(Cn, 2 * n, base_seed=556)
+    d = pkg.Demodulator(Cn, n)
+    host_in = _pinned(torch, iq[:, :n])
+    stride = B.bits_stride(n)
+    bits0 = torch.zeros((Cn, stride), dtype=torch.uint8).pin_memory()
+    nb0 = torch.zeros((Cn,), dtype=torch.int32).pin_memory()
+    d.process_async(host_in.data_ptr(), B.IQ_CF32, n, bits0.data_ptr(), stride, nb0.data_ptr())
+    bits1, nb1, _ = d.process(np.ascontiguousarray(iq[:, n:]))
+    d.wait()
+    for c in range(Cn):
+        o = oracle.Oracle()
+        r0, r1 = o.process(iq[c, :n]), o.process(iq[c, n:])
+        assert nb0[c] == r0["bits"].size and np.array_equal(bits0.numpy()[c][:nb0[c]], r0["bits"]), c
+        assert nb1[c] == r1["bits"].size and np.array_equal(bits1[c][:nb1[c]], r1["bits"]), c
+    d.close()
