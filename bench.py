@@ -126,9 +126,21 @@ def cpu_baseline(synth, n_samples, budget_s=8.0):
                     sample="%d x (%d channels x %d samples), %d OpenMP threads on %d physical cores, %.1f s"
                            % (reps, n_ch, n_samples, threads, cores, el))
 
+    def one_thread(call):
+        """The 1-thread figure SURVEY.md 8(d) asks for beside the all-cores one: 4 channels, ~2 s."""
+        small = np.ascontiguousarray(iq[:4])
+        st = call(small, None)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            st = call(small, st)
+            reps += 1
+        return round(reps * 4 * n_samples / (time.perf_counter() - t0) / 1e6, 3)
+
     port = leg("port", lambda st: ob.process_batch(iq, threads=threads, states=st)[3])
+    port["single_thread_msamples_s"] = one_thread(lambda x, st: ob.process_batch(x, threads=1, states=st)[3])
     try:
         fast = leg("port-fast", lambda st: ob.fast_process_batch(iq, threads=threads, states=st)[2])
+        fast["single_thread_msamples_s"] = one_thread(lambda x, st: ob.fast_process_batch(x, threads=1, states=st)[2])
     except Exception as e:          # the baseline must never take the bench line down
         fast = dict(error=str(e)[:200], kind="port-fast")
     return port, fast
