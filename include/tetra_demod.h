@@ -206,6 +206,9 @@ int tetra_demod_reset(tetra_demod_t* h, int channel);
  * (a rate / RRC setter with cfg.rrc_taps, a tap count with either FIR table) returns TETRA_ERR_UNSUPPORTED and changes nothing. */
 int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value);
 
+/* Checkpoint / restore of one channel's loop state.  set_state accepts what the chain can be in: |fll_phase| <= pi,
+ * |costas_phase| <= pi, |ph2| < 2 pi (the reference's loops wrap to these ranges on every step; anything else is
+ * TETRA_ERR_ARG), rrc_valid clamped to 0..80. */
 int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out);
 int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in);
 

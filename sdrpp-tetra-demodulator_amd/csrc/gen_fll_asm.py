@@ -140,8 +140,8 @@ R_K, R_R = 80, 81
 R_Z = 82                        # (z, -)
 R_Q = 84                        # (S3 constant, first cosine Horner value)
 R_PP = 86                       # (sine, cosine) Horner pair
-R_M = 88
-R_CC, R_SS = 90, 92             # (cos, -), (sin, -): the phasor in the low halves of two aligned pairs
+R_SGN = 88                      # (-1)^k of the reduction, low half of an aligned pair
+R_A2 = 90                       # the AGC sample times that sign
 R_T1, R_T2 = 94, 96
 R_C14, R_C32 = 98, 100
 R_D, R_U = 102, 104
@@ -262,26 +262,30 @@ def real_step(E, s):
     # NCO phasor: sincos_t<float, true>(-ph); sine and cosine polynomials as one packed Horner chain
     E.ins("v_mul_f32 v%d, %s, v%d" % (R_K, INV_PI_NEG, R_PH), "valu", [R_K], [R_PH])
     E.ins("v_rndne_f32 v%d, v%d" % (R_K, R_K), "valu", [R_K], [R_K])
+    E.ins("v_fma_f32 v%d, |v%d|, -2.0, 1.0" % (R_SGN, R_K), "valu", [R_SGN], [R_K])                                     # (-1)^k for |k| <= 1
     E.ins("v_fma_f32 v%d, v%d, %%[negc1], -v%d" % (R_R, R_K, R_PH), "valu", [R_R], [R_K, R_PH])
     E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C2N), R_K), "valu", [R_R], [R_R, R_K])
     E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C3N), R_K), "valu", [R_R], [R_R, R_K])
     E.ins("v_mul_f32 v%d, v%d, v%d" % (R_Z, R_R, R_R), "valu", [R_Z], [R_R])
+    if s & 1 == 0:
+        E.ins("s_waitcnt lgkmcnt(0)", "wait")          # this pair of AGC samples (loaded two steps ago)
+    E.ins("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair(R_A2), pair(a), pair(R_SGN)), "pk", [R_A2, R_A2 + 1], [a, a + 1, R_SGN])
     E.ins("v_fmamk_f32 v%d, v%d, %s, v%d" % (R_Q + 1, R_Z, f32(C4), R_CC3), "valu", [R_Q + 1], [R_Z, R_CC3])        # c4*z + c3
     E.ins("v_pk_fma_f32 %s, %s, %s, %%[k1] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_Q), pair(R_Z)), "pk", [R_PP, R_PP + 1],
           [R_Q, R_Q + 1, R_Z])                                                                                        # (s3*z + s2, . *z + c2)
     for kk in ("k2", "k3", "k4"):                                                                                     # k4: (ps*z - 0, pc*z + 1)
         E.ins("v_pk_fma_f32 %s, %s, %s, %%[%s] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z), kk), "pk", [R_PP, R_PP + 1],
               [R_PP, R_PP + 1, R_Z])
-    E.ins("v_lshlrev_b32 v%d, 8, v%d" % (R_M, R_K), "valu", [R_M], [R_K])
-    E.ins("v_fmac_f32 v%d, v%d, v%d" % (R_R, R_PP, R_R), "valu", [R_R], [R_PP, R_R])                                   # sin before the sign
-    E.ins("v_xor_b32 v%d, v%d, v%d" % (R_CC, R_M, R_PP + 1), "valu", [R_CC], [R_M, R_PP + 1])
-    E.ins("v_xor_b32 v%d, v%d, v%d" % (R_SS, R_M, R_R), "valu", [R_SS], [R_M, R_R])
-    if s & 1 == 0:
-        E.ins("s_waitcnt lgkmcnt(0)", "wait")          # this pair of AGC samples (loaded two steps ago)
-    # x = a * (c + j s): (ar*c, ai*c) + (-(ai*s), ar*s)
-    E.ins("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair(R_T1), pair(a), pair(R_CC)), "pk", [R_T1, R_T1 + 1], [a, a + 1, R_CC])
-    E.ins("v_pk_mul_f32 %s, %s, %s op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[0,1]" % (pair(R_T2), pair(a), pair(R_SS)), "pk",
-          [R_T2, R_T2 + 1], [a, a + 1, R_SS])
+    E.ins("v_fmac_f32 v%d, v%d, v%d" % (R_R, R_PP, R_R), "valu", [R_R], [R_PP, R_R])                                   # sin (before the sign)
+    # The sign (-1)^k of sincos_t goes onto the SAMPLE instead of onto sine and cosine: a' = a * sgn with sgn = 1 - 2|k|
+    # (the loop keeps |ph| <= pi, so k is -1, 0 or 1; tetra_demod_set_state refuses other phases).  Multiplying by +-1 is
+    # exact and commutes with every rounding below, so x has the same bits as a * ((-1)^k c + j (-1)^k s): one slot less
+    # than shift + two xors.
+    # x = a' * (c + j s): (ar*c, ai*c) + (-(ai*s), ar*s), c = high half of the Horner pair, s = R
+    E.ins("v_pk_mul_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,1]" % (pair(R_T1), pair(R_A2), pair(R_PP)), "pk", [R_T1, R_T1 + 1],
+          [R_A2, R_A2 + 1, R_PP + 1])
+    E.ins("v_pk_mul_f32 %s, %s, %s op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" % (pair(R_T2), pair(R_A2), pair(R_K)), "pk",
+          [R_T2, R_T2 + 1], [R_A2, R_A2 + 1, R_R])
     E.ins("v_pk_add_f32 %s, %s, %s" % (pair(n), pair(R_T1), pair(R_T2)), "pk", [n, n + 1], [R_T1, R_T1 + 1, R_T2, R_T2 + 1])
     if s & 1 == 1 and s + 3 < TILE:
         # both samples of this pair are consumed: the pair after the next one goes into their registers

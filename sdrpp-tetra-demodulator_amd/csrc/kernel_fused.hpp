@@ -227,7 +227,11 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                     for (int s = 0; s < kFT; s++) {
                         const Pair<float> x = buf[s];
                         buf[s] = ld_pair(in + (long long)(base + kFT + s) * p.in_t_stride);
+#if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 3      // experiment builds only: AGC wave without its arithmetic
+                        const Pair<float> a = x;
+#else
                         const Pair<float> a = agc_step<float>(p.k1, x, g);
+#endif
                         dst[s] = make_float2(a.x(), a.y());
                     }
                 } else {
@@ -319,7 +323,11 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         // taps) to start on a multiple of 8, so that no 8-sample chunk straddles the ring's wrap.
         const int c = lane & 15;
         const int rrc_pad = (8 - ((p.ntaps - 1) & 7)) & 7;
+#if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 2      // experiment builds only (profiles/r02): RRC wave with a ninth of its work
+        const int rrc_chunks = 1;
+#else
         const int rrc_chunks = (p.ntaps - 1 + rrc_pad) / 8 + 1;
+#endif
         const bool rrc_tri = rrc_pad == 0 && rrc_chunks >= 2;      // nt = 8k + 1 taps (the reference's 65): no alignment pad
         const unsigned x_base = pin_u32(lds_addr(&L.x_ring[c][kFXP]));
         // Reference-style reset / tap-count growth (tetra_demod.h, rrc_valid): delay-line samples older than the newest
@@ -463,7 +471,12 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                 while (S < avail) {
                     const float2 v = L.s_ring[c][S & (kFS - 1)];
                     float zr; float zi;
+#if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 1      // experiment builds only (profiles/r02): E without its arithmetic
+                    zr = v.x; zi = v.y;
+                    const int d = S & 3;
+#else
                     const int d = k2_costas(k2, st, v.x, v.y, &zr, &zi);
+#endif
                     if (wr) {
                         // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
                         *reinterpret_cast<unsigned short*>(brow + 2 * S) = (unsigned short)(((d >> 1) & 1) | ((d & 1) << 8));

@@ -10,6 +10,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -783,6 +784,9 @@ int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_sta
 
 int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in) {
     if (!h || !in || channel < 0 || channel >= h->C) return TETRA_ERR_ARG;
+    // Phases outside what the loops can produce are refused (every pcl.advance wraps to [-pi, pi], ph2 to (-2 pi, 2 pi),
+    // pi4dqpsk_costas.cpp:10-15): the kernel's phasor evaluation relies on those ranges.  NaN (a poisoned channel) passes.
+    if (std::fabs(in->fll_phase) > kFlPi || std::fabs(in->costas_phase) > kFlPi || std::fabs(in->ph2) >= 2 * kFlPi) return TETRA_ERR_ARG;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
