@@ -1,0 +1,62 @@
+"""Generates tests/golden/refshim_vectors.npz: inputs and the outputs of the REFERENCE'S OWN src/dsp code for them.
+
+Container only (needs /root/reference): the reference's pi4dqpsk.cpp / fll.cpp / complex_fd.cpp / pi4dqpsk_costas.cpp /
+dqpsk_sym_extr.cpp / bit_unpacker.cpp are compiled where they lie against the stand-in SDR++ core headers under
+tests/refshim/ (see tests/test_reference_shim.py) and run on synthetic IQ.  The fixture is DATA (inputs + expected outputs);
+it lets the oracle and the GPU be compared with what the reference's code computed on machines that do not have the
+reference (the GPU box).  Because the core headers are stand-ins, this is evidence, not a parity pin.
+Run from the repo root:  python tests/golden/make_refshim_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import tetra_amd  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+from tests import test_reference_shim as T  # noqa: E402
+
+
+def main():
+    synth = tetra_amd.pkg.synth
+    L = T.load_reference_build()
+    out = {}
+    # 1. the survey's probe scenario
+    # 2. a channel of the BASELINE generator, one second, processed in 180-sample calls like SDR++ delivers them
+    # 3. reset() and setters mid-stream (the reference's own reset / setter code)
+    iq1, _, _ = synth.gen_channel(40060, 7, cfo=0.03, tau=5 / 16.0, amp=0.2, esn0_db=25.0)
+    r = T.RefChain(L, ob.default_cfg())
+    out["probe_iq"] = iq1
+    out["probe_sym"], out["probe_bits"] = r.process(iq1)
+    r.close()
+    iq2, _, _ = synth.gen_channel(12000, 1234)
+    r = T.RefChain(L, ob.default_cfg())
+    parts = [r.process(iq2[i:i + 180]) for i in range(0, len(iq2), 180)]
+    r.close()
+    out["chunked_iq"] = iq2
+    out["chunked_sym"] = np.concatenate([p[0] for p in parts])
+    out["chunked_bits"] = np.concatenate([p[1] for p in parts])
+    iq3, _, _ = synth.gen_channel(24000, 77, cfo=0.01, tau=0.4, amp=0.3)
+    r = T.RefChain(L, ob.default_cfg())
+    a = r.process(iq3[:9001])
+    r.reset()
+    b = r.process(iq3[9001:16000])
+    for pid, v in ((4, 0.03), (5, 0.004), (6, 0.008), (7, 2e-4), (8, 0.02), (9, 0.02), (2, 49)):
+        r.set_param(pid, v)
+    c = r.process(iq3[16000:])
+    r.close()
+    out["ctl_iq"] = iq3
+    out["ctl_cuts"] = np.array([0, 9001, 16000, 24000], np.int32)
+    out["ctl_setters"] = np.array([(4, 0.03), (5, 0.004), (6, 0.008), (7, 2e-4), (8, 0.02), (9, 0.02), (2, 49)], np.float64)
+    for k, (sym, bits) in enumerate((a, b, c)):
+        out["ctl_sym%d" % k] = sym
+        out["ctl_bits%d" % k] = bits
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim_vectors.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
