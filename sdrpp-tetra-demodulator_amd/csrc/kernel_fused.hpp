@@ -10,12 +10,12 @@
 // channels.  A CU's 16 channels are therefore split by STAGE, each stage at the widest lane occupancy its recurrence
 // allows:
 //
-//   wave  role                                  lanes/channel   instruction slots / sample     SIMD
-//   F0,F1 FLL: NCO, band-edge FIRs, loop         8 (interleaved) 60 (hand-scheduled, fll_asm.inc) 2, 3: one each, alone
-//   E     Costas + slicer + diff. decoder + out  1               ~45                            0 (older wave)
-//   A     AGC                                    1               ~25                            0
-//   D     ML timing recovery                     1               ~40                            1 (older wave)
-//   C     RRC matched filter (time-parallel)     4 x 8 outputs   ~30                            1
+//   wave  role                                  lanes/channel   instruction slots / sample       SIMD
+//   F0,F1 FLL: NCO, band-edge FIRs, loop         8 (interleaved) 59 (hand-scheduled, fll_asm.inc) 2, 3: one each, alone
+//   E     Costas + slicer + diff. decoder + out  1               ~46                              0 (older wave)
+//   C     RRC matched filter (time-parallel)     4 x 8 outputs   ~24                              0
+//   D     ML timing recovery                     1               ~45                              1 (older wave)
+//   A     AGC                                    1               ~25                              1
 //
 // The issue arbiter serves the OLDEST wave of a SIMD first, so the recurrence-bound roles take the lower wave index of
 // their SIMD and the throughput roles fill the slots they leave.  (Cutting the FLL in two -- loop waves plus a helper wave
@@ -45,7 +45,6 @@ constexpr int kFYS = kFY + kFYM + 1;
 constexpr int kFS = 64;                  // symbol ring per channel
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 
-// wave index -> role.  A workgroup's waves are placed on SIMDs cyclically, so waves w and w+4 share a SIMD.
 // Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
 // the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
 //   SIMD0 {E (wave 0), C (wave 4)}   SIMD1 {D (wave 1), A (wave 5)}   SIMD2 {F0}   SIMD3 {F1}
