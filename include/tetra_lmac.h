@@ -72,6 +72,15 @@ uint32_t tetra_lmac_scramb_init(uint16_t mcc, uint16_t mnc, uint8_t colour);
 int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_blocks, int in_stride,
                                    const uint32_t* d_scramb_init, uint8_t* d_type2, int out_stride, int32_t* d_crc_ok,
                                    void* hip_stream);
+/*
+ * Counted form for rows that come out of tetra_burst_demux_compact_device: n_blocks is the CAPACITY of the row arrays, the
+ * number of rows actually present is read on the device from *d_n_blocks (NULL: all n_blocks), and the scrambling code of
+ * row j is d_scramb_init[d_init_index[j]] (d_init_index = the demultiplexer's d_row_frame, so that the per-frame-slot code
+ * array of tetra_lmac_track_scramb_device is used as it is; NULL: d_scramb_init[j]).  Rows past the count are not touched.
+ */
+int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blocks, const int32_t* d_n_blocks, int in_stride,
+                                     const uint32_t* d_scramb_init, const int32_t* d_init_index, uint8_t* d_type2, int out_stride,
+                                     int32_t* d_crc_ok, void* hip_stream);
 /* Host-pointer variant (copies in/out, synchronises; device = HIP ordinal or -1 for the current one). */
 int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
                             uint8_t* type2, int out_stride, int32_t* crc_ok, int device);

@@ -38,12 +38,21 @@ bufs = {k[0]: (torch.zeros((C * F, k[3]), dtype=torch.uint8, device=dev), torch.
                torch.zeros((C * F, k[4]), dtype=torch.uint8, device=dev), torch.zeros(C * F, dtype=torch.int32, device=dev)) for k in kinds}
 
 
+cbufs = {k[0]: (torch.zeros((C * F,), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)) for k in kinds}
+COMPACT = True      # set per run: rows only for the frames that carry the kind (tetra_burst_demux_compact_device + counted decoder)
+
+
 def chain(b, stream):
     bs.process_device(d_bits[b], stride, d_nbits[b], d_frames, d_ft, d_fb, d_nf, stream)
     for name, tpsap, blk, rs, os_ in kinds:
         rows, valid, t2, ok = bufs[name]
-        bb.demux_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, valid, stream)
-        lb.decode_batch_device(tpsap, rows, C * F, rs, d_scr, t2, os_, ok, stream)
+        if COMPACT:
+            idx, cnt = cbufs[name]
+            bb.demux_compact_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, idx, cnt, stream)
+            lb.decode_counted_device(tpsap, rows, C * F, cnt, rs, d_scr, idx, t2, os_, ok, stream)
+        else:
+            bb.demux_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, valid, stream)
+            lb.decode_batch_device(tpsap, rows, C * F, rs, d_scr, t2, os_, ok, stream)
 
 
 def run(overlap):
@@ -69,11 +78,17 @@ def run(overlap):
 
 
 run(True)                                                 # warm-up (allocator pools, clocks)
+run(True)
 res = {"channels": C, "samples_per_channel": N, "seconds": SEC}
-for name, ov in (("serial_one_stream", False), ("overlapped_two_streams", True), ("serial_one_stream_again", False),
-                 ("overlapped_two_streams_again", True)):
+for name, ov, comp in (("serial_one_stream", False, False), ("overlapped_two_streams", True, False),
+                       ("serial_one_stream_compact", False, True), ("overlapped_two_streams_compact", True, True),
+                       ("serial_one_stream_again", False, False), ("overlapped_two_streams_again", True, False),
+                       ("serial_one_stream_compact_again", False, True), ("overlapped_two_streams_compact_again", True, True)):
+    COMPACT = comp
     ms = run(ov)
     res[name + "_ms_per_second"] = round(ms, 3)
     res[name + "_x_real_time"] = round(1000.0 / ms, 1)
+res["rows_decoded_per_kind_compact"] = {k[0]: int(cbufs[k[0]][1].cpu().numpy()[0]) for k in kinds}
+res["rows_decoded_per_kind_slot_layout"] = C * F
 res["channels_locked"] = sum(1 for st in bs.states() if st[0] == bb.RX_S_LOCKED)
 print(json.dumps(res))

@@ -181,6 +181,72 @@ __global__ __launch_bounds__(256) void k_burst_demux(const uint8_t* __restrict__
     if (d == 0) valid[r] = p.len0 > 0;
 }
 
+// ---- compacting form of the demultiplexer: only frames that carry the block kind produce a row, in frame order ----
+// 1. per block of 256 frames: how many carry it
+__global__ __launch_bounds__(256) void k_demux_count(const int* __restrict__ frame_type, int n, int tpsap, int blk_num,
+                                                     int* __restrict__ block_count) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool has = r < n && pieces_for(frame_type[r], tpsap, blk_num).len0 > 0;
+    const int c = __syncthreads_count(has ? 1 : 0);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = c;
+}
+// 2. exclusive scan of the block counts (one workgroup; nblocks is a few thousand), total -> *n_rows
+__global__ __launch_bounds__(1024) void k_demux_scan(int* __restrict__ block_count, int nblocks, int* __restrict__ n_rows) {
+    __shared__ int part[1024];
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(nblocks, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += block_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) { const int c = block_count[i]; block_count[i] = run; run += c; }
+    if (threadIdx.x == 1023) *n_rows = part[1023];
+}
+// 3. row j <- frame index, frame order kept
+__global__ __launch_bounds__(256) void k_demux_index(const int* __restrict__ frame_type, int n, int tpsap, int blk_num,
+                                                     const int* __restrict__ block_off, int* __restrict__ row_frame) {
+    __shared__ int wave_cnt[4];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool has = r < n && pieces_for(frame_type[r], tpsap, blk_num).len0 > 0;
+    const unsigned long long m = __ballot(has);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int i = 0; i < w; ++i) base += wave_cnt[i];
+    if (has) row_frame[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+}
+// 4. the gather itself, one thread per output dword of the worst case; rows past *n_rows do not exist
+__global__ __launch_bounds__(256) void k_demux_gather(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type,
+                                                      const int* __restrict__ row_frame, const int* __restrict__ n_rows, int n,
+                                                      int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride) {
+    const int row_dw = row_stride >> 2;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)n * row_dw) return;
+    const int j = (int)(gid / row_dw), d = (int)(gid % row_dw);
+    if (j >= *n_rows) return;
+    const int r = row_frame[j];
+    const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
+    const uint8_t* f = frames + (size_t)r * TETRA_FRAME_STRIDE;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * d + k;
+        uint32_t byte = 0;
+        if (i < p.len0) byte = f[p.off0 + i];
+        else if (i < p.len0 + p.len1) byte = f[p.off1 + i - p.len0];
+        v |= byte << (8 * k);
+    }
+    reinterpret_cast<uint32_t*>(rows + (size_t)j * row_stride)[d] = v;
+}
+
 size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 5 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
 
 }  // namespace
@@ -311,6 +377,34 @@ int tetra_burst_demux_device(const uint8_t* d_frames, const int32_t* d_frame_typ
     hipLaunchKernelGGL(k_burst_demux, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames,
                        d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_valid);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                     uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream) {
+    if (!d_frames || !d_frame_type || !d_rows || !d_row_frame || !d_n_rows || n < 0) return TETRA_ERR_ARG;
+    if (tpsap < 0 || tpsap > 5) return TETRA_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (n == 0) return hipMemsetAsync(d_n_rows, 0, sizeof(int32_t), s) == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+    // same argument rules as tetra_burst_demux_device
+    const Pieces any[3] = { pieces_for(TETRA_TRAIN_SYNC, tpsap, blk_num), pieces_for(TETRA_TRAIN_NORM_1, tpsap, blk_num),
+                            pieces_for(TETRA_TRAIN_NORM_2, tpsap, blk_num) };
+    int longest = 0;
+    for (const Pieces& p : any) longest = p.len0 + p.len1 > longest ? p.len0 + p.len1 : longest;
+    if (longest == 0) return TETRA_ERR_ARG;                      // no burst type carries this (kind, block number)
+    if (row_stride < longest) return TETRA_ERR_SIZE;
+    if ((row_stride & 3) || ((uintptr_t)d_rows & 3)) return TETRA_ERR_ALIGN;
+    const int nblocks = (n + 255) / 256;
+    int* off = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&off), sizeof(int) * (size_t)nblocks, s) != hipSuccess) return TETRA_ERR_NOMEM;
+    hipLaunchKernelGGL(k_demux_count, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off);
+    hipLaunchKernelGGL(k_demux_scan, dim3(1), dim3(1024), 0, s, off, nblocks, d_n_rows);
+    hipLaunchKernelGGL(k_demux_index, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off, d_row_frame);
+    const long long total = (long long)n * (row_stride >> 2);
+    hipLaunchKernelGGL(k_demux_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_frames, d_frame_type, d_row_frame,
+                       d_n_rows, n, tpsap, blk_num, d_rows, row_stride);
+    const hipError_t launch = hipGetLastError();
+    if (hipFreeAsync(off, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
+    return TETRA_OK;
 }
 
 }  // extern "C"

@@ -46,18 +46,24 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                                         const uint32_t* __restrict__ scramb_init, int fixed_init,
                                                         int type345, int type2, int type1, int a,
                                                         uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
-                                                        uint16_t* __restrict__ dec_scratch, int dec_steps) {
+                                                        uint16_t* __restrict__ dec_scratch, int dec_steps,
+                                                        const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index) {
     __shared__ uint32_t stage[kLanes][kChunkDwords + 1];     // +1: odd row stride, conflict-free column reads
     __shared__ uint32_t cls[kClsWords][kLanes];
     __shared__ uint16_t outw[kOutHalves][kLanes];
     const int lane = threadIdx.x;
     const int blk0 = blockIdx.x * kLanes;
     const int blk = blk0 + lane;
+    if (n_blocks_dev) {           // counted form: the number of rows is a device-side result (compacting demultiplexer)
+        const int have = *n_blocks_dev;
+        n_blocks = have < n_blocks ? have : n_blocks;
+        if (blk0 >= n_blocks) return;
+    }
     const int rows_here = min(kLanes, n_blocks - blk0);
 
     // 1+2. rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
     //      descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
-    uint32_t lfsr = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[blk];
+    uint32_t lfsr = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[init_index ? init_index[blk] : blk];
     const int row_dw = type345 >> 2;
     for (int c0 = 0; c0 < row_dw; c0 += kChunkDwords) {
 #pragma unroll 4
@@ -98,10 +104,11 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
 // TPSAP_T_BBK: the reference only descrambles (tetra_lower_mac.c:231-236); 30 bits per block, one lane per block.
 __global__ __launch_bounds__(256) void k_lmac_bbk(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
                                                   const uint32_t* __restrict__ scramb_init, int nbits,
-                                                  uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok) {
+                                                  uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
+                                                  const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index) {
     const int blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= n_blocks) return;
-    uint32_t lfsr = scramb_init[blk];
+    if (blk >= n_blocks || (n_blocks_dev && blk >= *n_blocks_dev)) return;
+    uint32_t lfsr = scramb_init[init_index ? init_index[blk] : blk];
     const uint8_t* src = type5 + (size_t)blk * in_stride;
     uint8_t* dst = out + (size_t)blk * out_stride;
     for (int j = 0; j < nbits; ++j) dst[j] = src[j] ^ (uint8_t)lfsr_next(lfsr);
@@ -163,13 +170,20 @@ uint32_t tetra_lmac_scramb_init(uint16_t mcc, uint16_t mnc, uint8_t colour) {
 
 int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_blocks, int in_stride, const uint32_t* d_scramb_init,
                                    uint8_t* d_type2, int out_stride, int32_t* d_crc_ok, void* hip_stream) {
+    return tetra_lmac_decode_counted_device(type, d_type5, n_blocks, nullptr, in_stride, d_scramb_init, nullptr, d_type2, out_stride,
+                                            d_crc_ok, hip_stream);
+}
+
+int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blocks, const int32_t* d_n_blocks, int in_stride,
+                                     const uint32_t* d_scramb_init, const int32_t* d_init_index, uint8_t* d_type2, int out_stride,
+                                     int32_t* d_crc_ok, void* hip_stream) {
     const int rc = check_args(type, d_type5, n_blocks, in_stride, d_scramb_init, d_type2, out_stride, d_crc_ok, true);
     if (rc != TETRA_OK || n_blocks == 0) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const BlkParam& p = kBlk[type];
     if (type == TETRA_TPSAP_T_BBK) {
         hipLaunchKernelGGL(k_lmac_bbk, dim3((n_blocks + 255) / 256), dim3(256), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
-                           p.type345, d_type2, out_stride, d_crc_ok);
+                           p.type345, d_type2, out_stride, d_crc_ok, d_n_blocks, d_init_index);
     } else {
         // decision scratch: (type2 + 4) steps x 64 lanes x u16 per workgroup, from the stream-ordered allocator (pooled:
         // after the first call it is a free-list hit), released in stream order right behind the kernel
@@ -180,7 +194,7 @@ int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_block
             return TETRA_ERR_NOMEM;
         hipLaunchKernelGGL(k_lmac_decode, dim3(groups), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
                            type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride, d_crc_ok,
-                           scratch, dec_steps);
+                           scratch, dec_steps, d_n_blocks, d_init_index);
         const hipError_t launch = hipGetLastError();
         if (hipFreeAsync(scratch, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
         return TETRA_OK;

@@ -6,7 +6,7 @@ import numpy as np
 from .binding import TetraDemodError, load_library
 
 LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch",
-                "tetra_lmac_track_scramb_device"]
+                "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device"]
 # enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
 TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
 
@@ -29,6 +29,8 @@ def _lib():
         L.tetra_lmac_scramb_init.restype = C.c_uint32
         L.tetra_lmac_decode_batch_device.argtypes = [i32, vp, i32, i32, vp, vp, i32, vp, vp]
         L.tetra_lmac_decode_batch_device.restype = i32
+        L.tetra_lmac_decode_counted_device.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]
+        L.tetra_lmac_decode_counted_device.restype = i32
         L.tetra_lmac_decode_batch.argtypes = [i32, vp, i32, i32, vp, vp, i32, vp, i32]
         L.tetra_lmac_decode_batch.restype = i32
         L.tetra_lmac_track_scramb_device.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
@@ -80,6 +82,22 @@ def decode_batch_device(blk_type, d_type5, n_blocks, in_stride, d_scramb, d_type
                                                C.c_void_p(d_type2.data_ptr()), int(out_stride), C.c_void_p(d_crc_ok.data_ptr()), s)
     if rc:
         raise TetraDemodError(rc, "tetra_lmac_decode_batch_device")
+
+
+def decode_counted_device(blk_type, d_type5, capacity, d_n_blocks, in_stride, d_scramb, d_init_index, d_type2, out_stride, d_crc_ok,
+                          stream=None):
+    """Rows from the compacting demultiplexer: count and scrambling-code index are read on the device."""
+    s = None
+    if stream is not None:
+        s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+    vp = C.c_void_p
+    rc = _lib().tetra_lmac_decode_counted_device(int(blk_type), vp(d_type5.data_ptr()), int(capacity),
+                                                 None if d_n_blocks is None else vp(d_n_blocks.data_ptr()), int(in_stride),
+                                                 None if d_scramb is None else vp(d_scramb.data_ptr()),
+                                                 None if d_init_index is None else vp(d_init_index.data_ptr()),
+                                                 vp(d_type2.data_ptr()), int(out_stride), vp(d_crc_ok.data_ptr()), s)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_decode_counted_device")
 
 
 def track_scramb_device(d_sb1_type2, type2_stride, d_crc_ok, d_valid, n_channels, frames_per_channel, d_chan_scramb, d_row_scramb,

@@ -313,6 +313,51 @@ def test_gpu_demux_equals_restated_rx_cb(pkg, ref, oracle):
         pkg.bsync_binding.demux_device(d_frames, d_types, n, 5, 0, d_rows, 216, d_valid)
 
 
+@pytest.mark.gpu
+def test_gpu_compacting_demux_and_counted_decoder_equal_the_slot_layout(pkg, ref):
+    """tetra_burst_demux_compact_device + tetra_lmac_decode_counted_device (rows only for the frames that carry the kind, count
+    and scrambling-code index read on the device) give, row by row, what tetra_burst_demux_device +
+    tetra_lmac_decode_batch_device give for the same frame slot; rows come out in frame order."""
+    import torch
+    lb, bb_ = pkg.lmac_binding, pkg.bsync_binding
+    rng = np.random.default_rng(9)
+    n = 5000
+    types = rng.choice(np.array([0, 1, 3, -1, -2], np.int32), n, p=[0.3, 0.25, 0.25, 0.1, 0.1])
+    frames = np.zeros((n, 512), np.uint8)
+    frames[:, :510] = rng.integers(0, 2, (n, 510))
+    scr = rng.integers(1, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    dev = torch.device("cuda", 0)
+    d_frames, d_types = torch.from_numpy(frames).to(dev), torch.from_numpy(types).to(dev)
+    d_scr = torch.from_numpy(scr.view(np.int32)).to(dev)
+    for tpsap, blk, rs, os_ in ((lb.TPSAP_T_SB1, 1, 120, 80), (lb.TPSAP_T_SB2, 2, 216, 144), (lb.TPSAP_T_NDB, 1, 216, 144),
+                                (lb.TPSAP_T_SCH_F, 0, 432, 288), (lb.TPSAP_T_BBK, 0, 32, 32)):
+        rows = torch.full((n, rs), 7, dtype=torch.uint8, device=dev)
+        valid = torch.zeros(n, dtype=torch.int32, device=dev)
+        t2 = torch.zeros((n, os_), dtype=torch.uint8, device=dev)
+        ok = torch.zeros(n, dtype=torch.int32, device=dev)
+        bb_.demux_device(d_frames, d_types, n, tpsap, blk, rows, rs, valid)
+        lb.decode_batch_device(tpsap, rows, n, rs, d_scr, t2, os_, ok)
+        crow = torch.full((n, rs), 9, dtype=torch.uint8, device=dev)
+        cidx = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        ct2 = torch.zeros((n, os_), dtype=torch.uint8, device=dev)
+        cok = torch.full((n,), -3, dtype=torch.int32, device=dev)
+        bb_.demux_compact_device(d_frames, d_types, n, tpsap, blk, crow, rs, cidx, cnt)
+        lb.decode_counted_device(tpsap, crow, n, cnt, rs, d_scr, cidx, ct2, os_, cok)
+        torch.cuda.synchronize()
+        v = valid.cpu().numpy().astype(bool)
+        k = int(cnt.cpu().numpy()[0])
+        idx = cidx.cpu().numpy()
+        assert k == int(v.sum()) and np.array_equal(idx[:k], np.nonzero(v)[0])           # frame order
+        assert np.array_equal(crow.cpu().numpy()[:k], rows.cpu().numpy()[v])
+        assert np.array_equal(ct2.cpu().numpy()[:k], t2.cpu().numpy()[v]) and np.array_equal(cok.cpu().numpy()[:k], ok.cpu().numpy()[v])
+        assert not ct2.cpu().numpy()[k:].any() and (cok.cpu().numpy()[k:] == -3).all()        # rows past the count untouched
+    cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    bb_.demux_compact_device(d_frames, d_types, 0, lb.TPSAP_T_SB1, 1, crow, rs, cidx, cnt)
+    torch.cuda.synchronize()
+    assert int(cnt.cpu().numpy()[0]) == 0
+
+
 def _uint_bits(v, n):
     return [(v >> (n - 1 - i)) & 1 for i in range(n)]
 
