@@ -333,8 +333,13 @@ def main():
         host["host_path_async_cs16_msamples_s"] = round(timed(
             lambda r: dem.process_async(p_q.data_ptr(), B.IQ_CS16, N, p_bits[r & 1].data_ptr(), stride, p_nb[r & 1].data_ptr()),
             6, dem.wait), 1)
+        p_q8 = (torch.view_as_real(iq.cpu()) * 128.0).round().clamp(-128, 127).to(torch.int8).pin_memory()
+        host["host_path_async_cs8_msamples_s"] = round(timed(
+            lambda r: dem.process_async(p_q8.data_ptr(), B.IQ_CS8, N, p_bits[r & 1].data_ptr(), stride, p_nb[r & 1].data_ptr()),
+            6, dem.wait), 1)
+        del p_q8
         host["host_path_note"] = ("PCIe-inclusive, page-locked host buffers, informational: sync = tetra_demod_process; async = "
-                                  "tetra_demod_process_async with two calls in flight; cs16 = int16 IQ converted on the GPU")
+                                  "tetra_demod_process_async with two calls in flight; cs16 / cs8 = int16 / int8 IQ converted on the GPU")
         del p_iq, p_q, p_bits, p_nb
 
     if rank == 0:

@@ -173,13 +173,14 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
  *              is what makes the copies asynchronous; pageable memory works but serialises.
  *   iq_format  TETRA_IQ_CF32: complex float like the reference's complex_t stream;
  *              TETRA_IQ_CS16: interleaved int16 (re, im) as SDR hardware delivers it -- converted on the GPU as x / 32768
- *              (exact in binary32, the scaling SDR++'s sources apply on the host), half the PCIe bytes.
+ *              (exact in binary32, the scaling SDR++'s sources apply on the host), half the PCIe bytes;
+ *              TETRA_IQ_CS8: interleaved int8 (RTL-SDR / HackRF class front-ends), converted as x / 128, a quarter.
  *   bits / n_bits   host memory, [n_channels][bits_stride] / [n_channels]; valid after tetra_demod_wait().
  * The input and output buffers must stay untouched until tetra_demod_wait() returns.  tetra_demod_process, _reset,
  * _set_param, _get/_set_state and _destroy wait for calls in flight themselves; tetra_demod_process_device on a caller's
  * stream does not -- wait first.  No symbol output on this path.
  */
-enum { TETRA_IQ_CF32 = 0, TETRA_IQ_CS16 = 1 };
+enum { TETRA_IQ_CF32 = 0, TETRA_IQ_CS16 = 1, TETRA_IQ_CS8 = 2 };
 int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride,
                               int32_t* n_bits);
 /* Blocks until every tetra_demod_process_async call enqueued on this handle has delivered its output. */

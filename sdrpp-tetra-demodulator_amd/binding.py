@@ -32,7 +32,7 @@ EXPORTS = [
     "tetra_demod_bandedge_tap_count", "tetra_demod_process_async", "tetra_demod_wait", "tetra_demod_host_alloc",
     "tetra_demod_host_free", "tetra_demod_device_info",
 ]
-IQ_CF32, IQ_CS16 = 0, 1
+IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
 
 
 class Config(C.Structure):

@@ -70,6 +70,14 @@ __global__ void k_cs16_to_cf32(const short2* __restrict__ in, float2* __restrict
         out[i] = make_float2((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
     }
 }
+// int8 IQ (RTL-SDR / HackRF class front-ends): x / 128, exact.
+__global__ void k_cs8_to_cf32(const char2* __restrict__ in, float2* __restrict__ out, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const char2 v = in[i];
+        out[i] = make_float2((float)v.x * (1.0f / 128.0f), (float)v.y * (1.0f / 128.0f));
+    }
+}
 // One time chunk's bits appended to the call's output rows: out[c][out_n[c] ..] = chunk[c][0 .. chunk_n[c]).
 __global__ void k_append_bits(const uint8_t* __restrict__ chunk, int chunk_stride, const int* __restrict__ chunk_n,
                               uint8_t* __restrict__ out, int out_stride, int* __restrict__ out_n) {
@@ -593,7 +601,7 @@ int async_chunk_len(int n_samples) {
 int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride,
                               int32_t* n_bits) {
     if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
-    if (iq_format != TETRA_IQ_CF32 && iq_format != TETRA_IQ_CS16) return TETRA_ERR_ARG;
+    if (iq_format != TETRA_IQ_CF32 && iq_format != TETRA_IQ_CS16 && iq_format != TETRA_IQ_CS8) return TETRA_ERR_ARG;
     if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
     if (bits_stride < tetra_demod_bits_stride(n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
     DeviceGuard g(h->device);
@@ -616,8 +624,8 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
     }
     const int chunk = async_chunk_len(n_samples);
     const int cstride = tetra_demod_bits_stride(chunk);
-    const size_t in_elem = iq_format == TETRA_IQ_CS16 ? sizeof(short) * 2 : sizeof(float) * 2;
-    const size_t want_iq = sizeof(float) * 2 * C * (size_t)chunk, want_raw = iq_format == TETRA_IQ_CS16 ? in_elem * C * (size_t)chunk : 0;
+    const size_t in_elem = iq_format == TETRA_IQ_CS16 ? sizeof(short) * 2 : iq_format == TETRA_IQ_CS8 ? 2 : sizeof(float) * 2;
+    const size_t want_iq = sizeof(float) * 2 * C * (size_t)chunk, want_raw = iq_format != TETRA_IQ_CF32 ? in_elem * C * (size_t)chunk : 0;
     const size_t want_cbits = C * (size_t)cstride, want_out = C * (size_t)bits_stride;
     if (want_iq > a.iq_bytes || want_raw > a.raw_bytes || want_cbits > a.cbits_bytes || want_out > a.out_bytes) {
         HIP_TRY(h, hipDeviceSynchronize());          // buffers may be in use by calls still in flight
@@ -644,7 +652,7 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
         const int len = n_samples - pos < chunk ? n_samples - pos : chunk;
         const int sl = (int)(a.chunks & 1);
         if (a.chunks >= 2) HIP_TRY(h, hipStreamWaitEvent(a.s_in, a.ev_free[sl], 0));
-        void* dst = iq_format == TETRA_IQ_CS16 ? a.d_raw[sl] : (void*)a.d_iq[sl];
+        void* dst = iq_format != TETRA_IQ_CF32 ? a.d_raw[sl] : (void*)a.d_iq[sl];
         if (time_major) {      // iq[n][c]: a time chunk is contiguous
             HIP_TRY(h, hipMemcpyAsync(dst, src + in_elem * C * (size_t)pos, in_elem * C * (size_t)len, hipMemcpyHostToDevice, a.s_in));
         } else {               // iq[c][n]: one row piece per channel, packed to [C][len] on the device
@@ -656,6 +664,11 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
         if (iq_format == TETRA_IQ_CS16) {
             const long long n = (long long)C * len;
             hipLaunchKernelGGL(k_cs16_to_cf32, dim3(2048), dim3(256), 0, a.s_k, static_cast<const short2*>(a.d_raw[sl]),
+                               reinterpret_cast<float2*>(a.d_iq[sl]), n);
+            HIP_TRY(h, hipGetLastError());
+        } else if (iq_format == TETRA_IQ_CS8) {
+            const long long n = (long long)C * len;
+            hipLaunchKernelGGL(k_cs8_to_cf32, dim3(2048), dim3(256), 0, a.s_k, static_cast<const char2*>(a.d_raw[sl]),
                                reinterpret_cast<float2*>(a.d_iq[sl]), n);
             HIP_TRY(h, hipGetLastError());
         }

@@ -533,8 +533,8 @@ def _pinned(torch, arr):
 @pytest.mark.parametrize("layout", ["channel_major", "time_major"])
 def test_async_host_path_equals_the_synchronous_one(pkg, oracle, synth, layout):
     """tetra_demod_process_async (time-axis chunks double-buffered over three streams, up to two calls in flight) returns the
-    bits of tetra_demod_process / the oracle on the same samples, for float input and for int16 input (converted on the GPU as
-    x / 32768), in both layouts, with ragged call sizes (one chunk, several chunks, a last partial chunk)."""
+    bits of tetra_demod_process / the oracle on the same samples, for float input and for int16 / int8 input (converted on the
+    GPU as x / 32768, x / 128), in both layouts, with ragged call sizes (one chunk, several chunks, a last partial chunk)."""
     import torch
     B = pkg.binding
     Cn = 21
@@ -544,7 +544,9 @@ def test_async_host_path_equals_the_synchronous_one(pkg, oracle, synth, layout):
     iq_q = (q.astype(np.float32) / np.float32(32768.0)).view(np.complex64)
     tm = layout == "time_major"
     lay = B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR
-    for fmt, data, raw in ((B.IQ_CF32, iq, iq), (B.IQ_CS16, iq_q, q.reshape(Cn, -1, 2))):
+    q8 = np.clip(np.round(iq.view(np.float32) * 128.0), -128, 127).astype(np.int8)
+    iq_q8 = (q8.astype(np.float32) / np.float32(128.0)).view(np.complex64)
+    for fmt, data, raw in ((B.IQ_CF32, iq, iq), (B.IQ_CS16, iq_q, q.reshape(Cn, -1, 2)), (B.IQ_CS8, iq_q8, q8.reshape(Cn, -1, 2))):
         d = pkg.Demodulator(Cn, max(sizes), layout=lay)
         orcs = [oracle.Oracle() for _ in range(Cn)]
         keep, pos = [], 0
