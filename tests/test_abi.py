@@ -163,6 +163,13 @@ int main(void) {
     if (tetra_lmac_scramb_init(262, 1, 5) != 0x41800117u) return 3;
     if (tetra_demod_bits_stride(36000) < 36000) return 4;
     if (tetra_bsync_max_frames(NULL) != TETRA_ERR_ARG) return 5;
+    /* the ABI-2 additions reject bad arguments before touching the device */
+    if (tetra_demod_process_async(NULL, &cfg, TETRA_IQ_CF32, 16, (uint8_t*)&cfg, 32, (int32_t*)&cfg) != TETRA_ERR_ARG) return 6;
+    if (tetra_demod_wait(NULL) != TETRA_ERR_ARG) return 7;
+    if (tetra_burst_demux_compact_device(NULL, NULL, 4, TETRA_TPSAP_T_SB1, 1, NULL, 120, NULL, NULL, NULL) != TETRA_ERR_ARG) return 8;
+    if (tetra_lmac_decode_counted_device(7, NULL, 4, NULL, 120, NULL, NULL, NULL, 80, NULL, NULL) != TETRA_ERR_ARG) return 9;
+    { int clk = 0, cus = 0; const int rc = tetra_demod_device_info(12345, &clk, &cus); if (rc != TETRA_ERR_NO_DEVICE) return 10; }
+    tetra_demod_host_free(NULL);
     printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
     return 0;
 }
