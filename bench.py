@@ -104,11 +104,13 @@ def cpu_baseline(synth, n_samples, budget_s=8.0):
       port       oracle/tetra_oracle.c -- the bit-exact checker (-O2, one serial fmaf chain per FIR: built for parity)
       port-fast  oracle/tetra_fast.c   -- the same chain built for speed (-O3 -march=native -ffast-math, FIR sums over
                  independent accumulators, blocked RRC); its bits after lock equal the oracle's (tests/test_oracle.py)
-    `threads` = OpenMP threads used, `cores` = physical cores of this host."""
+    `threads` = OpenMP threads used = `cores` = the CPUs this container may use (scheduler affinity cut by the cgroup CPU
+    quota; `host_logical_cpus` and `cgroup_cpu_quota` say what the machine has and what the quota is)."""
     from oracle import binding as ob
-    threads = ob.max_threads()
-    cores = ob.physical_cores()
-    n_ch = min(4096, max(8, 4 * threads))
+    usable, quota = ob.usable_cpus()          # affinity cut by the cgroup CPU quota: more threads than that only throttle
+    threads = max(1, min(ob.max_threads(), usable))
+    cores = min(ob.physical_cores(), usable)
+    n_ch = min(4096, max(64, 16 * threads))
     base, _, _ = synth.gen_batch(min(n_ch, 32), n_samples, base_seed=999)
     iq = np.ascontiguousarray(np.tile(base, ((n_ch + base.shape[0] - 1) // base.shape[0], 1))[:n_ch])
 
@@ -119,12 +121,13 @@ def cpu_baseline(synth, n_samples, budget_s=8.0):
             states = call(states)
             reps += 1
             el = time.perf_counter() - t0
-            if el >= budget_s or reps >= 400:
+            if el >= budget_s or reps >= 4000:
                 break
         return dict(value=round(reps * n_ch * n_samples / el / 1e6, 3), unit="Msamples/s", cores=cores, threads=threads,
                     kind=kind, per_thread_msamples_s=round(reps * n_ch * n_samples / el / 1e6 / threads, 3),
-                    sample="%d x (%d channels x %d samples), %d OpenMP threads on %d physical cores, %.1f s"
-                           % (reps, n_ch, n_samples, threads, cores, el))
+                    host_logical_cpus=os.cpu_count(), cgroup_cpu_quota=quota,
+                    sample="%d x (%d channels x %d samples), %d OpenMP threads on the %d cores this container may use "
+                           "(host: %d logical CPUs), %.1f s" % (reps, n_ch, n_samples, threads, cores, os.cpu_count() or 0, el))
 
     def one_thread(call):
         """The 1-thread figure SURVEY.md 8(d) asks for beside the all-cores one: 4 channels, ~2 s."""

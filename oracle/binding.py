@@ -276,6 +276,28 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the scheduler affinity, cut by the cgroup CPU quota (a container that sees 256
+    logical CPUs but has `cpu.max = 1600000 100000` gets 16 CPUs' worth of time; more threads than that only throttle)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def bits_stride(n_samples):
     """Output row stride used by the tests: >= 2*(N/1.94+1) bits, multiple of 16."""
     s = int(n_samples / 0.95) + 16
