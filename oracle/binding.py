@@ -189,6 +189,8 @@ def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None)
     """iq: complex64[C][N] channel-major.  Returns (bits[C][stride] u8, n_bits[C] i32, sym or None, states)."""
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     Cn, N = iq.shape
+    if threads <= 0:
+        threads = usable_cpus()[0]          # not OpenMP's default (every CPU the host shows, whatever the container's quota)
     cfg = cfg if cfg is not None else default_cfg()
     tab = Tables()
     rc = lib().tetra_oracle_design(C.byref(cfg), C.byref(tab))
@@ -240,6 +242,8 @@ def fast_process_batch(iq, cfg=None, chunk=0, threads=0, states=None):
     """Like process_batch, through the speed-oriented port.  Returns (bits, n_bits, states)."""
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     Cn, N = iq.shape
+    if threads <= 0:
+        threads = usable_cpus()[0]
     cfg = cfg if cfg is not None else default_cfg()
     tab = Tables()
     if lib().tetra_oracle_design(C.byref(cfg), C.byref(tab)) != 0:
