@@ -178,7 +178,7 @@ int gpu_paths() {
 int main(int argc, char** argv) {
     const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
     if (stream_machinery()) return 1;
-    if (error_paths(gpu)) return 2;
+    if (error_paths(gpu || tetra_demod_device_count() > 0)) return 2;     // the "set-up fails" checks only where there is no GPU
     if (gpu && gpu_paths()) return 3;
     std::puts("san_host: ok");
     return 0;
