@@ -46,6 +46,9 @@ enum {
                                     (TETRA_ERR_UNSUPPORTED).  With it went tap counts 73..80: rrc_tap_count is 2..72. */
     TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
     TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
+    TETRA_FLAG_WIDE_WORKGROUPS = 16,   /* force 32-channel workgroups / ... */
+    TETRA_FLAG_NARROW_WORKGROUPS = 32, /* ... or 16-channel ones.  Default: chosen from the channel count (16 while every CU has at
+                                    most one workgroup, 32 beyond: DESIGN.md section 5).  Results are identical bit for bit. */
     TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
                                     the dsp::block sets it):
                                       - tetra_demod_reset keeps ph2 (src/dsp/pi4dqpsk_costas.h:32 is never reset by

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--channels", type=int, nargs="+", default=[256, 800, 4096, 8192, 16384, 32768])
     ap.add_argument("--samples", type=int, default=36000)
     ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--shape", choices=["auto", "narrow", "wide"], default="auto",
+                    help="workgroup shape: chosen by the library from the channel count, or forced (16 / 32 channels per workgroup)")
     a = ap.parse_args()
     import torch
     import tetra_amd
@@ -30,7 +32,8 @@ def main():
         iq, _ = bench.make_input(torch, pkg.synth, dev, C, N, seed=20260000)
         bits = torch.zeros((C, stride), dtype=torch.uint8, device=dev)
         nb = torch.zeros(C, dtype=torch.int32, device=dev)
-        dem = pkg.Demodulator(C, N)
+        flags = {"auto": 0, "narrow": pkg.binding.FLAG_NARROW_WORKGROUPS, "wide": pkg.binding.FLAG_WIDE_WORKGROUPS}[a.shape]
+        dem = pkg.Demodulator(C, N, flags=flags)
         st = torch.cuda.current_stream(dev)
         for _ in range(bench.RAMP_STEPS + 2):
             dem.process_device(iq, N, bits, stride, nb, None, st)
@@ -43,8 +46,8 @@ def main():
         wgs = (C + 15) // 16
         if C == 4096:
             base = ms
-        print(json.dumps({"channels": C, "samples": N, "kernel_ms": round(ms, 4), "workgroups": wgs, "cus": cus,
-                          "workgroups_per_cu": round(wgs / cus, 2), "msamples_s": round(C * N / ms / 1e3, 1),
+        print(json.dumps({"channels": C, "samples": N, "shape": a.shape, "kernel_ms": round(ms, 4), "workgroups_of_16": wgs, "cus": cus,
+                          "workgroups_of_16_per_cu": round(wgs / cus, 2), "msamples_s": round(C * N / ms / 1e3, 1),
                           "ms_per_4096_channels": round(ms * 4096 / C, 4),
                           "vs_4096": round(ms / base, 3) if base else None}), flush=True)
         dem.close()

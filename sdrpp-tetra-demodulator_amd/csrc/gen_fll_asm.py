@@ -168,7 +168,6 @@ def pk_consts():
     return [u(a) | (u(b) << 32) for (a, b) in pairs]
 
 
-A_BUF_TOGGLE = 16 * TILE * 8     # bytes between a_buf[0] and a_buf[1] (kFCh x kFT float2)
 BE_IM_OFFSET = 72 * 4            # byte offset of the imaginary taps behind the real ones in FusedLds::be72
 
 
@@ -361,7 +360,7 @@ def gen():
         real_step(E, s)
     per_tile = E.n - prologue
     assert [p[0] for p in E.pending] == at_top, "deferred FMAs must line up across the loop's back edge"
-    E.ins("v_xor_b32 v%d, 0x%x, v%d" % (R_AADDR, A_BUF_TOGGLE, R_AADDR), "valu", [R_AADDR], [R_AADDR])
+    E.ins("v_xor_b32 v%d, %%[toggle], v%d" % (R_AADDR, R_AADDR), "valu", [R_AADDR], [R_AADDR])   # a_buf[0] <-> a_buf[1]
     E.ins("s_add_u32 %[base], %[base], 32", "salu")
     E.ins("s_sub_u32 %[tiles], %[tiles], 1", "salu")
     E.ins("s_waitcnt lgkmcnt(0)", "wait")

@@ -33,8 +33,10 @@
 namespace {
 
 constexpr int kFT = 32;                  // samples per tile (pipeline epoch)
-constexpr int kFCh = 16;                 // channels per workgroup
-constexpr int kFThreads = 384;           // 6 waves
+constexpr int kFCh = 16;                 // channels per workgroup: the benchmark's shape (4096 channels = one workgroup per CU) ...
+constexpr int kFChWide = 32;             // ... and the wide shape for more than 16 channels per CU (four FLL waves, one per SIMD)
+constexpr int fused_threads(int ch) { return (ch / 8 + 4) * 64; }      // FLL waves (8 channels each) + E, D, C, A
+constexpr int kFThreads = fused_threads(kFCh);       // 384 = 6 waves
 constexpr int kFX = 256;                 // x ring (FLL output) per channel ...
 constexpr int kFXP = 8;                  // ... behind 8 slots of front padding: an FLL lane stores x_{i-pos} at slot i - pos of the
                                          // tile's window without wrapping (slots -7 .. -1 are never read, see fll_asm.inc)
@@ -55,7 +57,12 @@ static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 posi
 #define TETRA_ROLE_IDS 0, 1, 2, 3, 5, 4
 #endif
 namespace role_ids { constexpr int v[6] = { TETRA_ROLE_IDS }; }
-enum { kRoleE = role_ids::v[0], kRoleD = role_ids::v[1], kRoleF0 = role_ids::v[2], kRoleF1 = role_ids::v[3], kRoleA = role_ids::v[4], kRoleC = role_ids::v[5] };
+// The wide workgroup (32 channels, eight waves): the four FLL waves are the oldest wave of one SIMD each, then E and D (the two
+// heaviest of the rest) on SIMD0 / SIMD1, the RRC wave on SIMD2 and the AGC wave on SIMD3.
+template <int CH> struct Roles {
+    static constexpr int E = CH == 16 ? role_ids::v[0] : 4, D = CH == 16 ? role_ids::v[1] : 5, F0 = CH == 16 ? role_ids::v[2] : 0,
+                         A = CH == 16 ? role_ids::v[4] : 7, C = CH == 16 ? role_ids::v[5] : 6, NF = CH / 8;
+};
 
 struct FusedParams {
     const float2* iq;
@@ -93,19 +100,20 @@ struct FusedParams {
                          // bodies (barrier waits excluded), [7] = clocks from kernel entry to exit of wave 0; null = off
 };
 
-struct FusedLds {
-    float2 a_buf[2][kFCh][kFT];
-    float2 x_ring[kFCh][kFXS];
-    float2 y_ring[kFCh][kFYS];
-    float2 s_ring[kFCh][kFS];
-    int s_avail[kFCh];
+template <int CH> struct FusedLdsT {
+    float2 a_buf[2][CH][kFT];
+    float2 x_ring[CH][kFXS];
+    float2 y_ring[CH][kFYS];
+    float2 s_ring[CH][kFS];
+    int s_avail[CH];
     // interpolator bank with row 0 repeated in front and row 127 behind: rows max(p-1,0), p, min(p+1,127) of
     // complex_fd.cpp:102-121 are then the 24 contiguous floats at bank[p * 8]
     __attribute__((aligned(16))) float bank[(kInterpPhases + 2) * kInterpTaps];
     __attribute__((aligned(16))) float rrc[kRrcExt];       // zero-extended taps, see rrc_direct8
     float be72[2][kF8Pad];   // band-edge taps (re, im), zero-padded: the FLL waves' assembly loads its 18 taps from here
 };
-static_assert(sizeof(FusedLds) <= 80 * 1024, "two workgroups must fit one CU's 160 KB of LDS");
+typedef FusedLdsT<kFCh> FusedLds;
+static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256, "LDS budget of a CU");
 
 // Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
 // register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
@@ -117,17 +125,17 @@ typedef __attribute__((address_space(3))) const vfloat4 lds_cfloat4;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
 __device__ __forceinline__ unsigned pin_u32(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 
-__device__ __forceinline__ void x_ring_put(FusedLds& L, int c, int i, float2 v) { L.x_ring[c][kFXP + (i & (kFX - 1))] = v; }
-__device__ __forceinline__ float2 x_ring_get(const FusedLds& L, int c, int i) { return L.x_ring[c][kFXP + (i & (kFX - 1))]; }
-__device__ __forceinline__ void y_ring_put(FusedLds& L, int c, int i, float2 v) {
+template <class LDS> __device__ __forceinline__ void x_ring_put(LDS& L, int c, int i, float2 v) { L.x_ring[c][kFXP + (i & (kFX - 1))] = v; }
+template <class LDS> __device__ __forceinline__ float2 x_ring_get(const LDS& L, int c, int i) { return L.x_ring[c][kFXP + (i & (kFX - 1))]; }
+template <class LDS> __device__ __forceinline__ void y_ring_put(LDS& L, int c, int i, float2 v) {
     const int s = i & (kFY - 1);
     L.y_ring[c][s] = v;
     if (s < kFYM) L.y_ring[c][s + kFY] = v;
 }
 
 // LDS side of one FLL lane in the C++ form of the wave (see fll8_tile / fll8_replay in demod_core.hpp).
-struct FllDeviceIO {
-    FusedLds& L;
+template <class LDS> struct FllDeviceIOT {
+    LDS& L;
     const float2* a_tile;    // a_buf[parity][ch] of the tile being processed
     int c;                   // channel within the workgroup
     int pos;                 // position along the channel's 8 lanes (0 = head)
@@ -166,12 +174,17 @@ struct FllDeviceIO {
         __syncthreads();                                                         \
     }
 
-template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_bounds__(kFThreads) void k_fused(FusedParams p) {
-    __shared__ FusedLds L;
+template <bool ALPHA0, bool QUALITY, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH)) void k_fused(FusedParams p) {
+    typedef FusedLdsT<CH> Lds;
+    typedef FllDeviceIOT<Lds> FllDeviceIO;
+    typedef Roles<CH> R_;
+    constexpr int kRoleE = R_::E, kRoleD = R_::D, kRoleF0 = R_::F0, kRoleA = R_::A, kRoleC = R_::C;
+    constexpr int kThreadsCH = fused_threads(CH);
+    __shared__ Lds L;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int ch0 = blockIdx.x * kFCh;
+    const int ch0 = blockIdx.x * CH;
     const int n = p.n;
     const int ntiles = (n + kFT - 1) / kFT;
     long long busy_ = 0;
@@ -181,7 +194,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
     auto live = [&](int c) { return ch0 + c < p.n_channels; };
 
     // ---- prologue, phase 1: tables and delay lines into LDS ----------------------------------------
-    for (int i = tid; i < (kInterpPhases + 2) * kInterpTaps; i += kFThreads) {
+    for (int i = tid; i < (kInterpPhases + 2) * kInterpTaps; i += kThreadsCH) {
         int row = i / kInterpTaps - 1;
         row = row < 0 ? 0 : (row > kInterpPhases - 1 ? kInterpPhases - 1 : row);
         L.bank[i] = p.bank[row * kInterpTaps + i % kInterpTaps];
@@ -189,15 +202,15 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
     if (tid < kRrcExt) L.rrc[tid] = p.rrc_ext[tid];
     if (tid < kF8Pad) { L.be72[0][tid] = p.be_re72[tid]; L.be72[1][tid] = p.be_im72[tid]; }
     // rings start at zero: FIR windows touch slots that were never written (weighted by zero taps, so they must be finite)
-    for (int i = tid; i < kFCh * kFXS; i += kFThreads) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
-    for (int i = tid; i < kFCh * kFYS; i += kFThreads) (&L.y_ring[0][0])[i] = make_float2(0.f, 0.f);
-    if (tid < kFCh) L.s_avail[tid] = 0;
+    for (int i = tid; i < CH * kFXS; i += kThreadsCH) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
+    for (int i = tid; i < CH * kFYS; i += kThreadsCH) (&L.y_ring[0][0])[i] = make_float2(0.f, 0.f);
+    if (tid < CH) L.s_avail[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < kFCh * kHist; i += kFThreads) {
+    for (int i = tid; i < CH * kHist; i += kThreadsCH) {
         const int c = i / kHist, m = i % kHist;
         x_ring_put(L, c, m - kHist, p.hist[(long long)chan(c) * kHist + m]);
     }
-    for (int i = tid; i < kFCh * (kInterpTaps - 1); i += kFThreads) {
+    for (int i = tid; i < CH * (kInterpTaps - 1); i += kThreadsCH) {
         const int c = i / (kInterpTaps - 1), m = i % (kInterpTaps - 1);
         y_ring_put(L, c, m - (kInterpTaps - 1), p.ybuf[(long long)chan(c) * (kInterpTaps - 1) + m]);
     }
@@ -205,7 +218,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
 
     if (wave == kRoleA) {
         // ---- AGC: lane c < 16 owns channel c; tile e in epoch e --------------------------------------
-        const bool on = lane < kFCh;
+        const bool on = lane < CH;
         const int c = on ? lane : 0;
         float g = p.agc_g[chan(c)];
         const float2* in = p.iq + (long long)chan(c) * p.in_ch_stride;
@@ -248,7 +261,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
             }
         )
         if (on && live(c)) p.agc_g[ch0 + c] = g;
-    } else if (wave == kRoleF0 || wave == kRoleF1) {
+    } else if (wave >= kRoleF0 && wave < kRoleF0 + R_::NF) {
         // ---- FLL: lane -> (row r = lane>>4, pos = (lane&15)>>1, parity = lane&1); tile e-1 in epoch e ---
         const int fw = wave - kRoleF0;
         const int f_pos = (lane & 15) >> 1;
@@ -277,7 +290,8 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                            [maxf] "v"(k1.fll_max_freq),
                            [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                            [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
-                           [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4)
+                           [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4),
+                           [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
                          : "vcc", "scc", "memory", FLL_WAVE_CLOBBERS);
         }
         // the tiles the block did not take (the partial tile at the end of the call) and the trailing epochs
@@ -317,10 +331,12 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
             p.fll_fr[ch0 + f_c] = fr;
         }
     } else if (wave == kRoleC) {
-        // ---- RRC: lane -> (channel c = lane & 15, j = lane >> 4), outputs base + 8j + m; tile e-2 -------
+        // ---- RRC: lane -> (channel c = lane % CH, j = lane / CH), outputs base + 8 (j + groups * pass) + m; tile e-2 -------
+        // 16 channels: four lane groups cover the tile's 32 samples in one pass; 32 channels: two groups, two passes.
         // The window of eight consecutive outputs starts at x_{i0-(nt-1)}; it is widened at the old end (under zero
         // taps) to start on a multiple of 8, so that no 8-sample chunk straddles the ring's wrap.
-        const int c = lane & 15;
+        constexpr int kGroups = 64 / CH, kPasses = kFT / (8 * kGroups);
+        const int c = lane % CH;
         const int rrc_pad = (8 - ((p.ntaps - 1) & 7)) & 7;
 #if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 2      // experiment builds only (profiles/r02): RRC wave with a ninth of its work
         const int rrc_chunks = 1;
@@ -338,7 +354,8 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         FUSED_EPOCHS(
             const int t = e - 2;
             if (t >= 0 && t < ntiles) {
-                const int i0 = t * kFT + 8 * (lane >> 4);
+              for (int pass = 0; pass < kPasses; pass++) {
+                const int i0 = t * kFT + 8 * (lane / CH + kGroups * pass);
                 if (i0 < n) {
                     const int start = i0 - (p.ntaps - 1) - rrc_pad;
                     Pair<float> out[kRrcOut];
@@ -370,12 +387,13 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
                         }
                     }
                 }
+              }
             }
         )
-        if (lane < kFCh && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
+        if (lane < CH && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
     } else if (wave == kRoleD) {
         // ---- timing recovery: lane c < 16 owns channel c; consumes y of tiles <= e-3 ---------------------
-        const bool on = lane < kFCh;
+        const bool on = lane < CH;
         const int c = on ? lane : 0;
         K2State st;
         st.mu = p.mu[chan(c)];
@@ -440,7 +458,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
         }
     } else {
         // ---- kRoleE: Costas + slicer + differential decoder + bit unpacker; symbols published before e ----
-        const bool on = lane < kFCh;
+        const bool on = lane < CH;
         const int c = on ? lane : 0;
         K2State st;
         st.mu = 0; st.omega = 0; st.offset = 0;
@@ -501,7 +519,7 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
 #ifdef TETRA_DEMOD_DEBUG
     if (PROF && lane == 0) {
         int slot = 0;          // report in role order E, D, F0, F1, A, C whatever the wave indices are
-        for (int r = 0; r < 6; r++) slot = role_ids::v[r] == wave ? r : slot;
+        for (int r = 0; r < 6; r++) slot = (CH == 16 && role_ids::v[r] == wave) ? r : slot;
         p.prof[(long long)blockIdx.x * 8 + slot] = busy_;
         if (wave == 0) p.prof[(long long)blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - t_entry_;
     }
@@ -509,11 +527,11 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false> __global__ __launch_boun
     (void)t_entry_;
 #endif
     // delay lines: last 80 FLL outputs, last 7 RRC outputs (both rings still hold them; the loops end on a barrier)
-    for (int i = tid; i < kFCh * kHist; i += kFThreads) {
+    for (int i = tid; i < CH * kHist; i += kThreadsCH) {
         const int c = i / kHist, m = i % kHist;
         if (live(c)) p.hist[(long long)(ch0 + c) * kHist + m] = x_ring_get(L, c, n - kHist + m);
     }
-    for (int i = tid; i < kFCh * (kInterpTaps - 1); i += kFThreads) {
+    for (int i = tid; i < CH * (kInterpTaps - 1); i += kThreadsCH) {
         const int c = i / (kInterpTaps - 1), m = i % (kInterpTaps - 1);
         if (live(c))
             p.ybuf[(long long)(ch0 + c) * (kInterpTaps - 1) + m] = L.y_ring[c][(n - (kInterpTaps - 1) + m) & (kFY - 1)];

@@ -26,6 +26,8 @@ using namespace tdm;
 namespace {
 
 constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
+constexpr int kWg16ClocksPerSample = 277;       // measured shader clocks per sample of one workgroup round (profiles/r02)
+constexpr int kWg32ClocksPerSample = 535;       // 32-channel workgroup: 8.03 ms per 36000 samples (profiles/r02/r02_o)
 
 __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
     float2 v = *p;
@@ -114,6 +116,7 @@ struct tetra_demod {
     float2* hist = nullptr;
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
+    bool wide = false;          // k_fused with 32-channel workgroups
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
@@ -411,6 +414,20 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     h->user_be = cfg->bandedge_taps != nullptr;
     h->quirks = (cfg->flags & TETRA_FLAG_REFERENCE_QUIRKS) != 0;
     h->keep_y = (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT) != 0;
+    {
+        // Workgroup shape.  16 channels per workgroup is the fastest way through ONE workgroup (kWg16 clocks per sample) and
+        // right while there is at most one per CU; the 32-channel workgroup (four FLL waves, one per SIMD, the other roles'
+        // instruction streams shared by twice the channels; kWg32 clocks per sample) is a few per cent better when the
+        // channel count fills whole rounds of it.  Rounds of workgroups per CU x clocks per round decides; the flags force
+        // either shape.
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = cus > 0 ? cus : 256;
+        const long long r16 = ((h->C + kFCh - 1) / kFCh + cus - 1) / cus, r32 = ((h->C + kFChWide - 1) / kFChWide + cus - 1) / cus;
+        h->wide = r32 * kWg32ClocksPerSample < r16 * kWg16ClocksPerSample;
+        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) h->wide = true;
+        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) h->wide = false;
+    }
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
     if (cfg->flags & TETRA_FLAG_QUALITY) {
@@ -479,13 +496,14 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.q_err = h->q_err;
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
         pf.prof = nullptr;
-        const dim3 gf((h->C + kFCh - 1) / kFCh);
+        const bool wide = h->wide;          // 32 channels per workgroup: more than 16 channels per CU (see tetra_demod_create)
+        const dim3 gf(wide ? (h->C + kFChWide - 1) / kFChWide : (h->C + kFCh - 1) / kFCh);
         const bool a0 = pf.k1.fll_alpha == 0.0f, ql = pf.q_ring != nullptr;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
         const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
-        if (prof_path && !ql) {
+        if (prof_path && !ql && !wide) {
             const size_t nwg = (size_t)gf.x;
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
@@ -498,7 +516,13 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         else if (pf.prof) hipLaunchKernelGGL((k_fused<false, false, true>), gf, dim3(kFThreads), 0, s, pf);
         else
 #endif
-        if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
+        if (wide) {
+            const dim3 tw(fused_threads(kFChWide));
+            if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false, false, kFChWide>), gf, tw, 0, s, pf);
+            else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true, false, kFChWide>), gf, tw, 0, s, pf);
+            else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false, false, kFChWide>), gf, tw, 0, s, pf);
+            else hipLaunchKernelGGL((k_fused<false, true, false, kFChWide>), gf, tw, 0, s, pf);
+        } else if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
         else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
         else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false>), gf, dim3(kFThreads), 0, s, pf);
         else hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);

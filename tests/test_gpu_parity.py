@@ -64,7 +64,9 @@ def test_tables_match_oracle(pkg, oracle):
     assert np.array_equal(t["bank"], o.interp_bank())
 
 
-PIPELINES = {"fused": 2}   # flags: keep the RRC output for the stage check (ABI 1's second pipeline was retired in ABI 2)
+# flags: 2 = keep the RRC output for the stage check; 16 = force the 32-channel workgroup shape (default: chosen from the
+# channel count).  Both shapes run the same roles on the same arithmetic: every test runs on both.
+PIPELINES = {"fused": 2, "wide": 2 | 16}
 
 
 def _compare(tag, pkg, oracle, iq, chunks, want_state=True, flags=2):
@@ -155,7 +157,7 @@ def test_parity_256_channels_full_second(pkg, oracle, synth, pipeline):
     """BASELINE config 2: 256 synthetic channels @ 36 ksps, 1 s, every output bit compared with the CPU."""
     Cn, N = 256, 36000
     iq, txb, _ = synth.gen_batch(Cn, N, base_seed=4242)
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
     bits, nb, sym = d.process(iq, want_sym=True)
     rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
     bad = [c for c in range(Cn) if nb[c] != rnb[c] or not np.array_equal(bits[c][:nb[c]], rb[c][:rnb[c]])]
@@ -179,7 +181,7 @@ def test_parity_256_channels_full_second(pkg, oracle, synth, pipeline):
 def test_reset_and_state_roundtrip(pkg, oracle, synth, pipeline):
     Cn, N = 8, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=31)
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
     b1, n1, _ = d.process(iq)
     st3 = d.get_state(3)
     b2, n2, _ = d.process(iq)           # continues from carried state: differs from a fresh run
@@ -202,7 +204,7 @@ def test_time_major_layout(pkg, oracle, synth, pipeline):
     """TETRA_LAYOUT_TIME_MAJOR: iq[n][c] frames (what a channeliser emits) give the same bits as channel-major."""
     Cn, N = 19, 2500
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=61)
-    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, flags=PIPELINES[pipeline] & 1)
+    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, flags=PIPELINES[pipeline] & 16)
     bits, nb, sym = d.process(np.ascontiguousarray(iq.T), want_sym=True)
     rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
     assert np.array_equal(nb, rnb)
@@ -225,12 +227,12 @@ def test_retired_pipeline_and_tap_counts_above_72_are_refused(pkg):
     d.close()
 
 
-@pytest.mark.parametrize("pipeline,nt", [("fused", 2), ("fused", 33), ("fused", 72)])
+@pytest.mark.parametrize("pipeline,nt", [("fused", 2), ("fused", 33), ("fused", 72), ("wide", 33), ("wide", 72)])
 def test_other_tap_counts(pkg, oracle, synth, pipeline, nt):
     """rrcTapCount is a PI4DQPSK parameter (2..72 here; the reference builds with 65)."""
     Cn, N = 6, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=71)
-    d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & 1, rrc_tap_count=nt)
+    d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & 16, rrc_tap_count=nt)
     ocfg = oracle.default_cfg()
     ocfg.rrc_tap_count = nt
     orcs = [oracle.Oracle(ocfg) for _ in range(Cn)]
@@ -249,7 +251,7 @@ def test_setters_match_oracle_with_same_parameters(pkg, oracle, synth, pipeline)
     import ctypes as C
     Cn, N = 4, 4000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=81)
-    d = pkg.Demodulator(Cn, 2000, flags=PIPELINES[pipeline] & 1)
+    d = pkg.Demodulator(Cn, 2000, flags=PIPELINES[pipeline] & 16)
     orcs = [oracle.Oracle() for _ in range(Cn)]
     b1, n1, _ = d.process(iq[:, :2000])
     for c in range(Cn):
@@ -402,11 +404,11 @@ def test_non_finite_input_cannot_hang_or_overrun(pkg, synth, pipeline):
     its output stays inside its row, and the neighbours are untouched."""
     Cn, N = 18, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=91)
-    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1).process(iq)
+    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16).process(iq)
     bad = iq.copy()
     bad[3, 100] = np.nan
     bad[7, 200] = np.inf
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 1)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
     bits, nb, _ = d.process(bad)
     stride = bits.shape[1]
     assert (nb >= 0).all() and (nb <= stride).all()
@@ -468,7 +470,7 @@ def test_quality_statistic(pkg, oracle, synth, pipeline):
     rng = np.random.default_rng(3)
     iq[2] = (0.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)   # noise: no sync
     iq[5] = synth.gen_channel(N, 9, esn0_db=12.0)[0]
-    d = pkg.Demodulator(Cn, 3000, flags=(PIPELINES[pipeline] & 1) | pkg.binding.FLAG_QUALITY)
+    d = pkg.Demodulator(Cn, 3000, flags=(PIPELINES[pipeline] & 16) | pkg.binding.FLAG_QUALITY)
     orcs = [oracle.Oracle() for _ in range(Cn)]
     for pos in range(0, N, 3000):
         bits, nb, _ = d.process(iq[:, pos:pos + 3000])
