@@ -227,7 +227,10 @@ int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
  * the last 4096 symbols from their ideal constellation points, refreshed every 256 symbols, and sync = that < 0.35.
  * standarderr[n_channels] / sync[n_channels] host arrays (either may be NULL).  A GUI float, not on the bit path: held
  * to a tolerance (1e-4) against the reference formula rather than bit equality.  Needs TETRA_FLAG_QUALITY
- * (TETRA_ERR_UNSUPPORTED otherwise); costs ~15 % throughput when enabled. */
+ * (TETRA_ERR_UNSUPPORTED otherwise).  Only the value at the last 256-symbol boundary of a call is observable, so it is
+ * computed by a small kernel after the chain's launch from the symbols the chain wrote (kept in a scratch buffer of
+ * n_channels x max_samples/2 complex64 when the caller does not ask for them); costs ~2.5 % of a call's time when
+ * enabled (profiles/r02/r02_p_quality_statistic.md). */
 int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync);
 
 /* Debug/verification tap: RRC output (timing-recovery input) of the last process call,

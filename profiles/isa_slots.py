@@ -6,7 +6,7 @@ A gfx950 wavefront issues ONE instruction of any kind (VALU, SALU, s_nop, s_wait
 tetra_demod.hip to gfx950 assembly (no GPU needed), finds every backward branch of one kernel instantiation and prints the
 instruction mix of each loop body.
 
-    python profiles/isa_slots.py [--kernel k_fusedILb1ELb0ELb0] [--min 20] [--dump LABEL]
+    python profiles/isa_slots.py [--kernel k_fusedILb1ELb0ELi16] [--min 20] [--dump LABEL]
 """
 import argparse
 import os
@@ -53,7 +53,7 @@ def cat(ins):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="k_fusedILb1ELb0ELb0")
+    ap.add_argument("--kernel", default="k_fusedILb1ELb0ELi16")
     ap.add_argument("--min", type=int, default=20)
     ap.add_argument("--dump", default=None, help="print the body of the loop that starts at this label")
     ap.add_argument("--asm", default="/tmp/isa/tetra_demod.s")

@@ -602,13 +602,9 @@ TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* z
 // published as `standarderr`, and `sync = standarderr < 0.35`.  This is the GUI's signal-quality meter, NOT on the bit
 // path, so it is held to a tolerance instead of bit equality: the distance is pi/4 - atan(min/max) of the symbol's
 // |re|,|im| (equal to |atan2(ideal) - atan2(sym)| up to float rounding; Abramowitz-Stegun 4.4.49 polynomial,
-// |error| <= 2e-8, hardware reciprocal), and the ring mean is kept as a double running sum (new - old).
-struct QualityState {
-    double sum;
-    int ptr, disp;
-    float standarderr;
-    int sync;
-};
+// |error| <= 2e-8, hardware reciprocal).  The ring and the mean are kept by a separate small kernel after the launch
+// (k_quality in tetra_demod.hip), from the symbols the Costas wave wrote: only the value at the last 256-symbol boundary
+// of a call is observable, so nothing of it has to ride on the chain's critical wave.
 TD_FN float quality_distance(float zr, float zi) {
     const float ar = v_abs(zr), ai = v_abs(zi);
     const float hi = v_max(ar, ai), lo = v_min(ar, ai);
@@ -628,20 +624,6 @@ TD_FN float quality_distance(float zr, float zi) {
     p = v_fma(p, z, -0.3333314528f);
     p = v_fma(p, z, 1.0f);
     return 0.785398163397448f - p * r;
-}
-// ring: this channel's 4096 floats.
-TD_FN void quality_step(QualityState& q, float* ring, float zr, float zi) {
-    const float d = quality_distance(zr, zi);
-    const float old = ring[q.ptr];
-    ring[q.ptr] = d;
-    q.sum += (double)d - (double)old;
-    q.ptr = (q.ptr + 1) & 4095;
-    q.disp++;
-    if (q.disp >= 256) {
-        q.standarderr = (float)(q.sum * (1.0 / 4096.0));
-        q.sync = q.standarderr >= 0.35f ? 0 : 1;
-        q.disp = 0;
-    }
 }
 
 }  // namespace tdm

@@ -87,13 +87,9 @@ struct FusedParams {
     uint8_t* bits;
     long long bits_stride;
     int* n_bits;
-    float2* sym;         // optional
+    float2* sym;         // optional [C][sym_stride]
+    long long sym_stride;
     float2* y_dbg;       // optional: time-major scratch [(7+n)][C], row 7+i = y_i
-    // optional sync/quality statistic (TETRA_FLAG_QUALITY): ring [C][4096] + per-channel state; null = off
-    float* q_ring;
-    double* q_sum;
-    int *q_ptr, *q_disp, *q_sync;
-    float* q_err;
     K1Consts k1;
     K2Consts k2;
     long long* prof;     // TETRA_DEMOD_DEBUG builds only: [workgroups][8] = busy clocks of waves 0..5 inside their epoch
@@ -174,7 +170,7 @@ template <class LDS> struct FllDeviceIOT {
         __syncthreads();                                                         \
     }
 
-template <bool ALPHA0, bool QUALITY, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH)) void k_fused(FusedParams p) {
+template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH)) void k_fused(FusedParams p) {
     typedef FusedLdsT<CH> Lds;
     typedef FllDeviceIOT<Lds> FllDeviceIO;
     typedef Roles<CH> R_;
@@ -468,17 +464,8 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false, int CH = kFCh> __global_
         st.prev = p.prev[chan(c)];
         int S = 0;
         uint8_t* brow = p.bits + (long long)chan(c) * p.bits_stride;
-        float2* srow = p.sym ? p.sym + (long long)chan(c) * (p.bits_stride / 2) : nullptr;
+        float2* srow = p.sym ? p.sym + (long long)chan(c) * p.sym_stride : nullptr;
         const bool wr = on && live(c);
-        const bool qon = QUALITY;   // compile-time: the statistic's code must not weigh on the default kernel
-        QualityState q;
-        q.sum = 0.0; q.ptr = 0; q.disp = 0; q.standarderr = 0.0f; q.sync = 0;
-        float* qring = nullptr;
-        if (qon) {
-            q.sum = p.q_sum[chan(c)]; q.ptr = p.q_ptr[chan(c)]; q.disp = p.q_disp[chan(c)];
-            q.standarderr = p.q_err[chan(c)]; q.sync = p.q_sync[chan(c)];
-            qring = p.q_ring + (long long)chan(c) * 4096;
-        }
         K2Consts k2 = p.k2;
         k2.costas_max_freq = v_pin(k2.costas_max_freq);
         __syncthreads();
@@ -498,7 +485,6 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false, int CH = kFCh> __global_
                         // bit_unpacker.cpp:6-7: byte 2S = MSB, byte 2S+1 = LSB
                         *reinterpret_cast<unsigned short*>(brow + 2 * S) = (unsigned short)(((d >> 1) & 1) | ((d & 1) << 8));
                         if (srow) srow[S] = make_float2(zr, zi);
-                        if (qon) quality_step(q, qring, zr, zi);
                     }
                     S++;
                 }
@@ -510,10 +496,6 @@ template <bool ALPHA0, bool QUALITY, bool PROF = false, int CH = kFCh> __global_
             p.ph2[ch0 + c] = st.ph2;
             p.prev[ch0 + c] = st.prev;
             p.n_bits[ch0 + c] = 2 * S;
-            if (qon) {
-                p.q_sum[ch0 + c] = q.sum; p.q_ptr[ch0 + c] = q.ptr; p.q_disp[ch0 + c] = q.disp;
-                p.q_err[ch0 + c] = q.standarderr; p.q_sync[ch0 + c] = q.sync;
-            }
         }
     }
 #ifdef TETRA_DEMOD_DEBUG

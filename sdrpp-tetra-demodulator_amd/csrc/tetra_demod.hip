@@ -93,6 +93,40 @@ __global__ void k_append_bits(const uint8_t* __restrict__ chunk, int chunk_strid
     __syncthreads();
     if (threadIdx.x == 0) out_n[c] = at + n;
 }
+// TETRA_FLAG_QUALITY: DQPSKSymbolExtractor's statistic (dqpsk_sym_extr.cpp:8-31) brought up to date after a launch, one wave
+// per channel.  The reference pushes one angular distance per symbol into a 4096-entry ring and publishes the ring's mean
+// every 256 symbols; only the value at the LAST such boundary of a call can be observed, so the wave sums the ring as it
+// stood at that boundary (new distances where they had replaced old ones, old ring entries elsewhere; double accumulation),
+// then stores the call's last 4096 distances into the ring and advances the two counters.
+__global__ __launch_bounds__(256) void k_quality(const float2* __restrict__ sym, long long sym_stride, const int* __restrict__ n_bits,
+                                                 int n_channels, float* __restrict__ ring, int* __restrict__ q_ptr,
+                                                 int* __restrict__ q_disp, float* __restrict__ q_err, int* __restrict__ q_sync) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = c < n_channels;
+    const float2* z = sym + (long long)(live ? c : 0) * sym_stride;
+    float* r = ring + (long long)(live ? c : 0) * 4096;
+    const int n = live ? n_bits[c] / 2 : 0, ptr0 = live ? q_ptr[c] : 0, disp0 = live ? q_disp[c] : 0;
+    const int total = disp0 + n;
+    const int b = total >= 256 ? n - (total & 255) : 0;     // symbols of this call consumed at the last boundary (0 = none)
+    double acc = 0.0;
+    if (b > 0) {
+        for (int j = (b > 4096 ? b - 4096 : 0) + lane; j < b; j += 64) acc += (double)tdm::quality_distance(z[j].x, z[j].y);
+        for (int j = b + lane; j < 4096; j += 64) acc += (double)r[(ptr0 + j) & 4095];
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    }
+    __syncthreads();                                        // old ring entries are read before any is replaced
+    for (int j = (n > 4096 ? n - 4096 : 0) + lane; j < n; j += 64) r[(ptr0 + j) & 4095] = tdm::quality_distance(z[j].x, z[j].y);
+    if (live && lane == 0) {
+        q_ptr[c] = (ptr0 + n) & 4095;
+        q_disp[c] = total & 255;
+        if (b > 0) {
+            const float e = (float)(acc * (1.0 / 4096.0));
+            q_err[c] = e;
+            q_sync[c] = e >= 0.35f ? 0 : 1;
+        }
+    }
+}
+
 __global__ void k_min_i32(int* p, int v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && p[i] > v) p[i] = v;
@@ -120,10 +154,11 @@ struct tetra_demod {
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
-    float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state
-    double* q_sum = nullptr;
+    float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state (k_quality)
     int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
     float* q_err = nullptr;
+    float2* q_sym = nullptr;    // [C][q_sym_stride] symbols of the last launch when the caller did not ask for them
+    long long q_sym_stride = 0;
     bool user_rrc = false, user_be = false;   // caller-supplied FIR tables (cfg.rrc_taps / cfg.bandedge_taps)
     bool quirks = false;        // TETRA_FLAG_REFERENCE_QUIRKS
     bool keep_y = false;        // y scratch allocated
@@ -254,7 +289,6 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
         HIP_TRY(h, hipMemsetAsync(h->prev + first, 0, sizeof(int) * count, 0));
         if (h->q_ring) {
             HIP_TRY(h, hipMemsetAsync(h->q_ring + (size_t)first * 4096, 0, sizeof(float) * 4096 * (size_t)count, 0));
-            HIP_TRY(h, hipMemsetAsync(h->q_sum + first, 0, sizeof(double) * count, 0));
             HIP_TRY(h, hipMemsetAsync(h->q_ptr + first, 0, sizeof(int) * count, 0));
             HIP_TRY(h, hipMemsetAsync(h->q_disp + first, 0, sizeof(int) * count, 0));
             HIP_TRY(h, hipMemsetAsync(h->q_sync + first, 0, sizeof(int) * count, 0));
@@ -268,7 +302,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sum, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -431,8 +465,10 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
     if (cfg->flags & TETRA_FLAG_QUALITY) {
-        A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_sum, C)); A(dalloc(h, &h->q_ptr, C));
+        A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_ptr, C));
         A(dalloc(h, &h->q_disp, C)); A(dalloc(h, &h->q_sync, C)); A(dalloc(h, &h->q_err, C));
+        h->q_sym_stride = tetra_demod_bits_stride(h->max_samples) / 2;
+        A(dalloc(h, &h->q_sym, C * (size_t)h->q_sym_stride));
     }
     A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
     A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
@@ -492,18 +528,18 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
-        pf.q_ring = h->q_ring; pf.q_sum = h->q_sum; pf.q_ptr = h->q_ptr; pf.q_disp = h->q_disp; pf.q_sync = h->q_sync;
-        pf.q_err = h->q_err;
+        pf.sym_stride = bits_stride / 2;
+        if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
         pf.prof = nullptr;
         const bool wide = h->wide;          // 32 channels per workgroup: more than 16 channels per CU (see tetra_demod_create)
         const dim3 gf(wide ? (h->C + kFChWide - 1) / kFChWide : (h->C + kFCh - 1) / kFCh);
-        const bool a0 = pf.k1.fll_alpha == 0.0f, ql = pf.q_ring != nullptr;
+        const bool a0 = pf.k1.fll_alpha == 0.0f;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
         const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
-        if (prof_path && !ql && !wide) {
+        if (prof_path && !wide) {
             const size_t nwg = (size_t)gf.x;
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
@@ -512,20 +548,19 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
 #endif
         HIP_TRY(h, hipEventRecord(ev[0], s));
 #ifdef TETRA_DEMOD_DEBUG
-        if (pf.prof && a0) hipLaunchKernelGGL((k_fused<true, false, true>), gf, dim3(kFThreads), 0, s, pf);
-        else if (pf.prof) hipLaunchKernelGGL((k_fused<false, false, true>), gf, dim3(kFThreads), 0, s, pf);
+        if (pf.prof && a0) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
+        else if (pf.prof) hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
         else
 #endif
         if (wide) {
             const dim3 tw(fused_threads(kFChWide));
-            if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false, false, kFChWide>), gf, tw, 0, s, pf);
-            else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true, false, kFChWide>), gf, tw, 0, s, pf);
-            else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false, false, kFChWide>), gf, tw, 0, s, pf);
-            else hipLaunchKernelGGL((k_fused<false, true, false, kFChWide>), gf, tw, 0, s, pf);
-        } else if (a0 && !ql) hipLaunchKernelGGL((k_fused<true, false>), gf, dim3(kFThreads), 0, s, pf);
-        else if (a0 && ql) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
-        else if (!a0 && !ql) hipLaunchKernelGGL((k_fused<false, false>), gf, dim3(kFThreads), 0, s, pf);
-        else hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
+            if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gf, tw, 0, s, pf);
+            else hipLaunchKernelGGL((k_fused<false, false, kFChWide>), gf, tw, 0, s, pf);
+        } else if (a0) hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
+        else hipLaunchKernelGGL((k_fused<false>), gf, dim3(kFThreads), 0, s, pf);
+        if (h->q_ring)
+            hipLaunchKernelGGL(k_quality, dim3((h->C + 3) / 4), dim3(256), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->C, h->q_ring,
+                               h->q_ptr, h->q_disp, h->q_err, h->q_sync);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(ev[1], s));
         HIP_TRY(h, hipEventRecord(ev[2], s));

@@ -464,23 +464,29 @@ def test_parity_4096_channels_full_second(pkg, oracle, synth):
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 def test_quality_statistic(pkg, oracle, synth, pipeline):
     """standarderr / sync (dqpsk_sym_extr.cpp:8-31) per channel vs the oracle's faithful restatement (libm atan2f,
-    float ring, sequential sum): tolerance 1e-4 (GUI meter, not on the bit path); bits stay bit-exact with it on."""
-    Cn, N = 12, 9000
+    float ring, sequential sum): tolerance 1e-4 (GUI meter, not on the bit path); bits stay bit-exact with it on.  Call
+    lengths on both sides of the 256-symbol publishing period and of the 4096-symbol ring, with and without the caller
+    asking for the symbols."""
+    Cn, N = 12, 24000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=111)
     rng = np.random.default_rng(3)
     iq[2] = (0.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)   # noise: no sync
     iq[5] = synth.gen_channel(N, 9, esn0_db=12.0)[0]
-    d = pkg.Demodulator(Cn, 3000, flags=(PIPELINES[pipeline] & 16) | pkg.binding.FLAG_QUALITY)
+    d = pkg.Demodulator(Cn, 10000, flags=(PIPELINES[pipeline] & 16) | pkg.binding.FLAG_QUALITY)
     orcs = [oracle.Oracle() for _ in range(Cn)]
-    for pos in range(0, N, 3000):
-        bits, nb, _ = d.process(iq[:, pos:pos + 3000])
+    pos = 0
+    for k, n in enumerate([3000, 100, 37, 400, 10000, 0, 1, 3000, 462, 7000]):
+        out = d.process(iq[:, pos:pos + n], want_sym=bool(k & 1))
+        bits, nb = out[0], out[1]
         err, sync = d.quality()
         for c in range(Cn):
-            r = orcs[c].process(iq[c, pos:pos + 3000])
+            r = orcs[c].process(iq[c, pos:pos + n])
             assert np.array_equal(bits[c][:nb[c]], r["bits"])
-            assert abs(err[c] - orcs[c].st.standarderr) < 1e-4, (c, err[c], orcs[c].st.standarderr)
+            assert abs(err[c] - orcs[c].st.standarderr) < 1e-4, (k, c, err[c], orcs[c].st.standarderr)
             if abs(orcs[c].st.standarderr - 0.35) > 1e-3:
-                assert bool(sync[c]) == bool(orcs[c].st.sync), c
+                assert bool(sync[c]) == bool(orcs[c].st.sync), (k, c)
+        pos += n
+    assert pos == N
     assert not sync[2] and sync[0]
     with pytest.raises(pkg.TetraDemodError):
         pkg.Demodulator(1, 64).quality()
