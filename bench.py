@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 timed region, against 8 TB/s HBM peak;
   cpu_baseline  the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the
                 same workload.  The oracle is only the baseline/checker here, never the measured path.
+  host_path_*   PCIe-inclusive rates of the host entry points (informational);
+  large_batch   the same call with twice the channels on this GPU (32-channel workgroup shape; informational).
 """
 import argparse
 import json
@@ -65,7 +67,7 @@ def make_input(torch, synth, device, n_channels, n_samples, seed):
     return out, txb
 
 
-KERNEL_SOURCES = ("kernel_fused.hpp", "demod_core.hpp", "fll_asm.inc")      # what k_fused is compiled from (+ the flags below)
+KERNEL_SOURCES = ("kernel_fused.hpp", "demod_core.hpp", "fll_asm.inc", "fll4_asm.inc")      # what k_fused is compiled from (+ the flags below)
 
 
 def kernel_source_hash():
@@ -205,6 +207,8 @@ def main():
                     help="skip the PCIe-inclusive host-path legs (tetra_demod_process / tetra_demod_process_async on page-locked "
                          "buffers; informational fields host_path_*, never the metric value)")
     ap.add_argument("--host-path", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-large-batch", action="store_true",
+                    help="skip the informational leg with twice the channels per GPU (32-channel workgroup shape, field large_batch)")
     ap.add_argument("--chain", action="store_true",
                     help="also run the device-resident receive chain behind the demodulator (burst synchroniser -> demultiplexer "
                          "-> lower-MAC decoder; profiles/measure_pipeline*.py) and attach its timings as \"chain\" (informational)")
@@ -345,6 +349,32 @@ def main():
                                   "tetra_demod_process_async with two calls in flight; cs16 / cs8 = int16 / int8 IQ converted on the GPU")
         del p_iq, p_q, p_bits, p_nb
 
+    # Twice the channels on the same GPU (informational, never the metric): above one 16-channel workgroup per CU the library
+    # launches 32-channel workgroups whose FLL rows carry 16 channels per wave.
+    large = None
+    if not args.no_large_batch and rank == 0 and world == 1 and C == CHANNELS_PER_GPU:
+        iq2 = torch.cat([iq, iq])
+        bits2 = torch.zeros((2 * C, stride), dtype=torch.uint8, device=device)
+        nb2 = torch.zeros(2 * C, dtype=torch.int32, device=device)
+        dem2 = pkg.Demodulator(2 * C, N, device=local_rank, flags=0)
+        for _ in range(3):
+            dem2.process_device(iq2, N, bits2, stride, nb2, None, stream)
+        torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 6
+        ev0.record(stream)
+        for _ in range(reps):
+            dem2.process_device(iq2, N, bits2, stride, nb2, None, stream)
+        ev1.record(stream)
+        torch.cuda.synchronize(device)
+        ms2 = ev0.elapsed_time(ev1) / reps
+        same = bool(torch.equal(nb2[:C], nb2[C:]) and torch.equal(bits2[:C], bits2[C:]))      # both halves saw the same input
+        large = {"channels": 2 * C, "ms_per_step": round(ms2, 4), "msamples_s": round(2.0 * C * N / ms2 / 1e3, 1),
+                 "halves_identical": same,
+                 "note": "informational: %d channels x %d samples on this GPU in one call (32-channel workgroups)" % (2 * C, N)}
+        dem2.close()
+        del iq2, bits2, nb2
+
     if rank == 0:
         total_samples = float(world) * C * N * args.steps
         value = total_samples / elapsed / 1e6
@@ -386,6 +416,8 @@ def main():
             "check": check,
         }
         out.update(host)
+        if large is not None:
+            out["large_batch"] = large
         if dist is not None:
             out["rccl_world_size"] = dist.get_world_size() if args.backend == "nccl" else None
             out["dist_backend"] = args.backend

@@ -21,6 +21,7 @@
 #pragma once
 
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -132,6 +133,18 @@ TD_FN float row_shl2(float old, float src) {
 TD_FN float row_shl2_z(float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x102, 0xf, 0xf, true));
 }
+// H-lane variants (H = 2: two channels interleaved on the lanes of a row, 8 lanes per channel; H = 4: four channels, 4 lanes each)
+template <int H> TD_FN float row_shr_h(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x110 + H, 0xf, 0xf, false));
+}
+template <int H> TD_FN float row_shl_h(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x100 + H, 0xf, 0xf, false));
+}
+template <int H> TD_FN float row_shl_h_z(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x100 + H, 0xf, 0xf, true));
+}
 // row_shl:1 with zero fill (bound_ctrl): lane 15 of each row receives +0.
 TD_FN float row_shl1_z(float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x101, 0xf, 0xf, true));
@@ -214,8 +227,18 @@ TD_FN Row16 v_sqrt_agc(Row16 a) { return v_sqrt(a); }
 TD_FN Row16 row_shr2(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 2 ? old.l[i] : src.l[i - 2]; return r; }
 TD_FN Row16 row_shl2(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 14 ? src.l[i + 2] : old.l[i]; return r; }
 TD_FN Row16 row_shl2_z(Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 14 ? src.l[i + 2] : 0.0f; return r; }
+template <int H> TD_FN Row16 row_shr_h(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < H ? old.l[i] : src.l[i - H]; return r; }
+template <int H> TD_FN Row16 row_shl_h(Row16 old, Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 16 - H ? src.l[i + H] : old.l[i]; return r; }
+template <int H> TD_FN Row16 row_shl_h_z(Row16 src) { Row16 r; for (int i = 0; i < 16; i++) r.l[i] = i < 16 - H ? src.l[i + H] : 0.0f; return r; }
 #endif  // TETRA_HOST_EMUL
 
+template <int H, class V> TD_FN Pair<V> row_shr_h(Pair<V> old, Pair<V> src) {
+    return Pair<V>(row_shr_h<H>(old.x(), src.x()), row_shr_h<H>(old.y(), src.y()));
+}
+template <int H, class V> TD_FN Pair<V> row_shl_h(Pair<V> old, Pair<V> src) {
+    return Pair<V>(row_shl_h<H>(old.x(), src.x()), row_shl_h<H>(old.y(), src.y()));
+}
+template <int H, class V> TD_FN Pair<V> row_shl_h_z(Pair<V> src) { return Pair<V>(row_shl_h_z<H>(src.x()), row_shl_h_z<H>(src.y())); }
 template <class V> TD_FN Pair<V> row_shr1(Pair<V> old, Pair<V> src) {
     return Pair<V>(row_shr1(old.x(), src.x()), row_shr1(old.y(), src.y()));
 }
@@ -357,33 +380,49 @@ template <class V> TD_FN Pair<V> agc_step(const K1Consts& k, Pair<V> in, V& g) {
 // ---------------------------------------------------------------------------------------------
 // Fused kernel building blocks.
 //
-// FLL row with 8 lanes per channel: a 16-lane row carries TWO channels interleaved on even/odd
-// lanes, so every cross-lane move is a two-lane DPP shift and both channels' heads (lanes 0,1) and
-// tails (lanes 14,15) fall on the row boundary where DPP's keep-old / zero-fill do the right thing.
-// Band-edge taps are zero-padded at the old end to 72 = 8 positions x 9; padded tap kp lives at
-// position 7 - kp/9 (lane 2*pos + parity), slot kp%9.  The FIRs run as ONE systolic array along the
-// row: the derotated sample x_i is produced in the head lane and travels outward one position per step,
-// partial sums are created at the tail and travel inward one position per eight steps, receiving their
-// taps in ascending tap order -- bit-identical to a direct-form `for k: acc = fmaf(hist[k], tap[k], acc)`
-// -- and complete in the head lane in the very step that produces x_i, where the FLL error needs them.
+// FLL row with LANES lanes per channel: a 16-lane row carries 16/LANES channels interleaved on its lanes (lane = HOP * pos
+// + channel-in-row, HOP = 16/LANES), so every cross-lane move is a HOP-lane DPP shift and all channels' heads (lanes
+// 0..HOP-1) and tails (lanes 16-HOP..15) fall on the row boundary where DPP's keep-old / zero-fill do the right thing.
+// Band-edge taps are zero-padded at the old end to LANES positions x TAPS; padded tap kp lives at position
+// LANES - 1 - kp/TAPS, slot kp % TAPS.  The FIRs run as ONE systolic array along the row: the derotated sample x_i is
+// produced in the head lane and travels outward one position per step, partial sums are created at the tail and travel
+// inward one position per TAPS - 1 steps, receiving their taps in ascending tap order -- bit-identical to a direct-form
+// `for k: acc = fmaf(hist[k], tap[k], acc)` -- and complete in the head lane in the very step that produces x_i, where
+// the FLL error needs them.  Two geometries are used: 8 x 9 (two channels per row; the 16-channel workgroup, fll_asm.inc)
+// and 4 x 17 (four channels per row: half the loop code per channel; the 32-channel workgroup, fll4_asm.inc).
 // ---------------------------------------------------------------------------------------------
 constexpr int kF8Lanes = 8;
 constexpr int kF8Taps = 9;
 constexpr int kF8Pad = kF8Lanes * kF8Taps;   // 72
+constexpr int kF4Lanes = 4;
+constexpr int kF4Taps = 17;
+constexpr int kF4Pad = kF4Lanes * kF4Taps;   // 68
 
-template <class V> struct FllRow8 {
+template <int I, int N, class F> TD_FN void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <class V, int LANES, int TAPS> struct FllRowT {
     typedef Pair<V> P;
-    V ta[kF8Taps], tb[kF8Taps];
-    P r14[8], r32[8];
-    P xs;        // lane (pos, parity) holds x_{i-pos} of its channel
-    V ph, fr;    // FLL phase / freq (meaningful in the head lanes 0 and 1)
+    static constexpr int kLanes = LANES, kTaps = TAPS, kRes = TAPS - 1, kHop = 16 / LANES;
+    // the replay walks whole schedule periods: the newest kReplay >= LANES * TAPS stored samples (older ones only reach
+    // sums that complete, unused, before the first real step)
+    static constexpr int kReplay = ((LANES * TAPS + kRes - 1) / kRes) * kRes;
+    static_assert(kRes % LANES == 0 && 16 % LANES == 0, "row geometry");
+    V ta[TAPS], tb[TAPS];
+    P r14[kRes], r32[kRes];
+    P xs;        // lane (pos, channel-in-row) holds x_{i-pos} of its channel
+    V ph, fr;    // FLL phase / freq (meaningful in the head lanes)
 
     TD_MFN void clear_pipeline() {
-        for (int q = 0; q < 8; q++) { r14[q] = P(V(0.0f), V(0.0f)); r32[q] = P(V(0.0f), V(0.0f)); }
+        for (int q = 0; q < kRes; q++) { r14[q] = P(V(0.0f), V(0.0f)); r32[q] = P(V(0.0f), V(0.0f)); }
         xs = P(V(0.0f), V(0.0f));
     }
 
-    // One sample step; PH = step index mod 8.  `a` = AGC output (or a stored x when REPLAY), valid in
+    // One sample step; PH = step index mod (TAPS - 1).  `a` = AGC output (or a stored x when REPLAY), valid in
     // the head lanes.  After the step xs holds the new x pipeline.
     template <int PH, bool REPLAY, bool ALPHA0> TD_MFN void step(const K1Consts& k, P a) {
         P x;
@@ -394,68 +433,63 @@ template <class V> struct FllRow8 {
             sincos_t<V, true>(-ph, s, c);                             // fll.cpp:137-138
             x = cmul_phasor<V>(a, c, s);
         }
-        xs = row_shr2(x, xs);
-        P c14 = pk_fma(xs, P(ta[8], ta[8]), r14[PH]);
-        P c32 = pk_fma(xs, P(tb[8], tb[8]), r32[PH]);
-        r14[PH] = pk_fma(xs, P(ta[0], ta[0]), row_shl2_z(c14));
-        r32[PH] = pk_fma(xs, P(tb[0], tb[0]), row_shl2_z(c32));
-#define TD_F8_TAP(Q)                                                                              \
-        r14[(PH + Q) & 7] = pk_fma(xs, P(ta[8 - Q], ta[8 - Q]), r14[(PH + Q) & 7]);               \
-        r32[(PH + Q) & 7] = pk_fma(xs, P(tb[8 - Q], tb[8 - Q]), r32[(PH + Q) & 7]);
-        TD_F8_TAP(1) TD_F8_TAP(2) TD_F8_TAP(3) TD_F8_TAP(4) TD_F8_TAP(5) TD_F8_TAP(6) TD_F8_TAP(7)
-#undef TD_F8_TAP
+        xs = row_shr_h<kHop>(x, xs);
+        P c14 = pk_fma(xs, P(ta[TAPS - 1], ta[TAPS - 1]), r14[PH]);
+        P c32 = pk_fma(xs, P(tb[TAPS - 1], tb[TAPS - 1]), r32[PH]);
+        r14[PH] = pk_fma(xs, P(ta[0], ta[0]), row_shl_h_z<kHop>(c14));
+        r32[PH] = pk_fma(xs, P(tb[0], tb[0]), row_shl_h_z<kHop>(c32));
+        static_for<1, TAPS - 1>([&](auto Q) {
+            constexpr int q = decltype(Q)::value, i = (PH + q) % kRes;
+            r14[i] = pk_fma(xs, P(ta[TAPS - 1 - q], ta[TAPS - 1 - q]), r14[i]);
+            r32[i] = pk_fma(xs, P(tb[TAPS - 1 - q], tb[TAPS - 1 - q]), r32[i]);
+        });
         if (!REPLAY) {
             V err = fll_error<V>(c14, c32);                              // fll.cpp:141-145
             pcl_advance<V, true, ALPHA0>(err, ph, fr, k.fll_alpha, k.fll_beta, k.fll_min_freq, k.fll_max_freq);
         }
     }
 };
+template <class V> using FllRow8 = FllRowT<V, kF8Lanes, kF8Taps>;
+template <class V> using FllRow4 = FllRowT<V, kF4Lanes, kF4Taps>;
 
 // Drivers of an FLL row.  IO (device: LDS accesses of one lane; host emulation: arrays):
-//   P    load_hist(int g)               lane (pos,par) <- stored delay-line sample g*8 + pos (of the last 72)
+//   P    load_hist(int g)               lane (pos, ch) <- stored delay-line sample g*LANES + pos of the last Row::kReplay
 //   P    sample(int s)                  AGC output s of the current tile, broadcast to each channel's lanes
 //   void xs_store(int iend, int cnt, P xs)   lane with pos < cnt holds x_{iend-1-pos} (tile-relative iend)
-#define TD_F8_STEP(S, REPLAY)                                                                   \
-    {                                                                                           \
-        if (REPLAY) { R.template step<(S)&7, true, true>(k, cur); cur = row_shl2(cur, cur); }   \
-        else if (ALPHA0) R.template step<(S)&7, false, true>(k, io.sample(s0 + (S)));           \
-        else R.template step<(S)&7, false, false>(k, io.sample(s0 + (S)));                      \
-    }
-template <class V, class IO> TD_FN void fll8_replay(FllRow8<V>& R, const K1Consts& k, IO& io) {
-    typedef Pair<V> P;
-    const bool ALPHA0 = true;
-    const int s0 = 0;
-    (void)ALPHA0; (void)s0;
+template <class Row, class IO> TD_FN void fll_replay(Row& R, const K1Consts& k, IO& io) {
+    typedef typename Row::P P;
     R.clear_pipeline();
-    for (int g = 0; g < kF8Pad / 8; g++) {
-        P cur = io.load_hist(g);
-        TD_F8_STEP(0, true) TD_F8_STEP(1, true) TD_F8_STEP(2, true) TD_F8_STEP(3, true)
-        TD_F8_STEP(4, true) TD_F8_STEP(5, true) TD_F8_STEP(6, true) TD_F8_STEP(7, true)
+    for (int per = 0; per < Row::kReplay / Row::kRes; per++) {
+        P cur(0.0f, 0.0f);
+        static_for<0, Row::kRes>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if (s % Row::kLanes == 0) cur = io.load_hist(per * (Row::kRes / Row::kLanes) + s / Row::kLanes);
+            R.template step<s, true, true>(k, cur);
+            cur = row_shl_h<Row::kHop>(cur, cur);
+        });
     }
 }
-// One tile of cnt <= tile_len samples (tile_len a multiple of 8).
-template <class V, class IO, bool ALPHA0> TD_FN void fll8_tile(FllRow8<V>& R, const K1Consts& k, IO& io, int cnt) {
-    typedef Pair<V> P;
-    P cur(V(0.0f), V(0.0f));
-    (void)cur;
-    for (int s0 = 0; s0 < cnt; s0 += 8) {
-        const int c8 = (cnt - s0 < 8) ? (cnt - s0) : 8;
-        if (c8 == 8) {
-            TD_F8_STEP(0, false) TD_F8_STEP(1, false) TD_F8_STEP(2, false) TD_F8_STEP(3, false)
-            TD_F8_STEP(4, false) TD_F8_STEP(5, false) TD_F8_STEP(6, false) TD_F8_STEP(7, false)
+// One tile of cnt <= tile_len samples (tile_len a multiple of TAPS - 1).
+template <class Row, class IO, bool ALPHA0> TD_FN void fll_tile(Row& R, const K1Consts& k, IO& io, int cnt) {
+    for (int s0 = 0; s0 < cnt; s0 += Row::kRes) {
+        const int cg = (cnt - s0 < Row::kRes) ? (cnt - s0) : Row::kRes;
+        if (cg == Row::kRes) {
+            static_for<0, Row::kRes>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                R.template step<s, false, ALPHA0>(k, io.sample(s0 + s));
+                if (s % Row::kLanes == Row::kLanes - 1) io.xs_store(s0 + s + 1, Row::kLanes, R.xs);
+            });
         } else {
-            if (0 < c8) TD_F8_STEP(0, false)
-            if (1 < c8) TD_F8_STEP(1, false)
-            if (2 < c8) TD_F8_STEP(2, false)
-            if (3 < c8) TD_F8_STEP(3, false)
-            if (4 < c8) TD_F8_STEP(4, false)
-            if (5 < c8) TD_F8_STEP(5, false)
-            if (6 < c8) TD_F8_STEP(6, false)
+            static_for<0, Row::kRes - 1>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if (s < cg) {
+                    R.template step<s, false, ALPHA0>(k, io.sample(s0 + s));
+                    if (s % Row::kLanes == Row::kLanes - 1 || s == cg - 1) io.xs_store(s0 + s + 1, s % Row::kLanes + 1, R.xs);
+                }
+            });
         }
-        io.xs_store(s0 + c8, c8, R.xs);
     }
 }
-#undef TD_F8_STEP
 
 // RRC matched filter, direct form, eight consecutive outputs per lane (SDR++ core FIR<complex_t,float>,
 // called at src/dsp/pi4dqpsk.cpp:136).  With nt taps, output i0+m needs x_{i0+m-(nt-1)} .. x_{i0+m}; the

@@ -34,11 +34,34 @@ import struct
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "fll_asm.inc")
 
 TILE = 32
-TAPS = 9            # taps per position (kF8Taps); 8 positions x 9 = 72 padded taps
-NRES = TAPS - 1     # resident sums per position = schedule period
+
+
+class Shape:
+    """One FLL row geometry: `lanes` positions per channel x `taps` taps per position; the channels of a 16-lane DPP row are
+    interleaved, so a hop between neighbouring positions is a shift by 16/lanes lanes.  The schedule's period is taps - 1
+    steps (the residents of a position), which must divide the tile."""
+
+    def __init__(self, lanes, taps, out, prefix, what):
+        self.lanes, self.taps, self.out, self.prefix, self.what = lanes, taps, os.path.join(HERE, out), prefix, what
+        self.hop = 16 // lanes
+        self.nres = taps - 1
+        assert TILE % self.nres == 0 and self.nres % 2 == 0
+        self.pad = lanes * taps
+        self.replay_groups = -(-self.pad // self.nres)       # whole schedule periods covering the padded delay line
+
+
+SHAPES = {
+    # 16-channel workgroups: two FLL waves of 8 channels, 8 lanes per channel (72 = 8 x 9 padded taps)
+    "fll": Shape(8, 9, "fll_asm.inc", "FLL_WAVE", "FLL wave"),
+    # 32-channel workgroups: two FLL waves of 16 channels, 4 lanes per channel (68 = 4 x 17 padded taps)
+    "fll4": Shape(4, 17, "fll4_asm.inc", "FLL4_WAVE", "FLL wave, 4 lanes per channel"),
+}
+G = SHAPES["fll"]
+OUT = G.out
+TAPS = G.taps       # taps per position; lanes x taps padded taps
+NRES = G.nres       # resident sums per position = schedule period
 
 
 def f32(x):
@@ -131,25 +154,37 @@ def quad(r):
 # ----------------------------------------------------------------------------------------------------------------------
 # fixed registers of the block
 # ----------------------------------------------------------------------------------------------------------------------
-R_TA, R_TB = 16, 25             # ta[0..8] = v16..v24, tb[0..8] = v25..v33 (slot j <-> padded tap 9*(7-pos)+j)
-R_R14, R_R32 = 34, 50           # r14[i] = v[34+2i : 35+2i], r32[i] = v[50+2i : 51+2i], i = 0..7
-R_XS = (66, 68)                 # x pipeline, alternating by step parity: step s reads XS[s&1] and writes XS[(s+1)&1]
-R_PH, R_FR = 70, 71
-R_AQ = (72, 76)                 # AGC samples, two per load: sample s of a tile sits in AQ[(s>>1)&1] + 2*(s&1)
-R_K, R_R = 80, 81
-R_Z = 82                        # (z, -)
-R_Q = 84                        # (S3 constant, first cosine Horner value)
-R_PP = 86                       # (sine, cosine) Horner pair
-R_SGN = 88                      # (-1)^k of the reduction, low half of an aligned pair
-R_A2 = 90                       # the AGC sample times that sign
-R_T1, R_T2 = 94, 96
-R_C14, R_C32 = 98, 100
-R_D, R_U = 102, 104
-R_MX, R_MN = 106, 108
-R_E, R_T = 110, 111
-R_CC3, R_2PI, R_MAXF = 112, 113, 114       # constants that must sit in vector registers (constant-bus limit)
-R_AADDR, R_XLANE, R_XROWL, R_TAPADDR, R_HADDR = 115, 116, 117, 118, 119
-CLOBBER = list(range(16, 120))
+def configure(shape):
+    """Select the row geometry and lay out the block's fixed registers for it."""
+    global G, OUT, TAPS, NRES, R_TA, R_TB, R_R14, R_R32, R_XS, R_PH, R_FR, R_AQ, R_K, R_R, R_Z, R_Q, R_PP, R_SGN, R_A2, R_T1, R_T2
+    global R_C14, R_C32, R_D, R_U, R_MX, R_MN, R_E, R_T, R_CC3, R_2PI, R_MAXF, R_AADDR, R_XLANE, R_XROWL, R_TAPADDR, R_HADDR, CLOBBER
+    G, OUT, TAPS, NRES = shape, shape.out, shape.taps, shape.nres
+    R_TA = 16                       # ta[0..T-1], tb[0..T-1] (slot j <-> padded tap T*(lanes-1-pos)+j)
+    R_TB = R_TA + TAPS
+    R_R14 = (R_TB + TAPS + 1) & ~1  # r14[i] = v[R_R14+2i : +1], r32[i] likewise, i = 0..NRES-1
+    R_R32 = R_R14 + 2 * NRES
+    B = R_R32 + 2 * NRES
+    R_XS = (B, B + 2)               # x pipeline, alternating by step parity: step s reads XS[s&1] and writes XS[(s+1)&1]
+    R_PH, R_FR = B + 4, B + 5
+    R_AQ = (B + 6, B + 10)          # AGC samples, two per load: sample s of a tile sits in AQ[(s>>1)&1] + 2*(s&1)
+    R_K, R_R = B + 14, B + 15
+    R_Z = B + 16                    # (z, -)
+    R_Q = B + 18                    # (S3 constant, first cosine Horner value)
+    R_PP = B + 20                   # (sine, cosine) Horner pair
+    R_SGN = B + 22                  # (-1)^k of the reduction, low half of an aligned pair
+    R_A2 = B + 24                   # the AGC sample times that sign
+    R_T1, R_T2 = B + 28, B + 30
+    R_C14, R_C32 = B + 32, B + 34
+    R_D, R_U = B + 36, B + 38
+    R_MX, R_MN = B + 40, B + 42
+    R_E, R_T = B + 44, B + 45
+    R_CC3, R_2PI, R_MAXF = B + 46, B + 47, B + 48      # constants that must sit in vector registers (constant-bus limit)
+    R_AADDR, R_XLANE, R_XROWL, R_TAPADDR, R_HADDR = B + 49, B + 50, B + 51, B + 52, B + 53
+    CLOBBER = list(range(16, B + 54))
+
+
+configure(G)
+assert (R_TA, R_TB, R_R14, R_R32, R_XS, R_HADDR) == (16, 25, 34, 50, (66, 68), 119)
 
 # sincos_t constants (demod_core.hpp)
 INV_PI_NEG = f32(-0.318309886183790672)
@@ -214,7 +249,7 @@ def fir_and_hop(E, s, n, replay):
     def hop(k):
         src = (R_C14, R_C14 + 1, R_C32, R_C32 + 1)[k]
         dst = (sh14, sh14 + 1, sh32, sh32 + 1)[k]
-        E.ins("v_mov_b32_dpp v%d, v%d row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" % (dst, src), "dpp", [dst], [src])
+        E.ins("v_mov_b32_dpp v%d, v%d row_shl:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (dst, src, G.hop), "dpp", [dst], [src])
 
     if replay:
         for k in range(4):
@@ -290,27 +325,27 @@ def real_step(E, s):
         # both samples of this pair are consumed: the pair after the next one goes into their registers
         nq = R_AQ[(s >> 1) & 1]
         E.ins("ds_read_b128 %s, v%d offset:%d" % (quad(nq), R_AADDR, 8 * (s + 3)), "lds", list(range(nq, nq + 4)), [R_AADDR])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n, o), "dpp", [n], [o])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n + 1, o + 1), "dpp", [n + 1], [o + 1])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:%d row_mask:0xf bank_mask:0xf" % (n, o, G.hop), "dpp", [n], [o])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:%d row_mask:0xf bank_mask:0xf" % (n + 1, o + 1, G.hop), "dpp", [n + 1], [o + 1])
     used = had - len(E.pending)
     if had and used < 2:
         E.flush(2 - used)           # the deferred FMAs on r[ph] must precede this step's FMAs on it
     fir_and_hop(E, s, n, False)
     E.flush()                       # what is left of the previous step's middle FMAs
-    if s % 8 == 7:
-        # lane (pos) holds x_{s-pos}: eight samples of the tile to the ring
+    if s % G.lanes == G.lanes - 1:
+        # lane (pos) holds x_{s-pos}: `lanes` samples of the tile to the ring
         E.ins("ds_write_b64 v%d, %s offset:%d" % (R_XLANE, pair(n), 8 * s), "lds", [], [R_XLANE, n, n + 1])
     E.pending = middle_ops(s % NRES, n)
 
 
 def replay_step(E, g, n_reg, o_reg):
-    """Replay step g (0..7) of a group: x is a stored sample (no NCO, no loop update)."""
+    """Replay step g (0..NRES-1) of a group: x is a stored sample (no NCO, no loop update)."""
     E.comment("---- replay step %d" % g)
     E.ins("ds_read_b64 %s, v%d offset:%d" % (pair(n_reg), R_HADDR, 8 * g), "lds", [n_reg, n_reg + 1], [R_HADDR])
     E.flush()                       # the previous step's middle FMAs (they read o_reg)
     E.ins("s_waitcnt lgkmcnt(0)", "wait")
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n_reg, o_reg), "dpp", [n_reg], [o_reg])
-    E.ins("v_mov_b32_dpp v%d, v%d row_shr:2 row_mask:0xf bank_mask:0xf" % (n_reg + 1, o_reg + 1), "dpp", [n_reg + 1], [o_reg + 1])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:%d row_mask:0xf bank_mask:0xf" % (n_reg, o_reg, G.hop), "dpp", [n_reg], [o_reg])
+    E.ins("v_mov_b32_dpp v%d, v%d row_shr:%d row_mask:0xf bank_mask:0xf" % (n_reg + 1, o_reg + 1, G.hop), "dpp", [n_reg + 1], [o_reg + 1])
     fir_and_hop(E, g, n_reg, True)
     E.pending = middle_ops(g % NRES, n_reg)
 
@@ -336,14 +371,17 @@ def gen():
     # ---- rebuild the in-flight sums: replay of the last 72 stored samples, nine groups of eight steps.  The deferred
     # middle FMAs carry over the loop's back edge (and into the first real step); the very first batch meets an all-zero
     # pipeline and all-zero sums, where fma(0, t, 0) changes nothing.
-    E.pending = middle_ops(7, R_XS[0])
+    E.pending = middle_ops(NRES - 1, R_XS[0])
     at_top = [p[0] for p in E.pending]
-    E.ins("s_mov_b32 %[st], 9", "salu")
+    E.ins("s_mov_b32 %%[st], %d" % G.replay_groups, "salu")
     E.label(".Lreplay_%=:")
-    for g in range(8):
+    for g in range(NRES):
         replay_step(E, g, R_XS[(g + 1) & 1], R_XS[g & 1])
     assert [p[0] for p in E.pending] == at_top
-    E.ins("v_add_u32 v%d, 64, v%d" % (R_HADDR, R_HADDR), "valu", [R_HADDR], [R_HADDR])
+    if 8 * NRES <= 64:
+        E.ins("v_add_u32 v%d, %d, v%d" % (R_HADDR, 8 * NRES, R_HADDR), "valu", [R_HADDR], [R_HADDR])
+    else:
+        E.ins("v_add_u32 v%d, 0x%x, v%d" % (R_HADDR, 8 * NRES, R_HADDR), "valu", [R_HADDR], [R_HADDR])
     E.ins("s_sub_u32 %[st], %[st], 1", "salu")
     E.ins("s_cmp_lg_u32 %[st], 0", "salu")
     E.ins("s_cbranch_scc1 .Lreplay_%=", "br")
@@ -385,31 +423,37 @@ def c_string(text):
     return "\n".join(out)
 
 
-def generate():
+def generate(shape=None):
+    configure(shape or SHAPES["fll"])
     E, per_tile = gen()
+    P = G.prefix
     parts = []
-    parts.append("// fll_asm.inc -- GENERATED by gen_fll_asm.py; do not edit.  See that file for the schedule and the hazard rules.\n")
-    parts.append("// FLL wave: %d instruction slots per 32-sample tile (%.2f per sample), %d s_nop in the whole block\n" % (per_tile, per_tile / 32.0, E.nops))
-    parts.append("#define FLL_WAVE_ASM \\\n" + c_string(E.text()).replace("\n", " \\\n") + "\n")
-    parts.append("#define FLL_WAVE_CLOBBERS %s\n" % ", ".join('"v%d"' % r for r in CLOBBER))
+    parts.append("// %s -- GENERATED by gen_fll_asm.py; do not edit.  See that file for the schedule and the hazard rules.\n" % os.path.basename(G.out))
+    parts.append("// %s: %d instruction slots per 32-sample tile (%.2f per sample), %d s_nop in the whole block\n" % (G.what, per_tile, per_tile / 32.0, E.nops))
+    parts.append("#define %s_ASM \\\n" % P + c_string(E.text()).replace("\n", " \\\n") + "\n")
+    parts.append("#define %s_CLOBBERS %s\n" % (P, ", ".join('"v%d"' % r for r in CLOBBER)))
     k = pk_consts()
-    parts.append("#define FLL_WAVE_K1 0x%016xull\n#define FLL_WAVE_K2 0x%016xull\n#define FLL_WAVE_K3 0x%016xull\n#define FLL_WAVE_K4 0x%016xull\n" % tuple(k))
-    parts.append("#define FLL_WAVE_SLOTS_PER_TILE %d\n" % per_tile)
+    parts.append("#define %s_K1 0x%016xull\n#define %s_K2 0x%016xull\n#define %s_K3 0x%016xull\n#define %s_K4 0x%016xull\n" % (P, k[0], P, k[1], P, k[2], P, k[3]))
+    parts.append("#define %s_SLOTS_PER_TILE %d\n" % (P, per_tile))
     return "".join(parts), E, per_tile
 
 
 def main():
-    text, E, per_tile = generate()
-    if "--check" in sys.argv:
-        cur = open(OUT).read() if os.path.exists(OUT) else ""
-        if cur != text:
-            print("fll_asm.inc is stale: run gen_fll_asm.py")
-            return 1
-        return 0
-    with open(OUT, "w") as f:
-        f.write(text)
-    print("FLL wave: %d slots / tile = %.2f per sample; block: nops %d, %s" % (per_tile, per_tile / 32.0, E.nops, dict(sorted(E.counts.items()))))
-    return 0
+    rc = 0
+    for name in ("fll", "fll4"):
+        text, E, per_tile = generate(SHAPES[name])
+        out = SHAPES[name].out
+        if "--check" in sys.argv:
+            cur = open(out).read() if os.path.exists(out) else ""
+            if cur != text:
+                print("%s is stale: run gen_fll_asm.py" % os.path.basename(out))
+                rc = 1
+            continue
+        with open(out, "w") as f:
+            f.write(text)
+        print("%s: %d slots / tile = %.2f per sample; block: nops %d, %s" % (SHAPES[name].what, per_tile, per_tile / 32.0, E.nops, dict(sorted(E.counts.items()))))
+    configure(SHAPES["fll"])
+    return rc
 
 
 if __name__ == "__main__":

@@ -29,13 +29,17 @@
 #pragma once
 
 #include "fll_asm.inc"
+#include "fll4_asm.inc"
 
 namespace {
 
 constexpr int kFT = 32;                  // samples per tile (pipeline epoch)
 constexpr int kFCh = 16;                 // channels per workgroup: the benchmark's shape (4096 channels = one workgroup per CU) ...
-constexpr int kFChWide = 32;             // ... and the wide shape for more than 16 channels per CU (four FLL waves, one per SIMD)
-constexpr int fused_threads(int ch) { return (ch / 8 + 4) * 64; }      // FLL waves (8 channels each) + E, D, C, A
+constexpr int kFChWide = 32;             // ... and the wide shape for more than 16 channels per CU (FLL rows of 4 lanes per channel)
+#ifndef TETRA_WIDE_WAVES
+#define TETRA_WIDE_WAVES 8
+#endif
+constexpr int fused_threads(int ch) { return ch == 16 ? 6 * 64 : TETRA_WIDE_WAVES * 64; }      // 16: six roles; 32: see Roles<32>
 constexpr int kFThreads = fused_threads(kFCh);       // 384 = 6 waves
 constexpr int kFX = 256;                 // x ring (FLL output) per channel ...
 constexpr int kFXP = 8;                  // ... behind 8 slots of front padding: an FLL lane stores x_{i-pos} at slot i - pos of the
@@ -46,6 +50,7 @@ constexpr int kFYM = 8;                  // ... plus a mirror of the first slots
 constexpr int kFYS = kFY + kFYM + 1;
 constexpr int kFS = 64;                  // symbol ring per channel
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
+static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
 
 // Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
 // the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
@@ -57,11 +62,24 @@ static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 posi
 #define TETRA_ROLE_IDS 0, 1, 2, 3, 5, 4
 #endif
 namespace role_ids { constexpr int v[6] = { TETRA_ROLE_IDS }; }
-// The wide workgroup (32 channels, eight waves): the four FLL waves are the oldest wave of one SIMD each, then E and D (the two
-// heaviest of the rest) on SIMD0 / SIMD1, the RRC wave on SIMD2 and the AGC wave on SIMD3.
+// The wide workgroup (32 channels): the two FLL waves carry 16 channels each on rows of 4 lanes per channel (75 slots per
+// sample for 16 channels instead of 59 for 8: the loop code -- NCO, error, loop filter -- is shared by twice the channels)
+// and have a SIMD to themselves (waves 0, 1; waves 4 and 5 would land beside them and only keep the barriers).  The other
+// four roles share the remaining two SIMDs: E (older) and D on one, the RRC wave (older, two passes per tile) and the AGC
+// wave on the other.  Measured at 8192 x 36000, alternating on one box (profiles/r02/r02_q_wide_fll4.md): this placement
+// 5.34 ms; {E,C}{D,A} 6.36; {E,A}{D,C} 6.41; D older than E 5.63; AGC older than RRC 6.00; RRC as two waves beside E and D
+// with the AGC wave beside an FLL wave 5.75; twelve waves ({E,D,-}{C0,C1,A}) 5.36.  The FLL waves' floor is 75.19 x 4.65 =
+// 350 clocks per sample = 5.25 ms.
+#ifndef TETRA_ROLE_IDS_WIDE
+#define TETRA_ROLE_IDS_WIDE 2, 6, 0, 1, 7, 3, -1       // E, D, F0, F1, A, C, C2 (second RRC wave: one pass each; -1 = none)
+#endif
+namespace role_ids { constexpr int w[7] = { TETRA_ROLE_IDS_WIDE }; }
 template <int CH> struct Roles {
-    static constexpr int E = CH == 16 ? role_ids::v[0] : 4, D = CH == 16 ? role_ids::v[1] : 5, F0 = CH == 16 ? role_ids::v[2] : 0,
-                         A = CH == 16 ? role_ids::v[4] : 7, C = CH == 16 ? role_ids::v[5] : 6, NF = CH / 8;
+    static constexpr int E = CH == 16 ? role_ids::v[0] : role_ids::w[0], D = CH == 16 ? role_ids::v[1] : role_ids::w[1],
+                         F0 = CH == 16 ? role_ids::v[2] : role_ids::w[2], A = CH == 16 ? role_ids::v[4] : role_ids::w[4],
+                         C = CH == 16 ? role_ids::v[5] : role_ids::w[5], C2 = CH == 16 ? -1 : role_ids::w[6], NF = 2;
+    // FLL row geometry: lanes per channel, channels per FLL wave
+    static constexpr int FL = CH == 16 ? kF8Lanes : kF4Lanes, FCH = 64 / FL;
 };
 
 struct FusedParams {
@@ -129,17 +147,17 @@ template <class LDS> __device__ __forceinline__ void y_ring_put(LDS& L, int c, i
     if (s < kFYM) L.y_ring[c][s + kFY] = v;
 }
 
-// LDS side of one FLL lane in the C++ form of the wave (see fll8_tile / fll8_replay in demod_core.hpp).
-template <class LDS> struct FllDeviceIOT {
+// LDS side of one FLL lane in the C++ form of the wave (see fll_tile / fll_replay in demod_core.hpp).
+template <class LDS, class Row> struct FllDeviceIOT {
     LDS& L;
     const float2* a_tile;    // a_buf[parity][ch] of the tile being processed
     int c;                   // channel within the workgroup
-    int pos;                 // position along the channel's 8 lanes (0 = head)
+    int pos;                 // position along the channel's lanes (0 = head)
     int tile_base;           // first sample index of the tile (replay: index of the first sample to come)
 
-    // the delay line sits in the x ring: the 72 samples in front of tile_base
+    // the delay line sits in the x ring: the Row::kReplay samples in front of tile_base
     __device__ __forceinline__ Pair<float> load_hist(int g) const {
-        const float2 v = x_ring_get(L, c, tile_base - kF8Pad + g * 8 + pos);
+        const float2 v = x_ring_get(L, c, tile_base - Row::kReplay + g * Row::kLanes + pos);
         return Pair<float>(v.x, v.y);
     }
     __device__ __forceinline__ Pair<float> sample(int s) const {
@@ -172,7 +190,8 @@ template <class LDS> struct FllDeviceIOT {
 
 template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH)) void k_fused(FusedParams p) {
     typedef FusedLdsT<CH> Lds;
-    typedef FllDeviceIOT<Lds> FllDeviceIO;
+    typedef FllRowT<float, Roles<CH>::FL, (CH == 16 ? kF8Taps : kF4Taps)> FllRow;
+    typedef FllDeviceIOT<Lds, FllRow> FllDeviceIO;
     typedef Roles<CH> R_;
     constexpr int kRoleE = R_::E, kRoleD = R_::D, kRoleF0 = R_::F0, kRoleA = R_::A, kRoleC = R_::C;
     constexpr int kThreadsCH = fused_threads(CH);
@@ -258,44 +277,60 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         )
         if (on && live(c)) p.agc_g[ch0 + c] = g;
     } else if (wave >= kRoleF0 && wave < kRoleF0 + R_::NF) {
-        // ---- FLL: lane -> (row r = lane>>4, pos = (lane&15)>>1, parity = lane&1); tile e-1 in epoch e ---
+        // ---- FLL: lane -> (row r = lane>>4, pos = (lane&15) / hop, channel-in-row = lane % hop); tile e-1 in epoch e ---
+        constexpr int kHop = FllRow::kHop;
         const int fw = wave - kRoleF0;
-        const int f_pos = (lane & 15) >> 1;
-        const int f_c = fw * 8 + (lane >> 4) * 2 + (lane & 1);
+        const int f_pos = (lane & 15) / kHop;
+        const int f_c = fw * R_::FCH + (lane >> 4) * kHop + (lane % kHop);
         float ph = p.fll_ph[chan(f_c)];
         float fr = p.fll_fr[chan(f_c)];
         K1Consts k1 = p.k1;
         k1.fll_max_freq = v_pin(k1.fll_max_freq);
         __syncthreads();
         __syncthreads();      // epoch 0: nothing to do yet
-        // Every COMPLETE tile of the call runs in the assembly block of fll_asm.inc (generated by gen_fll_asm.py from the
-        // schedule of FllRow8<float>::step): rebuild of the in-flight sums from the 72 samples in front of the call, then 32
-        // steps and one barrier per tile = epochs 1 .. nfull.  The alpha != 0 variant of the loop filter (never produced by
-        // the reference's FLL, fll.cpp:25) takes the C++ form for every tile; the debug build does not instrument the block.
+        // Every COMPLETE tile of the call runs in the assembly block of fll_asm.inc / fll4_asm.inc (generated by gen_fll_asm.py
+        // from the schedule of FllRowT<float>::step): rebuild of the in-flight sums from the delay line in front of the call,
+        // then 32 steps and one barrier per tile = epochs 1 .. nfull.  The alpha != 0 variant of the loop filter (never
+        // produced by the reference's FLL, fll.cpp:25) takes the C++ form for every tile; the debug build does not
+        // instrument the block.
         const int nfull = ALPHA0 ? n / kFT : 0;
+        // padded tap kp of the row sits at be72[kp + 72 - LANES * TAPS] (both are padded at the old end)
+        constexpr int kTapOff = kF8Pad - FllRow::kLanes * FllRow::kTaps;
         if (nfull > 0) {
             int base_ = 0, tiles_ = nfull, st_;
             const unsigned a_addr = lds_addr(&L.a_buf[0][f_c][0]);
             const unsigned x_rowlane = lds_addr(&L.x_ring[f_c][kFXP]) - 8u * (unsigned)f_pos;
-            const unsigned tap_addr = lds_addr(&L.be72[0][kF8Taps * (kF8Lanes - 1 - f_pos)]);
-            const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - kF8Pad]);
+            const unsigned tap_addr = lds_addr(&L.be72[0][kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos)]);
+            const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - FllRow::kReplay]);
             const unsigned long long p4 = (unsigned long long)__builtin_bit_cast(unsigned, 0.4f);
-            asm volatile(FLL_WAVE_ASM
-                         : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
-                         : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
-                           [maxf] "v"(k1.fll_max_freq),
-                           [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
-                           [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
-                           [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4),
-                           [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
-                         : "vcc", "scc", "memory", FLL_WAVE_CLOBBERS);
+            if constexpr (CH == 16) {
+                asm volatile(FLL_WAVE_ASM
+                             : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
+                             : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
+                               [maxf] "v"(k1.fll_max_freq),
+                               [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                               [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4),
+                               [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
+                             : "vcc", "scc", "memory", FLL_WAVE_CLOBBERS);
+            } else {
+                asm volatile(FLL4_WAVE_ASM
+                             : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
+                             : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
+                               [maxf] "v"(k1.fll_max_freq),
+                               [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                               [k1] "s"(FLL4_WAVE_K1), [k2] "s"(FLL4_WAVE_K2), [k3] "s"(FLL4_WAVE_K3), [k4] "s"(FLL4_WAVE_K4),
+                               [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
+                             : "vcc", "scc", "memory", FLL4_WAVE_CLOBBERS);
+            }
         }
         // the tiles the block did not take (the partial tile at the end of the call) and the trailing epochs
         if (nfull < ntiles) {
-            FllRow8<float> R;
+            FllRow R;
 #pragma unroll
-            for (int j = 0; j < kF8Taps; j++) {
-                const int kp = kF8Taps * (kF8Lanes - 1 - f_pos) + j;
+            for (int j = 0; j < FllRow::kTaps; j++) {
+                const int kp = kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos) + j;
                 R.ta[j] = p.be_re72[kp];
                 R.tb[j] = p.be_im72[kp];
             }
@@ -303,7 +338,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             R.fr = fr;
             {
                 FllDeviceIO io{ L, nullptr, f_c, f_pos, nfull * kFT };
-                fll8_replay<float, FllDeviceIO>(R, k1, io);
+                fll_replay<FllRow, FllDeviceIO>(R, k1, io);
             }
             for (int e = nfull + 1; e < ntiles + 4; e++) {
                 FUSED_PROF_T0
@@ -312,7 +347,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                     const int base = t * kFT;
                     const int cnt = (n - base < kFT) ? (n - base) : kFT;
                     FllDeviceIO io{ L, &L.a_buf[t & 1][f_c][0], f_c, f_pos, base };
-                    fll8_tile<float, FllDeviceIO, ALPHA0>(R, k1, io, cnt);
+                    fll_tile<FllRow, FllDeviceIO, ALPHA0>(R, k1, io, cnt);
                 }
                 FUSED_PROF_T1
                 __syncthreads();
@@ -326,7 +361,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.fll_ph[ch0 + f_c] = ph;
             p.fll_fr[ch0 + f_c] = fr;
         }
-    } else if (wave == kRoleC) {
+    } else if (wave == kRoleC || wave == R_::C2) {
         // ---- RRC: lane -> (channel c = lane % CH, j = lane / CH), outputs base + 8 (j + groups * pass) + m; tile e-2 -------
         // 16 channels: four lane groups cover the tile's 32 samples in one pass; 32 channels: two groups, two passes.
         // The window of eight consecutive outputs starts at x_{i0-(nt-1)}; it is widened at the old end (under zero
@@ -350,7 +385,10 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         FUSED_EPOCHS(
             const int t = e - 2;
             if (t >= 0 && t < ntiles) {
-              for (int pass = 0; pass < kPasses; pass++) {
+              // two RRC waves share the passes of a tile, one does them all
+              const int pass0 = R_::C2 >= 0 && wave == R_::C2 ? kPasses / 2 : 0;
+              const int pass1 = R_::C2 >= 0 && wave == kRoleC ? kPasses / 2 : kPasses;
+              for (int pass = pass0; pass < pass1; pass++) {
                 const int i0 = t * kFT + 8 * (lane / CH + kGroups * pass);
                 if (i0 < n) {
                     const int start = i0 - (p.ntaps - 1) - rrc_pad;
@@ -386,7 +424,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
               }
             }
         )
-        if (lane < CH && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
+        if (wave == kRoleC && lane < CH && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
     } else if (wave == kRoleD) {
         // ---- timing recovery: lane c < 16 owns channel c; consumes y of tiles <= e-3 ---------------------
         const bool on = lane < CH;
@@ -452,7 +490,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.omega[ch0 + c] = st.omega;
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
         }
-    } else {
+    } else if (wave == kRoleE) {
         // ---- kRoleE: Costas + slicer + differential decoder + bit unpacker; symbols published before e ----
         const bool on = lane < CH;
         const int c = on ? lane : 0;
@@ -497,6 +535,10 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.prev[ch0 + c] = st.prev;
             p.n_bits[ch0 + c] = 2 * S;
         }
+    } else {
+        // ---- a wave without a role (wide workgroup: it would share a SIMD with an FLL wave): barriers only ----
+        __syncthreads();
+        for (int e = 0; e < ntiles + 4; e++) __syncthreads();
     }
 #ifdef TETRA_DEMOD_DEBUG
     if (PROF && lane == 0) {

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
 constexpr int kWg16ClocksPerSample = 277;       // measured shader clocks per sample of one workgroup round (profiles/r02)
-constexpr int kWg32ClocksPerSample = 535;       // 32-channel workgroup: 8.03 ms per 36000 samples (profiles/r02/r02_o)
+constexpr int kWg32ClocksPerSample = 365;       // 32-channel workgroup: 5.3-5.6 ms per 36000 samples (profiles/r02/r02_q)
 
 __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
     float2 v = *p;
@@ -532,7 +532,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
         pf.prof = nullptr;
-        const bool wide = h->wide;          // 32 channels per workgroup: more than 16 channels per CU (see tetra_demod_create)
+        // 32 channels per workgroup: more than 16 channels per CU (see tetra_demod_create); its FLL rows hold 4 x 17 taps
+        const bool wide = h->wide && h->design.ntaps_be <= kF4Pad;
         const dim3 gf(wide ? (h->C + kFChWide - 1) / kFChWide : (h->C + kFCh - 1) / kFCh);
         const bool a0 = pf.k1.fll_alpha == 0.0f;
 #ifdef TETRA_DEMOD_DEBUG

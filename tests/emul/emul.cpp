@@ -1,7 +1,7 @@
 // emul.cpp -- host emulation of the GPU kernel's lane-level algorithms (TEST TOOL).
 //
 // Compiles the product's shared kernel source (sdrpp-tetra-demodulator_amd/csrc/demod_core.hpp) with -DTETRA_HOST_EMUL:
-// the building blocks of k_fused (agc_step, the FLL row FllRow8 with fll8_replay / fll8_tile on a 16-lane Row16 with
+// the building blocks of k_fused (agc_step, the FLL row FllRowT with fll_replay / fll_tile on a 16-lane Row16 with
 // emulated DPP moves, rrc_direct8, k2_timing, k2_costas) run stage after stage over linear arrays.  The tests compare this
 // against the CPU oracle so that the systolic schedule, the replay of the delay line and the tile bookkeeping are verified
 // without a GPU.  It also exposes the product's host-side filter design (design.hpp) for comparison with the oracle's.
@@ -71,23 +71,26 @@ void emul_reset_state(const emul_tables* t, tetra_demod_channel_state_t* st) {
     st->rrc_valid = kHist;
 }
 
-// Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllRow8 + fll8_replay/fll8_tile,
+// Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllRowT + fll_replay/fll_tile,
 // rrc_direct8, k2_timing, k2_costas) run stage after stage over linear arrays -- a valid serialisation of the
 // device's barrier-synchronised software pipeline.  (The LDS ring/epoch bookkeeping itself is device-only.)
 // ---------------------------------------------------------------------------------------------------
+}  // extern "C"
 namespace {
-struct Fll8EmulIO {
-    const float* hist[2];   // per parity: stored delay line [80][2]
-    const float* a[2];      // per parity: AGC output of the whole chunk [n][2]
-    float* x[2];            // per parity: FLL output [n][2]
+// One DPP row of an FLL wave: Row::kHop channels interleaved on the 16 lanes, lane = kHop * pos + channel-in-row.
+template <class Row> struct FllEmulIO {
+    static constexpr int H = Row::kHop;
+    const float* hist[H];   // per channel of the row: stored delay line [80][2]
+    const float* a[H];      // AGC output of the whole chunk [n][2]
+    float* x[H];            // FLL output [n][2]
     int tile_base = 0;
     int n = 0;
 
     Pair<Row16> load_hist(int g) const {
         Row16 re, im;
         for (int l = 0; l < 16; l++) {
-            const int pos = l >> 1, par = l & 1;
-            const int m = (kHist - kF8Pad) + g * 8 + pos;
+            const int pos = l / H, par = l % H;
+            const int m = (kHist - Row::kReplay) + g * Row::kLanes + pos;
             re.l[l] = hist[par][2 * m];
             im.l[l] = hist[par][2 * m + 1];
         }
@@ -97,7 +100,7 @@ struct Fll8EmulIO {
         Row16 re, im;
         const int i = tile_base + s;
         for (int l = 0; l < 16; l++) {
-            const int par = l & 1;
+            const int par = l % H;
             re.l[l] = i < n ? a[par][2 * i] : 0.f;
             im.l[l] = i < n ? a[par][2 * i + 1] : 0.f;
         }
@@ -105,7 +108,7 @@ struct Fll8EmulIO {
     }
     void xs_store(int iend, int cnt, Pair<Row16> xs) {
         for (int l = 0; l < 16; l++) {
-            const int pos = l >> 1, par = l & 1;
+            const int pos = l / H, par = l % H;
             if (pos < cnt) {
                 const int i = tile_base + iend - 1 - pos;
                 x[par][2 * i] = xs.x().l[l];
@@ -114,13 +117,61 @@ struct Fll8EmulIO {
         }
     }
 };
+
+// F stage of emul_fused for one row geometry: FLL rows of Row::kHop interleaved channels.
+template <class Row> void emul_fll(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* re72,
+                                   const float* im72, std::vector<float>& a, std::vector<float>& x) {
+    constexpr int H = Row::kHop, tile = 32;
+    static_assert(Row::kReplay <= kHist, "the delay line holds the replayed samples");
+    constexpr int tap_off = kF8Pad - Row::kLanes * Row::kTaps;       // padded tap kp of the row = entry kp + tap_off of the 72-padded table
+    std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kHist, 0.f), dump((size_t)std::max(n, 1) * 2);
+    for (int c0 = 0; c0 < C; c0 += H) {
+        Row R;
+        for (int j = 0; j < Row::kTaps; j++) {
+            Row16 ta, tb;
+            for (int l = 0; l < 16; l++) {
+                const int pos = l / H;
+                const int kp = tap_off + Row::kTaps * (Row::kLanes - 1 - pos) + j;
+                ta.l[l] = re72[kp];
+                tb.l[l] = im72[kp];
+            }
+            R.ta[j] = ta;
+            R.tb[j] = tb;
+        }
+        FllEmulIO<Row> io;
+        for (int par = 0; par < H; par++) {
+            const bool have = c0 + par < C;
+            const int c = have ? c0 + par : c0;
+            io.hist[par] = have ? st[c].hist : zhist.data();
+            io.a[par] = have ? &a[(size_t)c * n * 2] : zeros.data();
+            io.x[par] = have ? &x[(size_t)c * n * 2] : dump.data();
+        }
+        for (int l = 0; l < 16; l++) {
+            const int c = c0 + l % H < C ? c0 + l % H : c0;
+            R.ph.l[l] = st[c].fll_phase;
+            R.fr.l[l] = st[c].fll_freq;
+        }
+        io.n = n;
+        fll_replay<Row, FllEmulIO<Row>>(R, t->k1, io);
+        for (int base = 0; base < n; base += tile) {
+            io.tile_base = base;
+            const int cnt = n - base < tile ? n - base : tile;
+            if (t->k1.fll_alpha == 0.0f) fll_tile<Row, FllEmulIO<Row>, true>(R, t->k1, io, cnt);
+            else fll_tile<Row, FllEmulIO<Row>, false>(R, t->k1, io, cnt);
+        }
+        for (int par = 0; par < H && c0 + par < C; par++) {
+            st[c0 + par].fll_phase = R.ph.l[par];
+            st[c0 + par].fll_freq = R.fr.l[par];
+        }
+    }
+}
 }  // namespace
+extern "C" {
 
 // C <= 64 channels (processed in rows of two).  iq [C][n] channel-major.  Outputs like emul_k2, plus y_out [C][n].
-int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
-               uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym) {
+int emul_fused_shape(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
+                     uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym, int fll_lanes) {
     if (C < 1 || C > 64 || t->ntaps > kF8Pad) return -1;
-    const int tile = 32;
     float re72[kF8Pad] = { 0 }, im72[kF8Pad] = { 0 };
     float rrc_ext[kRrcExt] = { 0 };
     const int o72 = kF8Pad - t->ntaps;
@@ -138,42 +189,10 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
         }
         st[c].agc_gain = g;
     }
-    // F: FLL rows of two interleaved channels
-    std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kHist, 0.f), dump((size_t)std::max(n, 1) * 2);
-    for (int c0 = 0; c0 < C; c0 += 2) {
-        const bool two = c0 + 1 < C;
-        FllRow8<Row16> R;
-        for (int j = 0; j < kF8Taps; j++) {
-            Row16 ta, tb;
-            for (int l = 0; l < 16; l++) {
-                const int pos = l >> 1;
-                const int kp = kF8Taps * (kF8Lanes - 1 - pos) + j;
-                ta.l[l] = re72[kp];
-                tb.l[l] = im72[kp];
-            }
-            R.ta[j] = ta;
-            R.tb[j] = tb;
-        }
-        for (int l = 0; l < 16; l++) {
-            const int c = (l & 1) && two ? c0 + 1 : c0;
-            R.ph.l[l] = st[c].fll_phase;
-            R.fr.l[l] = st[c].fll_freq;
-        }
-        Fll8EmulIO io;
-        io.hist[0] = st[c0].hist; io.hist[1] = two ? st[c0 + 1].hist : zhist.data();
-        io.a[0] = &a[(size_t)c0 * n * 2]; io.a[1] = two ? &a[(size_t)(c0 + 1) * n * 2] : zeros.data();
-        io.x[0] = &x[(size_t)c0 * n * 2]; io.x[1] = two ? &x[(size_t)(c0 + 1) * n * 2] : dump.data();
-        io.n = n;
-        fll8_replay<Row16, Fll8EmulIO>(R, t->k1, io);
-        for (int base = 0; base < n; base += tile) {
-            io.tile_base = base;
-            const int cnt = n - base < tile ? n - base : tile;
-            if (t->k1.fll_alpha == 0.0f) fll8_tile<Row16, Fll8EmulIO, true>(R, t->k1, io, cnt);
-            else fll8_tile<Row16, Fll8EmulIO, false>(R, t->k1, io, cnt);
-        }
-        st[c0].fll_phase = R.ph.l[0]; st[c0].fll_freq = R.fr.l[0];
-        if (two) { st[c0 + 1].fll_phase = R.ph.l[1]; st[c0 + 1].fll_freq = R.fr.l[1]; }
-    }
+    // F: FLL rows (8 lanes per channel: the 16-channel workgroup; 4 lanes: the 32-channel one; taps beyond 68 need the former)
+    if (fll_lanes == 4 && t->ntaps <= kF4Pad) emul_fll<FllRow4<Row16>>(t, st, C, n, re72, im72, a, x);
+    else if (fll_lanes == 8) emul_fll<FllRow8<Row16>>(t, st, C, n, re72, im72, a, x);
+    else return -1;
     // C: RRC, eight outputs at a time, over [history | x]
     std::vector<float> y((size_t)C * n * 2);
     for (int c = 0; c < C; c++) {
@@ -236,6 +255,11 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
         std::memcpy(st[c].ybuf, yf.data() + 2 * n, sizeof(float) * 2 * kYHist);
     }
     return 0;
+}
+
+int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
+               uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym) {
+    return emul_fused_shape(t, st, C, n, iq, y_out, bits, bits_stride, n_bits, sym, 8);
 }
 
 }  // extern "C"

@@ -61,6 +61,8 @@ def lib():
         L.emul_reset_state.restype = None
         L.emul_fused.argtypes = [C.POINTER(Tables), C.POINTER(ChannelState), C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]
         L.emul_fused.restype = C.c_int
+        L.emul_fused_shape.argtypes = L.emul_fused.argtypes + [C.c_int]
+        L.emul_fused_shape.restype = C.c_int
         _lib = L
     return _lib
 
@@ -92,8 +94,10 @@ def bits_stride(n):
 class EmulDemod:
     """C <= 64 channels through the emulated kernels, with carried state."""
 
-    def __init__(self, n_channels=1, cfg=None, fused=True):
+    def __init__(self, n_channels=1, cfg=None, fused=True, fll_lanes=8):
+        """fll_lanes: 8 = the FLL rows of the 16-channel workgroup, 4 = those of the 32-channel workgroup."""
         self.fused = True
+        self.fll_lanes = fll_lanes
         self.C = n_channels
         self.tab = design(cfg)
         self.st = (ChannelState * n_channels)()
@@ -111,6 +115,6 @@ class EmulDemod:
         bits = np.zeros((Cn, stride), np.uint8)
         nb = np.zeros(Cn, np.int32)
         sym = np.zeros((Cn, stride // 2), np.complex64) if want_sym else None
-        rc = lib().emul_fused(C.byref(self.tab), self.st, Cn, n, _p(iq), _p(y), _p(bits), stride, _p(nb), _p(sym))
+        rc = lib().emul_fused_shape(C.byref(self.tab), self.st, Cn, n, _p(iq), _p(y), _p(bits), stride, _p(nb), _p(sym), self.fll_lanes)
         assert rc == 0, rc
         return dict(y=y, bits=bits, n_bits=nb, sym=sym)

@@ -58,7 +58,8 @@ def test_emulated_kernels_match_oracle(emul, oracle, synth, N, chunks):
     assert np.array_equal(_u32(np.array(st.hist[:], np.float32)[32:]), _u32(np.array(os_.hist[:], np.float32)[-128:]))
 
 
-def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth):
+@pytest.mark.parametrize("fll_lanes", [8, 4])
+def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth, fll_lanes):
     """64 channels through the emulated stages, including a noise-only and an all-zero channel (their timing
     loops wander, so per-lane offsets diverge inside a tile)."""
     Cn, N = 64, 6000
@@ -68,21 +69,23 @@ def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth
     iq[6] = 0
     iq[7] = synth.gen_channel(N, 4, ppm=8000.0)[0]     # 0.8 % clock offset
     bits, nb, sym, _ = oracle.process_batch(iq, want_sym=True)
-    q = emul.EmulDemod(Cn).process(iq, want_sym=True)
+    q = emul.EmulDemod(Cn, fll_lanes=fll_lanes).process(iq, want_sym=True)
     assert np.array_equal(q["n_bits"], nb)
     for c in range(Cn):
         assert np.array_equal(q["bits"][c][:nb[c]], bits[c][:nb[c]]), c
 
 
-def test_fused_stage_code_equals_oracle(emul, oracle, synth, lanes=True):
-    """The fused kernel's building blocks (agc_step, the FLL row with its delay-line replay and 32-sample tiles,
+@pytest.mark.parametrize("fll_lanes", [8, 4])
+def test_fused_stage_code_equals_oracle(emul, oracle, synth, fll_lanes, lanes=True):
+    """(fll_lanes: the FLL row of the 16-channel workgroup, 8 lanes x 9 taps per channel, and of the 32-channel one, 4 x 17.)
+    The fused kernel's building blocks (agc_step, the FLL row with its delay-line replay and 32-sample tiles,
     rrc_direct8, k2_timing, k2_costas -- same source as the device) run stage after stage == the oracle, bit for bit:
     RRC output, bits, symbols; ragged call lengths with carried state (1, 7, 31, 33 ... samples: partial tiles, partial
     8-step groups), 5 channels."""
     Cn = 5
     N = 4200
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=321)
-    e = emul.EmulDemod(Cn, fused=lanes)
+    e = emul.EmulDemod(Cn, fused=lanes, fll_lanes=fll_lanes)
     orc = [oracle.Oracle() for _ in range(Cn)]
     pos = 0
     for n in (1, 7, 31, 33, 64, 17, 1000, 0, 2047, 1000):
@@ -97,8 +100,8 @@ def test_fused_stage_code_equals_oracle(emul, oracle, synth, lanes=True):
         pos += n
 
 
-@pytest.mark.parametrize("nt", [33, 72])
-def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, lanes=True):
+@pytest.mark.parametrize("nt,fll_lanes", [(33, 8), (72, 8), (33, 4), (68, 4), (2, 4)])
+def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, fll_lanes, lanes=True):
     N = 2500
     iq, _, _ = synth.gen_channel(N, 77)
     ocfg = oracle.default_cfg()
@@ -106,7 +109,7 @@ def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, lanes=True):
     o = oracle.Oracle(ocfg)
     ecfg = emul.default_cfg()
     ecfg.rrc_tap_count = nt
-    e = emul.EmulDemod(1, ecfg, fused=lanes)
+    e = emul.EmulDemod(1, ecfg, fused=lanes, fll_lanes=fll_lanes)
     for pos in (0, 1250):
         r = o.process(iq[pos:pos + 1250], stages=True)
         q = e.process(iq[pos:pos + 1250])

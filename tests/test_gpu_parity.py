@@ -227,9 +227,11 @@ def test_retired_pipeline_and_tap_counts_above_72_are_refused(pkg):
     d.close()
 
 
-@pytest.mark.parametrize("pipeline,nt", [("fused", 2), ("fused", 33), ("fused", 72), ("wide", 33), ("wide", 72)])
+@pytest.mark.parametrize("pipeline,nt", [("fused", 2), ("fused", 33), ("fused", 72), ("wide", 2), ("wide", 33), ("wide", 68), ("wide", 69),
+                                         ("wide", 72)])
 def test_other_tap_counts(pkg, oracle, synth, pipeline, nt):
-    """rrcTapCount is a PI4DQPSK parameter (2..72 here; the reference builds with 65)."""
+    """rrcTapCount is a PI4DQPSK parameter (2..72 here; the reference builds with 65).  The 32-channel workgroup's FLL rows hold
+    4 x 17 = 68 taps: above that the library launches the 16-channel shape whatever the flag says."""
     Cn, N = 6, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=71)
     d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & 16, rrc_tap_count=nt)
