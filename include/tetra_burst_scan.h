@@ -50,6 +50,37 @@ int tetra_find_train_seq_batch_device(const uint8_t* d_bits, int n_channels, int
 int tetra_find_train_seq_batch(const uint8_t* bits, int n_channels, int bits_stride, const int32_t* end_of_in, uint32_t mask,
                                int32_t* type, int32_t* offset, int device);
 
+/*
+ * The plugin's own training-sequence indicator (src/main.cpp:385-414 with the sequences at :457-468 and the state at
+ * :470-472; the GUI draws it as a box indicator in the NETSYMS mode, main.cpp:331), for C channels at once.  Per received bit the reference
+ * shifts the bit into a 45-entry window and compares the window's HEAD with eight sequences (normal n/p/q 22 bits, N/P 33,
+ * extended x 30 / X 45, synchronisation y 38); a hit sets `tsfound` and arms `symsbeforeexpire = 2048`, which every bit
+ * then counts down (the arming bit included), clearing `tsfound` when it reaches zero.  Only the value after the last bit
+ * of a call is observable, so the device finds the LAST hit of the call and derives both from it; the window (its newest
+ * 44 bits) and the counter are carried per channel.  State starts as the plugin's members would if zero-initialised
+ * (window all zero, counter 0, tsfound false).  Checker: oracle/burst_sync_oracle.c restates the handler literally
+ * (parity unpinned: main.cpp needs SDR++ and cannot be built here).
+ */
+typedef struct tetra_ts_indicator tetra_ts_indicator_t;
+
+/* device = HIP ordinal or -1 for the current one */
+int tetra_ts_indicator_create(int n_channels, int device, tetra_ts_indicator_t** out);
+void tetra_ts_indicator_destroy(tetra_ts_indicator_t* h);
+/* channel = -1: every channel back to the initial state */
+int tetra_ts_indicator_reset(tetra_ts_indicator_t* h, int channel);
+/*
+ * d_bits    [n_channels][bits_stride] uint8, one bit per byte (values 0 / 1), device pointer; bits_stride % 4 == 0
+ * d_n_bits  [n_channels] int32: bits of this call per channel (the demodulator's n_bits; cut back to bits_stride)
+ * d_found   [n_channels] uint8 out: the reference's tsfound after the call's last bit
+ * d_expire  [n_channels] int32 out or NULL: the reference's symsbeforeexpire after the call's last bit
+ * Enqueued on hip_stream of the handle's device, no synchronisation.
+ */
+int tetra_ts_indicator_process_device(tetra_ts_indicator_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits,
+                                      uint8_t* d_found, int32_t* d_expire, void* hip_stream);
+/* Host-pointer variant (copies in/out, synchronises). */
+int tetra_ts_indicator_process(tetra_ts_indicator_t* h, const uint8_t* bits, int bits_stride, const int32_t* n_bits,
+                               uint8_t* found, int32_t* expire);
+
 #ifdef __cplusplus
 }
 #endif

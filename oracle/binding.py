@@ -381,6 +381,10 @@ def bsync_lib():
         L.bs_oracle_demux.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.bs_oracle_demux.restype = C.c_int
         L.bs_oracle_state_size.restype = C.c_int
+        L.ts_indicator_init.argtypes = [vp]
+        L.ts_indicator_init.restype = None
+        L.ts_indicator_feed.argtypes = [vp, vp, C.c_int]
+        L.ts_indicator_feed.restype = None
         _bsync = L
     return _bsync
 
@@ -421,3 +425,17 @@ def bsync_demux(burst, train, tpsap, blk_num):
     out = np.zeros(432, np.uint8)
     n = bsync_lib().bs_oracle_demux(_ptr(b), int(train), int(tpsap), int(blk_num), _ptr(out))
     return out[:n].copy()
+
+
+class TsIndicatorOracle:
+    """The plugin's training-sequence indicator (src/main.cpp:385-414) for one channel, literal restatement."""
+
+    def __init__(self):
+        self._st = np.zeros(45 + 3 + 8, np.uint8)      # tsfind_buffer[45], padding, tsfound, symsbeforeexpire
+        bsync_lib().ts_indicator_init(_ptr(self._st))
+
+    def feed(self, bits):
+        b = np.ascontiguousarray(bits, np.uint8)
+        bsync_lib().ts_indicator_feed(_ptr(self._st), _ptr(b), int(b.size))
+        v = self._st[48:56].view(np.int32)
+        return bool(v[0]), int(v[1])

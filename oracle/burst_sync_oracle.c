@@ -205,3 +205,47 @@ int bs_oracle_demux(const uint8_t* burst, int train, int tpsap, int blk_num, uin
 }
 
 int bs_oracle_state_size(void) { return (int)sizeof(bs_oracle_state_t); }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The plugin's training-sequence indicator, src/main.cpp:385-414 (_demodSinkHandler without the UDP send), restated
+ * literally: sequences :457-468, state :470-472 (tsfind_buffer[45], tsfound, symsbeforeexpire), taken as zero-initialised.
+ * PARITY UNPINNED: main.cpp needs SDR++ and cannot be built here; the handler is 25 lines of byte compares.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static const uint8_t training_seq_n[22] = { 1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0 };
+static const uint8_t training_seq_p[22] = { 0,1, 1,1, 1,0, 1,0, 0,1, 0,0, 0,0, 1,1, 0,1, 1,1, 1,0 };
+static const uint8_t training_seq_q[22] = { 1,0, 1,1, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 1,0, 1,1, 0,1 };
+static const uint8_t training_seq_N[33] = { 1,1,1, 0,0,1, 1,0,1, 1,1,1, 0,0,0, 1,1,1, 1,0,0, 0,1,1, 1,1,0, 0,0,0, 0,0,0 };
+static const uint8_t training_seq_P[33] = { 1,0,1, 0,1,1, 1,1,1, 1,0,1, 0,1,0, 1,0,1, 1,1,0, 0,0,1, 1,0,0, 0,1,0, 0,1,0 };
+static const uint8_t training_seq_x[30] = { 1,0, 0,1, 1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0, 0,0, 1,1 };
+static const uint8_t training_seq_X[45] = { 0,1,1,1,0,0,1,1,0,1,0,0,0,0,1,0,0,0,1,1,1,0,1,1,0,1,0,1,0,1,1,1,1,1,0,1,0,0,0,0,0,1,1,1,0 };
+static const uint8_t training_seq_y[38] = { 1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1 };
+
+typedef struct {
+    uint8_t tsfind_buffer[45];
+    int32_t tsfound;
+    int32_t symsbeforeexpire;
+} ts_indicator_state;
+
+void ts_indicator_init(ts_indicator_state* s) { memset(s, 0, sizeof(*s)); }
+
+void ts_indicator_feed(ts_indicator_state* s, const uint8_t* data, int count) {
+    for (int j = 0; j < count; j++) {
+        for (int i = 0; i < 44; i++) s->tsfind_buffer[i] = s->tsfind_buffer[i + 1];
+        s->tsfind_buffer[44] = data[j];
+        if (!memcmp(s->tsfind_buffer, training_seq_n, sizeof(training_seq_n)) ||
+            !memcmp(s->tsfind_buffer, training_seq_p, sizeof(training_seq_p)) ||
+            !memcmp(s->tsfind_buffer, training_seq_q, sizeof(training_seq_q)) ||
+            !memcmp(s->tsfind_buffer, training_seq_N, sizeof(training_seq_N)) ||
+            !memcmp(s->tsfind_buffer, training_seq_P, sizeof(training_seq_P)) ||
+            !memcmp(s->tsfind_buffer, training_seq_x, sizeof(training_seq_x)) ||
+            !memcmp(s->tsfind_buffer, training_seq_X, sizeof(training_seq_X)) ||
+            !memcmp(s->tsfind_buffer, training_seq_y, sizeof(training_seq_y))) {
+            s->tsfound = 1;
+            s->symsbeforeexpire = 2048;
+        }
+        if (s->symsbeforeexpire > 0) {
+            s->symsbeforeexpire--;
+            if (s->symsbeforeexpire == 0) s->tsfound = 0;
+        }
+    }
+}

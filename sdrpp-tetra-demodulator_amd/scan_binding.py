@@ -5,7 +5,8 @@ import numpy as np
 
 from .binding import TetraDemodError, load_library
 
-SCAN_EXPORTS = ["tetra_find_train_seq_batch_device", "tetra_find_train_seq_batch"]
+SCAN_EXPORTS = ["tetra_find_train_seq_batch_device", "tetra_find_train_seq_batch", "tetra_ts_indicator_create",
+                "tetra_ts_indicator_reset", "tetra_ts_indicator_process_device", "tetra_ts_indicator_process"]
 TRAIN_NORM_1, TRAIN_NORM_2, TRAIN_NORM_3, TRAIN_SYNC, TRAIN_EXT = 0, 1, 2, 3, 4
 ALL_MASK = 0x1f
 
@@ -19,6 +20,12 @@ def _lib():
         vp, i32 = C.c_void_p, C.c_int
         L.tetra_find_train_seq_batch_device.argtypes = [vp, i32, i32, vp, C.c_uint32, vp, vp, vp]
         L.tetra_find_train_seq_batch.argtypes = [vp, i32, i32, vp, C.c_uint32, vp, vp, i32]
+        L.tetra_ts_indicator_create.argtypes = [i32, i32, C.POINTER(vp)]
+        L.tetra_ts_indicator_destroy.argtypes = [vp]
+        L.tetra_ts_indicator_destroy.restype = None
+        L.tetra_ts_indicator_reset.argtypes = [vp, i32]
+        L.tetra_ts_indicator_process_device.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+        L.tetra_ts_indicator_process.argtypes = [vp, vp, i32, vp, vp, vp]
         for n in SCAN_EXPORTS:
             getattr(L, n).restype = i32
         _ready = True
@@ -48,3 +55,54 @@ def find_train_seq_batch_device(d_bits, n_channels, bits_stride, d_end, mask, d_
                                                   C.c_void_p(d_offset.data_ptr()), s)
     if rc:
         raise TetraDemodError(rc, "tetra_find_train_seq_batch_device")
+
+
+class TsIndicator:
+    """The plugin's training-sequence indicator (src/main.cpp:385-414) for C channels on one GPU, state carried."""
+
+    def __init__(self, n_channels, device=-1):
+        self._h = C.c_void_p()
+        rc = _lib().tetra_ts_indicator_create(int(n_channels), int(device), C.byref(self._h))
+        if rc:
+            raise TetraDemodError(rc, "tetra_ts_indicator_create")
+        self.n_channels = int(n_channels)
+
+    def close(self):
+        if self._h:
+            _lib().tetra_ts_indicator_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, channel=-1):
+        rc = _lib().tetra_ts_indicator_reset(self._h, int(channel))
+        if rc:
+            raise TetraDemodError(rc, "tetra_ts_indicator_reset")
+
+    def process(self, bits, n_bits):
+        """bits uint8 [C][stride] (stride % 4 == 0), n_bits int32 [C] -> (found bool [C], expire int32 [C])."""
+        b = np.ascontiguousarray(bits, np.uint8)
+        nb = np.ascontiguousarray(n_bits, np.int32)
+        assert b.shape[0] == self.n_channels and nb.shape[0] == self.n_channels
+        found = np.zeros(self.n_channels, np.uint8)
+        expire = np.zeros(self.n_channels, np.int32)
+        vp = C.c_void_p
+        rc = _lib().tetra_ts_indicator_process(self._h, b.ctypes.data_as(vp), b.shape[1], nb.ctypes.data_as(vp),
+                                               found.ctypes.data_as(vp), expire.ctypes.data_as(vp))
+        if rc:
+            raise TetraDemodError(rc, "tetra_ts_indicator_process")
+        return found.astype(bool), expire
+
+    def process_device(self, d_bits, bits_stride, d_n_bits, d_found, d_expire=None, stream=None):
+        s = None
+        if stream is not None:
+            s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+        vp = C.c_void_p
+        rc = _lib().tetra_ts_indicator_process_device(self._h, vp(d_bits.data_ptr()), int(bits_stride), vp(d_n_bits.data_ptr()),
+                                                      vp(d_found.data_ptr()), None if d_expire is None else vp(d_expire.data_ptr()), s)
+        if rc:
+            raise TetraDemodError(rc, "tetra_ts_indicator_process_device")

@@ -38,9 +38,9 @@ def test_channeliser_header_symbols_all_exported(pkg):
 def test_burst_scan_header_symbols_all_exported(pkg):
     src = open(os.path.join(ROOT, "include", "tetra_burst_scan.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = sorted(set(re.findall(r"\b(tetra_find_train_seq_batch[a-z_]*)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(tetra_find_train_seq_batch[a-z_]*|tetra_ts_indicator_[a-z_]+)\s*\(", src)))
     L = pkg.load_library()
-    assert set(names) == set(pkg.scan_binding.SCAN_EXPORTS)
+    assert set(names) == set(pkg.scan_binding.SCAN_EXPORTS) | {"tetra_ts_indicator_destroy"}
     for n in names:
         assert hasattr(L, n), n
 

@@ -108,3 +108,102 @@ def test_reference_bursts_through_the_gpu_demodulator(pkg, ref, synth):
     tg, og = pkg.scan_binding.find_train_seq_batch(sub, end)
     for c in range(Cn):
         assert (int(tg[c]), int(og[c])) == ref.find_train_seq(sub[c], 4096), c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The plugin's own training-sequence indicator (src/main.cpp:385-414)
+# ---------------------------------------------------------------------------------------------------------------------
+IND_SEQS = {
+    "n": [1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0],
+    "p": [0,1, 1,1, 1,0, 1,0, 0,1, 0,0, 0,0, 1,1, 0,1, 1,1, 1,0],
+    "q": [1,0, 1,1, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 1,0, 1,1, 0,1],
+    "N": [1,1,1, 0,0,1, 1,0,1, 1,1,1, 0,0,0, 1,1,1, 1,0,0, 0,1,1, 1,1,0, 0,0,0, 0,0,0],
+    "P": [1,0,1, 0,1,1, 1,1,1, 1,0,1, 0,1,0, 1,0,1, 1,1,0, 0,0,1, 1,0,0, 0,1,0, 0,1,0],
+    "x": [1,0, 0,1, 1,1, 0,1, 0,0, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,1, 0,0, 0,0, 1,1],
+    "X": [0,1,1,1,0,0,1,1,0,1,0,0,0,0,1,0,0,0,1,1,1,0,1,1,0,1,0,1,0,1,1,1,1,1,0,1,0,0,0,0,0,1,1,1,0],
+    "y": [1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1, 0,0, 1,1, 1,0, 1,0, 0,1, 1,1, 0,0, 0,0, 0,1, 1,0, 0,1, 1,1],
+}
+
+
+def test_indicator_restatement_arms_and_expires(oracle):
+    """Known answers worked out by hand from main.cpp:385-414: a sequence of length L that ends at bit e is seen when the
+    window's head holds it, 45 - L bits later; that bit arms 2048 and counts it down to 2047; 2047 further bits clear it."""
+    for name, seq in IND_SEQS.items():
+        L = len(seq)
+        o = oracle.TsIndicatorOracle()
+        pre = np.zeros(100, np.uint8)
+        assert o.feed(pre) == (False, 0)
+        assert o.feed(np.array(seq, np.uint8)) == ((True, 2047) if L == 45 else (False, 0)), name
+        if L < 45:
+            assert o.feed(np.zeros(45 - L - 1, np.uint8)) == (False, 0), name
+            assert o.feed(np.zeros(1, np.uint8)) == (True, 2047), name
+        again = 4 if name == "x" else 0        # the extended sequence holds normal sequence 1 at its bit 4: a second hit re-arms
+        assert o.feed(np.zeros(2046, np.uint8)) == (True, 1 + again), name
+        assert o.feed(np.zeros(again, np.uint8)) == (True, 1), name
+        assert o.feed(np.zeros(1, np.uint8)) == (False, 0), name
+    # the ETSI sequences of the fixture are the plugin's n / p / q / y / x
+    ts = _seqs()
+    assert ts[0] == IND_SEQS["n"] and ts[1] == IND_SEQS["p"] and ts[2] == IND_SEQS["q"] and ts[3] == IND_SEQS["y"] and ts[4] == IND_SEQS["x"]
+
+
+@pytest.mark.gpu
+def test_gpu_indicator_equals_the_restatement_chunked_with_carried_state(pkg, oracle):
+    """600 channels of random bits with planted sequences (also across call boundaries and inside the first 44 bits of a
+    call), ragged per-channel counts and call lengths from 0 to several tiles: tsfound and symsbeforeexpire after every call
+    equal the literal restatement's; reset of one channel and of all."""
+    rng = np.random.default_rng(7)
+    Cn, total = 600, 60000
+    rows = rng.integers(0, 2, (Cn, total), dtype=np.uint8)
+    rows[:20] = 0                                           # quiet channels: only planted hits
+    names = list(IND_SEQS)
+    for c in range(Cn):
+        for _ in range(int(rng.integers(0, 5))):
+            s = IND_SEQS[names[int(rng.integers(0, 8))]]
+            pos = int(rng.integers(0, total - 64))
+            rows[c, pos:pos + len(s)] = s
+    ind = pkg.scan_binding.TsIndicator(Cn)
+    orcs = [oracle.TsIndicatorOracle() for _ in range(Cn)]
+    pos = np.zeros(Cn, np.int64)
+    for k, base_len in enumerate([1, 43, 44, 45, 0, 300, 2047, 2048, 2049, 9000, 17000, 8192, 31]):
+        nb = np.minimum(base_len + (rng.integers(0, 40, Cn) if k % 2 else 0), total - pos).astype(np.int32)
+        if base_len == 0:
+            nb[:] = 0
+        stride = (int(nb.max()) + 8 + 3) & ~3
+        bits = np.zeros((Cn, stride), np.uint8)
+        for c in range(Cn):
+            bits[c, :nb[c]] = rows[c, pos[c]:pos[c] + nb[c]]
+        found, expire = ind.process(bits, nb)
+        for c in range(Cn):
+            want = orcs[c].feed(rows[c, pos[c]:pos[c] + nb[c]])
+            assert (bool(found[c]), int(expire[c])) == want, (k, c, base_len)
+        pos += nb
+        if k == 6:
+            ind.reset(3)
+            orcs[3] = oracle.TsIndicatorOracle()
+    assert found[20:].any() and not found[20:].all()
+    ind.reset()
+    f, e = ind.process(np.zeros((Cn, 8), np.uint8), np.zeros(Cn, np.int32))
+    assert not f.any() and not e.any()
+    with pytest.raises(pkg.TetraDemodError):
+        ind.reset(Cn)
+    ind.close()
+
+
+@pytest.mark.gpu
+def test_gpu_indicator_sees_the_demodulated_downlink(pkg, synth):
+    """End of the chain the plugin runs in NETSYMS mode: synthetic downlink bursts -> demodulator -> indicator: found on the
+    burst channels, not on noise."""
+    import torch
+    Cn, N = 6, 36000
+    iq = np.zeros((Cn, N), np.complex64)
+    for c in range(Cn - 1):
+        iq[c] = synth.gen_channel(N, 100 + c, bits=synth.gen_slot_bits(N // 510 + 2, 100 + c))[0]
+    rng = np.random.default_rng(5)
+    iq[Cn - 1] = (0.3 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+    d = pkg.Demodulator(Cn, N)
+    bits, nb, _ = d.process(iq)
+    ind = pkg.scan_binding.TsIndicator(Cn)
+    found, expire = ind.process(bits, nb)
+    assert found[:Cn - 1].all() and not found[Cn - 1], (found, expire)
+    ind.close()
+    d.close()
