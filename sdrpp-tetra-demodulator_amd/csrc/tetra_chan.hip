@@ -36,9 +36,13 @@ struct ChanParams {
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 __global__ __launch_bounds__(kThreads) void k_channelise(ChanParams p) {
-    extern __shared__ float2 lds[];          // v[M] | b[M]
+    extern __shared__ float2 lds[];          // v[M] | b[N1][N2 + 1]
     float2* v = lds;
-    float2* b = lds + p.M;
+    __shared__ float2 tw1[kMaxFactor], tw2[kMaxFactor];     // the two short twiddle tables: few distinct entries per wave
+    if (threadIdx.x < p.N1) tw1[threadIdx.x] = p.w1[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x - 64 < p.N2) tw2[threadIdx.x - 64] = p.w2[threadIdx.x - 64];
+    float2* b = lds + p.M;                   // rows padded by one element: the row DFTs read b[k1][n2] with k1 across the lanes, and a
+                                             // row stride of N2 = 32 complex (64 dwords) would put every lane on the same LDS banks
     const int M = p.M, L = p.M * p.P;
     const int j = blockIdx.x;
     const int newest = (j + 1) * p.D - 1 - p.ph0;                 // index into the new samples
@@ -67,13 +71,13 @@ __global__ __launch_bounds__(kThreads) void k_channelise(ChanParams p) {
         float2 acc = make_float2(0.f, 0.f);
         int idx = 0;
         for (int n1 = 0; n1 < N1; n1++) {
-            const float2 t = cmul(v[n1 * N2 + n2], p.w1[idx]);
+            const float2 t = cmul(v[n1 * N2 + n2], tw1[idx]);
             acc.x += t.x;
             acc.y += t.y;
             idx += k1;
             if (idx >= N1) idx -= N1;
         }
-        b[o] = cmul(acc, p.wm[(n2 * k1) % M]);
+        b[k1 * (N2 + 1) + n2] = cmul(acc, p.wm[(n2 * k1) % M]);
     }
     __syncthreads();
     // row DFTs: X[k1 + N1*k2] = sum_{n2} b[k1][n2] * W_N2^{n2 k2}
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void k_channelise(ChanParams p) {
         float2 acc = make_float2(0.f, 0.f);
         int idx = 0;
         for (int n2 = 0; n2 < N2; n2++) {
-            const float2 t = cmul(b[k1 * N2 + n2], p.w2[idx]);
+            const float2 t = cmul(b[k1 * (N2 + 1) + n2], tw2[idx]);
             acc.x += t.x;
             acc.y += t.y;
             idx += k2;
@@ -277,7 +281,7 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
         p.w1 = h->d_w1; p.w2 = h->d_w2; p.wm = h->d_wm;
         p.M = h->M; p.P = h->P; p.D = h->D; p.N1 = h->N1; p.N2 = h->N2;
         p.ph0 = h->phase; p.abs0 = h->consumed;
-        hipLaunchKernelGGL(k_channelise, dim3(frames), dim3(kThreads), sizeof(float2) * 2 * (size_t)h->M, s, p);
+        hipLaunchKernelGGL(k_channelise, dim3(frames), dim3(kThreads), sizeof(float2) * ((size_t)h->M + (size_t)h->N1 * (h->N2 + 1)), s, p);
         CH_TRY(h, hipGetLastError());
     }
     CH_TRY(h, hipEventRecord(h->ev[1], s));
