@@ -495,6 +495,47 @@ def test_quality_statistic(pkg, oracle, synth, pipeline):
     d.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_combinations_of_shape_layout_outputs_and_chunking(pkg, oracle, synth, seed):
+    """Seeded random draws over what the other tests vary one at a time: channel count (1..75: ragged last workgroup of
+    either shape), workgroup shape (automatic / 16 / 32 channels), input layout, symbol output, quality statistic, call
+    lengths from 0 to 1500 samples with carried state, a reset of one channel in the middle.  Bits, bit counts and symbols
+    equal the oracle's for every channel after every call."""
+    rng = np.random.default_rng(9000 + seed)
+    B = pkg.binding
+    Cn = int(rng.integers(1, 76))
+    tm = bool(rng.integers(0, 2))
+    shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS]))
+    quality = bool(rng.integers(0, 2))
+    chunks = [int(rng.choice([0, 1, 31, 32, 33, 64, 255, 700, 1500])) for _ in range(6)]
+    N = sum(chunks)
+    iq, _, _ = synth.gen_batch(Cn, max(N, 1), base_seed=500 + 13 * seed)
+    d = pkg.Demodulator(Cn, 1500, layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR,
+                        flags=shape | (B.FLAG_QUALITY if quality else 0))
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    pos = 0
+    for k, n in enumerate(chunks):
+        blk = iq[:, pos:pos + n]
+        want_sym = bool(rng.integers(0, 2))
+        bits, nb, sym = d.process(np.ascontiguousarray(blk.T) if tm else blk, want_sym=want_sym)
+        for c in range(Cn):
+            r = orcs[c].process(blk[c], stages=True)
+            assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (seed, k, c)
+            if want_sym:
+                assert np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])), (seed, k, c)
+        if quality:
+            err, _ = d.quality()
+            for c in range(Cn):
+                assert abs(err[c] - orcs[c].st.standarderr) < 1e-4, (seed, k, c)
+        if k == 2:
+            c = int(rng.integers(0, Cn))
+            d.reset(c)
+            orcs[c].reset()
+        pos += n
+    d.close()
+
+
 def test_errors(pkg):
     B = pkg.binding
     d = pkg.Demodulator(2, 100)
