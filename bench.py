@@ -17,7 +17,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   cpu_baseline  the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the
                 same workload.  The oracle is only the baseline/checker here, never the measured path.
   host_path_*   PCIe-inclusive rates of the host entry points (informational);
-  large_batch   the same call with twice the channels on this GPU (32-channel workgroup shape; informational).
+  large_batch   the same call with twice the channels on this GPU (32-channel workgroup shape; informational);
+  config5       BASELINE config 5 (20 MHz wideband -> channeliser -> 800 channels -> bits; informational; also --config5 alone).
 """
 import argparse
 import json
@@ -181,14 +182,16 @@ def wideband_config5(args, torch, pkg, device, local_rank):
     torch.cuda.synchronize(device)
     el = time.perf_counter() - t0
     k1, _ = dem.kernel_ms_history(1)
-    print(json.dumps({"metric": "wideband IQ Msamples/s channelised and demodulated to bits (BASELINE config 5)",
-                      "value": round(args.steps * n_in / el / 1e6, 2), "unit": "Msamples/s (20 MHz capture)",
-                      "ms_per_step": round(el / args.steps * 1e3, 3), "realtime_factor": round(args.steps * n_in / el / 20e6, 1),
-                      "channeliser_kernel_ms": round(ch.last_kernel_ms(), 3), "demod_kernel_ms": round(float(k1[0]), 3),
-                      "config": {"workload": "5e6 samples @ 20 MHz -> 800 ch x 12500 frames @ 50 ksps -> bits",
-                                 "channels": M, "taps_per_channel": P, "decimation": D}}))
+    res = {"metric": "wideband IQ Msamples/s channelised and demodulated to bits (BASELINE config 5)",
+           "value": round(args.steps * n_in / el / 1e6, 2), "unit": "Msamples/s (20 MHz capture)",
+           "ms_per_step": round(el / args.steps * 1e3, 3), "realtime_factor": round(args.steps * n_in / el / 20e6, 1),
+           "channeliser_kernel_ms": round(ch.last_kernel_ms(), 3), "demod_kernel_ms": round(float(k1[0]), 3),
+           "config": {"workload": "5e6 samples @ 20 MHz -> 800 ch x 12500 frames @ 50 ksps -> bits",
+                      "channels": M, "taps_per_channel": P, "decimation": D}}
     ch.close()
     dem.close()
+    del x, out, bits, nbits
+    return res
 
 
 def main():
@@ -207,6 +210,8 @@ def main():
                     help="skip the PCIe-inclusive host-path legs (tetra_demod_process / tetra_demod_process_async on page-locked "
                          "buffers; informational fields host_path_*, never the metric value)")
     ap.add_argument("--host-path", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the informational BASELINE config 5 leg (wideband -> channeliser -> 800-channel demod, field config5)")
     ap.add_argument("--no-large-batch", action="store_true",
                     help="skip the informational leg with twice the channels per GPU (32-channel workgroup shape, field large_batch)")
     ap.add_argument("--chain", action="store_true",
@@ -236,7 +241,7 @@ def main():
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     if args.config5:
-        wideband_config5(args, torch, pkg, device, local_rank)
+        print(json.dumps(wideband_config5(args, torch, pkg, device, local_rank)))
         return
     C, N = args.channels, args.samples
     # rank r demodulates global channels [r*C, (r+1)*C) of a (world*C)-channel bank: independent channels,
@@ -418,13 +423,18 @@ def main():
         out.update(host)
         if large is not None:
             out["large_batch"] = large
+        if not args.no_config5 and world == 1 and C == CHANNELS_PER_GPU:
+            dem.close()
+            dem = None
+            out["config5"] = wideband_config5(args, torch, pkg, device, local_rank)      # informational, after the timed region
         if dist is not None:
             out["rccl_world_size"] = dist.get_world_size() if args.backend == "nccl" else None
             out["dist_backend"] = args.backend
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_baseline_fast"] = cpu_baseline(pkg.synth, N)
         if args.chain and world == 1:
-            dem.close()
+            if dem is not None:
+                dem.close()
             dem = None
             import subprocess
             chain = {}
