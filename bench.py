@@ -375,7 +375,8 @@ def main():
         ms2 = ev0.elapsed_time(ev1) / reps
         same = bool(torch.equal(nb2[:C], nb2[C:]) and torch.equal(bits2[:C], bits2[C:]))      # both halves saw the same input
         large = {"channels": 2 * C, "ms_per_step": round(ms2, 4), "msamples_s": round(2.0 * C * N / ms2 / 1e3, 1),
-                 "halves_identical": same,
+                 "halves_identical": same, "traffic": pmc_traffic("fused", 2 * C, N)[0],
+                 "cycles_per_sample": round(ms2 * 1e-3 * pkg.binding.device_info(local_rank)[0] * 1e3 / N, 1),
                  "note": "informational: %d channels x %d samples on this GPU in one call (32-channel workgroups)" % (2 * C, N)}
         dem2.close()
         del iq2, bits2, nb2
