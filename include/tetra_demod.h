@@ -48,8 +48,9 @@ enum {
     TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
     TETRA_FLAG_WIDE_WORKGROUPS = 16,   /* force 32-channel workgroups / ... */
     TETRA_FLAG_NARROW_WORKGROUPS = 32, /* ... or 16-channel ones.  Default: chosen from the channel count (16 while every CU has at
-                                    most one workgroup, 32 beyond -- 8192 channels then take 1.3x the 4096-channel time instead
-                                    of 2x: DESIGN.md section 5).  Results are identical bit for bit.  Band-edge filters of more
+                                    most one workgroup; beyond, whole rounds of 32-channel workgroups and the rest in whichever
+                                    shape is through first -- 8192 channels take 1.3x the 4096-channel time instead of 2x:
+                                    DESIGN.md section 5).  Results are identical bit for bit.  Band-edge filters of more
                                     than 68 taps (rrc_tap_count 69..72) always run in 16-channel workgroups. */
     TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
                                     the dsp::block sets it):

@@ -86,6 +86,7 @@ struct FusedParams {
     const float2* iq;
     long long in_ch_stride, in_t_stride;
     int n, n_channels;
+    int ch_base;         // first channel of this launch (a call may be cut into a 32-channel-workgroup launch and a 16-channel one)
     // state
     float *agc_g, *fll_ph, *fll_fr;
     float2* hist;        // [C][kHist]
@@ -199,7 +200,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int ch0 = blockIdx.x * CH;
+    const int ch0 = p.ch_base + blockIdx.x * CH;
     const int n = p.n;
     const int ntiles = (n + kFT - 1) / kFT;
     long long busy_ = 0;

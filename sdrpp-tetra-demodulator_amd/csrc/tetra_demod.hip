@@ -150,7 +150,7 @@ struct tetra_demod {
     float2* hist = nullptr;
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
-    bool wide = false;          // k_fused with 32-channel workgroups
+    int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
@@ -449,18 +449,22 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     h->quirks = (cfg->flags & TETRA_FLAG_REFERENCE_QUIRKS) != 0;
     h->keep_y = (cfg->flags & TETRA_FLAG_KEEP_RRC_OUT) != 0;
     {
-        // Workgroup shape.  16 channels per workgroup is the fastest way through ONE workgroup (kWg16 clocks per sample) and
-        // right while there is at most one per CU; the 32-channel workgroup (four FLL waves, one per SIMD, the other roles'
-        // instruction streams shared by twice the channels; kWg32 clocks per sample) is a few per cent better when the
-        // channel count fills whole rounds of it.  Rounds of workgroups per CU x clocks per round decides; the flags force
-        // either shape.
+        // Workgroup shapes.  16 channels per workgroup is the fastest way through ONE workgroup (kWg16 clocks per sample) and
+        // right while there is at most one per CU; the 32-channel workgroup (FLL rows of 4 lanes per channel: the loop code
+        // of an FLL wave serves twice the channels; kWg32 clocks per sample) gets a CU through 32 channels in 1.3x that time.
+        // Plan: whole rounds of 32-channel workgroups, then the rest in whichever shape is through first (rounds of
+        // workgroups per CU x clocks per round) -- at most two launches per call; the flags force one shape for everything.
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         cus = cus > 0 ? cus : 256;
-        const long long r16 = ((h->C + kFCh - 1) / kFCh + cus - 1) / cus, r32 = ((h->C + kFChWide - 1) / kFChWide + cus - 1) / cus;
-        h->wide = r32 * kWg32ClocksPerSample < r16 * kWg16ClocksPerSample;
-        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) h->wide = true;
-        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) h->wide = false;
+        // whole rounds of 32-channel workgroups first; what is left takes whichever shape gets it through in less time
+        const long long per_round32 = (long long)kFChWide * cus;
+        const long long full = (h->C / per_round32) * per_round32, rest = h->C - full;
+        const long long r16 = ((rest + kFCh - 1) / kFCh + cus - 1) / cus, r32 = ((rest + kFChWide - 1) / kFChWide + cus - 1) / cus;
+        const bool rest_wide = rest > 0 && r32 * kWg32ClocksPerSample < r16 * kWg16ClocksPerSample;
+        h->n_wide = (int)(rest_wide ? h->C : full);
+        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) h->n_wide = h->C;
+        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) h->n_wide = 0;
     }
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
@@ -519,7 +523,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.iq = reinterpret_cast<const float2*>(d_iq);
         if (h->cfg.layout == TETRA_LAYOUT_CHANNEL_MAJOR) { pf.in_ch_stride = n_samples; pf.in_t_stride = 1; }
         else { pf.in_ch_stride = 1; pf.in_t_stride = h->C; }
-        pf.n = n_samples; pf.n_channels = h->C;
+        pf.n = n_samples; pf.n_channels = h->C; pf.ch_base = 0;
         pf.agc_g = h->agc_g; pf.fll_ph = h->fll_ph; pf.fll_fr = h->fll_fr; pf.hist = h->hist;
         pf.rrc_valid = h->rrc_valid;
         pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
@@ -532,15 +536,16 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
         pf.prof = nullptr;
-        // 32 channels per workgroup: more than 16 channels per CU (see tetra_demod_create); its FLL rows hold 4 x 17 taps
-        const bool wide = h->wide && h->design.ntaps_be <= kF4Pad;
-        const dim3 gf(wide ? (h->C + kFChWide - 1) / kFChWide : (h->C + kFCh - 1) / kFCh);
+        // channels [0, n_wide) in 32-channel workgroups (see tetra_demod_create; their FLL rows hold 4 x 17 taps), the rest in
+        // 16-channel ones: at most two launches, back to back on the stream
+        const int n_wide = h->design.ntaps_be <= kF4Pad ? h->n_wide : 0;
+        const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh);
         const bool a0 = pf.k1.fll_alpha == 0.0f;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
         const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
-        if (prof_path && !wide) {
+        if (prof_path && n_wide == 0) {
             const size_t nwg = (size_t)gf.x;
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
@@ -553,12 +558,19 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         else if (pf.prof) hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
         else
 #endif
-        if (wide) {
-            const dim3 tw(fused_threads(kFChWide));
-            if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gf, tw, 0, s, pf);
-            else hipLaunchKernelGGL((k_fused<false, false, kFChWide>), gf, tw, 0, s, pf);
-        } else if (a0) hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
-        else hipLaunchKernelGGL((k_fused<false>), gf, dim3(kFThreads), 0, s, pf);
+        {
+            if (n_wide > 0) {
+                const dim3 tw(fused_threads(kFChWide));
+                pf.ch_base = 0;
+                if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gw, tw, 0, s, pf);
+                else hipLaunchKernelGGL((k_fused<false, false, kFChWide>), gw, tw, 0, s, pf);
+            }
+            if (n_wide < h->C) {
+                pf.ch_base = n_wide;
+                if (a0) hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
+                else hipLaunchKernelGGL((k_fused<false>), gf, dim3(kFThreads), 0, s, pf);
+            }
+        }
         if (h->q_ring)
             hipLaunchKernelGGL(k_quality, dim3((h->C + 3) / 4), dim3(256), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->C, h->q_ring,
                                h->q_ptr, h->q_disp, h->q_err, h->q_sync);

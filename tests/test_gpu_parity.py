@@ -379,10 +379,12 @@ def test_reference_quirks_flag(pkg, oracle, synth):
     d2.close()
 
 
-def test_parity_8192_channels_two_workgroup_rounds(pkg, oracle, synth):
-    """More workgroups than CUs (512 > 256: every CU runs two workgroups one after the other) and a channel count that is
-    not a multiple of 16 on top (8192 + 5): every output bit of two consecutive calls equals the oracle's."""
-    Cb, Cn, N = 128, 8197, 3000
+@pytest.mark.parametrize("Cn", [8197, 6101])
+def test_parity_8192_channels_two_workgroup_rounds(pkg, oracle, synth, Cn):
+    """More than one 16-channel workgroup per CU, through the library's own plan: 8192 + 5 channels = a full round of
+    32-channel workgroups plus a second launch of 16-channel ones for the (ragged) rest; 6101 channels = one round of
+    32-channel workgroups with a ragged last one.  Every output bit of two consecutive calls equals the oracle's."""
+    Cb, N = 128, 3000
     base, _, _ = synth.gen_batch(Cb, 2 * N, base_seed=778)
     rng = np.random.default_rng(6)
     amp = rng.uniform(0.1, 2.0, (Cn, 1)).astype(np.float32)
