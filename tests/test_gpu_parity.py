@@ -578,6 +578,36 @@ def test_soak_twelve_seconds_of_signal_with_carried_state(pkg, oracle, synth):
     assert total > Cn * SEC * 35000
 
 
+@pytest.mark.gpu
+def test_async_host_path_with_the_two_launch_plan(pkg, oracle, synth):
+    """8192 + 37 channels (a round of 32-channel workgroups + a launch of 16-channel ones per time chunk) through
+    tetra_demod_process_async, two calls: the bits equal the synchronous path's and the oracle's."""
+    import torch
+    B = pkg.binding
+    Cb, Cn, N = 64, 8229, 2500
+    base, _, _ = synth.gen_batch(Cb, 2 * N, base_seed=991)
+    iq = np.ascontiguousarray(base[np.arange(Cn) % Cb])
+    d = pkg.Demodulator(Cn, N)
+    ds = pkg.Demodulator(Cn, N)
+    states = None
+    for k in range(2):
+        blk = np.ascontiguousarray(iq[:, k * N:(k + 1) * N])
+        host_in = _pinned(torch, blk)
+        stride = B.bits_stride(N)
+        bits = torch.zeros((Cn, stride), dtype=torch.uint8).pin_memory()
+        nb = torch.zeros((Cn,), dtype=torch.int32).pin_memory()
+        d.process_async(host_in.data_ptr(), B.IQ_CF32, N, bits.data_ptr(), stride, nb.data_ptr())
+        d.wait()
+        sb, snb, _ = ds.process(blk)
+        rb, rnb, _, states = oracle.process_batch(blk, states=states)
+        assert np.array_equal(nb.numpy(), snb) and np.array_equal(snb, rnb), k
+        bad = [c for c in range(Cn) if not (np.array_equal(bits.numpy()[c][:snb[c]], sb[c][:snb[c]]) and
+                                           np.array_equal(sb[c][:snb[c]], rb[c][:snb[c]]))]
+        assert not bad, (k, bad[:10])
+    d.close()
+    ds.close()
+
+
 def _pinned(torch, arr):
     t = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
     return t
