@@ -49,15 +49,18 @@ def test_oracle_equals_reference_code_outputs(vec, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_equals_reference_code_outputs(vec, pkg):
-    """The HIP kernel through the C ABI against the reference code's outputs, no oracle in between."""
+@pytest.mark.parametrize("shape", ["narrow", "wide"])
+def test_gpu_equals_reference_code_outputs(vec, pkg, shape):
+    """The HIP kernel through the C ABI against the reference code's outputs, no oracle in between; both workgroup shapes
+    (FLL rows of 8 and of 4 lanes per channel)."""
     B = pkg.binding
-    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS)
+    shape_flag = B.FLAG_WIDE_WORKGROUPS if shape == "wide" else B.FLAG_NARROW_WORKGROUPS
+    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag)
     bits, nb, sym = d.process(vec["probe_iq"][None, :], want_sym=True)
     _close(sym[0][:nb[0] // 2], vec["probe_sym"], bits[0][:nb[0]], vec["probe_bits"], "probe")
     d.reset()
     d.close()
-    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS)
+    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag)
     iq = vec["chunked_iq"]
     out_s, out_b = [], []
     for i in range(0, len(iq), 180):
@@ -66,7 +69,7 @@ def test_gpu_equals_reference_code_outputs(vec, pkg):
         out_b.append(bits[0][:nb[0]].copy())
     _close(np.concatenate(out_s), vec["chunked_sym"], np.concatenate(out_b), vec["chunked_bits"], "180-sample calls")
     d.close()
-    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS)
+    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag)
     iq, cuts = vec["ctl_iq"], vec["ctl_cuts"]
     names = {v: k for k, v in B.PARAMS.items()}
     for k in range(3):
