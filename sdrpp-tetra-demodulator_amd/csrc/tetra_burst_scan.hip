@@ -289,8 +289,9 @@ struct IndDeviceGuard {
 }  // namespace
 
 int tetra_ts_indicator_create(int n_channels, int device, tetra_ts_indicator_t** out) {
-    if (!out || n_channels < 1) return TETRA_ERR_ARG;
+    if (!out) return TETRA_ERR_ARG;
     *out = nullptr;
+    if (n_channels < 1) return TETRA_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TETRA_ERR_NO_DEVICE;
     if (device < 0 && hipGetDevice(&device) != hipSuccess) return TETRA_ERR_NO_DEVICE;

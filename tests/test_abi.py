@@ -169,6 +169,12 @@ int main(void) {
     if (tetra_burst_demux_compact_device(NULL, NULL, 4, TETRA_TPSAP_T_SB1, 1, NULL, 120, NULL, NULL, NULL) != TETRA_ERR_ARG) return 8;
     if (tetra_lmac_decode_counted_device(7, NULL, 4, NULL, 120, NULL, NULL, NULL, 80, NULL, NULL) != TETRA_ERR_ARG) return 9;
     { int clk = 0, cus = 0; const int rc = tetra_demod_device_info(12345, &clk, &cus); if (rc != TETRA_ERR_NO_DEVICE) return 10; }
+    { tetra_ts_indicator_t* ind = (tetra_ts_indicator_t*)&cfg;
+      if (tetra_ts_indicator_create(0, -1, &ind) != TETRA_ERR_ARG || ind != NULL) return 11;
+      if (tetra_ts_indicator_create(4, -1, NULL) != TETRA_ERR_ARG) return 12;
+      if (tetra_ts_indicator_reset(NULL, -1) != TETRA_ERR_ARG) return 13;
+      if (tetra_ts_indicator_process_device(NULL, NULL, 64, NULL, NULL, NULL, NULL) != TETRA_ERR_ARG) return 14;
+      tetra_ts_indicator_destroy(NULL); }
     tetra_demod_host_free(NULL);
     printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
     return 0;
