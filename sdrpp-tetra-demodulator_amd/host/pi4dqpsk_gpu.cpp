@@ -96,6 +96,7 @@ int PI4DQPSKBank::process(int count, const complex_t* in, uint8_t* bits, int32_t
 }
 int PI4DQPSKBank::reset(int channel) { return h_ ? tetra_demod_reset(h_, channel) : TETRA_ERR_ARG; }
 int PI4DQPSKBank::setParam(int id, double v) { return h_ ? tetra_demod_set_param(h_, id, v) : TETRA_ERR_ARG; }
+int PI4DQPSKBank::quality(float* standarderr, uint8_t* sync) { return h_ ? tetra_demod_get_quality(h_, standarderr, sync) : TETRA_ERR_ARG; }
 
 PI4DQPSKMultiBank::~PI4DQPSKMultiBank() { shutdown(); }
 

@@ -100,6 +100,9 @@ public:
     int bitsStride(int count) const { return tetra_demod_bits_stride(count); }
     int reset(int channel = -1);
     int setParam(int paramId, double value);
+    // DQPSKSymbolExtractor's public standarderr / sync (src/dsp/dqpsk_sym_extr.h:36-37) for every channel; needs
+    // TETRA_FLAG_QUALITY in cfg.flags (TETRA_ERR_UNSUPPORTED otherwise).  Either pointer may be null.
+    int quality(float* standarderr, uint8_t* sync);
     int channels() const { return channels_; }
     tetra_demod_t* handle() { return h_; }
 
@@ -128,6 +131,9 @@ public:
     int bitsStride(int count) const { return tetra_demod_bits_stride(count); }
     int reset();
     int setParam(int paramId, double value);
+    // DQPSKSymbolExtractor's public standarderr / sync (src/dsp/dqpsk_sym_extr.h:36-37) for every channel; needs
+    // TETRA_FLAG_QUALITY in cfg.flags (TETRA_ERR_UNSUPPORTED otherwise).  Either pointer may be null.
+    int quality(float* standarderr, uint8_t* sync);
     int channels() const { return channels_; }
     int shards() const { return (int)shards_.size(); }
     // channel range [first, first + count) and device of a shard

@@ -158,6 +158,22 @@ int gpu_paths() {
         for (int c = 0; c < 19; c++) CHECK(nb[c] >= 0 && nb[c] <= stride);
     }
     CHECK(bank.process(1001, nullptr, nullptr, nullptr) != TETRA_OK);
+    { std::vector<float> err(19); std::vector<uint8_t> sy(19); CHECK(bank.quality(err.data(), sy.data()) == TETRA_ERR_UNSUPPORTED); }
+    {
+        dsp::demod::PI4DQPSKBank qb;
+        tetra_demod_config_t qc = cfg;
+        qc.n_channels = 3; qc.max_samples = 2000; qc.flags |= TETRA_FLAG_QUALITY;
+        CHECK(qb.init(qc) == TETRA_OK);
+        std::vector<dsp::complex_t> iq((size_t)3 * 2000, dsp::complex_t{ 0.1f, -0.2f });
+        const int stride = qb.bitsStride(2000);
+        std::vector<uint8_t> bits((size_t)3 * stride);
+        std::vector<int32_t> nb(3);
+        CHECK(qb.process(2000, iq.data(), bits.data(), nb.data()) == TETRA_OK);
+        std::vector<float> err(3, -1.f);
+        std::vector<uint8_t> sy(3, 9);
+        CHECK(qb.quality(err.data(), sy.data()) == TETRA_OK);
+        for (int c = 0; c < 3; c++) CHECK(err[c] >= 0.f && err[c] < 1.f && sy[c] <= 1);
+    }
     // two shards on one device: two worker threads, two handles, exactly-sized pageable rows
     dsp::demod::PI4DQPSKMultiBank mb;
     cfg.n_channels = 9; cfg.max_samples = 6000;
