@@ -43,8 +43,13 @@ class Shape:
     interleaved, so a hop between neighbouring positions is a shift by 16/lanes lanes.  The schedule's period is taps - 1
     steps (the residents of a position), which must divide the tile."""
 
-    def __init__(self, lanes, taps, out, prefix, what):
+    def __init__(self, lanes, taps, out, prefix, what, fold_c12=False):
         self.lanes, self.taps, self.out, self.prefix, self.what = lanes, taps, os.path.join(HERE, out), prefix, what
+        # the first two Cody-Waite steps as ONE fma with C1 + C2 (the operand %[negc1] then carries -(C1 + C2)): C1 + C2 is a
+        # binary32 number, k is -1, 0 or 1 and x - k*C1 is exact (Sterbenz) for every |x| <= pi, so fma(-k, C1 + C2, x) is
+        # fma(-k, C2, fma(-k, C1, x)) bit for bit -- checked over all 2 157 060 024 floats of [-pi, pi] in tests/test_oracle.py.
+        # Off for both shipped geometries: one slot less changed neither launch time (profiles/r02/r02_l, r02_q).
+        self.fold_c12 = fold_c12
         self.hop = 16 // lanes
         self.nres = taps - 1
         assert TILE % self.nres == 0 and self.nres % 2 == 0
@@ -298,7 +303,8 @@ def real_step(E, s):
     E.ins("v_rndne_f32 v%d, v%d" % (R_K, R_K), "valu", [R_K], [R_K])
     E.ins("v_fma_f32 v%d, |v%d|, -2.0, 1.0" % (R_SGN, R_K), "valu", [R_SGN], [R_K])                                     # (-1)^k for |k| <= 1
     E.ins("v_fma_f32 v%d, v%d, %%[negc1], -v%d" % (R_R, R_K, R_PH), "valu", [R_R], [R_K, R_PH])
-    E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C2N), R_K), "valu", [R_R], [R_R, R_K])
+    if not G.fold_c12:
+        E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C2N), R_K), "valu", [R_R], [R_R, R_K])
     E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C3N), R_K), "valu", [R_R], [R_R, R_K])
     E.ins("v_mul_f32 v%d, v%d, v%d" % (R_Z, R_R, R_R), "valu", [R_Z], [R_R])
     if s & 1 == 0:

@@ -190,3 +190,43 @@ def test_fast_port_decides_like_the_oracle(oracle, synth):
         lag, err, n = synth.align_and_count_errors(b1[c][:n1[c]], txb[c], skip=h)
         assert err == 0 and n > 11000
         assert abs(st0[c].agc_gain - st1[c].agc_gain) < 1e-3 * st0[c].agc_gain and st0[c].offset == st1[c].offset
+
+
+def test_folded_cody_waite_step_is_exact_for_every_phase(tmp_path):
+    """The generator's fold_c12 option (gen_fll_asm.py; measured, not shipped: one slot less moved neither launch time) reduces the
+    NCO phase with fma(-k, C1 + C2, x) instead of the oracle's fma(-k, C2, fma(-k, C1, x)).  C1 + C2 is a binary32 number, k = rint(x / pi) is -1, 0 or 1 for |x| <= pi and x - k*C1 is
+    then exact, so the two are the same rounding of the same real number -- and here every binary32 value of [-pi, pi]
+    (2 157 060 024 of them, both signs) is run through both forms."""
+    import subprocess
+    src = tmp_path / "fold.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    const float C1 = 3.140625f, C2 = 9.67502593994140625e-4f, C12 = 3.141592502593994140625f, pi = 3.1415926535f;
+    uint32_t hi;
+    memcpy(&hi, &pi, 4);
+    long long bad = 0, n = 0;
+    if ((double)C12 != (double)C1 + (double)C2) { puts("C1 + C2 is not representable"); return 1; }
+#pragma omp parallel for reduction(+ : bad, n) schedule(static)
+    for (long long u = 0; u <= (long long)hi; u++) {
+        for (int sgn = 0; sgn < 2; sgn++) {
+            const uint32_t b = (uint32_t)u | (sgn ? 0x80000000u : 0u);
+            float x;
+            memcpy(&x, &b, 4);
+            const float nk = -rintf(x * 0.318309886183790672f);
+            const float two = fmaf(nk, C2, fmaf(nk, C1, x)), one = fmaf(nk, C12, x);
+            n++;
+            if (memcmp(&two, &one, 4)) bad++;
+        }
+    }
+    printf("%lld %lld\n", n, bad);
+    return 0;
+}
+''')
+    exe = tmp_path / "fold"
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", str(src), "-o", str(exe), "-lm"], check=True)
+    n, bad = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(n) == 2 * 1078530012 and int(bad) == 0
