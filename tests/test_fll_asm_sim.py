@@ -21,7 +21,7 @@ def _u32(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None):
+def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65):
     lines, consts = gcn_sim.parse_block(os.path.join(CSRC, fname), macro)
     if mutate:
         lines = mutate(lines)
@@ -35,8 +35,10 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None):
     iq = np.stack([synth.gen_channel(N, 900 + c, cfo=0.04 * ((c % 5) - 2))[0] for c in range(nch)]).astype(np.complex64)
     ocfg = oracle.default_cfg()
     ocfg.agc_rate = 0.0
+    ocfg.rrc_tap_count = ntaps
     ecfg = emul.default_cfg()
     ecfg.agc_rate = 0.0
+    ecfg.rrc_tap_count = ntaps
     tab = emul.design(ecfg)
     want_x, want_state = [], []
     for c in range(nch):
@@ -106,6 +108,13 @@ GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4
 @pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
 def test_generated_fll_assembly_executes_to_the_oracle_s_samples(oracle, emul, synth, fname, macro, lanes, taps):
     assert _run(oracle, emul, synth, fname, macro, lanes, taps) == []
+
+
+@pytest.mark.parametrize("fname,macro,lanes,taps,ntaps", [GEOMETRIES[0] + (2,), GEOMETRIES[0] + (33,), GEOMETRIES[0] + (72,),
+                                                          GEOMETRIES[1] + (2,), GEOMETRIES[1] + (33,), GEOMETRIES[1] + (68,)])
+def test_generated_fll_assembly_other_tap_counts(oracle, emul, synth, fname, macro, lanes, taps, ntaps):
+    """Band-edge filters shorter than the row (zero-padded at the old end) and as long as the row holds."""
+    assert _run(oracle, emul, synth, fname, macro, lanes, taps, ntaps=ntaps) == []
 
 
 @pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
