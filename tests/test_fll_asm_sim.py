@@ -21,7 +21,7 @@ def _u32(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65):
+def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, warm=0):
     lines, consts = gcn_sim.parse_block(os.path.join(CSRC, fname), macro)
     if mutate:
         lines = mutate(lines)
@@ -32,7 +32,10 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65):
     ntiles = 6
     N = ntiles * TILE
     # input: TETRA channels with carrier offsets, so that the loop moves; AGC neutral
-    iq = np.stack([synth.gen_channel(N, 900 + c, cfo=0.04 * ((c % 5) - 2))[0] for c in range(nch)]).astype(np.complex64)
+    # (warm > 0: the call under test is the SECOND one -- the delay line in the ring and the loop state come from a first
+    # call of `warm` samples through the oracle, so the block's replay rebuilds its in-flight sums from real history)
+    iq_all = np.stack([synth.gen_channel(warm + N, 900 + c, cfo=0.04 * ((c % 5) - 2))[0] for c in range(nch)]).astype(np.complex64)
+    iq = np.ascontiguousarray(iq_all[:, warm:])
     ocfg = oracle.default_cfg()
     ocfg.agc_rate = 0.0
     ocfg.rrc_tap_count = ntaps
@@ -40,9 +43,13 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65):
     ecfg.agc_rate = 0.0
     ecfg.rrc_tap_count = ntaps
     tab = emul.design(ecfg)
-    want_x, want_state = [], []
+    want_x, want_state, hist, start = [], [], [], []
     for c in range(nch):
         o = oracle.Oracle(ocfg)
+        if warm:
+            r0 = o.process(iq_all[c, :warm], stages=True)
+            hist.append(r0["x"][-KHIST:])
+            start.append((o.st.fll_phase, o.st.fll_freq))
         r = o.process(iq[c], stages=True)
         want_x.append(r["x"])
         want_state.append((o.st.fll_phase, o.st.fll_freq))
@@ -67,12 +74,18 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65):
         lds[base:base + nch * TILE * 8] = blk.view(np.uint8).reshape(-1)
 
     put_tile(0)
+    if warm:
+        assert warm >= KHIST
+        for c in range(nch):          # the last 80 outputs of the first call sit at the end of the ring (kernel_fused.hpp prologue)
+            a = off_x + c * row + (KFXP + KFX - KHIST) * 8
+            lds[a:a + KHIST * 8] = np.ascontiguousarray(hist[c]).view(np.uint8)
     lane = np.arange(64)
     pos = (lane & 15) // hop
     ch = (lane >> 4) * hop + lane % hop
     tap_off = 72 - lanes * taps
     vec = {
-        "ph": np.zeros(64, np.uint32), "fr": np.zeros(64, np.uint32),
+        "ph": np.array([np.float32(start[c][0]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
+        "fr": np.array([np.float32(start[c][1]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
         "a_addr": (off_a + ch * TILE * 8).astype(np.uint32),
         "x_rowlane": (off_x + ch * row + KFXP * 8 - 8 * pos).astype(np.uint32),
         "tap_addr": (off_be + 4 * (tap_off + taps * (lanes - 1 - pos))).astype(np.uint32),
@@ -108,6 +121,11 @@ GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4
 @pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
 def test_generated_fll_assembly_executes_to_the_oracle_s_samples(oracle, emul, synth, fname, macro, lanes, taps):
     assert _run(oracle, emul, synth, fname, macro, lanes, taps) == []
+
+
+@pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
+def test_generated_fll_assembly_second_call_replays_the_delay_line(oracle, emul, synth, fname, macro, lanes, taps):
+    assert _run(oracle, emul, synth, fname, macro, lanes, taps, warm=150) == []
 
 
 @pytest.mark.parametrize("fname,macro,lanes,taps,ntaps", [GEOMETRIES[0] + (2,), GEOMETRIES[0] + (33,), GEOMETRIES[0] + (72,),
