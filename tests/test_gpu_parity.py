@@ -550,13 +550,14 @@ def test_errors(pkg):
 
 
 @pytest.mark.gpu
-def test_soak_twelve_seconds_of_signal_with_carried_state(pkg, oracle, synth):
-    """64 channels, twelve consecutive one-second calls (432 000 samples per channel, ~221 000 symbols) with the loop state
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_soak_twelve_seconds_of_signal_with_carried_state(pkg, oracle, synth, pipeline):
+    """(Both workgroup shapes.)  64 channels, twelve consecutive one-second calls (432 000 samples per channel, ~221 000 symbols) with the loop state
     carried on the device: every call's bits and bit counts equal the oracle's, and the state read back at the end equals
     the oracle's state -- nothing drifts between the two over long runs."""
     Cn, N, SEC = 64, 36000, 12
     iq = np.concatenate([synth.gen_batch(Cn, N, base_seed=5000 + 17 * s)[0] for s in range(SEC)], axis=1)
-    d = pkg.Demodulator(Cn, N)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
     states = None
     total = 0
     for s in range(SEC):
