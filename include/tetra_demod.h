@@ -229,7 +229,8 @@ int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
  * dqpsk_sym_extr.cpp:8-31, read by the GUI at src/main.cpp:211,215) for every channel: the mean angular distance of
  * the last 4096 symbols from their ideal constellation points, refreshed every 256 symbols, and sync = that < 0.35.
  * standarderr[n_channels] / sync[n_channels] host arrays (either may be NULL).  A GUI float, not on the bit path: held
- * to a tolerance (1e-4) against the reference formula rather than bit equality.  Needs TETRA_FLAG_QUALITY
+ * to a tolerance (2e-6) rather than bit equality: the ring is summed in the reference's order and precision (float, index
+ * order); the distance itself is pi/4 - atan(min/max) by a polynomial instead of two libm atan2f.  Needs TETRA_FLAG_QUALITY
  * (TETRA_ERR_UNSUPPORTED otherwise).  Only the value at the last 256-symbol boundary of a call is observable, so it is
  * computed by a small kernel after the chain's launch from the symbols the chain wrote (kept in a scratch buffer of
  * n_channels x max_samples/2 complex64 when the caller does not ask for them); costs ~2.5 % of a call's time when

@@ -93,37 +93,50 @@ __global__ void k_append_bits(const uint8_t* __restrict__ chunk, int chunk_strid
     __syncthreads();
     if (threadIdx.x == 0) out_n[c] = at + n;
 }
-// TETRA_FLAG_QUALITY: DQPSKSymbolExtractor's statistic (dqpsk_sym_extr.cpp:8-31) brought up to date after a launch, one wave
-// per channel.  The reference pushes one angular distance per symbol into a 4096-entry ring and publishes the ring's mean
-// every 256 symbols; only the value at the LAST such boundary of a call can be observed, so the wave sums the ring as it
-// stood at that boundary (new distances where they had replaced old ones, old ring entries elsewhere; double accumulation),
-// then stores the call's last 4096 distances into the ring and advances the two counters.
-__global__ __launch_bounds__(256) void k_quality(const float2* __restrict__ sym, long long sym_stride, const int* __restrict__ n_bits,
-                                                 int n_channels, float* __restrict__ ring, int* __restrict__ q_ptr,
-                                                 int* __restrict__ q_disp, float* __restrict__ q_err, int* __restrict__ q_sync) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const bool live = c < n_channels;
-    const float2* z = sym + (long long)(live ? c : 0) * sym_stride;
-    float* r = ring + (long long)(live ? c : 0) * 4096;
-    const int n = live ? n_bits[c] / 2 : 0, ptr0 = live ? q_ptr[c] : 0, disp0 = live ? q_disp[c] : 0;
+// TETRA_FLAG_QUALITY: DQPSKSymbolExtractor's statistic (dqpsk_sym_extr.cpp:8-31) brought up to date after a launch, one
+// 64-lane workgroup per channel.  The reference pushes one angular distance per symbol into a 4096-entry ring and, every 256
+// symbols, publishes the ring's mean -- summed in float, in ring-index order (:19-23).  Only the value at the LAST such
+// boundary of a call can be observed, so the workgroup rebuilds the ring as it stood at that boundary in LDS (old entries,
+// overwritten by this call's distances up to the boundary), one lane adds it up in exactly the reference's order, then the
+// image and the few symbols behind the boundary go to the ring in memory and the two counters advance.
+__global__ __launch_bounds__(64) void k_quality(const float2* __restrict__ sym, long long sym_stride, const int* __restrict__ n_bits,
+                                                float* __restrict__ ring, int* __restrict__ q_ptr, int* __restrict__ q_disp,
+                                                float* __restrict__ q_err, int* __restrict__ q_sync) {
+    __shared__ __attribute__((aligned(16))) float img[4096];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float2* z = sym + (long long)c * sym_stride;
+    float* r = ring + (long long)c * 4096;
+    const int n = n_bits[c] / 2, ptr0 = q_ptr[c], disp0 = q_disp[c];
     const int total = disp0 + n;
     const int b = total >= 256 ? n - (total & 255) : 0;     // symbols of this call consumed at the last boundary (0 = none)
-    double acc = 0.0;
     if (b > 0) {
-        for (int j = (b > 4096 ? b - 4096 : 0) + lane; j < b; j += 64) acc += (double)tdm::quality_distance(z[j].x, z[j].y);
-        for (int j = b + lane; j < 4096; j += 64) acc += (double)r[(ptr0 + j) & 4095];
-        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        if (b < 4096)                                       // entries this call has not reached by then keep their old value
+            for (int i = lane; i < 4096; i += 64) img[i] = r[i];
+        __syncthreads();
+        for (int j = (b > 4096 ? b - 4096 : 0) + lane; j < b; j += 64) img[(ptr0 + j) & 4095] = tdm::quality_distance(z[j].x, z[j].y);
+        __syncthreads();
+        if (lane == 0) {
+            float xerr = 0.0f;                              // dqpsk_sym_extr.cpp:20-23: float accumulator, index order
+            const float4* q = reinterpret_cast<const float4*>(img);
+            for (int i0 = 0; i0 < 1024; i0 += 16) {        // sixteen LDS loads in flight, then their 64 adds in order
+                float4 v[16];
+                _Pragma("unroll")
+                for (int k = 0; k < 16; k++) v[k] = q[i0 + k];
+                _Pragma("unroll")
+                for (int k = 0; k < 16; k++) { xerr += v[k].x; xerr += v[k].y; xerr += v[k].z; xerr += v[k].w; }
+            }
+            xerr = xerr / 4096.0f;
+            q_err[c] = xerr;
+            q_sync[c] = xerr >= 0.35f ? 0 : 1;
+        }
+        for (int i = lane; i < 4096; i += 64) r[i] = img[i];        // the ring at the boundary ...
+        __syncthreads();
     }
-    __syncthreads();                                        // old ring entries are read before any is replaced
-    for (int j = (n > 4096 ? n - 4096 : 0) + lane; j < n; j += 64) r[(ptr0 + j) & 4095] = tdm::quality_distance(z[j].x, z[j].y);
-    if (live && lane == 0) {
+    // ... and the (fewer than 256) symbols behind it
+    for (int j = b + lane; j < n; j += 64) r[(ptr0 + j) & 4095] = tdm::quality_distance(z[j].x, z[j].y);
+    if (lane == 0) {
         q_ptr[c] = (ptr0 + n) & 4095;
         q_disp[c] = total & 255;
-        if (b > 0) {
-            const float e = (float)(acc * (1.0 / 4096.0));
-            q_err[c] = e;
-            q_sync[c] = e >= 0.35f ? 0 : 1;
-        }
     }
 }
 
@@ -572,8 +585,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
             }
         }
         if (h->q_ring)
-            hipLaunchKernelGGL(k_quality, dim3((h->C + 3) / 4), dim3(256), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->C, h->q_ring,
-                               h->q_ptr, h->q_disp, h->q_err, h->q_sync);
+            hipLaunchKernelGGL(k_quality, dim3(h->C), dim3(64), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->q_ring, h->q_ptr, h->q_disp,
+                               h->q_err, h->q_sync);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(ev[1], s));
         HIP_TRY(h, hipEventRecord(ev[2], s));

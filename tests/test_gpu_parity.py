@@ -468,7 +468,8 @@ def test_parity_4096_channels_full_second(pkg, oracle, synth):
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 def test_quality_statistic(pkg, oracle, synth, pipeline):
     """standarderr / sync (dqpsk_sym_extr.cpp:8-31) per channel vs the oracle's faithful restatement (libm atan2f,
-    float ring, sequential sum): tolerance 1e-4 (GUI meter, not on the bit path); bits stay bit-exact with it on.  Call
+    float ring, sequential sum): tolerance 2e-6 (GUI meter, not on the bit path; the GPU sums the ring in the same order and
+    precision, its per-symbol distance is an atan polynomial); bits stay bit-exact with it on.  Call
     lengths on both sides of the 256-symbol publishing period and of the 4096-symbol ring, with and without the caller
     asking for the symbols."""
     Cn, N = 12, 24000
@@ -486,7 +487,7 @@ def test_quality_statistic(pkg, oracle, synth, pipeline):
         for c in range(Cn):
             r = orcs[c].process(iq[c, pos:pos + n])
             assert np.array_equal(bits[c][:nb[c]], r["bits"])
-            assert abs(err[c] - orcs[c].st.standarderr) < 1e-4, (k, c, err[c], orcs[c].st.standarderr)
+            assert abs(err[c] - orcs[c].st.standarderr) < 2e-6, (k, c, err[c], orcs[c].st.standarderr)
             if abs(orcs[c].st.standarderr - 0.35) > 1e-3:
                 assert bool(sync[c]) == bool(orcs[c].st.sync), (k, c)
         pos += n
@@ -529,7 +530,7 @@ def test_random_combinations_of_shape_layout_outputs_and_chunking(pkg, oracle, s
         if quality:
             err, _ = d.quality()
             for c in range(Cn):
-                assert abs(err[c] - orcs[c].st.standarderr) < 1e-4, (seed, k, c)
+                assert abs(err[c] - orcs[c].st.standarderr) < 2e-6, (seed, k, c)
         if k == 2:
             c = int(rng.integers(0, Cn))
             d.reset(c)
