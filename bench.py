@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 timed region, against 8 TB/s HBM peak;
   cpu_baseline  the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the
                 same workload.  The oracle is only the baseline/checker here, never the measured path.
+  time_major    the same workload handed over as iq[n][c] (TETRA_LAYOUT_TIME_MAJOR, what a channeliser emits), A/B beside the
+                channel-major headline (informational);
   host_path_*   PCIe-inclusive rates of the host entry points (informational);
   large_batch   the same call with twice the channels on this GPU (32-channel workgroup shape; informational);
   config5       BASELINE config 5 (20 MHz wideband -> channeliser -> 800 channels -> bits; informational; also --config5 alone).
@@ -152,19 +154,62 @@ def cpu_baseline(synth, n_samples, budget_s=8.0):
     return port, fast
 
 
+def wideband_tetra(torch, synth, device, M, n_in, carriers, seed=5):
+    """A wideband capture at Fs = M x 25 kHz holding pi/4-DQPSK TETRA carriers {channel k: seed} (18 ksymbols/s, RRC 0.35,
+    i.e. Fs / 18000 samples per symbol) over a noise floor: synth.modulate's formula evaluated on the GPU in float64 (the
+    numpy form takes seconds per carrier at 5e6 samples).  Returns (x complex64 [n_in] on device, {k: tx bits})."""
+    import math
+    fs = M * 25000.0
+    sps = fs / 18000.0
+    beta = 0.35
+    n = torch.arange(n_in, device=device, dtype=torch.float64)
+    x = torch.zeros(n_in, device=device, dtype=torch.complex128)
+    tx = {}
+
+    def rrc(t):          # synth.rrc_pulse (unit-energy root-raised cosine, t in symbol periods)
+        z = t.abs() < 1e-9
+        sg = (t.abs() - 1.0 / (4.0 * beta)).abs() < 1e-9
+        ts = torch.where(z | sg, torch.full_like(t, 0.123), t)
+        v = (torch.sin(math.pi * ts * (1 - beta)) + 4 * beta * ts * torch.cos(math.pi * ts * (1 + beta))) / (
+            math.pi * ts * (1 - (4 * beta * ts) ** 2))
+        v = torch.where(z, torch.full_like(t, 1 - beta + 4 * beta / math.pi), v)
+        return torch.where(sg, torch.full_like(t, (beta / math.sqrt(2)) * ((1 + 2 / math.pi) * math.sin(math.pi / (4 * beta)) +
+                                                                       (1 - 2 / math.pi) * math.cos(math.pi / (4 * beta)))), v)
+
+    for k, sd in carriers.items():
+        bits = np.random.default_rng(sd).integers(0, 2, synth.needed_bits(n_in, sps), dtype=np.uint8)
+        syms = torch.from_numpy(synth.bits_to_symbols(bits)).to(device)
+        K = syms.shape[0]
+        t = (n + 0.37 * sps) / sps - synth.SPAN
+        k0 = torch.floor(t).to(torch.int64)
+        s = torch.zeros(n_in, device=device, dtype=torch.complex128)
+        for j in range(-synth.SPAN, synth.SPAN + 1):
+            kk = k0 + j
+            valid = (kk >= 0) & (kk < K)
+            s += torch.where(valid, syms[kk.clamp(0, K - 1)], torch.zeros((), device=device, dtype=torch.complex128)) * rrc(t - kk)
+        kc = k if k <= M // 2 else k - M
+        x += 0.3 * s * torch.polar(torch.ones_like(n), 2.0 * math.pi * kc / M * n)
+        tx[k] = bits
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x += 0.003 * torch.view_as_complex(torch.randn((n_in, 2), device=device, generator=g, dtype=torch.float64))
+    return x.to(torch.complex64).contiguous(), tx
+
+
 def wideband_config5(args, torch, pkg, device, local_rank):
     """BASELINE config 5 (informational, NOT the metric line): 20 MHz wideband capture -> 800 x 25 kHz channels
-    (2x oversampled, 50 ksps each) -> demodulator in time-major layout -> bits.  One step = 0.25 s of capture."""
+    (2x oversampled, 50 ksps each) -> demodulator in time-major layout -> bits.  One step = 0.25 s of capture.  The capture
+    holds 16 TETRA carriers spread over the band (one at a negative frequency index, one at each band edge region) over a
+    noise floor; the known-answer check demodulates them back to their transmitted bits."""
     M, P, D = 800, 8, 400
     n_in = 5000000
     frames = n_in // D
-    g = torch.Generator(device=device)
-    g.manual_seed(5)
-    x = torch.view_as_complex(torch.randn((n_in, 2), device=device, generator=g) * 0.1).contiguous()
+    carriers = {k: 500 + i for i, k in enumerate((3, 57, 101, 150, 199, 250, 313, 377, 423, 480, 531, 590, 644, 700, 751, 797))}
+    x, tx = wideband_tetra(torch, pkg.synth, device, M, n_in, carriers)
     ch = pkg.Channeliser(M, P, D, max_in=n_in, device=local_rank)
     dem = pkg.Demodulator(M, frames, layout=pkg.binding.LAYOUT_TIME_MAJOR, device=local_rank, samplerate=50000.0)
     out = torch.zeros((frames, M), dtype=torch.complex64, device=device)
-    stride = pkg.binding.bits_stride(frames)
+    stride = dem.bits_stride(frames)
     bits = torch.zeros((M, stride), dtype=torch.uint8, device=device)
     nbits = torch.zeros(M, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream(device)
@@ -181,7 +226,7 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         step()
     torch.cuda.synchronize(device)
     el = time.perf_counter() - t0
-    k1, _ = dem.kernel_ms_history(1)
+    k1 = dem.kernel_ms_history(1)
     ch_ms = ch.last_kernel_ms()
     # steady-state streaming: the channeliser works on block k+1 (its own stream, the other frame buffer) while the
     # demodulator -- 800 channels = 50 of the 256 CUs -- is on block k
@@ -209,19 +254,55 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         pipelined(k)
     torch.cuda.synchronize(device)
     el2 = time.perf_counter() - t0
+    # known answer: fresh loops, two passes over the capture (0.5 s of signal per carrier; the block repeats, so the loops see one
+    # phase jump and stay in lock), then the second pass's second half against the transmitted bits of every carrier
+    check = None
+    if not args.no_check:
+        dem.reset()
+        step()
+        step()
+        torch.cuda.synchronize(device)
+        hb, hn = bits.cpu().numpy(), nbits.cpu().numpy()
+        errs = ncmp = 0
+        for k, b in tx.items():
+            lag, e, n = pkg.synth.align_and_count_errors(hb[k][: hn[k]], b, skip=hn[k] // 2, max_lag=600)
+            errs += e
+            ncmp += n
+        idle = [k for k in range(M) if k not in tx and all(abs(k - c) > 1 for c in tx)]
+        check = dict(carriers=len(tx), bits_compared_second_half=int(ncmp), bit_errors=int(errs), idle_channels=len(idle))
+        if ncmp < 2000 * len(tx) or errs > 1e-3 * ncmp:
+            raise SystemExit("config 5 known-answer check failed: %d bit errors in %d bits of %d carriers" % (errs, ncmp, len(tx)))
     res = {"metric": "wideband IQ Msamples/s channelised and demodulated to bits (BASELINE config 5)",
            "value": round(args.steps * n_in / el / 1e6, 2), "unit": "Msamples/s (20 MHz capture)",
            "ms_per_step": round(el / args.steps * 1e3, 3), "realtime_factor": round(args.steps * n_in / el / 20e6, 1),
            "channeliser_kernel_ms": round(ch_ms, 3), "demod_kernel_ms": round(float(k1[0]), 3),
            "two_streams_ms_per_step": round(el2 / args.steps * 1e3, 3),
            "two_streams_realtime_factor": round(args.steps * n_in / el2 / 20e6, 1),
-           "config": {"workload": "5e6 samples @ 20 MHz -> 800 ch x 12500 frames @ 50 ksps -> bits",
+           "check": check,
+           "config": {"workload": "5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> bits",
                       "channels": M, "taps_per_channel": P, "decimation": D}}
     del outs
     ch.close()
     dem.close()
     del x, out, bits, nbits
     return res
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command under
+    torch.distributed.run (one process per GPU; on a box with fewer GPUs than ranks they share -- functional runs only) and
+    pass the line rank 0 prints through.  Under a launcher (WORLD_SIZE set) main() runs the rank itself."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -247,13 +328,22 @@ def main():
     ap.add_argument("--chain", action="store_true",
                     help="also run the device-resident receive chain behind the demodulator (burst synchroniser -> demultiplexer "
                          "-> lower-MAC decoder; profiles/measure_pipeline*.py) and attach its timings as \"chain\" (informational)")
+    ap.add_argument("--no-time-major", action="store_true",
+                    help="skip the informational leg that hands the same workload over time-major (iq[n][c], field time_major)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import tetra_amd
     pkg = tetra_amd.pkg
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d is running as one of %d rank(s): launch it with --nproc-per-node %d, or without a "
+                         "launcher (it starts its ranks itself)" % (args.gpus, world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -315,8 +405,7 @@ def main():
 
     # per-launch kernel durations of the timed region (HIP events on the launch stream)
     nh = min(args.steps, 64)
-    k1, k2 = dem.kernel_ms_history(nh)
-    k1_ms, k2_ms = float(k1.mean()), float(k2.mean())
+    k1_ms = float(dem.kernel_ms_history(nh).mean())
 
     # size-independent property at full size: after lock every channel returns its transmitted bits
     check = None
@@ -334,6 +423,37 @@ def main():
         check = dict(channels_checked=len(hn), bits_compared_last_quarter=int(ncmp), bit_errors=int(errs))
         if errs > 1e-3 * ncmp:
             raise SystemExit("known-answer check failed: %d bit errors in %d bits after lock" % (errs, ncmp))
+
+    # The same workload handed over time-major, iq[n][c] (what a channeliser emits; the AGC wave's loads then coalesce across
+    # the channel axis as north_star words it): a second handle on the transposed samples, informational A/B.
+    tmaj = None
+    if not args.no_time_major and rank == 0 and world == 1:
+        iq_t = iq.transpose(0, 1).contiguous()
+        dem_t = pkg.Demodulator(C, N, device=local_rank, flags=0, layout=pkg.binding.LAYOUT_TIME_MAJOR)
+        bits_t = torch.zeros_like(bits)
+        nbits_t = torch.zeros_like(nbits)
+        reps = max(3, min(args.steps, 10))
+        for _ in range(3):
+            dem_t.process_device(iq_t, N, bits_t, stride, nbits_t, None, stream)
+        dem_t.reset()
+        dem.reset()
+        dem_t.process_device(iq_t, N, bits_t, stride, nbits_t, None, stream)
+        step()
+        torch.cuda.synchronize(device)
+        same = bool(torch.equal(nbits_t, nbits) and torch.equal(bits_t[:, : int(nbits.min())], bits[:, : int(nbits.min())]))
+        for _ in range(reps):
+            dem_t.process_device(iq_t, N, bits_t, stride, nbits_t, None, stream)
+        torch.cuda.synchronize(device)
+        t_ms = float(dem_t.kernel_ms_history(reps).mean())
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize(device)
+        c_ms = float(dem.kernel_ms_history(reps).mean())
+        tmaj = {"kernel_ms": round(t_ms, 4), "channel_major_kernel_ms_same_session": round(c_ms, 4),
+                "msamples_s": round(C * N / t_ms / 1e3, 1), "bits_identical_to_channel_major": same,
+                "note": "informational: the headline workload as iq[n][c] (TETRA_LAYOUT_TIME_MAJOR), %d launches each, alternated" % reps}
+        dem_t.close()
+        del iq_t, bits_t, nbits_t
 
     # End-to-end host path (beside the metric, never the metric): host buffers in, host buffers out, PCIe
     # included.  Page-locked caller buffers throughout.  sync = tetra_demod_process (copy, kernel, copy);
@@ -431,7 +551,7 @@ def main():
         out = {
             "metric": "IQ Msamples/s demodulated to bits, batched TETRA channels",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "warmup": args.warmup, "ramp_steps": RAMP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%d channels/GPU x %d complex64 samples (1 s @ 36 ksps), 65-tap RRC, "
@@ -445,12 +565,16 @@ def main():
                          "traffic_unit": traffic_unit,
                          "valu": valu,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_ms": round(k1_ms, 4), "second_kernel_ms": round(k2_ms, 4),
+                         "kernel_ms": round(k1_ms, 4),
                          "note": "HBM is the roofline BASELINE.json names; the kernel itself is VALU-issue bound "
                                  "(per-channel serial recurrences), see DESIGN.md",
                          "issue_counters": issue},
             "check": check,
+            "ramp_note": "%d untimed launches + a state reset precede the %d warm-up steps: after an idle second the shader clock "
+                         "needs ~5 launches to reach its steady value (profiles/r02/r02_f_clock_ramp.md)" % (RAMP_STEPS, args.warmup),
         }
+        if tmaj is not None:
+            out["time_major"] = tmaj
         out.update(host)
         if large is not None:
             out["large_batch"] = large

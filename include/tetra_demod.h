@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define TETRA_DEMOD_ABI_VERSION 2
+#define TETRA_DEMOD_ABI_VERSION 3
+#define TETRA_DEMOD_MAX_TAPS 80 /* capacity every tap table of this ABI is sized for (filters are 2..72 taps) */
 
 enum {
     TETRA_OK = 0,
@@ -37,7 +38,10 @@ enum {
     TETRA_ERR_HIP = -4,         /* a HIP runtime call failed (see tetra_demod_last_hip_error) */
     TETRA_ERR_NOMEM = -5,
     TETRA_ERR_SIZE = -6,        /* n_samples > max_samples, or an output stride too small */
-    TETRA_ERR_ALIGN = -7        /* output pointer / stride not 8-byte aligned */
+    TETRA_ERR_ALIGN = -7,       /* output pointer / stride not 8-byte aligned */
+    TETRA_ERR_OVERRUN = -8      /* a channel's output row filled up and the rest of its samples were dropped (only a NaN/Inf-poisoned
+                                   channel can do that: rows are sized for the slowest finite timing loop, tetra_demod_bits_stride_for).
+                                   The outputs of every other channel are valid and were delivered; see tetra_demod_get_overruns */
 };
 
 /* tetra_demod_config_t.flags */
@@ -47,7 +51,7 @@ enum {
     TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
     TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
     TETRA_FLAG_WIDE_WORKGROUPS = 16,   /* force 32-channel workgroups / ... */
-    TETRA_FLAG_NARROW_WORKGROUPS = 32, /* ... or 16-channel ones.  Default: chosen from the channel count (16 while every CU has at
+    TETRA_FLAG_NARROW_WORKGROUPS = 32, /* ... or 16-channel ones (both together: TETRA_ERR_ARG).  Default: chosen from the channel count (16 while every CU has at
                                     most one workgroup; beyond, whole rounds of 32-channel workgroups and the rest in whichever
                                     shape is through first -- 8192 channels take 1.3x the 4096-channel time instead of 2x:
                                     DESIGN.md section 5).  Results are identical bit for bit.  Band-edge filters of more
@@ -58,10 +62,10 @@ enum {
                                         PI4DQPSK::reset, pi4dqpsk.cpp:120-130), COMPLEX_FD's delay buffer (complex_fd.cpp:78-87
                                         does not clear it) and the slicer's previous symbol (another block); it clears the
                                         delay line for the RRC only -- the FLL's band-edge FIRs keep theirs (fll.cpp:120-127);
-                                      - TETRA_PARAM_RRC_TAP_COUNT re-designs only the RRC and leaves the FLL's band-edge filters
-                                        at their construction-time length (pi4dqpsk.cpp:56-70);
-                                      - TETRA_PARAM_RRC_BETA truncates its value to an integer like setRRCBeta(int)
-                                        (src/dsp/pi4dqpsk.h:56, pi4dqpsk.cpp:72). */
+                                      - TETRA_PARAM_RRC_TAP_COUNT / tetra_demod_set_rrc_params re-design only the RRC and leave the FLL's
+                                        band-edge filters at their construction-time length (pi4dqpsk.cpp:56-70).
+                                    (The reference's setRRCBeta(int) truncation, src/dsp/pi4dqpsk.h:56, lives in the C++ mirror's
+                                    setRRCBeta(int) signature, not here: TETRA_PARAM_RRC_BETA always takes the double.) */
 };
 
 /* Input sample layout of process(): element (channel c, sample n) of the complex64 stream. */
@@ -89,7 +93,9 @@ typedef struct tetra_demod_config {
     double fll_bandwidth;    /* 0.006 */
     double omega_gain;       /* timing loop beta, src/main.cpp:82 */
     double mu_gain;          /* timing loop alpha, src/main.cpp:81 */
-    double omega_rel_limit;  /* 0.02; 0 .. 0.05 accepted (the output rows are sized for omega >= 2 x 0.95) */
+    double omega_rel_limit;  /* 0.02.  Accepted: 0 <= limit < 1 with samplerate / symbolrate x (1 - limit) - |mu_gain| >= 1, i.e. a
+                              * timing loop whose every symbol advances by at least one sample (the reference below that emits
+                              * several symbols from one offset; not implemented: TETRA_ERR_UNSUPPORTED, also from the setters) */
     /* Optional caller-supplied tables (NULL = design them like the reference does).  In an SDR++
      * build the host may pass SDR++'s own tap generators' output here. */
     const float* rrc_taps;        /* [rrc_tap_count]                 taps::rootRaisedCosine, pi4dqpsk.cpp:18 */
@@ -121,7 +127,8 @@ enum {
     TETRA_PARAM_RRC_TAP_COUNT = 2,    /* setRRCTapCount     pi4dqpsk.cpp:68-70.  Without TETRA_FLAG_REFERENCE_QUIRKS a NEW count also re-designs the
                                        * FLL's band-edge filters to that length (what a fresh init with that count gives); with the flag only
                                        * the RRC changes, like the reference */
-    TETRA_PARAM_RRC_BETA = 3,         /* setRRCParams beta  pi4dqpsk.cpp:56-66 (a double; truncated like setRRCBeta(int) only with the quirks flag) */
+    TETRA_PARAM_RRC_BETA = 3,         /* the roll-off of setRRCParams, pi4dqpsk.cpp:56-66: a double, never truncated here (the reference's
+                                       * setRRCBeta(int) truncates in its signature; so does the C++ mirror's) */
     TETRA_PARAM_AGC_RATE = 4,         /* setAGCRate         pi4dqpsk.cpp:76-80 */
     TETRA_PARAM_COSTAS_BANDWIDTH = 5, /* setCostasBandwidth pi4dqpsk.cpp:82-86 */
     TETRA_PARAM_FLL_BANDWIDTH = 6,    /* setFllBandwidth    pi4dqpsk.cpp:88-92 */
@@ -144,8 +151,14 @@ int tetra_demod_device_count(void);
 int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out);
 int tetra_demod_destroy(tetra_demod_t* h);
 
-/* Smallest bits_stride accepted for n_samples: n/0.95 + 16 rounded up to a multiple of 16
- * (bits = 2 x symbols, symbols <= n/omega_min + 1 with omega_min = 2(1 - omega_rel_limit)). */
+/* Row length (bytes = bits) that holds any call of n_samples on THIS handle: 2 x the largest symbol count its timing loop
+ * can emit, K <= (n + 1) / (samplerate / symbolrate x (1 - omega_rel_limit) - |mu_gain|) + 1, plus margin, a multiple of 16.
+ * process* refuse a smaller bits_stride (TETRA_ERR_SIZE).  Changes with the rate and timing setters.  The reference has no
+ * such limit because its output is a STREAM_BUFFER_SIZE stream buffer (complex_fd.cpp:89-151). */
+int tetra_demod_bits_stride_for(tetra_demod_t* h, int n_samples);
+/* The same without a handle, for the common case: n/0.95 + 16 rounded up to a multiple of 16 covers every handle whose
+ * slowest timing step is >= 1.9 samples per symbol (the plugin's parameters: 2 x 0.98 - 0.0176 = 1.9424), so a caller that
+ * stays at ~2 samples per symbol may size rows with this one; it is never smaller than tetra_demod_bits_stride_for there. */
 int tetra_demod_bits_stride(int n_samples);
 
 /*
@@ -168,6 +181,20 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                                int bits_stride, int32_t* d_n_bits, float* d_sym, void* hip_stream);
 int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
                         int32_t* n_bits, float* sym);
+/* Device-resident and synchronous: the pointers of tetra_demod_process_device, enqueued on the handle's OWN stream (created on
+ * first use, non-blocking: handles driven from different host threads -- one per GPU, or several on one GPU -- overlap), and
+ * the call returns when the launch has finished, with TETRA_ERR_OVERRUN if it cut a channel off (below).  This is what a
+ * per-GPU worker thread of a multi-GPU host calls when the samples are already in that GPU's memory. */
+int tetra_demod_process_resident(tetra_demod_t* h, const float* d_iq, int n_samples, uint8_t* d_bits, int bits_stride,
+                                 int32_t* d_n_bits, float* d_sym);
+/* Only bits[c][0 .. n_bits[c]) (and sym[c][0 .. n_bits[c]/2)) are defined by a call; the rest of a row keeps whatever it held.
+ *
+ * A channel can only fill its row if NaN/Inf has poisoned its timing loop (then every symbol advances one sample).  Such a
+ * channel is cut off at the row's capacity, the rest of its samples of that call are dropped, and the event is REPORTED:
+ * tetra_demod_process and tetra_demod_wait return TETRA_ERR_OVERRUN (every output was delivered; the other channels'
+ * are valid), and tetra_demod_get_overruns gives the number of (channel, launch) events since create -- the way to learn
+ * of it after tetra_demod_process_device.  Synchronises. */
+int tetra_demod_get_overruns(tetra_demod_t* h, long long* total);
 
 /*
  * Asynchronous host entry point: the same call as tetra_demod_process (host buffers in, host buffers out, state carried),
@@ -199,9 +226,9 @@ void tetra_demod_host_free(void* p);
  * the timing loop and the FIR delay line.  Without TETRA_FLAG_REFERENCE_QUIRKS it also zeroes ph2, COMPLEX_FD's delay buffer,
  * the slicer's previous symbol and the quality statistic (= a fresh chain); with the flag those keep their values like in the
  * reference.  The delay line: the reference has one per FIR object and its reset clears the RRC's only (rrc.reset(),
- * pi4dqpsk.cpp:125; FLL::reset, fll.cpp:120-127, leaves the two band-edge FIRs' lines alone).  The kernels keep ONE line for the
+ * pi4dqpsk.cpp:125; FLL::reset, fll.cpp:120-127, leaves the two band-edge FIRs' lines alone).  The kernel keeps ONE line for the
  * three FIRs: without the flag it is cleared (fresh chain); with the flag it is kept and channel_state.rrc_valid = 0 hides it
- * from the RRC, which is the reference's behaviour to the letter (fused pipeline; the two-kernel pipeline always clears it). */
+ * from the RRC, which is the reference's behaviour to the letter. */
 int tetra_demod_reset(tetra_demod_t* h, int channel);
 
 /* The twelve PI4DQPSK setters collapse to one call (IDs above).  Like the reference: the loop setters (AGC rate, Costas / FLL
@@ -212,6 +239,9 @@ int tetra_demod_reset(tetra_demod_t* h, int channel);
  * cfg.bandedge_taps, cfg.interp_bank) survive every setter that does not have to re-design them; a setter that would
  * (a rate / RRC setter with cfg.rrc_taps, a tap count with either FIR table) returns TETRA_ERR_UNSUPPORTED and changes nothing. */
 int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value);
+/* PI4DQPSK::setRRCParams (pi4dqpsk.cpp:56-66): tap count and roll-off applied in one re-design of the RRC (same rules as
+ * TETRA_PARAM_RRC_TAP_COUNT + TETRA_PARAM_RRC_BETA). */
+int tetra_demod_set_rrc_params(tetra_demod_t* h, int rrc_tap_count, double rrc_beta);
 
 /* Checkpoint / restore of one channel's loop state.  set_state accepts what the chain can be in: |fll_phase| <= pi,
  * |costas_phase| <= pi, |ph2| < 2 pi (the reference's loops wrap to these ranges on every step; anything else is
@@ -219,10 +249,11 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value);
 int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out);
 int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in);
 
-/* Copies of the designed tables (any pointer may be NULL): rrc[taps], be_re[be_taps], be_im[be_taps] (lower band-edge
- * filter), bank[128*8]; *taps receives the RRC tap count.  be_taps = tetra_demod_bandedge_tap_count(h) equals taps except
- * after a TETRA_PARAM_RRC_TAP_COUNT under TETRA_FLAG_REFERENCE_QUIRKS; 80 entries always suffice. */
-int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank);
+/* Copies of the designed tables (any pointer may be NULL): rrc[*taps], be_re[*be_taps], be_im[*be_taps] (lower band-edge
+ * filter), bank[128*8].  The two lengths differ after a tap-count change under TETRA_FLAG_REFERENCE_QUIRKS (the FLL keeps its
+ * construction-time filters), so a caller cannot size be_re / be_im from *taps: every tap buffer handed in must hold
+ * TETRA_DEMOD_MAX_TAPS (80) floats, or call once with NULL buffers to learn both lengths first. */
+int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, int* be_taps, float* be_re, float* be_im, float* bank);
 int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
 
 /* DQPSKSymbolExtractor's public `standarderr` / `sync` members (src/dsp/dqpsk_sym_extr.h:36-37; computed at
@@ -242,18 +273,23 @@ int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync)
  * TETRA_FLAG_KEEP_RRC_OUT (TETRA_ERR_UNSUPPORTED otherwise). */
 int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples);
 
-/* GPU time of the kernels of the most recent process call, from HIP events recorded on the call's stream
- * (synchronises on them): k1 = k_fused; k2 = 0 (the slot of ABI 1's second kernel, kept for the signature). */
-int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms);
-/* Same for the n (1..64) most recent kernel-launching process calls, oldest first: k1_ms[n], k2_ms[n]
- * (either may be NULL).  The events are recorded on each call's own stream, so a benchmark can read the
- * per-launch kernel durations of its timed region after the region ends, without synchronising inside it. */
-int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* k1_ms, float* k2_ms);
+/* GPU time (ms) of the most recent process call's launches (k_fused, once or twice, plus k_quality when enabled), from HIP
+ * events recorded on the call's stream around them (synchronises on them). */
+int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* ms);
+/* Same for the n (1..64) most recent kernel-launching process calls, oldest first: ms[n].  The events are recorded on each
+ * call's own stream, so a benchmark can read the per-launch durations of its timed region after the region ends, without
+ * synchronising inside it. */
+int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* ms);
 
 /* Device self-test of the primitives the bit-exact contract rests on: in[0..63] -> sqrt, in[64..127] ->
  * sin/cos; out[0..63] = row_shr:1 DPP of lane ids (old = 100+lane), out[64..127] = row_shl:1 (old = 200+lane),
  * out[128..191] = sqrt, out[192..255] = sin, out[256..319] = cos.  Used by the GPU tests. */
 int tetra_demod_debug_selftest(tetra_demod_t* h, const float* in128, float* out320);
+
+/* Device self-test of the matrix pipe's f32 arithmetic: d[M][M] = a[M][k] . b[k][M] (row-major, M = shape = 16 or 32, k a
+ * multiple of 4, <= 4096) accumulated over ascending k from +0 by chained v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32.
+ * The GPU tests compare it bit for bit with the fmaf chain the arithmetic contract prescribes for every FIR sum. */
+int tetra_demod_debug_mfma_selftest(tetra_demod_t* h, int shape, int k, const float* a, const float* b, float* d);
 
 const char* tetra_demod_strerror(int status);
 /* hipError_t of the last failing HIP call on this handle (0 if none). */

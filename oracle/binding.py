@@ -105,6 +105,8 @@ def lib():
                                                  C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
         L.tetra_oracle_process_batch.restype = C.c_int
         L.tetra_oracle_max_threads.restype = C.c_int
+        L.tetra_oracle_fmaf_chain_matmul.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.tetra_oracle_fmaf_chain_matmul.restype = None
         _lib = L
     return _lib
 
@@ -170,7 +172,7 @@ class Oracle:
         """iq: complex64[count].  Returns dict(sym, dibits, bits[, x, y])."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         n = iq.shape[0]
-        cap = n // 2 + n // 16 + 8
+        cap = n + 16          # every symbol advances by >= 1 sample for the parameter sets the tests use
         sym = np.zeros(cap, np.complex64)
         dib = np.zeros(cap, np.uint8)
         bits = np.zeros(2 * cap, np.uint8)
@@ -185,7 +187,7 @@ class Oracle:
         return out
 
 
-def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None):
+def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None, stride=None):
     """iq: complex64[C][N] channel-major.  Returns (bits[C][stride] u8, n_bits[C] i32, sym or None, states)."""
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     Cn, N = iq.shape
@@ -200,7 +202,7 @@ def process_batch(iq, cfg=None, chunk=0, threads=0, want_sym=False, states=None)
         states = (State * Cn)()
         for c in range(Cn):
             lib().tetra_oracle_reset(C.byref(tab), C.byref(states[c]))
-    stride = bits_stride(N)
+    stride = bits_stride(N) if stride is None else int(stride)
     bits = np.zeros((Cn, stride), np.uint8)
     nb = np.zeros(Cn, np.int32)
     sym = np.zeros((Cn, stride // 2), np.complex64) if want_sym else None
@@ -300,6 +302,15 @@ def usable_cpus():
     if quota is not None:
         n = max(1, min(n, int(quota + 0.999)))
     return n, quota
+
+
+def fmaf_chain_matmul(a, b):
+    """d[i][j] = fmaf chain over ascending k from +0 (the contract's FIR sum), float32."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    d = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    lib().tetra_oracle_fmaf_chain_matmul(_ptr(a), _ptr(b), a.shape[0], b.shape[1], a.shape[1], _ptr(d))
+    return d
 
 
 def bits_stride(n_samples):

@@ -525,7 +525,7 @@ int tetra_oracle_process_batch(const tetra_oracle_tables_t* tab, tetra_oracle_st
         uint8_t* bo = bits + (size_t)c * (size_t)bits_stride;
         float* so = sym ? sym + (size_t)c * (size_t)(bits_stride / 2) * 2 : NULL;
         int nb = 0;
-        int maxs = chunk / 2 + chunk / 16 + 8;
+        int maxs = chunk + 8;      /* every symbol advances >= 1 sample for the parameter sets the tests use */
         uint8_t* tb = (uint8_t*)malloc((size_t)maxs * 2);
         float* ts = (float*)malloc(sizeof(float) * (size_t)maxs * 2);
         for (int pos = 0; pos < n_samples; pos += chunk) {
@@ -547,4 +547,15 @@ int tetra_oracle_process_batch(const tetra_oracle_tables_t* tab, tetra_oracle_st
         free(ts);
     }
     return rc;
+}
+
+/* d[i][j] = the fmaf chain of the arithmetic contract over ascending k from +0 (test helper for the GPU's matrix-pipe
+ * self-test: every FIR sum of the chain is such a chain). a [m][k], b [k][n], d [m][n], row-major. */
+void tetra_oracle_fmaf_chain_matmul(const float* a, const float* b, int m, int n, int k, float* d) {
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) {
+            float acc = 0.0f;
+            for (int q = 0; q < k; q++) acc = fmaf(a[(size_t)i * k + q], b[(size_t)q * n + j], acc);
+            d[(size_t)i * n + j] = acc;
+        }
 }

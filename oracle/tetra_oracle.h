@@ -145,7 +145,8 @@ void tetra_oracle_sincosf(float x, float* s, float* c);
  *   sym_out [2*S]      Costas output = PI4DQPSK::process output
  *   dibits  [S]        DQPSKSymbolExtractor output
  *   bits    [2*S]      BitUnpacker output (what tetra_burst_sync_in eats)
- * Output capacity needed: S <= count/1.9 + 2.  Returns S (symbols produced).
+ * Output capacity needed: S <= (count + 1) / (tr_min_freq - |tr_alpha|) + 1 (count/1.9 + 2 at the plugin's rates; count + 1
+ * whenever every symbol advances by at least one sample).  Returns S (symbols produced).
  */
 int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st,
                          int count, const float* iq,
@@ -166,6 +167,9 @@ int tetra_oracle_process_batch(const tetra_oracle_tables_t* tab, tetra_oracle_st
                                int32_t* n_bits, float* sym);
 
 int tetra_oracle_max_threads(void);
+
+/* fmaf-chain matrix product (ascending k from +0): checker for the GPU's matrix-pipe self-test. */
+void tetra_oracle_fmaf_chain_matmul(const float* a, const float* b, int m, int n, int k, float* d);
 
 #ifdef __cplusplus
 }

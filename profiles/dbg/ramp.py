@@ -12,7 +12,7 @@ st = torch.cuda.current_stream(dev)
 def run(k):
     for _ in range(k): dem.process_device(iq, N, bits, stride, nb, None, st)
     torch.cuda.synchronize()
-    return [round(float(x), 3) for x in dem.kernel_ms_history(k)[0]]
+    return [round(float(x), 3) for x in dem.kernel_ms_history(k)]
 print("fresh     ", run(12))
 dem.reset(); print("after reset", run(6))
 time.sleep(1.0); print("after 1s idle", run(6))

@@ -31,8 +31,10 @@ EXPORTS = [
     "tetra_demod_debug_read_rrc_out", "tetra_demod_last_kernel_ms", "tetra_demod_strerror",
     "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history", "tetra_demod_get_quality",
     "tetra_demod_bandedge_tap_count", "tetra_demod_process_async", "tetra_demod_wait", "tetra_demod_host_alloc",
-    "tetra_demod_host_free", "tetra_demod_device_info",
+    "tetra_demod_host_free", "tetra_demod_device_info", "tetra_demod_bits_stride_for", "tetra_demod_get_overruns",
+    "tetra_demod_set_rrc_params", "tetra_demod_process_resident", "tetra_demod_debug_mfma_selftest",
 ]
+ERR_OVERRUN = -8
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
 
 
@@ -98,16 +100,21 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_set_param.argtypes = [vp, i32, C.c_double]
     L.tetra_demod_get_state.argtypes = [vp, i32, C.POINTER(ChannelState)]
     L.tetra_demod_set_state.argtypes = [vp, i32, C.POINTER(ChannelState)]
-    L.tetra_demod_get_tables.argtypes = [vp, C.POINTER(i32), vp, vp, vp, vp]
+    L.tetra_demod_get_tables.argtypes = [vp, C.POINTER(i32), vp, C.POINTER(i32), vp, vp, vp]
+    L.tetra_demod_bits_stride_for.argtypes = [vp, i32]
+    L.tetra_demod_get_overruns.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.tetra_demod_set_rrc_params.argtypes = [vp, i32, C.c_double]
+    L.tetra_demod_process_resident.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.tetra_demod_debug_mfma_selftest.argtypes = [vp, i32, i32, vp, vp, vp]
     L.tetra_demod_bandedge_tap_count.argtypes = [vp]
     L.tetra_demod_debug_read_rrc_out.argtypes = [vp, vp, i32]
-    L.tetra_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.tetra_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.tetra_demod_strerror.argtypes = [i32]
     L.tetra_demod_strerror.restype = C.c_char_p
     L.tetra_demod_last_hip_error.argtypes = [vp]
     L.tetra_demod_abi_version.argtypes = []
     L.tetra_demod_debug_selftest.argtypes = [vp, vp, vp]
-    L.tetra_demod_kernel_ms_history.argtypes = [vp, i32, vp, vp]
+    L.tetra_demod_kernel_ms_history.argtypes = [vp, i32, vp]
     L.tetra_demod_get_quality.argtypes = [vp, vp, vp]
     L.tetra_demod_process_async.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     L.tetra_demod_wait.argtypes = [vp]
@@ -152,6 +159,8 @@ def device_count():
 
 
 def bits_stride(n_samples):
+    """Handle-free row length: covers every handle at ~2 samples per symbol (tetra_demod_bits_stride); Demodulator.bits_stride
+    is the one for a particular handle's rates."""
     return int(load_library().tetra_demod_bits_stride(int(n_samples)))
 
 
@@ -195,6 +204,19 @@ class Demodulator:
         if rc:
             raise TetraDemodError(rc, what, self._lib.tetra_demod_last_hip_error(self._h))
 
+    def bits_stride(self, n_samples):
+        """tetra_demod_bits_stride_for: the row length this handle's timing loop needs for calls of n_samples."""
+        rc = int(self._lib.tetra_demod_bits_stride_for(self._h, int(n_samples)))
+        if rc < 0:
+            raise TetraDemodError(rc, "tetra_demod_bits_stride_for")
+        return rc
+
+    def overruns(self):
+        """(channel, launch) events cut off at the row capacity since create (tetra_demod_get_overruns)."""
+        v = C.c_longlong(0)
+        self._check(self._lib.tetra_demod_get_overruns(self._h, C.byref(v)), "tetra_demod_get_overruns")
+        return int(v.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.tetra_demod_destroy(self._h)
@@ -207,9 +229,10 @@ class Demodulator:
             pass
 
     # --- PI4DQPSK::process + DQPSKSymbolExtractor::process + BitUnpacker::process --------------------
-    def process(self, iq, want_sym=False):
+    def process(self, iq, want_sym=False, allow_overrun=False):
         """Host path.  iq complex64 [C][N] (channel-major) or [N][C] (time-major handle).
-        Returns (bits u8 [C][stride], n_bits i32 [C], sym complex64 [C][stride/2] or None)."""
+        Returns (bits u8 [C][stride], n_bits i32 [C], sym complex64 [C][stride/2] or None).  TETRA_ERR_OVERRUN (a poisoned
+        channel filled its row; everything was delivered) raises unless allow_overrun; self.last_status keeps it."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         if iq.ndim == 1:
             iq = iq[None, :] if self.layout == LAYOUT_CHANNEL_MAJOR else iq[:, None]
@@ -217,12 +240,14 @@ class Demodulator:
         cdim = iq.shape[0] if self.layout == LAYOUT_CHANNEL_MAJOR else iq.shape[1]
         if cdim != self.n_channels:
             raise ValueError("expected %d channels, got %d" % (self.n_channels, cdim))
-        stride = bits_stride(n)
+        stride = max(bits_stride(n), self.bits_stride(n))
         bits = np.zeros((self.n_channels, stride), np.uint8)
         nb = np.zeros(self.n_channels, np.int32)
         sym = np.zeros((self.n_channels, stride // 2), np.complex64) if want_sym else None
         rc = self._lib.tetra_demod_process(self._h, _np_ptr(iq), n, _np_ptr(bits), stride, _np_ptr(nb), _np_ptr(sym))
-        self._check(rc, "tetra_demod_process")
+        self.last_status = rc
+        if not (allow_overrun and rc == ERR_OVERRUN):
+            self._check(rc, "tetra_demod_process")
         return bits, nb, sym
 
     def process_async(self, iq_ptr, iq_format, n_samples, bits_ptr, bits_stride_, n_bits_ptr):
@@ -234,6 +259,15 @@ class Demodulator:
 
     def wait(self):
         self._check(self._lib.tetra_demod_wait(self._h), "tetra_demod_wait")
+
+    def process_resident(self, d_iq, n_samples, d_bits, bits_stride_, d_n_bits, d_sym=None):
+        """tetra_demod_process_resident: device buffers, the handle's own stream, returns when the launch is done."""
+        def p(x):
+            if x is None:
+                return None
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self._lib.tetra_demod_process_resident(self._h, p(d_iq), int(n_samples), p(d_bits), int(bits_stride_),
+                                                           p(d_n_bits), p(d_sym)), "tetra_demod_process_resident")
 
     def process_device(self, d_iq, n_samples, d_bits, bits_stride_, d_n_bits, d_sym=None, stream=None):
         """Device path: arguments are objects with .data_ptr() (torch tensors on this GPU) or ints."""
@@ -255,6 +289,10 @@ class Demodulator:
     def set_param(self, name, value):
         self._check(self._lib.tetra_demod_set_param(self._h, PARAMS[name], float(value)), "tetra_demod_set_param")
 
+    def set_rrc_params(self, rrc_tap_count, rrc_beta):
+        """PI4DQPSK::setRRCParams: both in one re-design."""
+        self._check(self._lib.tetra_demod_set_rrc_params(self._h, int(rrc_tap_count), float(rrc_beta)), "tetra_demod_set_rrc_params")
+
     def get_state(self, channel):
         st = ChannelState()
         self._check(self._lib.tetra_demod_get_state(self._h, channel, C.byref(st)), "tetra_demod_get_state")
@@ -264,17 +302,15 @@ class Demodulator:
         self._check(self._lib.tetra_demod_set_state(self._h, channel, C.byref(st)), "tetra_demod_set_state")
 
     def tables(self):
-        nt = C.c_int(0)
-        self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), None, None, None, None), "tetra_demod_get_tables")
-        n = nt.value
-        nb = self._lib.tetra_demod_bandedge_tap_count(self._h)
-        rrc = np.zeros(n, np.float32)
+        nt, nbe = C.c_int(0), C.c_int(0)
+        rrc = np.zeros(80, np.float32)
         re = np.zeros(80, np.float32)
         im = np.zeros(80, np.float32)
         bank = np.zeros((128, 8), np.float32)
-        self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), _np_ptr(rrc), _np_ptr(re), _np_ptr(im),
+        self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), _np_ptr(rrc), C.byref(nbe), _np_ptr(re), _np_ptr(im),
                                                      _np_ptr(bank)), "tetra_demod_get_tables")
-        return dict(rrc=rrc, be_re=re[:nb].copy(), be_im=im[:nb].copy(), bank=bank)
+        assert nbe.value == self._lib.tetra_demod_bandedge_tap_count(self._h)
+        return dict(rrc=rrc[:nt.value].copy(), be_re=re[:nbe.value].copy(), be_im=im[:nbe.value].copy(), bank=bank)
 
     def read_rrc_out(self, n_samples):
         y = np.zeros((self.n_channels, n_samples), np.complex64)
@@ -289,6 +325,17 @@ class Demodulator:
         self._check(self._lib.tetra_demod_debug_selftest(self._h, _np_ptr(a), _np_ptr(out)), "tetra_demod_debug_selftest")
         return out.reshape(5, 64)
 
+    def mfma_selftest(self, a, b):
+        """d = a . b on the matrix pipe (chained f32 MFMAs over ascending k from +0); a [M][K], b [K][M], M = 16 or 32."""
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        m, k = a.shape
+        assert b.shape == (k, m)
+        d = np.zeros((m, m), np.float32)
+        self._check(self._lib.tetra_demod_debug_mfma_selftest(self._h, m, k, _np_ptr(a), _np_ptr(b), _np_ptr(d)),
+                    "tetra_demod_debug_mfma_selftest")
+        return d
+
     def quality(self):
         """(standarderr float32[C], sync bool[C]) -- DQPSKSymbolExtractor's public members per channel."""
         err = np.zeros(self.n_channels, np.float32)
@@ -297,13 +344,12 @@ class Demodulator:
         return err, sync.astype(bool)
 
     def kernel_ms_history(self, n):
-        k1 = np.zeros(n, np.float32)
-        k2 = np.zeros(n, np.float32)
-        self._check(self._lib.tetra_demod_kernel_ms_history(self._h, n, _np_ptr(k1), _np_ptr(k2)),
-                    "tetra_demod_kernel_ms_history")
-        return k1, k2
+        """GPU ms of the n most recent process calls' launches, oldest first (HIP events on each call's stream)."""
+        ms = np.zeros(n, np.float32)
+        self._check(self._lib.tetra_demod_kernel_ms_history(self._h, n, _np_ptr(ms)), "tetra_demod_kernel_ms_history")
+        return ms
 
     def last_kernel_ms(self):
-        a, b = C.c_float(0), C.c_float(0)
-        self._check(self._lib.tetra_demod_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "tetra_demod_last_kernel_ms")
-        return a.value, b.value
+        a = C.c_float(0)
+        self._check(self._lib.tetra_demod_last_kernel_ms(self._h, C.byref(a)), "tetra_demod_last_kernel_ms")
+        return a.value

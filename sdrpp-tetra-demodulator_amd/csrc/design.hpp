@@ -157,13 +157,30 @@ inline void design_bandedge(const DesignParams& p, Design& d, int count) {
     // FLL::init takes the rates through int parameters (src/dsp/fll.h:33)
     bandedge_filters(count, (float)p.rrc_beta, (double)(int)p.symbolrate, (double)(int)p.samplerate, d.be_re.data(), d.be_im.data());
 }
-// The kernels size an output row for omega >= 2 * 0.95 (tetra_demod_bits_stride) and their forward-progress clamp is
-// neutral only while omega_min > 1 + |alpha|: limits outside [0, 0.05] are refused.
+// What the kernels cover.  The timing loop moves floor(mu) samples per symbol with mu = frac + freq + alpha * err,
+// freq >= omega (1 - rel_limit), |err| <= 1 (complex_fd.cpp:136-143).  While omega (1 - rel_limit) - |mu_gain| >= 1 every
+// symbol advances by at least one sample, which the kernel's forward-progress clamp relies on (it is then neutral); below
+// that the reference emits several symbols from one offset -- not implemented, refused.  Output rows are sized from the
+// same bound (tetra_demod_bits_stride_for), so any accepted parameter set fits its rows.
 inline bool params_ok(const DesignParams& p) {
     if (p.rrc_tap_count < 2 || p.rrc_tap_count > kPadTaps) return false;
     if (!(p.symbolrate > 0) || !(p.samplerate > 0)) return false;
-    if (!(p.omega_rel_limit >= 0.0) || !(p.omega_rel_limit <= 0.05)) return false;
+    if (!(p.omega_rel_limit >= 0.0) || !(p.omega_rel_limit < 1.0)) return false;
+    const float omega_min = (float)(p.samplerate / p.symbolrate * (1.0 - p.omega_rel_limit));
+    if (!((double)omega_min - std::fabs((double)(float)p.mu_gain) >= 1.0)) return false;
     return true;
+}
+
+// Output row length (bytes = bits) that holds any call of n samples under design d (tetra_demod_bits_stride_for).
+// Smallest advance of the timing loop per symbol, in samples: every step adds freq + alpha * err to mu with
+// freq >= omega (1 - rel_limit) and |err| <= 1 (complex_fd.cpp:136-143), and floor(mu) of it moves the offset.
+inline double min_step(const Design& d) { return (double)d.k2.tr_min_freq - std::fabs((double)d.k2.tr_alpha); }
+inline long long bits_stride_for(const Design& d, long long n) {
+    // K symbols are emitted only while (K - 1) min_step - 1 < n (the offsets of a call start at >= 0 and the fractional
+    // parts of mu telescope to less than one sample):  K <= (n + 1) / min_step + 1; two symbols of margin for the float
+    // rounding of the loop, rows a multiple of 16 bytes
+    const long long k = (long long)std::floor((double)(n + 1) / (min_step(d) * (1.0 - 1e-6))) + 3;
+    return (2 * k + 15) / 16 * 16;
 }
 
 // Full design (PI4DQPSK::init).  user_* may be null.  Returns false on unsupported parameters.

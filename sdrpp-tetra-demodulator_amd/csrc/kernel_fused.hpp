@@ -108,6 +108,7 @@ struct FusedParams {
     int* n_bits;
     float2* sym;         // optional [C][sym_stride]
     long long sym_stride;
+    int* overruns;       // [1] channels whose output row filled up in this launch (the rest of their samples were dropped)
     float2* y_dbg;       // optional: time-major scratch [(7+n)][C], row 7+i = y_i
     K1Consts k1;
     K2Consts k2;
@@ -436,7 +437,11 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         st.offset = p.offset[chan(c)];
         st.cph = 0; st.cfr = 0; st.ph2 = 0; st.prev = 0;
         int S = 0;
-        const int sym_cap = (int)(p.bits_stride / 2);
+        // symbols a row can take: the bits row, and the symbol row when one is written (the caller's, or the quality
+        // statistic's scratch, whose rows may be shorter than the caller's bits rows)
+        const long long cap_ = p.sym && p.sym_stride < p.bits_stride / 2 ? p.sym_stride : p.bits_stride / 2;
+        const int sym_cap = (int)cap_;
+        bool cut = false;
         const unsigned y_base = pin_u32(lds_addr(&L.y_ring[c][0]));
         const unsigned bank_base = pin_u32(lds_addr(&L.bank[0]));
         K2Consts k2 = p.k2;
@@ -479,7 +484,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                     while (st.offset < limit) one_symbol();
                 } else {
                     while (st.offset < limit) {
-                        if (S >= sym_cap) { st.offset = limit; break; }
+                        if (S >= sym_cap) { st.offset = limit; cut = true; break; }
                         one_symbol();
                     }
                 }
@@ -490,6 +495,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.mu[ch0 + c] = st.mu;
             p.omega[ch0 + c] = st.omega;
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
+            if (cut) atomicAdd(p.overruns, 1);          // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
         }
     } else if (wave == kRoleE) {
         // ---- kRoleE: Costas + slicer + differential decoder + bit unpacker; symbols published before e ----

@@ -54,6 +54,35 @@ __global__ void k_selftest(const float* in, float* out) {
     out[256 + l] = c;
 }
 
+// Matrix-pipe self-test: D = A . B accumulated over K in ASCENDING k by chained
+// v_mfma_f32_16x16x4_f32 (M = N = 16) or v_mfma_f32_32x32x2_f32 (M = N = 32) from C = +0 -- to be compared on the host with
+// the oracle's fmaf chain `for k: acc = fmaf(A[i][k], B[k][j], acc)`, bit for bit (incl. zero taps, -0, subnormals).
+// A [M][K] row-major, B [K][N] row-major, D [M][N] row-major; K a multiple of 4; one wave.
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void k_mfma_selftest(int shape, int K, const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ D) {
+    const int l = threadIdx.x;
+    if (shape == 16) {
+        mfma_f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+        for (int kb = 0; kb < K; kb += 4) {
+            const float a = A[(l & 15) * K + kb + (l >> 4)];
+            const float b = B[(kb + (l >> 4)) * 16 + (l & 15)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; r++) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = acc[r];
+    } else {
+        mfma_f32x16 acc;
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int kb = 0; kb < K; kb += 2) {
+            const float a = A[(l & 31) * K + kb + (l >> 5)];
+            const float b = B[(kb + (l >> 5)) * 32 + (l & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; r++) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+    }
+}
+
 // Small helper kernels for state management.
 __global__ void k_fill_f32(float* p, float v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,8 +194,10 @@ struct tetra_demod {
     int *offset = nullptr, *prev = nullptr;
     int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
-    float2* y = nullptr;        // two-kernel pipeline / debug: time-major RRC output scratch [(7 + max_samples)][C]
-    float2* ybuf = nullptr;     // fused pipeline: COMPLEX_FD delay buffer [C][7]
+    float2* y = nullptr;        // TETRA_FLAG_KEEP_RRC_OUT: time-major RRC output scratch [(7 + max_samples)][C]
+    float2* ybuf = nullptr;     // COMPLEX_FD delay buffer [C][7]
+    int* d_overruns = nullptr;  // [1] channels cut off at their row capacity, counted by the kernels since create
+    long long overruns_seen = 0;   // ... and what the host entry points have already reported of it
     float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state (k_quality)
     int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
     float* q_err = nullptr;
@@ -175,7 +206,7 @@ struct tetra_demod {
     bool user_rrc = false, user_be = false;   // caller-supplied FIR tables (cfg.rrc_taps / cfg.bandedge_taps)
     bool quirks = false;        // TETRA_FLAG_REFERENCE_QUIRKS
     bool keep_y = false;        // y scratch allocated
-    float *d_be_re = nullptr, *d_be_im = nullptr, *d_rrc = nullptr, *d_bank = nullptr;
+    float* d_bank = nullptr;
     float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 72, RRC zero-extended
     // host-path staging
     float* st_iq = nullptr;
@@ -183,10 +214,11 @@ struct tetra_demod {
     int* st_nbits = nullptr;
     float* st_sym = nullptr;
     size_t st_iq_bytes = 0, st_bits_bytes = 0, st_sym_bytes = 0;
-    // ring of HIP-event triplets (start, after k1, after k2), one slot per process call
+    // ring of HIP-event pairs (before / after the call's launches), one slot per process call
     static constexpr int kEvSlots = 64;
-    hipEvent_t ev[kEvSlots][3] = {};
+    hipEvent_t ev[kEvSlots][2] = {};
     long long n_calls = 0;      // process calls that launched kernels
+    hipStream_t own_stream = nullptr;   // tetra_demod_process_resident: the handle's own (non-blocking) stream
     long long* d_prof = nullptr;   // TETRA_DEMOD_PROFILE scratch
     int last_n = 0;
     // tetra_demod_process_async: three streams, time chunks double-buffered in HBM (see the function)
@@ -229,17 +261,6 @@ struct DeviceGuard {
 };
 
 int upload_tables(tetra_demod* h) {
-    // zero-pad the FIR taps at the old end to kPadTaps
-    std::vector<float> re(kPadTaps, 0.f), im(kPadTaps, 0.f), rr(kPadTaps, 0.f);
-    const int off = kPadTaps - h->design.ntaps, off_be = kPadTaps - h->design.ntaps_be;
-    for (int k = 0; k < h->design.ntaps_be; k++) {
-        re[off_be + k] = h->design.be_re[k];
-        im[off_be + k] = h->design.be_im[k];
-    }
-    for (int k = 0; k < h->design.ntaps; k++) rr[off + k] = h->design.rrc[k];
-    HIP_TRY(h, hipMemcpy(h->d_be_re, re.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_be_im, im.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_rrc, rr.data(), sizeof(float) * kPadTaps, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
     if (h->design.ntaps <= kF8Pad && h->design.ntaps_be <= kF8Pad) {
@@ -315,7 +336,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_be_re, h->d_be_im, h->d_rrc, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_overruns, h->d_bank, h->d_be_re72, h->d_be_im72,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -331,9 +352,19 @@ void free_all(tetra_demod* h) {
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
-    hipStream_t ss[] = { a.s_in, a.s_k, a.s_out };
+    hipStream_t ss[] = { a.s_in, a.s_k, a.s_out, h->own_stream };
     for (hipStream_t st : ss)
         if (st) (void)hipStreamDestroy(st);
+}
+
+// Reads the kernels' overrun counter (the device must be idle for this handle's work) and tells whether it moved since the
+// last report: > 0 = channels newly cut off, 0 = none, < 0 = a TETRA_ERR_* status.
+int new_overruns(tetra_demod* h) {
+    int total = 0;
+    HIP_TRY(h, hipMemcpy(&total, h->d_overruns, sizeof(int), hipMemcpyDeviceToHost));
+    const long long fresh = (long long)total - h->overruns_seen;
+    h->overruns_seen = total;
+    return fresh > 0 ? (int)(fresh > 0x7fffffff ? 0x7fffffff : fresh) : 0;
 }
 
 template <class T> int dalloc(tetra_demod* h, T** p, size_t count) {
@@ -403,10 +434,21 @@ int tetra_demod_device_count(void) {
 
 int tetra_demod_bits_stride(int n_samples) {
     if (n_samples < 0) return TETRA_ERR_ARG;
-    // bits = 2 * symbols, symbols <= n / (omega_min ~ 1.94) + 1  ->  n / 0.95 + 16 covers omega_rel_limit up to ~5 %
+    // bits = 2 * symbols; n / 0.95 + 16 covers every timing loop whose slowest step is >= 1.9 samples per symbol
+    // (tetra_demod_bits_stride_for: the reference plugin's parameters give 1.9424)
     long long s = (long long)((double)n_samples / 0.95) + 16;
     s = (s + 15) / 16 * 16;
-    return (int)s;
+    return s > 0x7ffffff0ll ? TETRA_ERR_SIZE : (int)s;
+}
+
+namespace {
+long long stride_for(const host::Design& d, long long n) { return host::bits_stride_for(d, n); }
+}  // namespace
+
+int tetra_demod_bits_stride_for(tetra_demod_t* h, int n_samples) {
+    if (!h || n_samples < 0) return TETRA_ERR_ARG;
+    const long long s = stride_for(h->design, n_samples);
+    return s > 0x7ffffff0ll ? TETRA_ERR_SIZE : (int)s;
 }
 
 int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
@@ -414,6 +456,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     *out = nullptr;
     if (cfg->n_channels < 1 || cfg->max_samples < 1) return TETRA_ERR_ARG;
     if (cfg->layout != TETRA_LAYOUT_CHANNEL_MAJOR && cfg->layout != TETRA_LAYOUT_TIME_MAJOR) return TETRA_ERR_ARG;
+    if ((cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) && (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS)) return TETRA_ERR_ARG;
     int ndev = tetra_demod_device_count();
     if (ndev <= 0) return TETRA_ERR_NO_DEVICE;
     int dev = cfg->device;
@@ -484,13 +527,14 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     if (cfg->flags & TETRA_FLAG_QUALITY) {
         A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_ptr, C));
         A(dalloc(h, &h->q_disp, C)); A(dalloc(h, &h->q_sync, C)); A(dalloc(h, &h->q_err, C));
-        h->q_sym_stride = tetra_demod_bits_stride(h->max_samples) / 2;
+        h->q_sym_stride = stride_for(h->design, h->max_samples) / 2;
         A(dalloc(h, &h->q_sym, C * (size_t)h->q_sym_stride));
     }
+    A(dalloc(h, &h->d_overruns, (size_t)1));
     A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
     A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
-    A(dalloc(h, &h->d_be_re, (size_t)kPadTaps)); A(dalloc(h, &h->d_be_im, (size_t)kPadTaps));
-    A(dalloc(h, &h->d_rrc, (size_t)kPadTaps)); A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
+    A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
+    if (rc == TETRA_OK && hipMemset(h->d_overruns, 0, sizeof(int)) != hipSuccess) rc = TETRA_ERR_HIP;
     for (auto& slot : h->ev)
         for (auto& e : slot)
             if (rc == TETRA_OK && hipEventCreate(&e) != hipSuccess) rc = TETRA_ERR_HIP;
@@ -519,7 +563,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                                int32_t* d_n_bits, float* d_sym, void* hip_stream) {
     if (!h || !d_iq || !d_bits || !d_n_bits) return TETRA_ERR_ARG;
     if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
-    if (bits_stride < tetra_demod_bits_stride(n_samples)) return TETRA_ERR_SIZE;
+    if (bits_stride < stride_for(h->design, n_samples)) return TETRA_ERR_SIZE;
     if ((bits_stride & 7) || (reinterpret_cast<uintptr_t>(d_bits) & 7) || (reinterpret_cast<uintptr_t>(d_sym) & 7))
         return TETRA_ERR_ALIGN;
     DeviceGuard g(h->device);
@@ -545,6 +589,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
+        pf.overruns = h->d_overruns;
         pf.sym_stride = bits_stride / 2;
         if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
@@ -589,7 +634,6 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                                h->q_err, h->q_sync);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(ev[1], s));
-        HIP_TRY(h, hipEventRecord(ev[2], s));
         h->n_calls++;
 #ifdef TETRA_DEMOD_DEBUG
         if (pf.prof) {
@@ -611,11 +655,24 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
     }
 }
 
+int tetra_demod_process_resident(tetra_demod_t* h, const float* d_iq, int n_samples, uint8_t* d_bits, int bits_stride,
+                                 int32_t* d_n_bits, float* d_sym) {
+    if (!h) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    const int rc = tetra_demod_process_device(h, d_iq, n_samples, d_bits, bits_stride, d_n_bits, d_sym, h->own_stream);
+    if (rc != TETRA_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    const int cut = new_overruns(h);
+    return cut > 0 ? TETRA_ERR_OVERRUN : cut;
+}
+
 int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_t* bits, int bits_stride,
                         int32_t* n_bits, float* sym) {
     if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
     if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
-    if (bits_stride < tetra_demod_bits_stride(n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
+    if (bits_stride < stride_for(h->design, n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     if (h->as.ready) {      // asynchronous calls still in flight run on their own streams: let them finish first (state order)
@@ -637,6 +694,7 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
         if (h->st_bits) (void)hipFree(h->st_bits);
         h->st_bits = nullptr; h->st_bits_bytes = 0;
         HIP_TRY(h, hipMalloc((void**)&h->st_bits, bits_bytes));
+        HIP_TRY(h, hipMemset(h->st_bits, 0, bits_bytes));      // once: the kernels define bits[c][0 .. n_bits[c]) per call, the rest stays as it is
         h->st_bits_bytes = bits_bytes;
     }
     if (!h->st_nbits) HIP_TRY(h, hipMalloc((void**)&h->st_nbits, sizeof(int) * C));
@@ -647,7 +705,9 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
         h->st_sym_bytes = sym_bytes;
     }
     if (iq_bytes) HIP_TRY(h, hipMemcpy(h->st_iq, iq, iq_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemset(h->st_bits, 0, bits_bytes));
+#ifdef TETRA_DEMOD_DEBUG
+    HIP_TRY(h, hipMemset(h->st_bits, 0, bits_bytes));      // release builds: only bits[c][0 .. n_bits[c]) are defined
+#endif
     int rc = tetra_demod_process_device(h, h->st_iq ? h->st_iq : reinterpret_cast<const float*>(h->agc_g), n_samples,
                                         h->st_bits, bits_stride, h->st_nbits, sym ? h->st_sym : nullptr, nullptr);
     if (rc != TETRA_OK) return rc;
@@ -655,7 +715,8 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
     HIP_TRY(h, hipMemcpy(bits, h->st_bits, bits_bytes, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(n_bits, h->st_nbits, sizeof(int) * C, hipMemcpyDeviceToHost));
     if (sym) HIP_TRY(h, hipMemcpy(sym, h->st_sym, sym_bytes, hipMemcpyDeviceToHost));
-    return TETRA_OK;
+    const int cut = new_overruns(h);
+    return cut > 0 ? TETRA_ERR_OVERRUN : cut;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,32 +744,13 @@ int async_chunk_len(int n_samples) {
 }
 }  // namespace
 
-int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride,
-                              int32_t* n_bits) {
-    if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
-    if (iq_format != TETRA_IQ_CF32 && iq_format != TETRA_IQ_CS16 && iq_format != TETRA_IQ_CS8) return TETRA_ERR_ARG;
-    if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
-    if (bits_stride < tetra_demod_bits_stride(n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
-    DeviceGuard g(h->device);
-    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+namespace {
+// The body of tetra_demod_process_async after its resources exist; any failure leaves work enqueued on the three streams.
+int async_enqueue(tetra_demod* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride, int32_t* n_bits) {
     auto& a = h->as;
     const size_t C = (size_t)h->C;
-    if (!a.ready) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&a.s_in, hipStreamNonBlocking));
-        HIP_TRY(h, hipStreamCreateWithFlags(&a.s_k, hipStreamNonBlocking));
-        HIP_TRY(h, hipStreamCreateWithFlags(&a.s_out, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_in[i], hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_free[i], hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_done[i], hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&a.ev_out[i], hipEventDisableTiming));
-            HIP_TRY(h, hipMalloc((void**)&a.d_cnb[i], sizeof(int) * C));
-            HIP_TRY(h, hipMalloc((void**)&a.d_onb[i], sizeof(int) * C));
-        }
-        a.ready = true;
-    }
     const int chunk = async_chunk_len(n_samples);
-    const int cstride = tetra_demod_bits_stride(chunk);
+    const int cstride = (int)stride_for(h->design, chunk);
     const size_t in_elem = iq_format == TETRA_IQ_CS16 ? sizeof(short) * 2 : iq_format == TETRA_IQ_CS8 ? 2 : sizeof(float) * 2;
     const size_t want_iq = sizeof(float) * 2 * C * (size_t)chunk, want_raw = iq_format != TETRA_IQ_CF32 ? in_elem * C * (size_t)chunk : 0;
     const size_t want_cbits = C * (size_t)cstride, want_out = C * (size_t)bits_stride;
@@ -721,6 +763,7 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
             if (want_raw) { t = a.raw_bytes; if ((rc = grow(h, &a.d_raw[i], &t, want_raw))) return rc; }
             t = a.cbits_bytes; if ((rc = grow(h, (void**)&a.d_cbits[i], &t, want_cbits))) return rc;
             t = a.out_bytes; if ((rc = grow(h, (void**)&a.d_out[i], &t, want_out))) return rc;
+            if (want_out > a.out_bytes) HIP_TRY(h, hipMemset(a.d_out[i], 0, want_out));      // once; a call defines bits[c][0 .. n_bits[c])
         }
         a.iq_bytes = a.iq_bytes > want_iq ? a.iq_bytes : want_iq;
         if (want_raw) a.raw_bytes = a.raw_bytes > want_raw ? a.raw_bytes : want_raw;
@@ -729,7 +772,6 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
     }
     const int os = (int)(a.calls & 1);               // output slot of this call
     if (a.calls >= 2) HIP_TRY(h, hipStreamWaitEvent(a.s_k, a.ev_out[os], 0));     // its previous user's D2H is done
-    HIP_TRY(h, hipMemsetAsync(a.d_out[os], 0, want_out, a.s_k));
     HIP_TRY(h, hipMemsetAsync(a.d_onb[os], 0, sizeof(int) * C, a.s_k));
     const bool time_major = h->cfg.layout == TETRA_LAYOUT_TIME_MAJOR;
     const uint8_t* src = static_cast<const uint8_t*>(iq);
@@ -773,6 +815,50 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
     a.calls++;
     return TETRA_OK;
 }
+}  // namespace
+
+int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, int n_samples, uint8_t* bits, int bits_stride,
+                              int32_t* n_bits) {
+    if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
+    if (iq_format != TETRA_IQ_CF32 && iq_format != TETRA_IQ_CS16 && iq_format != TETRA_IQ_CS8) return TETRA_ERR_ARG;
+    if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
+    if (bits_stride < stride_for(h->design, n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    auto& a = h->as;
+    const size_t C = (size_t)h->C;
+    if (n_samples == 0) {      // nothing to enqueue: the counts are final right away
+        for (size_t c = 0; c < C; c++) n_bits[c] = 0;
+        return TETRA_OK;
+    }
+    if (!a.ready) {
+        // every resource is created only where it is still missing, so a call after a failed set-up neither leaks nor
+        // re-creates what already exists
+        if (!a.s_in) HIP_TRY(h, hipStreamCreateWithFlags(&a.s_in, hipStreamNonBlocking));
+        if (!a.s_k) HIP_TRY(h, hipStreamCreateWithFlags(&a.s_k, hipStreamNonBlocking));
+        if (!a.s_out) HIP_TRY(h, hipStreamCreateWithFlags(&a.s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            if (!a.ev_in[i]) HIP_TRY(h, hipEventCreateWithFlags(&a.ev_in[i], hipEventDisableTiming));
+            if (!a.ev_free[i]) HIP_TRY(h, hipEventCreateWithFlags(&a.ev_free[i], hipEventDisableTiming));
+            if (!a.ev_done[i]) HIP_TRY(h, hipEventCreateWithFlags(&a.ev_done[i], hipEventDisableTiming));
+            if (!a.ev_out[i]) HIP_TRY(h, hipEventCreateWithFlags(&a.ev_out[i], hipEventDisableTiming));
+            if (!a.d_cnb[i]) HIP_TRY(h, hipMalloc((void**)&a.d_cnb[i], sizeof(int) * C));
+            if (!a.d_onb[i]) HIP_TRY(h, hipMalloc((void**)&a.d_onb[i], sizeof(int) * C));
+        }
+        a.ready = true;
+    }
+    const int rc = async_enqueue(h, iq, iq_format, n_samples, bits, bits_stride, n_bits);
+    if (rc != TETRA_OK) {
+        // part of the call may be enqueued: let it drain, then start the slot / event bookkeeping afresh (no wait of a later
+        // call refers to an event this call did not get to record)
+        (void)hipStreamSynchronize(a.s_in);
+        (void)hipStreamSynchronize(a.s_k);
+        (void)hipStreamSynchronize(a.s_out);
+        a.chunks = 0;
+        a.calls = 0;
+    }
+    return rc;
+}
 
 int tetra_demod_wait(tetra_demod_t* h) {
     if (!h) return TETRA_ERR_ARG;
@@ -782,6 +868,18 @@ int tetra_demod_wait(tetra_demod_t* h) {
     HIP_TRY(h, hipStreamSynchronize(h->as.s_in));
     HIP_TRY(h, hipStreamSynchronize(h->as.s_k));
     HIP_TRY(h, hipStreamSynchronize(h->as.s_out));
+    const int cut = new_overruns(h);
+    return cut > 0 ? TETRA_ERR_OVERRUN : cut;
+}
+
+int tetra_demod_get_overruns(tetra_demod_t* h, long long* total) {
+    if (!h || !total) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    int v = 0;
+    HIP_TRY(h, hipMemcpy(&v, h->d_overruns, sizeof(int), hipMemcpyDeviceToHost));
+    *total = v;
     return TETRA_OK;
 }
 
@@ -803,35 +901,16 @@ int tetra_demod_reset(tetra_demod_t* h, int channel) {
     return channel < 0 ? reset_range(h, 0, h->C, !h->quirks) : reset_range(h, channel, 1, !h->quirks);
 }
 
-int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
-    if (!h) return TETRA_ERR_ARG;
-    host::DesignParams np = h->dp;
+namespace {
+// What every setter ends in: validate the new parameter set, re-design what `tables` / `with_tap_count` ask for, then commit
+// (device tables, the RRC's view of a longer delay line, the timing loop, the statistic's symbol scratch).
+int apply_params(tetra_demod* h, const host::DesignParams& np, bool tables, bool new_tap_count, bool timing_reset) {
     host::Design nd = h->design;          // caller-supplied tables and everything a setter does not own are carried over
-    bool timing_reset = false, tables = false;
-    switch (param_id) {
-    // loop setters (pi4dqpsk.cpp:76-118): loop constants only
-    case TETRA_PARAM_AGC_RATE: np.agc_rate = value; break;
-    case TETRA_PARAM_COSTAS_BANDWIDTH: np.costas_bandwidth = value; break;
-    case TETRA_PARAM_FLL_BANDWIDTH: np.fll_bandwidth = value; break;
-    case TETRA_PARAM_OMEGA_GAIN: np.omega_gain = value; break;
-    case TETRA_PARAM_MU_GAIN: np.mu_gain = value; break;
-    case TETRA_PARAM_OMEGA_REL_LIMIT: np.omega_rel_limit = value; break;
-    // rate setters (pi4dqpsk.cpp:32-54): RRC taps + COMPLEX_FD::setOmega; the FLL's filters are not touched
-    case TETRA_PARAM_SYMBOLRATE:
-    case TETRA_PARAM_SAMPLERATE:
-        if (param_id == TETRA_PARAM_SYMBOLRATE) np.symbolrate = value; else np.samplerate = value;
-        timing_reset = tables = true;
-        break;
-    // setRRCParams (pi4dqpsk.cpp:56-74)
-    case TETRA_PARAM_RRC_TAP_COUNT: np.rrc_tap_count = (int)value; tables = true; break;
-    case TETRA_PARAM_RRC_BETA: np.rrc_beta = h->quirks ? (double)(int)value : value; tables = true; break;   // setRRCBeta(int), pi4dqpsk.h:56
-    default: return TETRA_ERR_ARG;
-    }
     if (!host::params_ok(np)) return TETRA_ERR_UNSUPPORTED;
     if (tables) {
         if (h->user_rrc) return TETRA_ERR_UNSUPPORTED;                 // would have to re-design a caller-supplied table
         host::design_rrc(np, nd);
-        if (param_id == TETRA_PARAM_RRC_TAP_COUNT && !h->quirks && np.rrc_tap_count != nd.ntaps_be) {
+        if (new_tap_count && !h->quirks && np.rrc_tap_count != nd.ntaps_be) {
             if (h->user_be) return TETRA_ERR_UNSUPPORTED;
             host::design_bandedge(np, nd, np.rrc_tap_count);           // documented deviation: one length for the three FIRs
         }
@@ -839,9 +918,19 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
     }
     host::design_loops(np, nd);
     host::design_timing_limits(np, nd);
+    if (stride_for(nd, h->max_samples) > 0x7ffffff0ll) return TETRA_ERR_UNSUPPORTED;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
+    if (h->q_ring && stride_for(nd, h->max_samples) / 2 > h->q_sym_stride) {
+        // a slower timing loop emits more symbols per sample: the statistic's symbol scratch grows with it
+        const long long want = stride_for(nd, h->max_samples) / 2;
+        float2* q = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&q, sizeof(float2) * (size_t)h->C * (size_t)want));
+        (void)hipFree(h->q_sym);
+        h->q_sym = q;
+        h->q_sym_stride = want;
+    }
     const int old_ntaps = h->design.ntaps;
     h->dp = np;
     h->design = nd;
@@ -861,6 +950,42 @@ int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
         HIP_TRY(h, hipStreamSynchronize(0));
     }
     return TETRA_OK;
+}
+}  // namespace
+
+int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value) {
+    if (!h) return TETRA_ERR_ARG;
+    host::DesignParams np = h->dp;
+    bool timing_reset = false, tables = false;
+    switch (param_id) {
+    // loop setters (pi4dqpsk.cpp:76-118): loop constants only
+    case TETRA_PARAM_AGC_RATE: np.agc_rate = value; break;
+    case TETRA_PARAM_COSTAS_BANDWIDTH: np.costas_bandwidth = value; break;
+    case TETRA_PARAM_FLL_BANDWIDTH: np.fll_bandwidth = value; break;
+    case TETRA_PARAM_OMEGA_GAIN: np.omega_gain = value; break;
+    case TETRA_PARAM_MU_GAIN: np.mu_gain = value; break;
+    case TETRA_PARAM_OMEGA_REL_LIMIT: np.omega_rel_limit = value; break;
+    // rate setters (pi4dqpsk.cpp:32-54): RRC taps + COMPLEX_FD::setOmega; the FLL's filters are not touched
+    case TETRA_PARAM_SYMBOLRATE:
+    case TETRA_PARAM_SAMPLERATE:
+        if (param_id == TETRA_PARAM_SYMBOLRATE) np.symbolrate = value; else np.samplerate = value;
+        timing_reset = tables = true;
+        break;
+    // setRRCTapCount / the beta half of setRRCParams (pi4dqpsk.cpp:56-74)
+    case TETRA_PARAM_RRC_TAP_COUNT: np.rrc_tap_count = (int)value; tables = true; break;
+    case TETRA_PARAM_RRC_BETA: np.rrc_beta = value; tables = true; break;
+    default: return TETRA_ERR_ARG;
+    }
+    return apply_params(h, np, tables, param_id == TETRA_PARAM_RRC_TAP_COUNT, timing_reset);
+}
+
+// PI4DQPSK::setRRCParams (pi4dqpsk.cpp:56-66): tap count and roll-off in ONE re-design of the RRC.
+int tetra_demod_set_rrc_params(tetra_demod_t* h, int rrc_tap_count, double rrc_beta) {
+    if (!h) return TETRA_ERR_ARG;
+    host::DesignParams np = h->dp;
+    np.rrc_tap_count = rrc_tap_count;
+    np.rrc_beta = rrc_beta;
+    return apply_params(h, np, true, true, false);
 }
 
 int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out) {
@@ -901,10 +1026,11 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     return TETRA_OK;
 }
 
-int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, float* be_re, float* be_im, float* bank) {
+int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, int* be_taps, float* be_re, float* be_im, float* bank) {
     if (!h) return TETRA_ERR_ARG;
     const int nt = h->design.ntaps;
     if (taps) *taps = nt;
+    if (be_taps) *be_taps = h->design.ntaps_be;
     if (rrc) std::memcpy(rrc, h->design.rrc.data(), sizeof(float) * nt);
     if (be_re) std::memcpy(be_re, h->design.be_re.data(), sizeof(float) * h->design.ntaps_be);
     if (be_im) std::memcpy(be_im, h->design.be_im.data(), sizeof(float) * h->design.ntaps_be);
@@ -920,7 +1046,7 @@ int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples) {
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
-    // NOTE: k2 has already rotated the last 7 rows to the front; rows kYHist.. still hold this call's y.
+    // rows kYHist.. of the time-major scratch hold this call's y
     const size_t C = (size_t)h->C;
     std::vector<float2> tm((size_t)n_samples * C);
     if (n_samples)
@@ -931,25 +1057,19 @@ int tetra_demod_debug_read_rrc_out(tetra_demod_t* h, float* y, int n_samples) {
     return TETRA_OK;
 }
 
-int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* k1_ms, float* k2_ms) {
-    if (!h || n < 1 || n > tetra_demod::kEvSlots || (long long)n > h->n_calls) return TETRA_ERR_ARG;
+int tetra_demod_kernel_ms_history(tetra_demod_t* h, int n, float* ms) {
+    if (!h || !ms || n < 1 || n > tetra_demod::kEvSlots || (long long)n > h->n_calls) return TETRA_ERR_ARG;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     for (int i = 0; i < n; i++) {
         hipEvent_t* ev = h->ev[(h->n_calls - n + i) % tetra_demod::kEvSlots];
-        HIP_TRY(h, hipEventSynchronize(ev[2]));
-        float a = 0, b = 0;
-        HIP_TRY(h, hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIP_TRY(h, hipEventElapsedTime(&b, ev[1], ev[2]));
-        if (k1_ms) k1_ms[i] = a;
-        if (k2_ms) k2_ms[i] = b;
+        HIP_TRY(h, hipEventSynchronize(ev[1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms[i], ev[0], ev[1]));
     }
     return TETRA_OK;
 }
 
-int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* k1_ms, float* k2_ms) {
-    return tetra_demod_kernel_ms_history(h, 1, k1_ms, k2_ms);
-}
+int tetra_demod_last_kernel_ms(tetra_demod_t* h, float* ms) { return tetra_demod_kernel_ms_history(h, 1, ms); }
 
 int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync) {
     if (!h) return TETRA_ERR_ARG;
@@ -982,6 +1102,26 @@ int tetra_demod_debug_selftest(tetra_demod_t* h, const float* in128, float* out3
     hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, din.p, dout.p);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpy(out320, dout.p, sizeof(float) * 320, hipMemcpyDeviceToHost));
+    return TETRA_OK;
+}
+
+int tetra_demod_debug_mfma_selftest(tetra_demod_t* h, int shape, int k, const float* a, const float* b, float* d) {
+    if (!h || !a || !b || !d || (shape != 16 && shape != 32) || k < 4 || (k & 3) || k > 4096) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    struct Tmp {
+        float* p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } da, db, dd;
+    const size_t na = (size_t)shape * k, nd = (size_t)shape * shape;
+    HIP_TRY(h, hipMalloc((void**)&da.p, sizeof(float) * na));
+    HIP_TRY(h, hipMalloc((void**)&db.p, sizeof(float) * na));
+    HIP_TRY(h, hipMalloc((void**)&dd.p, sizeof(float) * nd));
+    HIP_TRY(h, hipMemcpy(da.p, a, sizeof(float) * na, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(db.p, b, sizeof(float) * na, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, 0, shape, k, da.p, db.p, dd.p);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpy(d, dd.p, sizeof(float) * nd, hipMemcpyDeviceToHost));
     return TETRA_OK;
 }
 

@@ -32,10 +32,21 @@ void PI4DQPSK::init(stream<complex_t>* in, double symbolrate, double samplerate,
     cfg.flags |= TETRA_FLAG_REFERENCE_QUIRKS;   // this class IS the reference's block: reset() and the RRC setters behave like pi4dqpsk.cpp
     if (h_) { tetra_demod_destroy(h_); h_ = nullptr; }
     status_ = tetra_demod_create(&cfg, &h_);
-    const int stride = tetra_demod_bits_stride(STREAM_BUFFER_SIZE);
-    bitbuf_.assign(stride, 0);
-    symbuf_.assign((size_t)stride, 0.f);   // stride/2 complex
+    maxStride_ = 0;
+    resizeBuffers();
     base_type::init(in);
+}
+
+// Output rows for the largest call (count <= STREAM_BUFFER_SIZE) at the handle's current rates: grown after every setter
+// that can slow the timing loop down (more symbols per sample).
+void PI4DQPSK::resizeBuffers() {
+    if (!h_) return;
+    const int stride = tetra_demod_bits_stride_for(h_, STREAM_BUFFER_SIZE);
+    if (stride > maxStride_) {
+        maxStride_ = stride;
+        bitbuf_.assign((size_t)stride, 0);
+        symbuf_.assign((size_t)stride, 0.f);   // stride/2 complex
+    }
 }
 
 void PI4DQPSK::set(int id, double v) {
@@ -43,13 +54,22 @@ void PI4DQPSK::set(int id, double v) {
     std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
     base_type::tempStop();
     status_ = tetra_demod_set_param(h_, id, v);
+    resizeBuffers();
     base_type::tempStart();
 }
 void PI4DQPSK::setSymbolrate(double v) { set(TETRA_PARAM_SYMBOLRATE, v); }
 void PI4DQPSK::setSamplerate(double v) { set(TETRA_PARAM_SAMPLERATE, v); }
-void PI4DQPSK::setRRCParams(int n, double beta) { set(TETRA_PARAM_RRC_TAP_COUNT, n); set(TETRA_PARAM_RRC_BETA, beta); }
+// pi4dqpsk.cpp:56-66: tap count and roll-off (the double, untruncated) in one re-design of the RRC
+void PI4DQPSK::setRRCParams(int n, double beta) {
+    assert(base_type::_block_init);
+    std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
+    base_type::tempStop();
+    status_ = tetra_demod_set_rrc_params(h_, n, beta);
+    base_type::tempStart();
+}
 void PI4DQPSK::setRRCTapCount(int n) { set(TETRA_PARAM_RRC_TAP_COUNT, n); }
-void PI4DQPSK::setRRCBeta(double beta) { set(TETRA_PARAM_RRC_BETA, beta); }
+// pi4dqpsk.cpp:72 through the int parameter of pi4dqpsk.h:56: setRRCBeta(0.35) designs with roll-off 0, like the reference
+void PI4DQPSK::setRRCBeta(int beta) { set(TETRA_PARAM_RRC_BETA, (double)beta); }
 void PI4DQPSK::setAGCRate(double v) { set(TETRA_PARAM_AGC_RATE, v); }
 void PI4DQPSK::setCostasBandwidth(double v) { set(TETRA_PARAM_COSTAS_BANDWIDTH, v); }
 void PI4DQPSK::setFllBandwidth(double v) { set(TETRA_PARAM_FLL_BANDWIDTH, v); }
@@ -70,11 +90,14 @@ void PI4DQPSK::reset() {
 
 int PI4DQPSK::process(int count, const complex_t* in, complex_t* out) {
     if (!h_) return -1;
-    const int stride = tetra_demod_bits_stride(count);
+    const int stride = tetra_demod_bits_stride_for(h_, count);
+    if (stride < 0 || stride > maxStride_) { status_ = TETRA_ERR_SIZE; return -1; }
     int32_t nb = 0;
     status_ = tetra_demod_process(h_, reinterpret_cast<const float*>(in), count, bitbuf_.data(), stride, &nb,
                                   symbuf_.data());
-    if (status_ != TETRA_OK) return -1;
+    // TETRA_ERR_OVERRUN: the symbols up to the row's capacity were delivered (a NaN/Inf-poisoned stream); the reference's
+    // process() cannot fail, so the block keeps running and lastStatus() tells
+    if (status_ != TETRA_OK && status_ != TETRA_ERR_OVERRUN) return -1;
     const int nsym = nb / 2;
     std::memcpy(out, symbuf_.data(), sizeof(complex_t) * (size_t)nsym);
     bits_.assign(bitbuf_.begin(), bitbuf_.begin() + nb);
@@ -91,7 +114,7 @@ int PI4DQPSKBank::init(const tetra_demod_config_t& cfg) {
 }
 int PI4DQPSKBank::process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits, complex_t* symbols) {
     if (!h_) return TETRA_ERR_ARG;
-    return tetra_demod_process(h_, reinterpret_cast<const float*>(in), count, bits, tetra_demod_bits_stride(count), nBits,
+    return tetra_demod_process(h_, reinterpret_cast<const float*>(in), count, bits, tetra_demod_bits_stride_for(h_, count), nBits,
                                reinterpret_cast<float*>(symbols));
 }
 int PI4DQPSKBank::reset(int channel) { return h_ ? tetra_demod_reset(h_, channel) : TETRA_ERR_ARG; }
@@ -143,18 +166,30 @@ void PI4DQPSKMultiBank::workerLoop(Shard* s) {
     long long seen = 0;
     for (;;) {
         Job j;
+        int shard = 0;
         {
             std::unique_lock<std::mutex> l(m_);
             cv_.wait(l, [&] { return quit_ || epoch_ != seen; });
             if (quit_) return;
             seen = epoch_;
             j = job_;
+            while (shards_[(size_t)shard].get() != s) shard++;
         }
         // this shard's rows of the caller's buffers; its own handle, device and streams
-        const size_t stride = (size_t)tetra_demod_bits_stride(j.count);
-        int rc = tetra_demod_process_async(s->h, j.in + (size_t)s->first * (size_t)j.count, TETRA_IQ_CF32, j.count,
-                                           j.bits + (size_t)s->first * stride, (int)stride, j.nBits + s->first);
-        if (rc == TETRA_OK) rc = tetra_demod_wait(s->h);
+        const int stride = tetra_demod_bits_stride_for(s->h, j.count);
+        int rc;
+        if (j.dIn) {
+            // samples already on this shard's GPU: one launch on the handle's own stream, waited for here
+            rc = tetra_demod_process_resident(s->h, reinterpret_cast<const float*>(j.dIn[shard]), j.count, j.dBits[shard], stride,
+                                              j.dNBits[shard], nullptr);
+        } else {
+            const size_t elem = j.format == TETRA_IQ_CS16 ? 2 * sizeof(int16_t) : sizeof(complex_t);
+            rc = stride < 0 ? stride
+                            : tetra_demod_process_async(s->h, static_cast<const uint8_t*>(j.in) + elem * (size_t)s->first * (size_t)j.count,
+                                                        j.format, j.count, j.bits + (size_t)s->first * (size_t)stride, stride,
+                                                        j.nBits + s->first);
+            if (rc == TETRA_OK) rc = tetra_demod_wait(s->h);
+        }
         {
             std::lock_guard<std::mutex> l(m_);
             s->status = rc;
@@ -164,16 +199,51 @@ void PI4DQPSKMultiBank::workerLoop(Shard* s) {
     }
 }
 
-int PI4DQPSKMultiBank::process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits) {
-    if (shards_.empty() || !in || !bits || !nBits) return TETRA_ERR_ARG;
+int PI4DQPSKMultiBank::run(const Job& j) {
     std::unique_lock<std::mutex> l(m_);
-    job_.count = count; job_.in = in; job_.bits = bits; job_.nBits = nBits;
+    job_ = j;
     pending_ = (int)shards_.size();
     epoch_++;
     cv_.notify_all();
     cv_.wait(l, [&] { return pending_ == 0; });
-    for (auto& s : shards_)
-        if (s->status != TETRA_OK) return s->status;
+    int overrun = TETRA_OK;
+    for (auto& s : shards_) {
+        if (s->status == TETRA_ERR_OVERRUN) overrun = TETRA_ERR_OVERRUN;      // every shard delivered; report it last
+        else if (s->status != TETRA_OK) return s->status;
+    }
+    return overrun;
+}
+
+int PI4DQPSKMultiBank::process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits) {
+    if (shards_.empty() || !in || !bits || !nBits) return TETRA_ERR_ARG;
+    Job j;
+    j.count = count; j.format = TETRA_IQ_CF32; j.in = in; j.bits = bits; j.nBits = nBits;
+    return run(j);
+}
+
+int PI4DQPSKMultiBank::processCS16(int count, const int16_t* in, uint8_t* bits, int32_t* nBits) {
+    if (shards_.empty() || !in || !bits || !nBits) return TETRA_ERR_ARG;
+    Job j;
+    j.count = count; j.format = TETRA_IQ_CS16; j.in = in; j.bits = bits; j.nBits = nBits;
+    return run(j);
+}
+
+int PI4DQPSKMultiBank::processDevice(int count, const complex_t* const* in, uint8_t* const* bits, int32_t* const* nBits) {
+    if (shards_.empty() || !in || !bits || !nBits) return TETRA_ERR_ARG;
+    for (size_t g = 0; g < shards_.size(); g++)
+        if (!in[g] || !bits[g] || !nBits[g]) return TETRA_ERR_ARG;
+    Job j;
+    j.count = count; j.dIn = in; j.dBits = bits; j.dNBits = nBits;
+    return run(j);
+}
+
+// DQPSKSymbolExtractor's standarderr / sync of every channel, shard by shard into the caller's arrays
+int PI4DQPSKMultiBank::quality(float* standarderr, uint8_t* sync) {
+    if (shards_.empty()) return TETRA_ERR_ARG;
+    for (auto& s : shards_) {
+        const int rc = tetra_demod_get_quality(s->h, standarderr ? standarderr + s->first : nullptr, sync ? sync + s->first : nullptr);
+        if (rc != TETRA_OK) return rc;
+    }
     return TETRA_OK;
 }
 

@@ -31,10 +31,12 @@ class PI4DQPSK : public Processor<complex_t, complex_t> {
 
 public:
     PI4DQPSK() {}
+    // Like the reference's constructor (src/dsp/pi4dqpsk.h:32), this one does NOT forward omegaRelLimit: init() runs with
+    // its default 0.01 whatever is passed here.  (The plugin default-constructs and calls init, src/main.cpp:84.)
     PI4DQPSK(stream<complex_t>* in, double symbolrate, double samplerate, int rrcTapCount, double rrcBeta, double agcRate,
              double costasBandwidth, double fllBandwidth, double omegaGain, double muGain, double omegaRelLimit = 0.01) {
-        init(in, symbolrate, samplerate, rrcTapCount, rrcBeta, agcRate, costasBandwidth, fllBandwidth, omegaGain, muGain,
-             omegaRelLimit);
+        (void)omegaRelLimit;
+        init(in, symbolrate, samplerate, rrcTapCount, rrcBeta, agcRate, costasBandwidth, fllBandwidth, omegaGain, muGain);
     }
     ~PI4DQPSK();
 
@@ -58,7 +60,7 @@ public:
     void setSamplerate(double samplerate);
     void setRRCParams(int rrcTapCount, double rrcBeta);
     void setRRCTapCount(int rrcTapCount);
-    void setRRCBeta(double rrcBeta);
+    void setRRCBeta(int rrcBeta);      // an int, like src/dsp/pi4dqpsk.h:56: a fractional roll-off is truncated by the call itself
     void setAGCRate(double agcRate);
     void setCostasBandwidth(double bandwidth);
     void setFllBandwidth(double fllBandwidth);
@@ -75,10 +77,14 @@ public:
     // Extras the GPU path gives for free: the unpacked bits of the last process() call
     // (= DQPSKSymbolExtractor + BitUnpacker output for the same symbols).
     const std::vector<uint8_t>& lastBits() const { return bits_; }
+    // TETRA_OK, or the status of the last failing C-ABI call.  TETRA_ERR_OVERRUN after process() means the call delivered
+    // its symbols but a NaN/Inf-poisoned stream filled the output row and the rest of the call's samples were dropped.
     int lastStatus() const { return status_; }
 
 private:
     void set(int id, double v);
+    void resizeBuffers();
+    int maxStride_ = 0;
     tetra_demod_t* h_ = nullptr;
     int status_ = TETRA_ERR_ARG;
     std::vector<uint8_t> bitbuf_, bits_;
@@ -97,7 +103,8 @@ public:
     // in: n_channels x count complex samples in cfg.layout; bits: [n_channels][bitsStride(count)];
     // nBits: [n_channels].  Returns a TETRA_* status.
     int process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits, complex_t* symbols = nullptr);
-    int bitsStride(int count) const { return tetra_demod_bits_stride(count); }
+    // row length for calls of `count` samples with this bank's rates and timing-loop limits (tetra_demod_bits_stride_for)
+    int bitsStride(int count) const { return tetra_demod_bits_stride_for(h_, count); }
     int reset(int channel = -1);
     int setParam(int paramId, double value);
     // DQPSKSymbolExtractor's public standarderr / sync (src/dsp/dqpsk_sym_extr.h:36-37) for every channel; needs
@@ -128,7 +135,14 @@ public:
     // in: [n_channels][count] (page-locked memory makes the shards' copies overlap); bits: [n_channels][bitsStride(count)];
     // nBits: [n_channels].  Runs every shard concurrently and returns when all are done: TETRA_OK or the first failure.
     int process(int count, const complex_t* in, uint8_t* bits, int32_t* nBits);
-    int bitsStride(int count) const { return tetra_demod_bits_stride(count); }
+    // The same with interleaved int16 IQ as SDR hardware delivers it (converted on the GPUs as x / 32768; half the PCIe bytes).
+    int processCS16(int count, const int16_t* in, uint8_t* bits, int32_t* nBits);
+    // Input and output already on the GPUs (what a channeliser or a capture DMA leaves there; the path the throughput metric
+    // is quoted on): per shard s, in[s] = device pointer on devices[s] to that shard's [count_s channels][count] samples,
+    // bits[s] / nBits[s] = device rows [count_s][bitsStride(count)] / [count_s].  Every shard's launch goes onto its own
+    // stream on its own device from its own host thread; returns when all have finished (TETRA_OK or the first failure).
+    int processDevice(int count, const complex_t* const* in, uint8_t* const* bits, int32_t* const* nBits);
+    int bitsStride(int count) const { return shards_.empty() ? TETRA_ERR_ARG : tetra_demod_bits_stride_for(shards_[0]->h, count); }
     int reset();
     int setParam(int paramId, double value);
     // DQPSKSymbolExtractor's public standarderr / sync (src/dsp/dqpsk_sym_extr.h:36-37) for every channel; needs
@@ -146,7 +160,12 @@ private:
         std::thread worker;
         int status = TETRA_OK;
     };
-    struct Job { int count = 0; const complex_t* in = nullptr; uint8_t* bits = nullptr; int32_t* nBits = nullptr; };
+    struct Job {
+        int count = 0, format = TETRA_IQ_CF32;
+        const void* in = nullptr; uint8_t* bits = nullptr; int32_t* nBits = nullptr;                              // host buffers, all channels
+        const complex_t* const* dIn = nullptr; uint8_t* const* dBits = nullptr; int32_t* const* dNBits = nullptr;   // or per-shard device buffers
+    };
+    int run(const Job& j);
     void workerLoop(Shard* s);
     void shutdown();
     std::vector<std::unique_ptr<Shard>> shards_;

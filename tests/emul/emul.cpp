@@ -55,6 +55,18 @@ int emul_design(const tetra_demod_config_t* cfg, emul_tables* t) {
     return 0;
 }
 
+// The product's output-row rule (design.hpp bits_stride_for = tetra_demod_bits_stride_for): -1 when the design is refused.
+long long emul_bits_stride_for(const tetra_demod_config_t* cfg, long long n) {
+    host::DesignParams dp;
+    dp.symbolrate = cfg->symbolrate; dp.samplerate = cfg->samplerate; dp.rrc_tap_count = cfg->rrc_tap_count;
+    dp.rrc_beta = cfg->rrc_beta; dp.agc_rate = cfg->agc_rate; dp.costas_bandwidth = cfg->costas_bandwidth;
+    dp.fll_bandwidth = cfg->fll_bandwidth; dp.omega_gain = cfg->omega_gain; dp.mu_gain = cfg->mu_gain;
+    dp.omega_rel_limit = cfg->omega_rel_limit;
+    host::Design d;
+    if (!host::make_design(dp, nullptr, nullptr, nullptr, d)) return -1;
+    return host::bits_stride_for(d, n);
+}
+
 void emul_default_cfg(tetra_demod_config_t* cfg) {
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->n_channels = 1; cfg->max_samples = 65536; cfg->device = -1;

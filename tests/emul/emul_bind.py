@@ -63,6 +63,8 @@ def lib():
         L.emul_fused.restype = C.c_int
         L.emul_fused_shape.argtypes = L.emul_fused.argtypes + [C.c_int]
         L.emul_fused_shape.restype = C.c_int
+        L.emul_bits_stride_for.argtypes = [C.POINTER(Config), C.c_longlong]
+        L.emul_bits_stride_for.restype = C.c_longlong
         _lib = L
     return _lib
 
@@ -80,6 +82,11 @@ def design(cfg=None):
     if rc:
         raise ValueError("emul_design failed")
     return t
+
+
+def bits_stride_for(cfg, n):
+    """The product's row rule for a configuration (-1 = the product refuses the parameters)."""
+    return int(lib().emul_bits_stride_for(C.byref(cfg), int(n)))
 
 
 def _p(a):

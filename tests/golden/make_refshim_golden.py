@@ -53,6 +53,37 @@ def main():
     for k, (sym, bits) in enumerate((a, b, c)):
         out["ctl_sym%d" % k] = sym
         out["ctl_bits%d" % k] = bits
+    # 4. BASELINE config 5's rate: the chain created at 50 ksps (2.78 samples per symbol), one call
+    cfg50 = ob.default_cfg()
+    cfg50.samplerate = 50000.0
+    iq4, _, _ = synth.gen_channel(14000, 321, sps=50000.0 / 18000.0, cfo=0.015)
+    r = T.RefChain(L, cfg50)
+    out["rate50_iq"] = iq4
+    out["rate50_sym"], out["rate50_bits"] = r.process(iq4)
+    r.close()
+    # 5. eight chains side by side (one reference object set per channel), for the batched kernel: [8][7000] in, ragged out
+    iq5 = np.stack([synth.gen_channel(7000, 900 + c)[0] for c in range(8)])
+    syms, bitss = [], []
+    for c in range(8):
+        r = T.RefChain(L, ob.default_cfg())
+        s_, b_ = r.process(iq5[c])
+        r.close()
+        syms.append(s_)
+        bitss.append(b_)
+    out["multi8_iq"] = iq5
+    out["multi8_nsym"] = np.array([len(s_) for s_ in syms], np.int32)
+    out["multi8_sym"] = np.concatenate(syms)
+    out["multi8_bits"] = np.concatenate(bitss)
+    # 6. setRRCParams(49, 0.35) mid-stream: the roll-off stays a double (only setRRCBeta(int) truncates)
+    iq6, _, _ = synth.gen_channel(12000, 79, cfo=0.012, tau=0.9, amp=0.4)
+    r = T.RefChain(L, ob.default_cfg())
+    a6 = r.process(iq6[:6000])
+    r.set_rrc_params(49, 0.35)
+    b6 = r.process(iq6[6000:])
+    r.close()
+    out["rrcp_iq"] = iq6
+    out["rrcp_sym0"], out["rrcp_bits0"] = a6
+    out["rrcp_sym1"], out["rrcp_bits1"] = b6
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim_vectors.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")

@@ -3,6 +3,9 @@
 // Usage: test_block <iq.f32 (interleaved re,im)> <chunk> <out_symbols.f32> <out_bits.u8>   (chunk must be >= 2 so
 // that every chunk yields at least one symbol: like the reference, run() only swaps when symbols were produced)
 // Without arguments: only constructs the classes (compile/link check; needs no GPU).
+#include <hip/hip_runtime_api.h>      // only the "multibank-device" mode stages its own device buffers (the plugin side never needs HIP)
+
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,10 +14,15 @@
 
 #include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
 
-// test_block multibank <iq.f32 [C][n]> <C> <n> <calls> <out_bits.u8> <out_nbits.i32> [dev0 dev1 ...]
+// test_block multibank|multibank-cs16|multibank-device <iq.f32 [C][n]> <C> <n> <calls> <out_bits.u8> <out_nbits.i32> [dev0 dev1 ...]
 // PI4DQPSKMultiBank over the given devices (default: 0 0 = two shards, two host threads, two handles on ONE GPU), the
 // stream cut into `calls` equal calls; writes every call's bit rows [calls][C][stride] and counts [calls][C].
+//   multibank         process(): float IQ from page-locked host memory
+//   multibank-cs16    processCS16(): the same samples as interleaved int16 (x * 32768 rounded; the caller compares with the
+//                     oracle on the dequantised samples)
+//   multibank-device  processDevice(): every shard's samples, bit rows and counts live on that shard's GPU
 static int multibank_main(int argc, char** argv) {
+    const bool cs16 = !std::strcmp(argv[1], "multibank-cs16"), resident = !std::strcmp(argv[1], "multibank-device");
     const int C = std::atoi(argv[3]), n = std::atoi(argv[4]), calls = std::atoi(argv[5]);
     std::vector<int> devs;
     for (int i = 8; i < argc; i++) devs.push_back(std::atoi(argv[i]));
@@ -32,6 +40,21 @@ static int multibank_main(int argc, char** argv) {
     int rc = mb.init(cfg, devs);
     if (rc != TETRA_OK) { std::fprintf(stderr, "init failed: %s\n", tetra_demod_strerror(rc)); return 3; }
     const int stride = mb.bitsStride(per);
+    std::printf("stride %d\n", stride);
+    std::vector<int16_t> q;
+    // per-shard device buffers (multibank-device)
+    std::vector<dsp::complex_t*> dIn((size_t)mb.shards(), nullptr);
+    std::vector<uint8_t*> dBits((size_t)mb.shards(), nullptr);
+    std::vector<int32_t*> dNb((size_t)mb.shards(), nullptr);
+    if (resident)
+        for (int g = 0; g < mb.shards(); g++) {
+            int first, count, dev;
+            mb.shardInfo(g, first, count, dev);
+            if (hipSetDevice(dev) != hipSuccess) return 7;
+            if (hipMalloc((void**)&dIn[g], sizeof(dsp::complex_t) * (size_t)count * per) != hipSuccess) return 7;
+            if (hipMalloc((void**)&dBits[g], (size_t)count * stride) != hipSuccess) return 7;
+            if (hipMalloc((void**)&dNb[g], sizeof(int32_t) * count) != hipSuccess) return 7;
+        }
     // page-locked buffers: the shards' copies then really run side by side
     dsp::complex_t* in = (dsp::complex_t*)tetra_demod_host_alloc(sizeof(dsp::complex_t) * (size_t)C * per);
     uint8_t* bits = (uint8_t*)tetra_demod_host_alloc((size_t)C * stride);
@@ -42,7 +65,32 @@ static int multibank_main(int argc, char** argv) {
     for (int k = 0; k < calls; k++) {
         for (int c = 0; c < C; c++)
             std::memcpy(in + (size_t)c * per, iq.data() + 2 * ((size_t)c * n + (size_t)k * per), sizeof(dsp::complex_t) * per);
-        rc = mb.process(per, in, bits, nb);
+        if (cs16) {
+            q.resize((size_t)C * per * 2);
+            const float* fp = reinterpret_cast<const float*>(in);
+            for (size_t i = 0; i < q.size(); i++) {
+                float v = std::nearbyint(fp[i] * 32768.0f);
+                q[i] = (int16_t)(v > 32767.f ? 32767.f : v < -32768.f ? -32768.f : v);
+            }
+            rc = mb.processCS16(per, q.data(), bits, nb);
+        } else if (resident) {
+            for (int g = 0; g < mb.shards(); g++) {
+                int first, count, dev;
+                mb.shardInfo(g, first, count, dev);
+                if (hipSetDevice(dev) != hipSuccess ||
+                    hipMemcpy(dIn[g], in + (size_t)first * per, sizeof(dsp::complex_t) * (size_t)count * per, hipMemcpyHostToDevice) != hipSuccess) return 8;
+            }
+            rc = mb.processDevice(per, dIn.data(), dBits.data(), dNb.data());
+            for (int g = 0; g < mb.shards() && rc == TETRA_OK; g++) {
+                int first, count, dev;
+                mb.shardInfo(g, first, count, dev);
+                if (hipSetDevice(dev) != hipSuccess ||
+                    hipMemcpy(bits + (size_t)first * stride, dBits[g], (size_t)count * stride, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(nb + first, dNb[g], sizeof(int32_t) * count, hipMemcpyDeviceToHost) != hipSuccess) return 8;
+            }
+        } else {
+            rc = mb.process(per, in, bits, nb);
+        }
         if (rc != TETRA_OK) { std::fprintf(stderr, "process failed: %s\n", tetra_demod_strerror(rc)); return 5; }
         std::fwrite(bits, 1, (size_t)C * stride, fb);
         std::fwrite(nb, sizeof(int32_t), C, fn);
@@ -55,12 +103,18 @@ static int multibank_main(int argc, char** argv) {
         mb.shardInfo(g, first, count, dev);
         std::printf("shard %d: channels [%d, %d) on device %d\n", g, first, first + count, dev);
     }
+    if (cfg.flags & TETRA_FLAG_QUALITY) {      // not set by this driver today; exercises the link of MultiBank::quality
+        std::vector<float> e((size_t)C);
+        std::vector<uint8_t> sy((size_t)C);
+        if (mb.quality(e.data(), sy.data()) != TETRA_OK) return 9;
+    }
+    for (int g = 0; g < mb.shards(); g++) { (void)hipFree(dIn[g]); (void)hipFree(dBits[g]); (void)hipFree(dNb[g]); }
     tetra_demod_host_free(in); tetra_demod_host_free(bits); tetra_demod_host_free(nb);
     return 0;
 }
 
 int main(int argc, char** argv) {
-    if (argc >= 8 && !std::strcmp(argv[1], "multibank")) return multibank_main(argc, argv);
+    if (argc >= 8 && !std::strncmp(argv[1], "multibank", 9)) return multibank_main(argc, argv);
     tetra_demod_config_t cfg;
     tetra_demod_default_config(&cfg);
     if (argc < 5) {

@@ -64,6 +64,9 @@ int ref_set_param(void* h, int id, double v) {
     return 0;
 }
 
+// PI4DQPSK::setRRCParams (pi4dqpsk.cpp:56-66): tap count and the (untruncated, double) roll-off in one call.
+void ref_set_rrc_params(void* h, int taps, double beta) { ((Chain*)h)->demod.setRRCParams(taps, beta); }
+
 void ref_reset(void* h) { ((Chain*)h)->demod.reset(); }
 
 int ref_sync(void* h) { return ((Chain*)h)->extractor.sync ? 1 : 0; }

@@ -22,7 +22,7 @@ def test_header_symbols_all_exported(pkg):
     for n in names:
         assert hasattr(L, n), "declared in include/tetra_demod.h but not exported: " + n
     assert set(pkg.binding.EXPORTS) == set(names)
-    assert L.tetra_demod_abi_version() == 2
+    assert L.tetra_demod_abi_version() == 3
 
 
 def test_channeliser_header_symbols_all_exported(pkg):
@@ -175,6 +175,14 @@ int main(void) {
       if (tetra_ts_indicator_reset(NULL, -1) != TETRA_ERR_ARG) return 13;
       if (tetra_ts_indicator_process_device(NULL, NULL, 64, NULL, NULL, NULL, NULL) != TETRA_ERR_ARG) return 14;
       tetra_ts_indicator_destroy(NULL); }
+    /* the ABI-3 additions likewise */
+    { long long ov = 0;
+      if (tetra_demod_bits_stride_for(NULL, 16) != TETRA_ERR_ARG || tetra_demod_get_overruns(NULL, &ov) != TETRA_ERR_ARG) return 15;
+      if (tetra_demod_set_rrc_params(NULL, 65, 0.35) != TETRA_ERR_ARG) return 16;
+      if (tetra_demod_process_resident(NULL, NULL, 0, NULL, 0, NULL, NULL) != TETRA_ERR_ARG) return 17;
+      if (tetra_demod_kernel_ms_history(NULL, 1, NULL) != TETRA_ERR_ARG) return 18;
+      cfg.flags = TETRA_FLAG_WIDE_WORKGROUPS | TETRA_FLAG_NARROW_WORKGROUPS;       /* contradictory: refused before any device work */
+      { tetra_demod_t* hh = NULL; if (tetra_demod_create(&cfg, &hh) != TETRA_ERR_ARG || hh != NULL) return 19; } }
     tetra_demod_host_free(NULL);
     printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
     return 0;
@@ -184,7 +192,7 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), lib, "-Wl,-rpath," + os.path.dirname(lib),
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["65", "800", "2"]
+    assert out == ["65", "800", "3"]
 
 
 def test_generated_fll_assembly_is_current():

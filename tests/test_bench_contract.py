@@ -42,3 +42,32 @@ def test_line_constants():
     assert bench.CHANNELS_PER_GPU == 4096 and bench.SAMPLES == 36000
     # the flop count's itemisation adds up
     assert 9 + 36 + 520 + 12 + 260 + (96 + 12 + 72 + 16) / 2 == bench.FLOP_PER_SAMPLE
+
+
+def test_gpus_flag_launches_that_many_ranks(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no launcher around it) starts N ranks of the same command under torch.distributed.run
+    on 127.0.0.1 -- the driver's plain command line must not record N copies of the 1-GPU number."""
+    import subprocess
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert bench.launch_ranks(4, ["--gpus", "4", "--steps", "3"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.abspath(bench.__file__), "--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_rank_count_must_equal_gpus_flag():
+    """Under a launcher the world size has to be what --gpus says, or the line would claim a GPU count it did not run on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "is running as one of 2 rank(s)" in r.stderr

@@ -1,0 +1,43 @@
+"""bench.py's N > 1 path on real hardware: `python bench.py --gpus 2` by itself starts two ranks (here both mapped onto the
+one GPU of the box), once over gloo and once over RCCL; the line says n_gpus 2 and the known-answer check is green."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _run(backend):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--backend", backend]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+def _line(r):
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_gpus_2_runs_two_ranks(backend):
+    r = _run(backend)
+    if backend == "nccl" and r.returncode != 0 and "uplicate GPU" in (r.stderr + r.stdout):
+        # RCCL refuses two ranks on one device; the same command on a box with >= 2 GPUs is what the driver runs
+        os.makedirs(OUT, exist_ok=True)
+        open(os.path.join(OUT, "bench_gpus2_nccl_refused.txt"), "w").write((r.stderr + r.stdout)[-3000:])
+        pytest.skip("RCCL refuses two ranks on the one GPU of this box (Duplicate GPU)")
+    d = _line(r)
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(d, open(os.path.join(OUT, "bench_gpus2_%s.json" % backend), "w"))
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["dist_backend"] == backend and d["rccl_world_size"] == (2 if backend == "nccl" else None)
+    assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
+    # two ranks of 4096 channels each: the whole-job value counts both
+    assert abs(d["value"] - 2 * 4096 * 36000 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]

@@ -31,6 +31,93 @@ def test_host_design_equals_oracle_design(emul, oracle):
     assert t.tr_omega == o.tab.tr_omega
 
 
+@pytest.mark.parametrize("rates", [(18000.0, 50000.0), (18000.0, 40000.0), (20000.0, 36000.0), (17000.0, 36000.0)])
+def test_host_design_equals_oracle_design_at_other_rates(emul, oracle, rates):
+    """BASELINE config 5 runs the demodulator at 50 ksps (2.78 samples per symbol): another band-edge design (fll.cpp:61-95
+    with sps != 2), another RRC, another omega and its limits (complex_fd.cpp:12-28) -- product and oracle tables bit for bit."""
+    sym, samp = rates
+    cfg = emul.default_cfg()
+    cfg.symbolrate, cfg.samplerate = sym, samp
+    t = emul.design(cfg)
+    oc = oracle.default_cfg()
+    oc.symbolrate, oc.samplerate = sym, samp
+    o = oracle.Oracle(oc)
+    a, b = o.bandedge_taps()
+    assert np.array_equal(np.ctypeslib.as_array(t.rrc)[:65], o.rrc_taps())
+    assert np.array_equal(np.ctypeslib.as_array(t.be_re)[:65], a) and np.array_equal(np.ctypeslib.as_array(t.be_im)[:65], b)
+    for f in ("tr_alpha", "tr_beta", "tr_min_freq", "tr_max_freq"):
+        assert getattr(t.k2, f) == getattr(o.tab, f), f
+    assert t.tr_omega == o.tab.tr_omega == np.float32(samp / sym)
+
+
+def test_emulated_kernels_match_oracle_at_50_ksps(emul, oracle, synth):
+    """The lane-level code at config 5's rate (a longer timing stride, other filters), two calls with carried state."""
+    cfg = emul.default_cfg()
+    cfg.samplerate = 50000.0
+    oc = oracle.default_cfg()
+    oc.samplerate = 50000.0
+    N = 9000
+    iq, _, _ = synth.gen_channel(N, 4242, sps=50000.0 / 18000.0, cfo=0.02)
+    o = oracle.Oracle(oc)
+    for lanes in (8, 4):
+        o = oracle.Oracle(oc)
+        e = emul.EmulDemod(1, cfg=cfg, fll_lanes=lanes)
+        for a, b in ((0, 5003), (5003, N)):
+            r = o.process(iq[a:b], stages=True)
+            q = e.process(iq[a:b], want_sym=True)
+            nb = int(q["n_bits"][0])
+            assert np.array_equal(_u32(q["y"][0]), _u32(r["y"]))
+            assert nb == r["bits"].size and np.array_equal(q["bits"][0][:nb], r["bits"])
+            assert np.array_equal(_u32(q["sym"][0][:nb // 2]), _u32(r["sym"]))
+        assert (e.st[0].mu, e.st[0].omega, e.st[0].offset) == (o.st.mu, o.st.omega, o.st.offset)
+
+
+@pytest.mark.parametrize("sym,samp,lim,mug", [(18000.0, 36000.0, 0.02, None), (20000.0, 36000.0, 0.02, None), (18000.0, 50000.0, 0.02, None),
+                                              (18000.0, 36000.0, 0.3, None), (30000.0, 36000.0, 0.05, 0.1), (18000.0, 36000.0, 0.0, 0.5)])
+def test_output_rows_hold_the_worst_stream(emul, oracle, sym, samp, lim, mug):
+    """No silent truncation: the product sizes a row from the slowest step its timing loop can take,
+    omega (1 - limit) - |mu_gain|.  The oracle (no row limit, like the reference's stream buffer) run on streams that push the
+    loop to its limits -- noise, a tone, a clock that is too fast -- never emits more than the row holds, at every call
+    length; and the parameter sets whose symbols would stop advancing are the ones the product refuses."""
+    cfg = emul.default_cfg()
+    cfg.symbolrate, cfg.samplerate, cfg.omega_rel_limit = sym, samp, lim
+    oc = oracle.default_cfg()
+    oc.symbolrate, oc.samplerate, oc.omega_rel_limit = sym, samp, lim
+    if mug is not None:
+        cfg.mu_gain = oc.mu_gain = mug
+    rng = np.random.default_rng(7)
+    N = 6000
+    noise = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    tone = np.exp(2j * np.pi * 0.23 * np.arange(N)).astype(np.complex64)
+    fast = emul_fast_clock(N, samp / sym * (1 - 1.5 * lim - 0.01))
+    for x in (noise, tone, fast):
+        for n in (1, 2, 7, 180, 1000, N):
+            o = oracle.Oracle(oc)
+            pos = 0
+            while pos + n <= N and pos < 3 * max(n, 700):
+                nb = o.process(x[pos:pos + n])["bits"].size
+                assert nb <= emul.bits_stride_for(cfg, n), (n, pos, nb)
+                pos += n
+
+
+def emul_fast_clock(N, sps):
+    """pi/4-DQPSK whose symbol clock runs at sps samples per symbol (faster than nominal: the loop sits on its lower limit)."""
+    from tetra_amd import pkg
+    return pkg.synth.gen_channel(N, 99, sps=sps, esn0_db=30.0)[0]
+
+
+def test_product_refuses_timing_loops_that_can_stall(emul):
+    """omega (1 - limit) - |mu_gain| < 1: the reference would emit several symbols from one offset (floor(mu) = 0); the
+    kernel does not implement that and says so (TETRA_ERR_UNSUPPORTED from create and from the setters) instead of dropping
+    samples.  Everything above is accepted -- there is no other limit on the rates."""
+    cfg = emul.default_cfg()
+    for sym, samp, lim, ok in ((18000.0, 36000.0, 0.02, True), (20000.0, 36000.0, 0.02, True), (30000.0, 36000.0, 0.1, True),
+                               (34000.0, 36000.0, 0.02, True), (36000.0, 36000.0, 0.02, False), (18000.0, 36000.0, 0.5, False),
+                               (18000.0, 36000.0, 0.49, True), (18000.0, 100000.0, 0.02, True), (18000.0, 36000.0, 1.0, False)):
+        cfg.symbolrate, cfg.samplerate, cfg.omega_rel_limit = sym, samp, lim
+        assert (emul.bits_stride_for(cfg, 1000) > 0) == ok, (sym, samp, lim)
+
+
 @pytest.mark.parametrize("N,chunks", [
     (5000, [5000]),
     (5000, [7] * 100 + [4300]),

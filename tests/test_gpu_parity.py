@@ -309,7 +309,7 @@ def test_setter_sequences_keep_what_they_do_not_own(pkg, oracle, synth):
     assert d.tables()["be_re"].size == 49 and np.array_equal(d.tables()["be_re"], orcs[0].bandedge_taps()[0])
     _run_vs_oracles(d, orcs, iq[:, 4000:])
     with pytest.raises(pkg.TetraDemodError):
-        d.set_param("omega_rel_limit", 0.2)                           # rows are sized for omega >= 2 x 0.95
+        d.set_param("omega_rel_limit", 0.6)                           # 2.22 x 0.4 - mu_gain < 1: symbols would stop advancing
     d.close()
 
 
@@ -365,7 +365,9 @@ def test_reference_quirks_flag(pkg, oracle, synth):
     assert d.get_state(2).rrc_valid == 32 == orcs[2].st.rrc_valid
     _run_vs_oracles(d, orcs, iq[:, 4500:4517])
     _run_vs_oracles(d, orcs, iq[:, 4517:6000])
-    d.set_param("rrc_beta", 1.7)                           # setRRCBeta(int): 1
+    # setRRCBeta(int), pi4dqpsk.h:56: the truncation happens in the call's own signature -- in the reference and in the C++
+    # mirror (host/pi4dqpsk_gpu.h) -- so what reaches the C ABI of setRRCBeta(1.7) is 1; the oracle restates the truncation
+    d.set_param("rrc_beta", float(int(1.7)))
     for o in orcs:
         o.set_param(3, 1.7, quirks=True)
     assert np.array_equal(d.tables()["rrc"], orcs[0].rrc_taps())
@@ -413,9 +415,17 @@ def test_non_finite_input_cannot_hang_or_overrun(pkg, synth, pipeline):
     bad[3, 100] = np.nan
     bad[7, 200] = np.inf
     d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
-    bits, nb, _ = d.process(bad)
+    with pytest.raises(pkg.TetraDemodError) as ei:      # never silently: the call reports that rows filled up
+        d.process(bad)
+    assert ei.value.status == pkg.binding.ERR_OVERRUN
+    assert d.overruns() == 2
+    d.close()
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    bits, nb, _ = d.process(bad, allow_overrun=True)
+    assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 2
     stride = bits.shape[1]
     assert (nb >= 0).all() and (nb <= stride).all()
+    assert nb[3] >= stride - 16 and nb[7] >= stride - 16            # the two poisoned rows are the full ones
     for c in range(Cn):
         if c not in (3, 7):
             assert nb[c] == clean[1][c] and np.array_equal(bits[c][:nb[c]], clean[0][c][:nb[c]]), c
@@ -456,7 +466,7 @@ def test_parity_4096_channels_full_second(pkg, oracle, synth):
         iq[k * Cb:(k + 1) * Cb] = base * (amp * rot)
     d = pkg.Demodulator(Cn, N)
     bits, nb, _ = d.process(iq)
-    k1, _ = d.last_kernel_ms()
+    k1 = d.last_kernel_ms()
     d.close()
     rb, rnb, _, _ = oracle.process_batch(iq)
     assert np.array_equal(nb, rnb)
@@ -676,4 +686,156 @@ def test_sync_call_after_an_async_one_without_wait(pkg, oracle, synth):
         r0, r1 = o.process(iq[c, :n]), o.process(iq[c, n:])
         assert nb0[c] == r0["bits"].size and np.array_equal(bits0.numpy()[c][:nb0[c]], r0["bits"]), c
         assert nb1[c] == r1["bits"].size and np.array_equal(bits1[c][:nb1[c]], r1["bits"]), c
+    d.close()
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_config5_rates_800_channels_time_major(pkg, oracle, synth, pipeline):
+    """BASELINE config 5's demodulator as the channeliser feeds it: 800 channels, time-major frames, samplerate 50000 AT CREATE
+    (2.78 samples per symbol: another band-edge design, fll.cpp:61-95 with sps != 2; another RRC; omega 2.78 and its limits,
+    complex_fd.cpp:12-28; a longer timing stride), 12500 frames per call, two consecutive calls -- every bit, symbol and the
+    carried state against the oracle created with the same rates, on both workgroup shapes."""
+    Cn, N = 800, 12500
+    sps = 50000.0 / 18000.0
+    base = 40
+    src, _, _ = synth.gen_batch(base, 2 * N, base_seed=5500, sps=sps)
+    rng = np.random.default_rng(55)
+    amp = rng.uniform(0.1, 2.0, (Cn, 1)).astype(np.float32)
+    rot = np.exp(1j * rng.uniform(-np.pi, np.pi, (Cn, 1))).astype(np.complex64)
+    iq = (src[np.arange(Cn) % base] * (amp * rot)).astype(np.complex64)
+    iq[7] = 0                                                              # an idle channel, like most of a real band
+    iq[8] = (0.05 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64)
+    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, samplerate=50000.0, flags=PIPELINES[pipeline] & 16)
+    oc = oracle.default_cfg()
+    oc.samplerate = 50000.0
+    t, o = d.tables(), oracle.Oracle(oc)
+    assert np.array_equal(t["rrc"], o.rrc_taps()) and np.array_equal(t["be_re"], o.bandedge_taps()[0])
+    assert np.array_equal(t["be_im"], o.bandedge_taps()[1])
+    assert d.bits_stride(N) < pkg.binding.bits_stride(N)                   # fewer symbols per sample than at 36 ksps
+    states = None
+    for k in range(2):
+        blk = np.ascontiguousarray(iq[:, k * N:(k + 1) * N])
+        bits, nb, sym = d.process(np.ascontiguousarray(blk.T), want_sym=True)
+        rb, rnb, rsym, states = oracle.process_batch(blk, cfg=oc, want_sym=True, states=states)
+        assert np.array_equal(nb, rnb), k
+        assert abs(int(nb[0]) - 2 * N / sps) < 40
+        bad = [c for c in range(Cn) if not np.array_equal(bits[c][:nb[c]], rb[c][:nb[c]])]
+        badsym = [c for c in range(Cn) if not np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(rsym[c][:nb[c] // 2]))]
+        assert not bad and not badsym, (k, bad[:10], badsym[:10])
+    for c in (0, 7, 8, 399, 799):
+        st, os_ = d.get_state(c), states[c]
+        for f in ("agc_gain", "fll_phase", "fll_freq", "mu", "omega", "offset", "costas_phase", "costas_freq", "ph2", "prev"):
+            assert getattr(st, f) == getattr(os_, f), (c, f)
+    d.close()
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_symbol_rate_setter_outside_two_samples_per_symbol(pkg, oracle, synth, pipeline):
+    """set_param(SYMBOLRATE, 20000) at 36 ksps (omega 1.8, omega_min 1.764: up to 1.15 n bits per call).
+    Rows are sized from the handle (tetra_demod_bits_stride_for), a call with the handle-free row length is refused loudly
+    (TETRA_ERR_SIZE), and with the right rows every bit and symbol equals the oracle's driven through the same setter; a
+    symbol rate whose symbols could stop advancing is refused (TETRA_ERR_UNSUPPORTED) and changes nothing."""
+    import ctypes as C
+    Cn, N = 20, 9000
+    iq, _, _ = synth.gen_batch(Cn, 2 * N, base_seed=2020, sps=1.8)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    d.set_param("symbolrate", 20000.0)
+    for o in orcs:
+        o.set_param(0, 20000.0)
+    small, need = pkg.binding.bits_stride(N), d.bits_stride(N)
+    assert need > small
+    bits = np.zeros((Cn, small), np.uint8)
+    nb = np.zeros(Cn, np.int32)
+    blk = np.ascontiguousarray(iq[:, :N])
+    rc = d._lib.tetra_demod_process(d._h, blk.ctypes.data_as(C.c_void_p), N, bits.ctypes.data_as(C.c_void_p), small,
+                                    nb.ctypes.data_as(C.c_void_p), None)
+    assert rc == -6                                                        # TETRA_ERR_SIZE, not a silently shortened row
+    for k in range(2):
+        _run_vs_oracles(d, orcs, iq[:, k * N:(k + 1) * N])
+    assert d.overruns() == 0
+    nbits = d.process(np.ascontiguousarray(iq[:, :N]))[1]
+    assert (nbits > small - 32).any() or (nbits > 2 * N / 1.9).all()      # more bits than the 2-samples-per-symbol row holds
+    with pytest.raises(pkg.TetraDemodError) as ei:
+        d.set_param("symbolrate", 36000.0)                                 # omega 1: symbols could stop advancing
+    assert ei.value.status == -2
+    assert d.bits_stride(N) == need                                        # nothing changed
+    d.close()
+
+
+def test_quality_scratch_rows_are_respected(pkg, oracle, synth):
+    """with TETRA_FLAG_QUALITY and no caller symbol buffer the Costas wave writes into the handle's own scratch,
+    whose rows are sized from max_samples; a caller's LARGER bits rows must not let a poisoned channel (one symbol per
+    sample) run past its scratch row into the next channel's.  The neighbours' statistic stays what it is without the poison."""
+    Cn, N = 6, 4000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=606)
+    ref = pkg.Demodulator(Cn, N, flags=pkg.binding.FLAG_QUALITY)
+    ref.process(iq)
+    err0, _ = ref.quality()
+    ref.close()
+    bad = iq.copy()
+    bad[2, 50] = np.nan
+    d = pkg.Demodulator(Cn, N, flags=pkg.binding.FLAG_QUALITY)
+    import torch
+    dev = torch.device("cuda", 0)
+    stride = 2 * N + 64                                                    # rows that could hold one symbol per sample
+    t_iq = torch.from_numpy(bad).to(dev)
+    t_bits = torch.zeros((Cn, stride), dtype=torch.uint8, device=dev)
+    t_nb = torch.zeros(Cn, dtype=torch.int32, device=dev)
+    d.process_device(t_iq, N, t_bits, stride, t_nb, None, torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    assert d.overruns() == 1                                               # cut at the scratch row, and said so
+    err, _ = d.quality()
+    for c in range(Cn):
+        if c != 2:
+            assert err[c] == err0[c], c
+    assert int(t_nb[2]) <= 2 * (d.bits_stride(N) // 2)
+    d.close()
+
+
+@pytest.mark.parametrize("shape", [16, 32])
+def test_matrix_pipe_f32_is_the_contract_fmaf_chain(pkg, oracle, shape):
+    """v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 chained over ascending k from +0 give,
+    bit for bit, the fmaf chain the arithmetic contract prescribes for every FIR sum (`for k: acc = fmaf(x[k], h[k], acc)`) --
+    also with zero taps at either end of the chain (the banded-Toeplitz form of a FIR pads every row with zeros: x * 0 = +-0
+    must leave the accumulator untouched), with negative zeros, huge dynamic range and subnormal products."""
+    d = pkg.Demodulator(1, 64)
+    rng = np.random.default_rng(shape)
+    M, K = shape, 96
+    cases = []
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((K, M)).astype(np.float32)
+    cases.append(("gaussian", a, b))
+    a2 = (rng.standard_normal((M, K)) * 10.0 ** rng.uniform(-12, 12, (M, K))).astype(np.float32)
+    b2 = (rng.standard_normal((K, M)) * 10.0 ** rng.uniform(-12, 12, (K, M))).astype(np.float32)
+    cases.append(("wide dynamic range", a2, b2))
+    # banded Toeplitz of a 65-tap filter: row i holds the taps at columns i .. i+64 of a 96 + M wide window, zeros elsewhere
+    taps = rng.standard_normal(65).astype(np.float32)
+    Kt = (65 + M - 1 + 3) // 4 * 4
+    t = np.zeros((M, Kt), np.float32)
+    for i in range(M):
+        t[i, i:i + 65] = taps
+    x = rng.standard_normal((Kt, M)).astype(np.float32)
+    x[::7] *= -1.0
+    cases.append(("banded Toeplitz", t, x))
+    tz = t.copy()
+    tz[:, ::2] *= 0.0          # zero taps inside the chain too
+    tz[tz == 0] = 0.0
+    xn = x.copy()
+    xn[5] = -np.abs(xn[5])     # negative samples against zero taps: products of -0
+    cases.append(("zeros and signed zeros", tz, xn))
+    a4 = (rng.standard_normal((M, K)) * 1e-22).astype(np.float32)
+    b4 = (rng.standard_normal((K, M)) * 1e-22).astype(np.float32)
+    cases.append(("subnormal products", a4, b4))
+    a5 = np.zeros((M, K), np.float32)
+    b5 = -np.abs(rng.standard_normal((K, M))).astype(np.float32)
+    cases.append(("all-zero taps, negative samples: the sum stays +0", a5, b5))
+    report = {}
+    for name, aa, bb in cases:
+        got = d.mfma_selftest(aa, bb)
+        want = oracle.fmaf_chain_matmul(aa, bb)
+        nbad = int(np.count_nonzero(_u32(got) != _u32(want)))
+        report[name] = nbad
+    _dump("mfma_selftest_%d.json" % shape, report)
+    assert not any(report.values()), report
     d.close()

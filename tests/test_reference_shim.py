@@ -48,6 +48,8 @@ def load_reference_build():
     L.ref_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.ref_set_param.restype = C.c_int
     L.ref_reset.argtypes = [C.c_void_p]
+    L.ref_set_rrc_params.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.ref_set_rrc_params.restype = None
     return L
 
 
@@ -76,6 +78,9 @@ class RefChain:
 
     def set_param(self, pid, v):
         assert self.L.ref_set_param(self.h, pid, float(v)) == 0
+
+    def set_rrc_params(self, taps, beta):
+        self.L.ref_set_rrc_params(self.h, int(taps), float(beta))
 
     def reset(self):
         self.L.ref_reset(self.h)
@@ -187,3 +192,44 @@ def test_reference_tap_count_setter_mid_stream(ref, oracle, synth):
         rms, mx, nbad = _compare(sym, bits, o.process(blk))
         assert nbad == 0 and rms <= RMS_TOL and mx <= MAX_TOL, (k, rms, mx, nbad)
     r.close()
+
+
+def test_set_rrc_params_keeps_the_double_roll_off(ref, oracle, synth):
+    """setRRCParams(int, double) (pi4dqpsk.cpp:56-66) keeps the roll-off as given -- only setRRCBeta(int)
+    truncates.  setRRCParams(49, 0.35) mid-stream on the reference's code versus the oracle's tap count (quirks: RRC only)
+    + untruncated roll-off: the stream stays locked and every bit is equal; the truncating form gives another filter."""
+    iq, _, _ = synth.gen_channel(14000, 79, cfo=0.012, tau=0.9, amp=0.4)
+    r = RefChain(ref, oracle.default_cfg())
+    o = oracle.Oracle()
+    r.process(iq[:7000]); o.process(iq[:7000])
+    r.set_rrc_params(49, 0.35)
+    o.set_param(2, 49, quirks=True); o.set_param(3, 0.35, quirks=False)
+    sym, bits = r.process(iq[7000:])
+    r.close()
+    oo = o.process(iq[7000:])
+    rms, mx, nbad = _compare(sym, bits, oo)
+    assert nbad == 0 and rms <= RMS_TOL and mx <= MAX_TOL, (rms, mx, nbad)
+    o2 = oracle.Oracle()
+    o2.process(iq[:7000])
+    o2.set_param(2, 49, quirks=True); o2.set_param(3, 0.35, quirks=True)       # setRRCBeta(int): roll-off 0
+    assert np.abs(o2.process(iq[7000:])["sym"][:200] - sym[:200]).max() > MAX_TOL
+
+
+def test_other_sample_rate_and_several_chains(ref, oracle, synth):
+    """50 ksps (BASELINE config 5's rate: sps 2.78 -- FLL::createBandedgeFilters fll.cpp:61-95 and COMPLEX_FD::init
+    complex_fd.cpp:12-28 with sps != 2) and eight chains side by side: reference code versus oracle."""
+    cfg = oracle.default_cfg()
+    cfg.samplerate = 50000.0
+    iq, _, _ = synth.gen_channel(30000, 321, sps=50000.0 / 18000.0, cfo=0.015)
+    r = RefChain(ref, cfg)
+    sym, bits = r.process(iq)
+    r.close()
+    rms, mx, nbad = _compare(sym, bits, oracle.Oracle(cfg).process(iq))
+    assert nbad == 0 and rms <= RMS_TOL and mx <= MAX_TOL, (rms, mx, nbad)
+    for c in range(8):
+        x, _, _ = synth.gen_channel(7000, 900 + c)
+        r = RefChain(ref, oracle.default_cfg())
+        sym, bits = r.process(x)
+        r.close()
+        rms, mx, nbad = _compare(sym, bits, oracle.Oracle().process(x))
+        assert nbad == 0 and rms <= RMS_TOL and mx <= MAX_TOL, (c, rms, mx, nbad)

@@ -48,6 +48,65 @@ def test_oracle_equals_reference_code_outputs(vec, oracle):
         _close(r["sym"], vec["ctl_sym%d" % k], r["bits"], vec["ctl_bits%d" % k], "control %d" % k)
 
 
+def _split(flat, counts):
+    out, pos = [], 0
+    for n in counts:
+        out.append(flat[pos:pos + n])
+        pos += n
+    return out
+
+
+def test_oracle_equals_reference_code_outputs_at_50_ksps_and_for_eight_chains(vec, oracle):
+    cfg = oracle.default_cfg()
+    cfg.samplerate = 50000.0
+    r = oracle.Oracle(cfg).process(vec["rate50_iq"])
+    _close(r["sym"], vec["rate50_sym"], r["bits"], vec["rate50_bits"], "50 ksps")
+    assert abs(len(r["sym"]) - 14000 / (50000.0 / 18000.0)) < 20
+    ns = vec["multi8_nsym"]
+    syms, bitss = _split(vec["multi8_sym"], ns), _split(vec["multi8_bits"], 2 * ns)
+    for c in range(8):
+        r = oracle.Oracle().process(vec["multi8_iq"][c])
+        _close(r["sym"], syms[c], r["bits"], bitss[c], "chain %d of 8" % c)
+    o = oracle.Oracle()
+    iq = vec["rrcp_iq"]
+    r0 = o.process(iq[:6000])
+    o.set_param(2, 49, quirks=True)
+    o.set_param(3, 0.35, quirks=False)             # setRRCParams: the roll-off is not truncated
+    r1 = o.process(iq[6000:])
+    _close(r0["sym"], vec["rrcp_sym0"], r0["bits"], vec["rrcp_bits0"], "setRRCParams 0")
+    _close(r1["sym"], vec["rrcp_sym1"], r1["bits"], vec["rrcp_bits1"], "setRRCParams 1")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["narrow", "wide"])
+def test_gpu_equals_reference_code_outputs_at_50_ksps_and_batched(vec, pkg, shape):
+    """The kernel against the reference code's outputs at config 5's rate, for eight chains in ONE handle (what batching
+    means: the reference ran eight separate object sets), and through tetra_demod_set_rrc_params mid-stream."""
+    B = pkg.binding
+    shape_flag = B.FLAG_WIDE_WORKGROUPS if shape == "wide" else B.FLAG_NARROW_WORKGROUPS
+    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag, samplerate=50000.0)
+    bits, nb, sym = d.process(vec["rate50_iq"][None, :], want_sym=True)
+    _close(sym[0][:nb[0] // 2], vec["rate50_sym"], bits[0][:nb[0]], vec["rate50_bits"], "50 ksps")
+    d.close()
+    d = pkg.Demodulator(8, 7000, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag)
+    bits, nb, sym = d.process(vec["multi8_iq"], want_sym=True)
+    ns = vec["multi8_nsym"]
+    syms, bitss = _split(vec["multi8_sym"], ns), _split(vec["multi8_bits"], 2 * ns)
+    for c in range(8):
+        _close(sym[c][:nb[c] // 2], syms[c], bits[c][:nb[c]], bitss[c], "chain %d of 8" % c)
+    d.close()
+    d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag)
+    iq = vec["rrcp_iq"]
+    bits, nb, sym = d.process(iq[None, :6000], want_sym=True)
+    _close(sym[0][:nb[0] // 2], vec["rrcp_sym0"], bits[0][:nb[0]], vec["rrcp_bits0"], "setRRCParams 0")
+    d.set_rrc_params(49, 0.35)
+    t = d.tables()
+    assert t["rrc"].size == 49 and t["be_re"].size == 65
+    bits, nb, sym = d.process(iq[None, 6000:], want_sym=True)
+    _close(sym[0][:nb[0] // 2], vec["rrcp_sym1"], bits[0][:nb[0]], vec["rrcp_bits1"], "setRRCParams 1")
+    d.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["narrow", "wide"])
 def test_gpu_equals_reference_code_outputs(vec, pkg, shape):
