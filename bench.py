@@ -355,6 +355,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL carries only the barrier and the MAX of the elapsed time (no data-path collective).  One rank per GPU: RCCL
+        # refuses ranks that share a device ("Duplicate GPU detected") -- a functional run of the N > 1 path on fewer GPUs
+        # than ranks takes --backend gloo.  A communicator that cannot be built fails the run at once, loudly.
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:

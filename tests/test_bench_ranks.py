@@ -16,7 +16,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 def _run(backend):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
            "--backend", backend]
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
 
 
 def _line(r):
@@ -27,16 +27,17 @@ def _line(r):
 
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_bench_gpus_2_runs_two_ranks(backend):
+    import torch
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        # RCCL refuses two ranks on one device ("Duplicate GPU detected : rank 0 and rank 1 both on CUDA device", observed on
+        # this box: gpurun_out/bench_gpus2_nccl_refused.txt of the first run); the gloo case covers bench.py's whole N > 1 path
+        # here, and the same command line runs on RCCL where there is a GPU per rank
+        pytest.skip("one GPU: RCCL refuses two ranks on the same device")
     r = _run(backend)
-    if backend == "nccl" and r.returncode != 0 and "uplicate GPU" in (r.stderr + r.stdout):
-        # RCCL refuses two ranks on one device; the same command on a box with >= 2 GPUs is what the driver runs
-        os.makedirs(OUT, exist_ok=True)
-        open(os.path.join(OUT, "bench_gpus2_nccl_refused.txt"), "w").write((r.stderr + r.stdout)[-3000:])
-        pytest.skip("RCCL refuses two ranks on the one GPU of this box (Duplicate GPU)")
     d = _line(r)
     os.makedirs(OUT, exist_ok=True)
     json.dump(d, open(os.path.join(OUT, "bench_gpus2_%s.json" % backend), "w"))
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["ramp_steps"] == 8
     assert d["dist_backend"] == backend and d["rccl_world_size"] == (2 if backend == "nccl" else None)
     assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
     # two ranks of 4096 channels each: the whole-job value counts both
