@@ -1,0 +1,21 @@
+#!/bin/sh
+# Timing-only EXPERIMENT builds of the library (never the product: their output is wrong by construction).  A copy of csrc/ is
+# made under profiles/dbg/exp_<name>/, the FLL assembly is re-generated there with the experiment's environment, and the copy
+# is compiled with the experiment's -D flags.
+#   sh profiles/build_exp.sh <name> "<-D flags>" [ENV=VALUE ...]      -> profiles/dbg/lib_<name>.so
+# e.g. sh profiles/build_exp.sh rrc9   "-DTETRA_EXP_ABLATE=2"
+#      sh profiles/build_exp.sh nomid  ""  TETRA_EXP_FLL_NO_MIDDLE=1
+#      sh profiles/build_exp.sh cores2 "-DTETRA_EXP_XRING=128 -DTETRA_EXP_YRING=64 -DTETRA_EXP_SRING=32" TETRA_EXP_XRING=128
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
+NAME=$1; FLAGS=$2; shift 2
+D="$HERE/dbg/exp_$NAME"
+rm -rf "$D" && mkdir -p "$D/sdrpp-tetra-demodulator_amd" "$HERE/dbg"
+cp -r "$HERE/../sdrpp-tetra-demodulator_amd/csrc" "$D/sdrpp-tetra-demodulator_amd/csrc"
+cp -r "$HERE/../include" "$D/include"
+env "$@" python3 "$D/sdrpp-tetra-demodulator_amd/csrc/gen_fll_asm.py" > /dev/null
+C="$D/sdrpp-tetra-demodulator_amd/csrc"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $FLAGS \
+    -fPIC -shared -o "$HERE/dbg/lib_$NAME.so" "$C/tetra_demod.hip" "$C/tetra_chan.hip" "$C/tetra_burst_scan.hip" "$C/tetra_lmac.hip" "$C/tetra_burst_sync.hip"
+rm -rf "$D"
+echo "built $HERE/dbg/lib_$NAME.so"

@@ -237,6 +237,8 @@ def middle_ops(ph, xs):
     """The seven middle taps of both sums of a step: r[(ph+q) % 8] += xs * t[8-q], q = 1..7, in the order the next step
     needs them (it reads r[(ph+1) % 8] first)."""
     ops = []
+    if os.environ.get("TETRA_EXP_FLL_NO_MIDDLE"):      # timing-only experiment (profiles/build_exp.sh): the FIR bulk taken out
+        return ops
     for q in range(1, TAPS - 1):
         ops.append(fma_op(r14(ph + q), xs, R_TA, TAPS - 1 - q, r14(ph + q)))
         ops.append(fma_op(r32(ph + q), xs, R_TB, TAPS - 1 - q, r32(ph + q)))
@@ -394,7 +396,7 @@ def gen():
     # ---- the tiles
     E.label(".Ltile_%=:")
     # x ring address of this lane for the tile: row + 8*(8 + (base & 255) - pos) (front padding of 8 slots, see FusedLds)
-    E.ins("s_and_b32 %[st], %[base], 0xff", "salu")
+    E.ins("s_and_b32 %%[st], %%[base], 0x%x" % (int(os.environ.get("TETRA_EXP_XRING", "256")) - 1), "salu")
     E.ins("s_lshl_b32 %[st], %[st], 3", "salu")
     E.ins("v_add_u32 v%d, %%[st], v%d" % (R_XLANE, R_XROWL), "valu", [R_XLANE], [R_XROWL])
     E.ins("ds_read_b128 %s, v%d" % (quad(R_AQ[0]), R_AADDR), "lds", list(range(R_AQ[0], R_AQ[0] + 4)), [R_AADDR])

@@ -41,14 +41,25 @@ constexpr int kFChWide = 32;             // ... and the wide shape for more than
 #endif
 constexpr int fused_threads(int ch) { return ch == 16 ? 6 * 64 : TETRA_WIDE_WAVES * 64; }      // 16: six roles; 32: see Roles<32>
 constexpr int kFThreads = fused_threads(kFCh);       // 384 = 6 waves
-constexpr int kFX = 256;                 // x ring (FLL output) per channel ...
+// Ring depths.  The TETRA_EXP_* overrides exist for TIMING-ONLY experiment builds (profiles/build_exp.sh: rings too short to
+// hold the data, output garbage, same instruction streams); the product is built without them.
+#ifndef TETRA_EXP_XRING
+#define TETRA_EXP_XRING 256
+#endif
+#ifndef TETRA_EXP_YRING
+#define TETRA_EXP_YRING 128
+#endif
+#ifndef TETRA_EXP_SRING
+#define TETRA_EXP_SRING 64
+#endif
+constexpr int kFX = TETRA_EXP_XRING;     // x ring (FLL output) per channel ...
 constexpr int kFXP = 8;                  // ... behind 8 slots of front padding: an FLL lane stores x_{i-pos} at slot i - pos of the
                                          // tile's window without wrapping (slots -7 .. -1 are never read, see fll_asm.inc)
 constexpr int kFXS = kFXP + kFX + 1;     // row stride (odd: spreads channels over LDS banks)
-constexpr int kFY = 128;                 // y ring (RRC output) per channel ...
+constexpr int kFY = TETRA_EXP_YRING;     // y ring (RRC output) per channel ...
 constexpr int kFYM = 8;                  // ... plus a mirror of the first slots so the interpolator window never wraps
 constexpr int kFYS = kFY + kFYM + 1;
-constexpr int kFS = 64;                  // symbol ring per channel
+constexpr int kFS = TETRA_EXP_SRING;     // symbol ring per channel
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
 
@@ -190,7 +201,10 @@ template <class LDS, class Row> struct FllDeviceIOT {
         __syncthreads();                                                         \
     }
 
-template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH)) void k_fused(FusedParams p) {
+#ifndef TETRA_EXP_WAVES_PER_EU
+#define TETRA_EXP_WAVES_PER_EU 1      // experiment builds: a larger value caps the VGPRs so that more waves fit a SIMD
+#endif
+template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParams p) {
     typedef FusedLdsT<CH> Lds;
     typedef FllRowT<float, Roles<CH>::FL, (CH == 16 ? kF8Taps : kF4Taps)> FllRow;
     typedef FllDeviceIOT<Lds, FllRow> FllDeviceIO;
