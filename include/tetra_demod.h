@@ -51,11 +51,15 @@ enum {
     TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
     TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
     TETRA_FLAG_WIDE_WORKGROUPS = 16,   /* force 32-channel workgroups / ... */
-    TETRA_FLAG_NARROW_WORKGROUPS = 32, /* ... or 16-channel ones (both together: TETRA_ERR_ARG).  Default: chosen from the channel count (16 while every CU has at
-                                    most one workgroup; beyond, whole rounds of 32-channel workgroups and the rest in whichever
-                                    shape is through first -- 8192 channels take 1.3x the 4096-channel time instead of 2x:
-                                    DESIGN.md section 5).  Results are identical bit for bit.  Band-edge filters of more
-                                    than 68 taps (rrc_tap_count 69..72) always run in 16-channel workgroups. */
+    TETRA_FLAG_NARROW_WORKGROUPS = 32, /* ... or 16-channel ones / ... */
+    TETRA_FLAG_SMALL_WORKGROUPS = 64,  /* ... or 4-channel ones (more than one of the three: TETRA_ERR_ARG).  Default: chosen from the
+                                    channel count -- 4-channel workgroups (FLL rows of 16 lanes per channel: the shortest
+                                    per-sample step) while every workgroup has a CU to itself (<= 4 channels per CU: 1024 channels
+                                    on an MI355X); 16-channel ones up to one per CU (4096 channels); beyond, whole rounds of
+                                    32-channel workgroups and the rest in whichever shape is through first -- 8192 channels take
+                                    1.3x the 4096-channel time instead of 2x.  Results are identical bit for
+                                    bit.  Band-edge filters of more than 68 taps (rrc_tap_count 69..72) never run in 32-channel
+                                    workgroups. */
     TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
                                     the dsp::block sets it):
                                       - tetra_demod_reset keeps ph2 (src/dsp/pi4dqpsk_costas.h:32 is never reset by

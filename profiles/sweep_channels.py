@@ -16,8 +16,8 @@ def main():
     ap.add_argument("--channels", type=int, nargs="+", default=[256, 800, 4096, 8192, 16384, 32768])
     ap.add_argument("--samples", type=int, default=36000)
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--shape", choices=["auto", "narrow", "wide"], default="auto",
-                    help="workgroup shape: chosen by the library from the channel count, or forced (16 / 32 channels per workgroup)")
+    ap.add_argument("--shape", choices=["auto", "narrow", "wide", "small"], default="auto",
+                    help="workgroup shape: chosen by the library from the channel count, or forced (16 / 32 / 4 channels per workgroup)")
     a = ap.parse_args()
     import torch
     import tetra_amd
@@ -32,7 +32,8 @@ def main():
         iq, _ = bench.make_input(torch, pkg.synth, dev, C, N, seed=20260000)
         bits = torch.zeros((C, stride), dtype=torch.uint8, device=dev)
         nb = torch.zeros(C, dtype=torch.int32, device=dev)
-        flags = {"auto": 0, "narrow": pkg.binding.FLAG_NARROW_WORKGROUPS, "wide": pkg.binding.FLAG_WIDE_WORKGROUPS}[a.shape]
+        flags = {"auto": 0, "narrow": pkg.binding.FLAG_NARROW_WORKGROUPS, "wide": pkg.binding.FLAG_WIDE_WORKGROUPS,
+                 "small": pkg.binding.FLAG_SMALL_WORKGROUPS}[a.shape]
         dem = pkg.Demodulator(C, N, flags=flags)
         st = torch.cuda.current_stream(dev)
         for _ in range(bench.RAMP_STEPS + 2):

@@ -15,7 +15,7 @@ from . import build as _build
 
 LAYOUT_CHANNEL_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1
-FLAG_WIDE_WORKGROUPS, FLAG_NARROW_WORKGROUPS = 16, 32
+FLAG_WIDE_WORKGROUPS, FLAG_NARROW_WORKGROUPS, FLAG_SMALL_WORKGROUPS = 16, 32, 64
 FLAG_RETIRED_TWO_KERNEL = 1      # refused by tetra_demod_create since ABI 2
 FLAG_KEEP_RRC_OUT = 2
 FLAG_QUALITY = 4

@@ -388,15 +388,21 @@ template <class V> TD_FN Pair<V> agc_step(const K1Consts& k, Pair<V> in, V& g) {
 // produced in the head lane and travels outward one position per step, partial sums are created at the tail and travel
 // inward one position per TAPS - 1 steps, receiving their taps in ascending tap order -- bit-identical to a direct-form
 // `for k: acc = fmaf(hist[k], tap[k], acc)` -- and complete in the head lane in the very step that produces x_i, where
-// the FLL error needs them.  Two geometries are used: 8 x 9 (two channels per row; the 16-channel workgroup, fll_asm.inc)
-// and 4 x 17 (four channels per row: half the loop code per channel; the 32-channel workgroup, fll4_asm.inc).
+// the FLL error needs them.  Three geometries are used: 8 x 9 (two channels per row; the 16-channel workgroup, fll_asm.inc),
+// 4 x 17 (four channels per row: half the loop code per channel; the 32-channel workgroup, fll4_asm.inc) and 16 x 5 (one
+// channel per row: the fewest tap FMAs per step, the shortest step; the 4-channel workgroup, fll16_asm.inc).
 // ---------------------------------------------------------------------------------------------
 constexpr int kF8Lanes = 8;
 constexpr int kF8Taps = 9;
-constexpr int kF8Pad = kF8Lanes * kF8Taps;   // 72
+constexpr int kF8Pad = kF8Lanes * kF8Taps;   // 72: the longest filters the kernels take (the RRC window walk ends there too)
 constexpr int kF4Lanes = 4;
 constexpr int kF4Taps = 17;
 constexpr int kF4Pad = kF4Lanes * kF4Taps;   // 68
+constexpr int kF16Lanes = 16;                // a whole DPP row per channel: the 4-channel workgroup (at most 4 channels per CU)
+constexpr int kF16Taps = 5;
+constexpr int kF16Pad = kF16Lanes * kF16Taps;   // 80
+constexpr int kBePad = kPadTaps;             // band-edge tap tables are handed to the kernel zero-padded (old end) to 80 entries
+constexpr int ct_gcd(int a, int b) { return b == 0 ? a : ct_gcd(b, a % b); }
 
 template <int I, int N, class F> TD_FN void static_for(F&& f) {
     if constexpr (I < N) {
@@ -408,10 +414,13 @@ template <int I, int N, class F> TD_FN void static_for(F&& f) {
 template <class V, int LANES, int TAPS> struct FllRowT {
     typedef Pair<V> P;
     static constexpr int kLanes = LANES, kTaps = TAPS, kRes = TAPS - 1, kHop = 16 / LANES;
-    // the replay walks whole schedule periods: the newest kReplay >= LANES * TAPS stored samples (older ones only reach
+    // the drivers below walk groups of kGroup = lcm(kRes, LANES) steps: whole schedule periods (the step's phase is a
+    // compile-time index) and whole lane groups (delay-line samples are fetched, and x is stored, LANES at a time)
+    static constexpr int kGroup = kRes / ct_gcd(kRes, LANES) * LANES;
+    // the replay walks whole groups: the newest kReplay >= LANES * TAPS stored samples (older ones only reach
     // sums that complete, unused, before the first real step)
-    static constexpr int kReplay = ((LANES * TAPS + kRes - 1) / kRes) * kRes;
-    static_assert(kRes % LANES == 0 && 16 % LANES == 0, "row geometry");
+    static constexpr int kReplay = ((LANES * TAPS + kGroup - 1) / kGroup) * kGroup;
+    static_assert(16 % LANES == 0 && kReplay <= kHist, "row geometry");
     V ta[TAPS], tb[TAPS];
     P r14[kRes], r32[kRes];
     P xs;        // lane (pos, channel-in-row) holds x_{i-pos} of its channel
@@ -451,6 +460,7 @@ template <class V, int LANES, int TAPS> struct FllRowT {
 };
 template <class V> using FllRow8 = FllRowT<V, kF8Lanes, kF8Taps>;
 template <class V> using FllRow4 = FllRowT<V, kF4Lanes, kF4Taps>;
+template <class V> using FllRow16 = FllRowT<V, kF16Lanes, kF16Taps>;
 
 // Drivers of an FLL row.  IO (device: LDS accesses of one lane; host emulation: arrays):
 //   P    load_hist(int g)               lane (pos, ch) <- stored delay-line sample g*LANES + pos of the last Row::kReplay
@@ -459,31 +469,31 @@ template <class V> using FllRow4 = FllRowT<V, kF4Lanes, kF4Taps>;
 template <class Row, class IO> TD_FN void fll_replay(Row& R, const K1Consts& k, IO& io) {
     typedef typename Row::P P;
     R.clear_pipeline();
-    for (int per = 0; per < Row::kReplay / Row::kRes; per++) {
+    for (int grp = 0; grp < Row::kReplay / Row::kGroup; grp++) {
         P cur(0.0f, 0.0f);
-        static_for<0, Row::kRes>([&](auto S) {
+        static_for<0, Row::kGroup>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            if (s % Row::kLanes == 0) cur = io.load_hist(per * (Row::kRes / Row::kLanes) + s / Row::kLanes);
-            R.template step<s, true, true>(k, cur);
+            if (s % Row::kLanes == 0) cur = io.load_hist(grp * (Row::kGroup / Row::kLanes) + s / Row::kLanes);
+            R.template step<s % Row::kRes, true, true>(k, cur);
             cur = row_shl_h<Row::kHop>(cur, cur);
         });
     }
 }
-// One tile of cnt <= tile_len samples (tile_len a multiple of TAPS - 1).
+// One tile of cnt <= tile_len samples (tile_len a multiple of the group).
 template <class Row, class IO, bool ALPHA0> TD_FN void fll_tile(Row& R, const K1Consts& k, IO& io, int cnt) {
-    for (int s0 = 0; s0 < cnt; s0 += Row::kRes) {
-        const int cg = (cnt - s0 < Row::kRes) ? (cnt - s0) : Row::kRes;
-        if (cg == Row::kRes) {
-            static_for<0, Row::kRes>([&](auto S) {
+    for (int s0 = 0; s0 < cnt; s0 += Row::kGroup) {
+        const int cg = (cnt - s0 < Row::kGroup) ? (cnt - s0) : Row::kGroup;
+        if (cg == Row::kGroup) {
+            static_for<0, Row::kGroup>([&](auto S) {
                 constexpr int s = decltype(S)::value;
-                R.template step<s, false, ALPHA0>(k, io.sample(s0 + s));
+                R.template step<s % Row::kRes, false, ALPHA0>(k, io.sample(s0 + s));
                 if (s % Row::kLanes == Row::kLanes - 1) io.xs_store(s0 + s + 1, Row::kLanes, R.xs);
             });
         } else {
-            static_for<0, Row::kRes - 1>([&](auto S) {
+            static_for<0, Row::kGroup - 1>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 if (s < cg) {
-                    R.template step<s, false, ALPHA0>(k, io.sample(s0 + s));
+                    R.template step<s % Row::kRes, false, ALPHA0>(k, io.sample(s0 + s));
                     if (s % Row::kLanes == Row::kLanes - 1 || s == cg - 1) io.xs_store(s0 + s + 1, s % Row::kLanes + 1, R.xs);
                 }
             });
@@ -605,14 +615,14 @@ TD_FN int k2_phase(float mu) {
     return phase > kInterpPhases - 1 ? kInterpPhases - 1 : phase;
 }
 
-// Costas loop + slicer + differential decoder for one symbol (pi4dqpsk_costas.cpp:7-28,
-// dqpsk_sym_extr.cpp:6-7,32-52).  Returns the dibit; (*zr, *zi) = PI4DQPSK::process output.
-TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
-    // pi4dqpsk_costas.cpp:10-15 as two selects (same values as the if / else-if, no divergent branch in the wave)
+// Costas loop for one symbol (pi4dqpsk_costas.cpp:7-28): (*zr, *zi) = PI4DQPSK::process output; advances the loop state.
+TD_FN void k2_costas_rot(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
+    // pi4dqpsk_costas.cpp:10-15.  ph2 only ever decreases (by pi/4 per symbol) and starts inside (-2 pi, 2 pi) -- a fresh
+    // chain at 0, tetra_demod_set_state refuses anything else -- so `ph2 >= 2 pi -> ph2 - 2 pi` can never fire and only the
+    // lower wrap is evaluated: the same values as the reference's if / else-if for every reachable state.
     const float t2 = st.ph2 + (-kFlPi / 4.0f);
-    const float dn2 = t2 - 2 * kFlPi, up2 = t2 + 2 * kFlPi;
-    float ph2 = v_sel(t2 <= -2 * kFlPi, up2, t2);
-    ph2 = v_sel(t2 >= 2 * kFlPi, dn2, ph2);
+    const float up2 = t2 + 2 * kFlPi;
+    const float ph2 = v_sel(t2 <= -2 * kFlPi, up2, t2);
     st.ph2 = ph2;
     Pair<float> s2, c2;                                   // (loop phasor, pi/4-rotation phasor) in one packed evaluation
     sincos_pair(Pair<float>(-st.cph, ph2), s2, c2);
@@ -624,11 +634,25 @@ TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* z
     pcl_advance<float, true>(cerr, st.cph, st.cfr, k.costas_alpha, k.costas_beta, k.costas_min_freq, k.costas_max_freq);
     *zr_out = zr;
     *zi_out = zi;
-    int a = zi < 0, b = zr < 0;
-    int symq = (a << 1) | (a != b);
-    int pd = (symq - st.prev + 4) & 3;
+}
+// dqpsk_sym_extr.cpp:6-7,32: quadrant index of a symbol, counter-clockwise
+TD_FN int k2_quadrant(float zr, float zi) {
+    const int a = zi < 0, b = zr < 0;
+    return (a << 1) | (a != b);
+}
+// dqpsk_sym_extr.cpp:33-51: phase step between two quadrants -> dibit, {0,1,2,3} -> {0,1,3,2}
+TD_FN int k2_dibit(int symq, int prevq) {
+    const int pd = (symq - prevq + 4) & 3;
+    return pd ^ (pd >> 1);
+}
+// Costas loop + slicer + differential decoder for one symbol (pi4dqpsk_costas.cpp:7-28,
+// dqpsk_sym_extr.cpp:6-7,32-52).  Returns the dibit; (*zr, *zi) = PI4DQPSK::process output.
+TD_FN int k2_costas(const K2Consts& k, K2State& st, float vr, float vi, float* zr_out, float* zi_out) {
+    k2_costas_rot(k, st, vr, vi, zr_out, zi_out);
+    const int symq = k2_quadrant(*zr_out, *zi_out);
+    const int d = k2_dibit(symq, st.prev);
     st.prev = symq;
-    return pd ^ (pd >> 1);  // {0,1,2,3} -> {0,1,3,2}
+    return d;
 }
 
 // Sync/quality statistic of DQPSKSymbolExtractor::process (dqpsk_sym_extr.cpp:8-31): per symbol the angular distance

@@ -62,6 +62,8 @@ SHAPES = {
     "fll": Shape(8, 9, "fll_asm.inc", "FLL_WAVE", "FLL wave"),
     # 32-channel workgroups: two FLL waves of 16 channels, 4 lanes per channel (68 = 4 x 17 padded taps)
     "fll4": Shape(4, 17, "fll4_asm.inc", "FLL4_WAVE", "FLL wave, 4 lanes per channel"),
+    # 4-channel workgroups (at most 4 channels per CU): one FLL wave of 4 channels, a whole DPP row per channel (80 = 16 x 5)
+    "fll16": Shape(16, 5, "fll16_asm.inc", "FLL16_WAVE", "FLL wave, 16 lanes per channel"),
 }
 G = SHAPES["fll"]
 OUT = G.out
@@ -208,7 +210,7 @@ def pk_consts():
     return [u(a) | (u(b) << 32) for (a, b) in pairs]
 
 
-BE_IM_OFFSET = 72 * 4            # byte offset of the imaginary taps behind the real ones in FusedLds::be72
+BE_IM_OFFSET = 80 * 4            # byte offset of the imaginary taps behind the real ones in FusedLds::be80
 
 
 def tap_operand(base, j):
@@ -448,7 +450,7 @@ def generate(shape=None):
 
 def main():
     rc = 0
-    for name in ("fll", "fll4"):
+    for name in ("fll", "fll4", "fll16"):
         text, E, per_tile = generate(SHAPES[name])
         out = SHAPES[name].out
         if "--check" in sys.argv:

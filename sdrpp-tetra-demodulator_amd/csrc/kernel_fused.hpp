@@ -30,16 +30,18 @@
 
 #include "fll_asm.inc"
 #include "fll4_asm.inc"
+#include "fll16_asm.inc"
 
 namespace {
 
 constexpr int kFT = 32;                  // samples per tile (pipeline epoch)
 constexpr int kFCh = 16;                 // channels per workgroup: the benchmark's shape (4096 channels = one workgroup per CU) ...
-constexpr int kFChWide = 32;             // ... and the wide shape for more than 16 channels per CU (FLL rows of 4 lanes per channel)
+constexpr int kFChWide = 32;             // ... the wide shape for more than 16 channels per CU (FLL rows of 4 lanes per channel) ...
+constexpr int kFChSmall = 4;             // ... and the small shape for at most 4 channels per CU (FLL rows of 16 lanes per channel)
 #ifndef TETRA_WIDE_WAVES
 #define TETRA_WIDE_WAVES 8
 #endif
-constexpr int fused_threads(int ch) { return ch == 16 ? 6 * 64 : TETRA_WIDE_WAVES * 64; }      // 16: six roles; 32: see Roles<32>
+constexpr int fused_threads(int ch) { return ch == 16 ? 6 * 64 : ch == 4 ? 8 * 64 : TETRA_WIDE_WAVES * 64; }   // 16: six roles; 32, 4: see Roles
 constexpr int kFThreads = fused_threads(kFCh);       // 384 = 6 waves
 // Ring depths.  The TETRA_EXP_* overrides exist for TIMING-ONLY experiment builds (profiles/build_exp.sh: rings too short to
 // hold the data, output garbage, same instruction streams); the product is built without them.
@@ -62,6 +64,7 @@ constexpr int kFYS = kFY + kFYM + 1;
 constexpr int kFS = TETRA_EXP_SRING;     // symbol ring per channel
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
+static_assert(kF16Pad == 80 && kF16Taps == 5, "fll16_asm.inc is generated for 16 positions x 5 taps");
 
 // Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
 // the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
@@ -85,12 +88,25 @@ namespace role_ids { constexpr int v[6] = { TETRA_ROLE_IDS }; }
 #define TETRA_ROLE_IDS_WIDE 2, 6, 0, 1, 7, 3, -1       // E, D, F0, F1, A, C, C2 (second RRC wave: one pass each; -1 = none)
 #endif
 namespace role_ids { constexpr int w[7] = { TETRA_ROLE_IDS_WIDE }; }
+// The small workgroup (4 channels; for at most 4 channels per CU, i.e. up to 1024 channels per GPU: BASELINE configs 2 and 5):
+// ONE FLL wave whose rows spend all 16 lanes on a channel (16 positions x 5 taps: 10 tap FMAs per step instead of 18, the
+// shortest FLL step, 52.56 slots) alone on SIMD0, the Costas wave alone on SIMD1, the timing wave alone on SIMD2, RRC (older)
+// + AGC on SIMD3; waves 4..6 would land beside the three recurrences and only keep the barriers.
+#ifndef TETRA_ROLE_IDS_SMALL
+#define TETRA_ROLE_IDS_SMALL 1, 2, 0, -1, 7, 3        // E, D, F0, (no F1), A, C
+#endif
+namespace role_ids { constexpr int m[6] = { TETRA_ROLE_IDS_SMALL }; }
 template <int CH> struct Roles {
-    static constexpr int E = CH == 16 ? role_ids::v[0] : role_ids::w[0], D = CH == 16 ? role_ids::v[1] : role_ids::w[1],
-                         F0 = CH == 16 ? role_ids::v[2] : role_ids::w[2], A = CH == 16 ? role_ids::v[4] : role_ids::w[4],
-                         C = CH == 16 ? role_ids::v[5] : role_ids::w[5], C2 = CH == 16 ? -1 : role_ids::w[6], NF = 2;
-    // FLL row geometry: lanes per channel, channels per FLL wave
-    static constexpr int FL = CH == 16 ? kF8Lanes : kF4Lanes, FCH = 64 / FL;
+    static constexpr int E = CH == 16 ? role_ids::v[0] : CH == 4 ? role_ids::m[0] : role_ids::w[0],
+                         D = CH == 16 ? role_ids::v[1] : CH == 4 ? role_ids::m[1] : role_ids::w[1],
+                         F0 = CH == 16 ? role_ids::v[2] : CH == 4 ? role_ids::m[2] : role_ids::w[2],
+                         A = CH == 16 ? role_ids::v[4] : CH == 4 ? role_ids::m[4] : role_ids::w[4],
+                         C = CH == 16 ? role_ids::v[5] : CH == 4 ? role_ids::m[5] : role_ids::w[5],
+                         C2 = CH == 32 ? role_ids::w[6] : -1, NF = CH == 4 ? 1 : 2;
+    // FLL row geometry: lanes per channel, taps per lane, channels per FLL wave
+    static constexpr int FL = CH == 16 ? kF8Lanes : CH == 4 ? kF16Lanes : kF4Lanes, FT = CH == 16 ? kF8Taps : CH == 4 ? kF16Taps : kF4Taps,
+                         FCH = 64 / FL;
+    static_assert(NF * FCH == CH, "the FLL waves cover the workgroup's channels");
 };
 
 struct FusedParams {
@@ -108,8 +124,8 @@ struct FusedParams {
     int* prev;
     float2* ybuf;        // [C][7]
     // tables
-    const float* be_re72;   // band-edge taps zero-padded (old end) to 72
-    const float* be_im72;
+    const float* be_re80;   // band-edge taps zero-padded (old end) to kBePad = 80
+    const float* be_im80;
     const float* rrc_ext;   // [kRrcExt] RRC taps as rrc_direct8 wants them: ext[7 + rrc_pad + k] = h[k], zero elsewhere
     int ntaps;
     const float* bank;
@@ -133,14 +149,16 @@ template <int CH> struct FusedLdsT {
     float2 y_ring[CH][kFYS];
     float2 s_ring[CH][kFS];
     int s_avail[CH];
+    int e_span[2][CH];       // 4-channel workgroup: the symbols [first, end) the Costas wave's recurrence lane has just finished
     // interpolator bank with row 0 repeated in front and row 127 behind: rows max(p-1,0), p, min(p+1,127) of
     // complex_fd.cpp:102-121 are then the 24 contiguous floats at bank[p * 8]
     __attribute__((aligned(16))) float bank[(kInterpPhases + 2) * kInterpTaps];
     __attribute__((aligned(16))) float rrc[kRrcExt];       // zero-extended taps, see rrc_direct8
-    float be72[2][kF8Pad];   // band-edge taps (re, im), zero-padded: the FLL waves' assembly loads its 18 taps from here
+    float be80[2][kBePad];   // band-edge taps (re, im), zero-padded at the old end: the FLL waves' assembly loads its taps from here
 };
 typedef FusedLdsT<kFCh> FusedLds;
-static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256, "LDS budget of a CU");
+static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256 &&
+              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024, "LDS budget of a CU");
 
 // Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
 // register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
@@ -206,7 +224,7 @@ template <class LDS, class Row> struct FllDeviceIOT {
 #endif
 template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParams p) {
     typedef FusedLdsT<CH> Lds;
-    typedef FllRowT<float, Roles<CH>::FL, (CH == 16 ? kF8Taps : kF4Taps)> FllRow;
+    typedef FllRowT<float, Roles<CH>::FL, Roles<CH>::FT> FllRow;
     typedef FllDeviceIOT<Lds, FllRow> FllDeviceIO;
     typedef Roles<CH> R_;
     constexpr int kRoleE = R_::E, kRoleD = R_::D, kRoleF0 = R_::F0, kRoleA = R_::A, kRoleC = R_::C;
@@ -231,7 +249,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         L.bank[i] = p.bank[row * kInterpTaps + i % kInterpTaps];
     }
     if (tid < kRrcExt) L.rrc[tid] = p.rrc_ext[tid];
-    if (tid < kF8Pad) { L.be72[0][tid] = p.be_re72[tid]; L.be72[1][tid] = p.be_im72[tid]; }
+    if (tid < kBePad) { L.be80[0][tid] = p.be_re80[tid]; L.be80[1][tid] = p.be_im80[tid]; }
     // rings start at zero: FIR windows touch slots that were never written (weighted by zero taps, so they must be finite)
     for (int i = tid; i < CH * kFXS; i += kThreadsCH) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < CH * kFYS; i += kThreadsCH) (&L.y_ring[0][0])[i] = make_float2(0.f, 0.f);
@@ -310,16 +328,26 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         // produced by the reference's FLL, fll.cpp:25) takes the C++ form for every tile; the debug build does not
         // instrument the block.
         const int nfull = ALPHA0 ? n / kFT : 0;
-        // padded tap kp of the row sits at be72[kp + 72 - LANES * TAPS] (both are padded at the old end)
-        constexpr int kTapOff = kF8Pad - FllRow::kLanes * FllRow::kTaps;
+        // padded tap kp of the row sits at be80[kp + 80 - LANES * TAPS] (both are padded at the old end)
+        constexpr int kTapOff = kBePad - FllRow::kLanes * FllRow::kTaps;
         if (nfull > 0) {
             int base_ = 0, tiles_ = nfull, st_;
             const unsigned a_addr = lds_addr(&L.a_buf[0][f_c][0]);
             const unsigned x_rowlane = lds_addr(&L.x_ring[f_c][kFXP]) - 8u * (unsigned)f_pos;
-            const unsigned tap_addr = lds_addr(&L.be72[0][kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos)]);
+            const unsigned tap_addr = lds_addr(&L.be80[0][kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos)]);
             const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - FllRow::kReplay]);
             const unsigned long long p4 = (unsigned long long)__builtin_bit_cast(unsigned, 0.4f);
-            if constexpr (CH == 16) {
+            if constexpr (CH == 4) {
+                asm volatile(FLL16_WAVE_ASM
+                             : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
+                             : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
+                               [maxf] "v"(k1.fll_max_freq),
+                               [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                               [k1] "s"(FLL16_WAVE_K1), [k2] "s"(FLL16_WAVE_K2), [k3] "s"(FLL16_WAVE_K3), [k4] "s"(FLL16_WAVE_K4),
+                               [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
+                             : "vcc", "scc", "memory", FLL16_WAVE_CLOBBERS);
+            } else if constexpr (CH == 16) {
                 asm volatile(FLL_WAVE_ASM
                              : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
@@ -347,8 +375,8 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
 #pragma unroll
             for (int j = 0; j < FllRow::kTaps; j++) {
                 const int kp = kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos) + j;
-                R.ta[j] = p.be_re72[kp];
-                R.tb[j] = p.be_im72[kp];
+                R.ta[j] = p.be_re80[kp];
+                R.tb[j] = p.be_im80[kp];
             }
             R.ph = ph;
             R.fr = fr;
@@ -382,7 +410,9 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         // 16 channels: four lane groups cover the tile's 32 samples in one pass; 32 channels: two groups, two passes.
         // The window of eight consecutive outputs starts at x_{i0-(nt-1)}; it is widened at the old end (under zero
         // taps) to start on a multiple of 8, so that no 8-sample chunk straddles the ring's wrap.
-        constexpr int kGroups = 64 / CH, kPasses = kFT / (8 * kGroups);
+        // (4 channels: four groups cover the tile, lanes 16..63 idle)
+        constexpr int kGroups = 64 / CH < kFT / 8 ? 64 / CH : kFT / 8, kPasses = kFT / (8 * kGroups);
+        const bool c_on = lane < CH * kGroups;
         const int c = lane % CH;
         const int rrc_pad = (8 - ((p.ntaps - 1) & 7)) & 7;
 #if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 2      // experiment builds only (profiles/r02): RRC wave with a ninth of its work
@@ -406,7 +436,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
               const int pass1 = R_::C2 >= 0 && wave == kRoleC ? kPasses / 2 : kPasses;
               for (int pass = pass0; pass < pass1; pass++) {
                 const int i0 = t * kFT + 8 * (lane / CH + kGroups * pass);
-                if (i0 < n) {
+                if (i0 < n && c_on) {
                     const int start = i0 - (p.ntaps - 1) - rrc_pad;
                     Pair<float> out[kRrcOut];
                     auto tap4 = [&](int q) { const float4 t4 = reinterpret_cast<const float4*>(L.rrc)[q];
@@ -510,6 +540,70 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.omega[ch0 + c] = st.omega;
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
             if (cut) atomicAdd(p.overruns, 1);          // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
+        }
+    } else if (wave == kRoleE && CH == kFChSmall) {
+        // ---- kRoleE, 4-channel workgroup (this wave has a SIMD to itself and sets the pace once the FLL step is short): the
+        // recurrence -- Costas loop only -- runs on lanes 0..3 and leaves z in place of v in the symbol ring; then ALL 64 lanes
+        // (16 per channel, one symbol each) slice, decode differentially against the symbol before, and store: the part of the
+        // reference's per-symbol work that is not a recurrence (dqpsk_sym_extr.cpp:32-52, bit_unpacker.cpp:6-7) costs one pass
+        // per epoch instead of ~35 instruction slots per symbol.
+        const bool on = lane < CH;
+        const int c = on ? lane : 0;
+        K2State st;
+        st.mu = 0; st.omega = 0; st.offset = 0; st.prev = 0;
+        st.cph = p.cph[chan(c)];
+        st.cfr = p.cfr[chan(c)];
+        st.ph2 = p.ph2[chan(c)];
+        int S = 0;
+        constexpr int kFin = 64 / CH;                      // finishing lanes per channel
+        const int fc = lane / kFin, fj = lane % kFin;
+        uint8_t* brow = p.bits + (long long)chan(fc) * p.bits_stride;
+        float2* srow = p.sym ? p.sym + (long long)chan(fc) * p.sym_stride : nullptr;
+        const bool fwr = live(fc);
+        const int prev0 = p.prev[chan(fc)];                // the slicer's carried previous symbol: for this call's symbol 0
+        K2Consts k2 = p.k2;
+        k2.costas_max_freq = v_pin(k2.costas_max_freq);
+        __syncthreads();
+        FUSED_EPOCHS(
+            if (e >= 4) {
+                if (on) {
+                    const int avail = L.s_avail[c];
+                    L.e_span[0][c] = S;
+                    L.e_span[1][c] = avail;
+                    while (S < avail) {
+                        const float2 v = L.s_ring[c][S & (kFS - 1)];
+                        float zr; float zi;
+                        k2_costas_rot(k2, st, v.x, v.y, &zr, &zi);
+                        L.s_ring[c][S & (kFS - 1)] = make_float2(zr, zi);
+                        S++;
+                    }
+                }
+                // same wave: its LDS operations execute in order, the fence only keeps the compiler from moving them
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int f0 = L.e_span[0][fc], f1 = L.e_span[1][fc];
+                for (int i = f0 + fj; i < f1; i += kFin) {
+                    const float2 z = L.s_ring[fc][i & (kFS - 1)];
+                    const float2 zp = L.s_ring[fc][(i - 1) & (kFS - 1)];      // z of the symbol before (an earlier epoch left it there)
+                    const int prevq = i == 0 ? prev0 : k2_quadrant(zp.x, zp.y);
+                    const int d = k2_dibit(k2_quadrant(z.x, z.y), prevq);
+                    if (fwr) {
+                        // bit_unpacker.cpp:6-7: byte 2i = MSB, byte 2i+1 = LSB
+                        *reinterpret_cast<unsigned short*>(brow + 2 * i) = (unsigned short)(((d >> 1) & 1) | ((d & 1) << 8));
+                        if (srow) srow[i] = z;
+                    }
+                }
+            }
+        )
+        if (on && live(c)) {
+            p.cph[ch0 + c] = st.cph;
+            p.cfr[ch0 + c] = st.cfr;
+            p.ph2[ch0 + c] = st.ph2;
+            if (S > 0) {
+                const float2 zl = L.s_ring[c][(S - 1) & (kFS - 1)];
+                p.prev[ch0 + c] = k2_quadrant(zl.x, zl.y);
+            }
+            p.n_bits[ch0 + c] = 2 * S;
         }
     } else if (wave == kRoleE) {
         // ---- kRoleE: Costas + slicer + differential decoder + bit unpacker; symbols published before e ----

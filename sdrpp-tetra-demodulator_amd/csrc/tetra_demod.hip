@@ -28,6 +28,7 @@ namespace {
 constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
 constexpr int kWg16ClocksPerSample = 277;       // measured shader clocks per sample of one workgroup round (profiles/r02)
 constexpr int kWg32ClocksPerSample = 365;       // 32-channel workgroup: 5.3-5.6 ms per 36000 samples (profiles/r02/r02_q)
+constexpr int kWg4ClocksPerSample = 250;        // 4-channel workgroup (profiles/r03)
 
 __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
     float2 v = *p;
@@ -192,7 +193,8 @@ struct tetra_demod {
     float2* hist = nullptr;
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
-    int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones
+    int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones ...
+    bool small = false;         // ... unless every channel runs in 4-channel workgroups (at most 4 channels per CU)
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // TETRA_FLAG_KEEP_RRC_OUT: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // COMPLEX_FD delay buffer [C][7]
@@ -207,7 +209,7 @@ struct tetra_demod {
     bool quirks = false;        // TETRA_FLAG_REFERENCE_QUIRKS
     bool keep_y = false;        // y scratch allocated
     float* d_bank = nullptr;
-    float *d_be_re72 = nullptr, *d_be_im72 = nullptr, *d_rrc_ext = nullptr;   // fused kernel: band-edge padded to 72, RRC zero-extended
+    float *d_be_re80 = nullptr, *d_be_im80 = nullptr, *d_rrc_ext = nullptr;   // band-edge taps zero-padded (old end) to 80, RRC zero-extended
     // host-path staging
     float* st_iq = nullptr;
     uint8_t* st_bits = nullptr;
@@ -264,16 +266,16 @@ int upload_tables(tetra_demod* h) {
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
     if (h->design.ntaps <= kF8Pad && h->design.ntaps_be <= kF8Pad) {
-        std::vector<float> re72(kF8Pad, 0.f), im72(kF8Pad, 0.f), rrx(kRrcExt, 0.f);
-        const int o72 = kF8Pad - h->design.ntaps_be;
+        std::vector<float> re72(kBePad, 0.f), im72(kBePad, 0.f), rrx(kRrcExt, 0.f);
+        const int o72 = kBePad - h->design.ntaps_be;
         const int rpad = (8 - ((h->design.ntaps - 1) & 7)) & 7;     // RRC windows start on a multiple of 8, see kernel_fused.hpp
         for (int k = 0; k < h->design.ntaps_be; k++) {
             re72[o72 + k] = h->design.be_re[k];
             im72[o72 + k] = h->design.be_im[k];
         }
         for (int k = 0; k < h->design.ntaps; k++) rrx[7 + rpad + k] = h->design.rrc[k];
-        HIP_TRY(h, hipMemcpy(h->d_be_re72, re72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_be_im72, im72.data(), sizeof(float) * kF8Pad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_re80, re72.data(), sizeof(float) * kBePad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_im80, im72.data(), sizeof(float) * kBePad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rrx.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
     }
     return TETRA_OK;
@@ -336,7 +338,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
 
 void free_all(tetra_demod* h) {
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_overruns, h->d_bank, h->d_be_re72, h->d_be_im72,
+                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_overruns, h->d_bank, h->d_be_re80, h->d_be_im80,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -456,7 +458,10 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     *out = nullptr;
     if (cfg->n_channels < 1 || cfg->max_samples < 1) return TETRA_ERR_ARG;
     if (cfg->layout != TETRA_LAYOUT_CHANNEL_MAJOR && cfg->layout != TETRA_LAYOUT_TIME_MAJOR) return TETRA_ERR_ARG;
-    if ((cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) && (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS)) return TETRA_ERR_ARG;
+    {
+        const int shapes = cfg->flags & (TETRA_FLAG_WIDE_WORKGROUPS | TETRA_FLAG_NARROW_WORKGROUPS | TETRA_FLAG_SMALL_WORKGROUPS);
+        if (shapes & (shapes - 1)) return TETRA_ERR_ARG;      // at most one shape can be forced
+    }
     int ndev = tetra_demod_device_count();
     if (ndev <= 0) return TETRA_ERR_NO_DEVICE;
     int dev = cfg->device;
@@ -521,6 +526,12 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         h->n_wide = (int)(rest_wide ? h->C : full);
         if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) h->n_wide = h->C;
         if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) h->n_wide = 0;
+        // Up to 4 channels per CU every 4-channel workgroup has a CU to itself, and its FLL wave (a whole DPP row per channel)
+        // has the shortest step of the three shapes: one round of kWg4 clocks per sample against one of kWg16.
+        h->small = (long long)h->C <= (long long)kFChSmall * cus && kWg4ClocksPerSample < kWg16ClocksPerSample;
+        if (cfg->flags & (TETRA_FLAG_WIDE_WORKGROUPS | TETRA_FLAG_NARROW_WORKGROUPS)) h->small = false;
+        if (cfg->flags & TETRA_FLAG_SMALL_WORKGROUPS) h->small = true;
+        if (h->small) h->n_wide = 0;
     }
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
@@ -531,7 +542,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         A(dalloc(h, &h->q_sym, C * (size_t)h->q_sym_stride));
     }
     A(dalloc(h, &h->d_overruns, (size_t)1));
-    A(dalloc(h, &h->d_be_re72, (size_t)kF8Pad)); A(dalloc(h, &h->d_be_im72, (size_t)kF8Pad));
+    A(dalloc(h, &h->d_be_re80, (size_t)kBePad)); A(dalloc(h, &h->d_be_im80, (size_t)kBePad));
     A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
     A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
     if (rc == TETRA_OK && hipMemset(h->d_overruns, 0, sizeof(int)) != hipSuccess) rc = TETRA_ERR_HIP;
@@ -585,7 +596,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.rrc_valid = h->rrc_valid;
         pf.mu = h->mu; pf.omega = h->omega; pf.offset = h->offset;
         pf.cph = h->cph; pf.cfr = h->cfr; pf.ph2 = h->ph2; pf.prev = h->prev; pf.ybuf = h->ybuf;
-        pf.be_re72 = h->d_be_re72; pf.be_im72 = h->d_be_im72; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
+        pf.be_re80 = h->d_be_re80; pf.be_im80 = h->d_be_im80; pf.rrc_ext = h->d_rrc_ext; pf.ntaps = h->design.ntaps;
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
@@ -597,13 +608,13 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         // channels [0, n_wide) in 32-channel workgroups (see tetra_demod_create; their FLL rows hold 4 x 17 taps), the rest in
         // 16-channel ones: at most two launches, back to back on the stream
         const int n_wide = h->design.ntaps_be <= kF4Pad ? h->n_wide : 0;
-        const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh);
+        const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh), gs((h->C + kFChSmall - 1) / kFChSmall);
         const bool a0 = pf.k1.fll_alpha == 0.0f;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
         const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
-        if (prof_path && n_wide == 0) {
+        if (prof_path && n_wide == 0 && !h->small) {
             const size_t nwg = (size_t)gf.x;
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
@@ -616,7 +627,12 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         else if (pf.prof) hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
         else
 #endif
-        {
+        if (h->small) {
+            const dim3 ts(fused_threads(kFChSmall));
+            pf.ch_base = 0;
+            if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, pf);
+            else hipLaunchKernelGGL((k_fused<false, false, kFChSmall>), gs, ts, 0, s, pf);
+        } else {
             if (n_wide > 0) {
                 const dim3 tw(fused_threads(kFChWide));
                 pf.ch_base = 0;

@@ -135,7 +135,7 @@ template <class Row> void emul_fll(const emul_tables* t, tetra_demod_channel_sta
                                    const float* im72, std::vector<float>& a, std::vector<float>& x) {
     constexpr int H = Row::kHop, tile = 32;
     static_assert(Row::kReplay <= kHist, "the delay line holds the replayed samples");
-    constexpr int tap_off = kF8Pad - Row::kLanes * Row::kTaps;       // padded tap kp of the row = entry kp + tap_off of the 72-padded table
+    constexpr int tap_off = kBePad - Row::kLanes * Row::kTaps;       // padded tap kp of the row = entry kp + tap_off of the 80-padded table
     std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kHist, 0.f), dump((size_t)std::max(n, 1) * 2);
     for (int c0 = 0; c0 < C; c0 += H) {
         Row R;
@@ -184,9 +184,9 @@ extern "C" {
 int emul_fused_shape(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
                      uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym, int fll_lanes) {
     if (C < 1 || C > 64 || t->ntaps > kF8Pad) return -1;
-    float re72[kF8Pad] = { 0 }, im72[kF8Pad] = { 0 };
+    float re72[kBePad] = { 0 }, im72[kBePad] = { 0 };
     float rrc_ext[kRrcExt] = { 0 };
-    const int o72 = kF8Pad - t->ntaps;
+    const int o72 = kBePad - t->ntaps;
     const int rpad = (8 - ((t->ntaps - 1) & 7)) & 7;      // RRC windows start on a multiple of 8 (see kernel_fused.hpp)
     for (int k = 0; k < t->ntaps; k++) { re72[o72 + k] = t->be_re[k]; im72[o72 + k] = t->be_im[k]; rrc_ext[7 + rpad + k] = t->rrc[k]; }
     const int rrc_chunks = (t->ntaps - 1 + rpad) / 8 + 1;
@@ -204,6 +204,7 @@ int emul_fused_shape(const emul_tables* t, tetra_demod_channel_state_t* st, int 
     // F: FLL rows (8 lanes per channel: the 16-channel workgroup; 4 lanes: the 32-channel one; taps beyond 68 need the former)
     if (fll_lanes == 4 && t->ntaps <= kF4Pad) emul_fll<FllRow4<Row16>>(t, st, C, n, re72, im72, a, x);
     else if (fll_lanes == 8) emul_fll<FllRow8<Row16>>(t, st, C, n, re72, im72, a, x);
+    else if (fll_lanes == 16) emul_fll<FllRow16<Row16>>(t, st, C, n, re72, im72, a, x);
     else return -1;
     // C: RRC, eight outputs at a time, over [history | x]
     std::vector<float> y((size_t)C * n * 2);

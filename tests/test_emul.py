@@ -59,7 +59,7 @@ def test_emulated_kernels_match_oracle_at_50_ksps(emul, oracle, synth):
     N = 9000
     iq, _, _ = synth.gen_channel(N, 4242, sps=50000.0 / 18000.0, cfo=0.02)
     o = oracle.Oracle(oc)
-    for lanes in (8, 4):
+    for lanes in (8, 4, 16):
         o = oracle.Oracle(oc)
         e = emul.EmulDemod(1, cfg=cfg, fll_lanes=lanes)
         for a, b in ((0, 5003), (5003, N)):
@@ -145,7 +145,7 @@ def test_emulated_kernels_match_oracle(emul, oracle, synth, N, chunks):
     assert np.array_equal(_u32(np.array(st.hist[:], np.float32)[32:]), _u32(np.array(os_.hist[:], np.float32)[-128:]))
 
 
-@pytest.mark.parametrize("fll_lanes", [8, 4])
+@pytest.mark.parametrize("fll_lanes", [8, 4, 16])
 def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth, fll_lanes):
     """64 channels through the emulated stages, including a noise-only and an all-zero channel (their timing
     loops wander, so per-lane offsets diverge inside a tile)."""
@@ -162,7 +162,7 @@ def test_emulated_wave_of_64_channels_with_degenerate_inputs(emul, oracle, synth
         assert np.array_equal(q["bits"][c][:nb[c]], bits[c][:nb[c]]), c
 
 
-@pytest.mark.parametrize("fll_lanes", [8, 4])
+@pytest.mark.parametrize("fll_lanes", [8, 4, 16])
 def test_fused_stage_code_equals_oracle(emul, oracle, synth, fll_lanes, lanes=True):
     """(fll_lanes: the FLL row of the 16-channel workgroup, 8 lanes x 9 taps per channel, and of the 32-channel one, 4 x 17.)
     The fused kernel's building blocks (agc_step, the FLL row with its delay-line replay and 32-sample tiles,
@@ -187,7 +187,7 @@ def test_fused_stage_code_equals_oracle(emul, oracle, synth, fll_lanes, lanes=Tr
         pos += n
 
 
-@pytest.mark.parametrize("nt,fll_lanes", [(33, 8), (72, 8), (33, 4), (68, 4), (2, 4)])
+@pytest.mark.parametrize("nt,fll_lanes", [(33, 8), (72, 8), (33, 4), (68, 4), (2, 4), (2, 16), (33, 16), (72, 16)])
 def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, fll_lanes, lanes=True):
     N = 2500
     iq, _, _ = synth.gen_channel(N, 77)

@@ -81,7 +81,7 @@ def _check(seq, where):
     return bad
 
 
-@pytest.mark.parametrize("fname,macro", [("fll_asm.inc", "FLL_WAVE"), ("fll4_asm.inc", "FLL4_WAVE")])
+@pytest.mark.parametrize("fname,macro", [("fll_asm.inc", "FLL_WAVE"), ("fll4_asm.inc", "FLL4_WAVE"), ("fll16_asm.inc", "FLL16_WAVE")])
 def test_generated_assembly_respects_the_hazard_distances(fname, macro):
     items = _parse(os.path.join(CSRC, fname), macro)
     instrs = [it for it in items if it[0] != "label"]

@@ -53,18 +53,18 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
         r = o.process(iq[c], stages=True)
         want_x.append(r["x"])
         want_state.append((o.st.fll_phase, o.st.fll_freq))
-    # LDS image: [a_buf[2][nch][32] float2] [tap table re[72] | im[72]] [x_ring[nch][8 + 256 + 1] float2]; a_buf first, like in
+    # LDS image: [a_buf[2][nch][32] float2] [tap table re[80] | im[80]] [x_ring[nch][8 + 256 + 1] float2]; a_buf first, like in
     # FusedLds: the block flips between its halves with an XOR of the address
     nt = int(tab.ntaps)
-    be = np.zeros((2, 72), np.float32)
-    be[0, 72 - nt:] = np.array(tab.be_re[:nt], np.float32)
-    be[1, 72 - nt:] = np.array(tab.be_im[:nt], np.float32)
+    be = np.zeros((2, 80), np.float32)
+    be[0, 80 - nt:] = np.array(tab.be_re[:nt], np.float32)
+    be[1, 80 - nt:] = np.array(tab.be_im[:nt], np.float32)
     a_bytes = 2 * nch * TILE * 8
     off_a, off_be = 0, a_bytes
-    off_x = off_be + 2 * 72 * 4
+    off_x = off_be + 2 * 80 * 4
     row = (KFXP + KFX + 1) * 8
     lds = np.zeros(off_x + nch * row + 64, np.uint8)
-    lds[off_be:off_be + 2 * 72 * 4] = be.view(np.uint8).reshape(-1)
+    lds[off_be:off_be + 2 * 80 * 4] = be.view(np.uint8).reshape(-1)
 
     def put_tile(t):
         if t >= ntiles:
@@ -82,7 +82,7 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     lane = np.arange(64)
     pos = (lane & 15) // hop
     ch = (lane >> 4) * hop + lane % hop
-    tap_off = 72 - lanes * taps
+    tap_off = 80 - lanes * taps
     vec = {
         "ph": np.array([np.float32(start[c][0]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
         "fr": np.array([np.float32(start[c][1]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
@@ -115,7 +115,7 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     return bad
 
 
-GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4, 17)]
+GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4, 17), ("fll16_asm.inc", "FLL16_WAVE", 16, 5)]
 
 
 @pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
@@ -129,7 +129,8 @@ def test_generated_fll_assembly_second_call_replays_the_delay_line(oracle, emul,
 
 
 @pytest.mark.parametrize("fname,macro,lanes,taps,ntaps", [GEOMETRIES[0] + (2,), GEOMETRIES[0] + (33,), GEOMETRIES[0] + (72,),
-                                                          GEOMETRIES[1] + (2,), GEOMETRIES[1] + (33,), GEOMETRIES[1] + (68,)])
+                                                          GEOMETRIES[1] + (2,), GEOMETRIES[1] + (33,), GEOMETRIES[1] + (68,),
+                                                          GEOMETRIES[2] + (2,), GEOMETRIES[2] + (33,), GEOMETRIES[2] + (72,)])
 def test_generated_fll_assembly_other_tap_counts(oracle, emul, synth, fname, macro, lanes, taps, ntaps):
     """Band-edge filters shorter than the row (zero-padded at the old end) and as long as the row holds."""
     assert _run(oracle, emul, synth, fname, macro, lanes, taps, ntaps=ntaps) == []
@@ -146,6 +147,13 @@ def test_the_execution_check_sees_planted_faults(oracle, emul, synth, fname, mac
 
     def no_zero_fill(lines):
         return [ln.replace(" bound_ctrl:1", "") for ln in lines]
+    def wrong_x_hop(lines):          # the x pipeline moved two positions instead of one
+        hop = 16 // lanes
+        return [ln.replace("row_shr:%d " % hop, "row_shr:%d " % (2 * hop)) if "row_shr" in ln else ln for ln in lines]
     nch = 64 // lanes
     assert len(_run(oracle, emul, synth, fname, macro, lanes, taps, mutate=one_op_sel)) >= nch // 2
-    assert len(_run(oracle, emul, synth, fname, macro, lanes, taps, mutate=no_zero_fill)) == nch
+    assert len(_run(oracle, emul, synth, fname, macro, lanes, taps, mutate=wrong_x_hop)) == nch
+    if lanes * taps - 65 < taps:
+        # (with 16 x 5 = 80 padded taps the 15 zero taps in front of a 65-tap filter cover the three outermost positions: the
+        # sums born there stay +0 with or without the zero fill, so this fault cannot show at that geometry)
+        assert len(_run(oracle, emul, synth, fname, macro, lanes, taps, mutate=no_zero_fill)) == nch

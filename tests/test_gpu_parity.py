@@ -64,9 +64,11 @@ def test_tables_match_oracle(pkg, oracle):
     assert np.array_equal(t["bank"], o.interp_bank())
 
 
-# flags: 2 = keep the RRC output for the stage check; 16 = force the 32-channel workgroup shape (default: chosen from the
-# channel count).  Both shapes run the same roles on the same arithmetic: every test runs on both.
-PIPELINES = {"fused": 2, "wide": 2 | 16}
+# flags: 2 = keep the RRC output for the stage check; 32 / 16 / 64 = force the 16-channel ("fused") / the 32-channel / the 4-channel
+# workgroup shape (without a shape flag the library chooses from the channel count: tests that pass flags=0 run whatever it
+# picks).  All shapes run the same roles on the same arithmetic: every test runs on all three.
+PIPELINES = {"fused": 2 | 32, "wide": 2 | 16, "small": 2 | 64}
+SHAPE = 16 | 32 | 64          # the workgroup-shape bits of a PIPELINES entry
 
 
 def _compare(tag, pkg, oracle, iq, chunks, want_state=True, flags=2):
@@ -157,7 +159,7 @@ def test_parity_256_channels_full_second(pkg, oracle, synth, pipeline):
     """BASELINE config 2: 256 synthetic channels @ 36 ksps, 1 s, every output bit compared with the CPU."""
     Cn, N = 256, 36000
     iq, txb, _ = synth.gen_batch(Cn, N, base_seed=4242)
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE)
     bits, nb, sym = d.process(iq, want_sym=True)
     rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
     bad = [c for c in range(Cn) if nb[c] != rnb[c] or not np.array_equal(bits[c][:nb[c]], rb[c][:rnb[c]])]
@@ -181,7 +183,7 @@ def test_parity_256_channels_full_second(pkg, oracle, synth, pipeline):
 def test_reset_and_state_roundtrip(pkg, oracle, synth, pipeline):
     Cn, N = 8, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=31)
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE)
     b1, n1, _ = d.process(iq)
     st3 = d.get_state(3)
     b2, n2, _ = d.process(iq)           # continues from carried state: differs from a fresh run
@@ -204,7 +206,7 @@ def test_time_major_layout(pkg, oracle, synth, pipeline):
     """TETRA_LAYOUT_TIME_MAJOR: iq[n][c] frames (what a channeliser emits) give the same bits as channel-major."""
     Cn, N = 19, 2500
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=61)
-    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, flags=PIPELINES[pipeline] & SHAPE)
     bits, nb, sym = d.process(np.ascontiguousarray(iq.T), want_sym=True)
     rb, rnb, rsym, _ = oracle.process_batch(iq, want_sym=True)
     assert np.array_equal(nb, rnb)
@@ -228,13 +230,13 @@ def test_retired_pipeline_and_tap_counts_above_72_are_refused(pkg):
 
 
 @pytest.mark.parametrize("pipeline,nt", [("fused", 2), ("fused", 33), ("fused", 72), ("wide", 2), ("wide", 33), ("wide", 68), ("wide", 69),
-                                         ("wide", 72)])
+                                         ("wide", 72), ("small", 2), ("small", 33), ("small", 72)])
 def test_other_tap_counts(pkg, oracle, synth, pipeline, nt):
     """rrcTapCount is a PI4DQPSK parameter (2..72 here; the reference builds with 65).  The 32-channel workgroup's FLL rows hold
     4 x 17 = 68 taps: above that the library launches the 16-channel shape whatever the flag says."""
     Cn, N = 6, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=71)
-    d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & 16, rrc_tap_count=nt)
+    d = pkg.Demodulator(Cn, 1500, flags=PIPELINES[pipeline] & SHAPE, rrc_tap_count=nt)
     ocfg = oracle.default_cfg()
     ocfg.rrc_tap_count = nt
     orcs = [oracle.Oracle(ocfg) for _ in range(Cn)]
@@ -253,7 +255,7 @@ def test_setters_match_oracle_with_same_parameters(pkg, oracle, synth, pipeline)
     import ctypes as C
     Cn, N = 4, 4000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=81)
-    d = pkg.Demodulator(Cn, 2000, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, 2000, flags=PIPELINES[pipeline] & SHAPE)
     orcs = [oracle.Oracle() for _ in range(Cn)]
     b1, n1, _ = d.process(iq[:, :2000])
     for c in range(Cn):
@@ -410,11 +412,11 @@ def test_non_finite_input_cannot_hang_or_overrun(pkg, synth, pipeline):
     its output stays inside its row, and the neighbours are untouched."""
     Cn, N = 18, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=91)
-    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16).process(iq)
+    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE).process(iq)
     bad = iq.copy()
     bad[3, 100] = np.nan
     bad[7, 200] = np.inf
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE)
     bits, nb, _ = d.process(bad, allow_overrun=True)
     stride = bits.shape[1]
     assert (nb >= 0).all() and (nb <= stride).all()
@@ -433,10 +435,10 @@ def test_a_full_row_is_reported_never_silent(pkg, synth, pipeline):
     asynchronous path reports it from tetra_demod_wait, the device path through tetra_demod_get_overruns."""
     Cn, N = 18, 3000
     iq, _, _ = synth.gen_batch(Cn, N, base_seed=92)
-    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16).process(iq)
+    clean = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE).process(iq)
 
     def poisoned():
-        d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+        d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE)
         for c in (3, 7):
             st = d.get_state(c)
             st.mu = float("nan")
@@ -539,7 +541,7 @@ def test_quality_statistic(pkg, oracle, synth, pipeline):
     rng = np.random.default_rng(3)
     iq[2] = (0.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)   # noise: no sync
     iq[5] = synth.gen_channel(N, 9, esn0_db=12.0)[0]
-    d = pkg.Demodulator(Cn, 10000, flags=(PIPELINES[pipeline] & 16) | pkg.binding.FLAG_QUALITY)
+    d = pkg.Demodulator(Cn, 10000, flags=(PIPELINES[pipeline] & SHAPE) | pkg.binding.FLAG_QUALITY)
     orcs = [oracle.Oracle() for _ in range(Cn)]
     pos = 0
     for k, n in enumerate([3000, 100, 37, 400, 10000, 0, 1, 3000, 462, 7000]):
@@ -564,7 +566,7 @@ def test_quality_statistic(pkg, oracle, synth, pipeline):
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_combinations_of_shape_layout_outputs_and_chunking(pkg, oracle, synth, seed):
     """Seeded random draws over what the other tests vary one at a time: channel count (1..75: ragged last workgroup of
-    either shape), workgroup shape (automatic / 16 / 32 channels), input layout, symbol output, quality statistic, call
+    either shape), workgroup shape (automatic / 16 / 32 / 4 channels), input layout, symbol output, quality statistic, call
     lengths from 0 to 1500 samples with carried state, a reset of one channel in the middle.  Bits, bit counts and symbols
     equal the oracle's for every channel after every call."""
     rng = np.random.default_rng(9000 + seed)
@@ -573,6 +575,8 @@ def test_random_combinations_of_shape_layout_outputs_and_chunking(pkg, oracle, s
     tm = bool(rng.integers(0, 2))
     shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS]))
     quality = bool(rng.integers(0, 2))
+    if seed % 3 == 2:                    # (drawn after the others so that the earlier seeds keep their combinations)
+        shape = B.FLAG_SMALL_WORKGROUPS
     chunks = [int(rng.choice([0, 1, 31, 32, 33, 64, 255, 700, 1500])) for _ in range(6)]
     N = sum(chunks)
     iq, _, _ = synth.gen_batch(Cn, max(N, 1), base_seed=500 + 13 * seed)
@@ -620,7 +624,7 @@ def test_soak_twelve_seconds_of_signal_with_carried_state(pkg, oracle, synth, pi
     the oracle's state -- nothing drifts between the two over long runs."""
     Cn, N, SEC = 64, 36000, 12
     iq = np.concatenate([synth.gen_batch(Cn, N, base_seed=5000 + 17 * s)[0] for s in range(SEC)], axis=1)
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE)
     states = None
     total = 0
     for s in range(SEC):
@@ -757,7 +761,7 @@ def test_config5_rates_800_channels_time_major(pkg, oracle, synth, pipeline):
     iq = (src[np.arange(Cn) % base] * (amp * rot)).astype(np.complex64)
     iq[7] = 0                                                              # an idle channel, like most of a real band
     iq[8] = (0.05 * (rng.standard_normal(2 * N) + 1j * rng.standard_normal(2 * N))).astype(np.complex64)
-    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, samplerate=50000.0, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR, samplerate=50000.0, flags=PIPELINES[pipeline] & SHAPE)
     oc = oracle.default_cfg()
     oc.samplerate = 50000.0
     t, o = d.tables(), oracle.Oracle(oc)
@@ -790,7 +794,7 @@ def test_symbol_rate_setter_outside_two_samples_per_symbol(pkg, oracle, synth, p
     import ctypes as C
     Cn, N = 20, 9000
     iq, _, _ = synth.gen_batch(Cn, 2 * N, base_seed=2020, sps=1.8)
-    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & 16)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE)
     orcs = [oracle.Oracle() for _ in range(Cn)]
     d.set_param("symbolrate", 20000.0)
     for o in orcs:

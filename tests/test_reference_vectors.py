@@ -78,12 +78,12 @@ def test_oracle_equals_reference_code_outputs_at_50_ksps_and_for_eight_chains(ve
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["narrow", "wide"])
+@pytest.mark.parametrize("shape", ["narrow", "wide", "small"])
 def test_gpu_equals_reference_code_outputs_at_50_ksps_and_batched(vec, pkg, shape):
     """The kernel against the reference code's outputs at config 5's rate, for eight chains in ONE handle (what batching
     means: the reference ran eight separate object sets), and through tetra_demod_set_rrc_params mid-stream."""
     B = pkg.binding
-    shape_flag = B.FLAG_WIDE_WORKGROUPS if shape == "wide" else B.FLAG_NARROW_WORKGROUPS
+    shape_flag = {"wide": B.FLAG_WIDE_WORKGROUPS, "narrow": B.FLAG_NARROW_WORKGROUPS, "small": B.FLAG_SMALL_WORKGROUPS}[shape]
     d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag, samplerate=50000.0)
     bits, nb, sym = d.process(vec["rate50_iq"][None, :], want_sym=True)
     _close(sym[0][:nb[0] // 2], vec["rate50_sym"], bits[0][:nb[0]], vec["rate50_bits"], "50 ksps")
@@ -108,12 +108,12 @@ def test_gpu_equals_reference_code_outputs_at_50_ksps_and_batched(vec, pkg, shap
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["narrow", "wide"])
+@pytest.mark.parametrize("shape", ["narrow", "wide", "small"])
 def test_gpu_equals_reference_code_outputs(vec, pkg, shape):
     """The HIP kernel through the C ABI against the reference code's outputs, no oracle in between; both workgroup shapes
     (FLL rows of 8 and of 4 lanes per channel)."""
     B = pkg.binding
-    shape_flag = B.FLAG_WIDE_WORKGROUPS if shape == "wide" else B.FLAG_NARROW_WORKGROUPS
+    shape_flag = {"wide": B.FLAG_WIDE_WORKGROUPS, "narrow": B.FLAG_NARROW_WORKGROUPS, "small": B.FLAG_SMALL_WORKGROUPS}[shape]
     d = pkg.Demodulator(1, 65536, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag)
     bits, nb, sym = d.process(vec["probe_iq"][None, :], want_sym=True)
     _close(sym[0][:nb[0] // 2], vec["probe_sym"], bits[0][:nb[0]], vec["probe_bits"], "probe")
