@@ -216,6 +216,9 @@ struct tetra_demod {
     int* st_nbits = nullptr;
     float* st_sym = nullptr;
     size_t st_iq_bytes = 0, st_bits_bytes = 0, st_sym_bytes = 0;
+    // small synchronous calls (the single-channel drop-in's 180-sample chunks): page-locked host staging, one packed output
+    uint8_t *pk_dev = nullptr, *pk_host = nullptr, *pk_in = nullptr;
+    size_t pk_bytes = 0, pk_in_bytes = 0;
     // ring of HIP-event pairs (before / after the call's launches), one slot per process call
     static constexpr int kEvSlots = 64;
     hipEvent_t ev[kEvSlots][2] = {};
@@ -354,6 +357,9 @@ void free_all(tetra_demod* h) {
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
+    if (h->pk_dev) (void)hipFree(h->pk_dev);
+    if (h->pk_host) (void)hipHostFree(h->pk_host);
+    if (h->pk_in) (void)hipHostFree(h->pk_in);
     hipStream_t ss[] = { a.s_in, a.s_k, a.s_out, h->own_stream };
     for (hipStream_t st : ss)
         if (st) (void)hipStreamDestroy(st);
@@ -700,6 +706,56 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
     const size_t iq_bytes = sizeof(float) * 2 * C * (size_t)n_samples;
     const size_t bits_bytes = C * (size_t)bits_stride;
     const size_t sym_bytes = sym ? sizeof(float) * 2 * C * (size_t)(bits_stride / 2) : 0;
+    // Small calls -- the single-channel drop-in hands over 180 samples at a time (SDR++'s stream chunks at 36 ksps) -- are
+    // dominated by the four blocking copies around a ~40 us launch.  They take one asynchronous chain on the handle's own
+    // stream instead: samples through a page-locked bounce buffer, ONE packed output [n_bits | bits | symbols] back into
+    // page-locked memory, one synchronisation, then plain memcpys into the caller's arrays.
+    constexpr size_t kSmallCall = 256 * 1024;
+    const size_t nb_bytes = (sizeof(int) * C + 15) / 16 * 16;
+    const size_t pack_bytes = nb_bytes + bits_bytes + sym_bytes + 16;      // + the overrun counter, so that it rides along
+    if (n_samples > 0 && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall) {
+        if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        if (pack_bytes > h->pk_bytes) {
+            if (h->pk_dev) (void)hipFree(h->pk_dev);
+            if (h->pk_host) (void)hipHostFree(h->pk_host);
+            h->pk_dev = h->pk_host = nullptr; h->pk_bytes = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->pk_dev, kSmallCall));
+            HIP_TRY(h, hipMemset(h->pk_dev, 0, kSmallCall));
+            HIP_TRY(h, hipHostMalloc((void**)&h->pk_host, kSmallCall, hipHostMallocDefault));
+            h->pk_bytes = kSmallCall;
+        }
+        if (iq_bytes > h->pk_in_bytes) {
+            if (h->pk_in) (void)hipHostFree(h->pk_in);
+            h->pk_in = nullptr; h->pk_in_bytes = 0;
+            HIP_TRY(h, hipHostMalloc((void**)&h->pk_in, kSmallCall, hipHostMallocDefault));
+            h->pk_in_bytes = kSmallCall;
+        }
+        if (iq_bytes > h->st_iq_bytes) {
+            if (h->st_iq) (void)hipFree(h->st_iq);
+            h->st_iq = nullptr; h->st_iq_bytes = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->st_iq, iq_bytes));
+            h->st_iq_bytes = iq_bytes;
+        }
+        std::memcpy(h->pk_in, iq, iq_bytes);
+        HIP_TRY(h, hipMemcpyAsync(h->st_iq, h->pk_in, iq_bytes, hipMemcpyHostToDevice, h->own_stream));
+        uint8_t* d_nb = h->pk_dev;
+        uint8_t* d_bits = h->pk_dev + nb_bytes;
+        uint8_t* d_sym = d_bits + bits_bytes;
+        int rc = tetra_demod_process_device(h, h->st_iq, n_samples, d_bits, bits_stride, reinterpret_cast<int32_t*>(d_nb),
+                                            sym ? reinterpret_cast<float*>(d_sym) : nullptr, h->own_stream);
+        if (rc != TETRA_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->pk_dev + pack_bytes - 16, h->d_overruns, sizeof(int), hipMemcpyDeviceToDevice, h->own_stream));
+        HIP_TRY(h, hipMemcpyAsync(h->pk_host, h->pk_dev, pack_bytes, hipMemcpyDeviceToHost, h->own_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+        std::memcpy(n_bits, h->pk_host, sizeof(int) * C);
+        std::memcpy(bits, h->pk_host + nb_bytes, bits_bytes);
+        if (sym) std::memcpy(sym, h->pk_host + nb_bytes + bits_bytes, sym_bytes);
+        int total = 0;
+        std::memcpy(&total, h->pk_host + pack_bytes - 16, sizeof(int));
+        const long long fresh = (long long)total - h->overruns_seen;
+        h->overruns_seen = total;
+        return fresh > 0 ? TETRA_ERR_OVERRUN : TETRA_OK;
+    }
     if (iq_bytes > h->st_iq_bytes) {
         if (h->st_iq) (void)hipFree(h->st_iq);
         h->st_iq = nullptr; h->st_iq_bytes = 0;
