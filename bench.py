@@ -328,6 +328,9 @@ def main():
     ap.add_argument("--chain", action="store_true",
                     help="also run the device-resident receive chain behind the demodulator (burst synchroniser -> demultiplexer "
                          "-> lower-MAC decoder; profiles/measure_pipeline*.py) and attach its timings as \"chain\" (informational)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="build the torch.distributed group even for ONE rank: runs the RCCL set-up, barrier and MAX reduction of the "
+                         "N > 1 path on a one-GPU box (RCCL refuses several ranks on one device, so this is how its half is exercised there)")
     ap.add_argument("--no-time-major", action="store_true",
                     help="skip the informational leg that hands the same workload over time-major (iq[n][c], field time_major)")
     args = ap.parse_args()
@@ -352,9 +355,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         # RCCL carries only the barrier and the MAX of the elapsed time (no data-path collective).  One rank per GPU: RCCL
         # refuses ranks that share a device ("Duplicate GPU detected") -- a functional run of the N > 1 path on fewer GPUs
         # than ranks takes --backend gloo.  A communicator that cannot be built fails the run at once, loudly.

@@ -42,3 +42,17 @@ def test_bench_gpus_2_runs_two_ranks(backend):
     assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
     # two ranks of 4096 channels each: the whole-job value counts both
     assert abs(d["value"] - 2 * 4096 * 36000 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+
+
+def test_bench_rccl_half_of_the_rank_path_on_one_gpu():
+    """RCCL refuses several ranks on one device, so on a one-GPU box its half of bench.py's N > 1 path -- communicator set-up
+    with device_id, barrier, MAX all-reduce of the elapsed time on a device tensor, tear-down -- runs as a ONE-rank group
+    (--force-dist); the two-rank half runs over gloo above."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-host-path", "--no-large-batch", "--no-config5", "--no-time-major", "--force-dist", "--backend", "nccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    d = _line(r)
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(d, open(os.path.join(OUT, "bench_force_dist_nccl.json"), "w"))
+    assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_world_size"] == 1
+    assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
