@@ -187,6 +187,54 @@ int gpu_paths() {
         for (int c = 0; c < 9; c++) CHECK(nb[c] >= 0 && nb[c] <= stride);
     }
     CHECK(mb.reset() == TETRA_OK && mb.setParam(TETRA_PARAM_FLL_BANDWIDTH, 0.004) == TETRA_OK);
+    {   // int16 input through both shards; null device-pointer tables are refused before any worker runs
+        const int count = 777;
+        std::vector<int16_t> q((size_t)9 * count * 2, (int16_t)1234);
+        const int stride = mb.bitsStride(count);
+        std::vector<uint8_t> bits((size_t)9 * stride);
+        std::vector<int32_t> nb(9);
+        CHECK(mb.processCS16(count, q.data(), bits.data(), nb.data()) == TETRA_OK);
+        for (int c = 0; c < 9; c++) CHECK(nb[c] >= 0 && nb[c] <= stride);
+        CHECK(mb.processDevice(count, nullptr, nullptr, nullptr) == TETRA_ERR_ARG);
+        const dsp::complex_t* none[2] = { nullptr, nullptr };
+        uint8_t* nob[2] = { nullptr, nullptr };
+        int32_t* non[2] = { nullptr, nullptr };
+        CHECK(mb.processDevice(count, none, nob, non) == TETRA_ERR_ARG);
+        CHECK(mb.quality(nullptr, nullptr) == TETRA_ERR_UNSUPPORTED);      // no TETRA_FLAG_QUALITY on this bank
+    }
+    {   // the statistic across shards
+        dsp::demod::PI4DQPSKMultiBank qm;
+        tetra_demod_config_t qc = cfg;
+        qc.n_channels = 5; qc.max_samples = 1500; qc.flags |= TETRA_FLAG_QUALITY;
+        CHECK(qm.init(qc, { 0, 0 }) == TETRA_OK);
+        std::vector<dsp::complex_t> iq((size_t)5 * 1500, dsp::complex_t{ 0.1f, 0.2f });
+        const int stride = qm.bitsStride(1500);
+        std::vector<uint8_t> bits((size_t)5 * stride);
+        std::vector<int32_t> nb(5);
+        CHECK(qm.process(1500, iq.data(), bits.data(), nb.data()) == TETRA_OK);
+        std::vector<float> err(5, -1.f);
+        std::vector<uint8_t> sy(5, 9);
+        CHECK(qm.quality(err.data(), sy.data()) == TETRA_OK);
+        for (int c = 0; c < 5; c++) CHECK(err[c] >= 0.f && err[c] < 1.f && sy[c] <= 1);
+    }
+    {   // the drop-in block at another symbol rate (rows follow the rates), setRRCParams / setRRCBeta(int), a refused rate
+        dsp::stream<dsp::complex_t> s2;
+        dsp::demod::PI4DQPSK d2;
+        d2.init(&s2, 18000, 36000, 65, 0.35, 0.02, 0.01, 0.006, cfg.omega_gain, cfg.mu_gain, 0.02);
+        CHECK(d2.lastStatus() == TETRA_OK);
+        d2.setSymbolrate(20000);
+        CHECK(d2.lastStatus() == TETRA_OK);
+        std::vector<dsp::complex_t> in(5000, dsp::complex_t{ 0.2f, -0.1f }), out(5000);
+        const int ns = d2.process(5000, in.data(), out.data());
+        CHECK(ns > 5000 / 2 && ns <= 5000 && (int)d2.lastBits().size() == 2 * ns);
+        d2.setRRCParams(33, 0.4);
+        CHECK(d2.lastStatus() == TETRA_OK);
+        d2.setRRCBeta(1);
+        CHECK(d2.lastStatus() == TETRA_OK);
+        d2.setSymbolrate(36000);                      // one sample per symbol: symbols could stop advancing
+        CHECK(d2.lastStatus() == TETRA_ERR_UNSUPPORTED);
+        CHECK(d2.process(100, in.data(), out.data()) > 0);      // nothing changed: the block still runs at 20 ksymbols/s
+    }
     return 0;
 }
 }  // namespace
