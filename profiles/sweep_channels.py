@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--shape", choices=["auto", "narrow", "wide", "small"], default="auto",
                     help="workgroup shape: chosen by the library from the channel count, or forced (16 / 32 / 4 channels per workgroup)")
+    ap.add_argument("--layout", choices=["channel_major", "time_major"], default="channel_major")
     a = ap.parse_args()
     import torch
     import tetra_amd
@@ -34,7 +35,10 @@ def main():
         nb = torch.zeros(C, dtype=torch.int32, device=dev)
         flags = {"auto": 0, "narrow": pkg.binding.FLAG_NARROW_WORKGROUPS, "wide": pkg.binding.FLAG_WIDE_WORKGROUPS,
                  "small": pkg.binding.FLAG_SMALL_WORKGROUPS}[a.shape]
-        dem = pkg.Demodulator(C, N, flags=flags)
+        tm = a.layout == "time_major"
+        if tm:
+            iq = iq.transpose(0, 1).contiguous()
+        dem = pkg.Demodulator(C, N, flags=flags, layout=pkg.binding.LAYOUT_TIME_MAJOR if tm else pkg.binding.LAYOUT_CHANNEL_MAJOR)
         st = torch.cuda.current_stream(dev)
         for _ in range(bench.RAMP_STEPS + 2):
             dem.process_device(iq, N, bits, stride, nb, None, st)
@@ -47,7 +51,7 @@ def main():
         wgs = (C + 15) // 16
         if C == 4096:
             base = ms
-        print(json.dumps({"channels": C, "samples": N, "shape": a.shape, "kernel_ms": round(ms, 4), "workgroups_of_16": wgs, "cus": cus,
+        print(json.dumps({"channels": C, "samples": N, "shape": a.shape, "layout": a.layout, "kernel_ms": round(ms, 4), "workgroups_of_16": wgs, "cus": cus,
                           "workgroups_of_16_per_cu": round(wgs / cus, 2), "msamples_s": round(C * N / ms / 1e3, 1),
                           "ms_per_4096_channels": round(ms * 4096 / C, 4),
                           "vs_4096": round(ms / base, 3) if base else None}), flush=True)
