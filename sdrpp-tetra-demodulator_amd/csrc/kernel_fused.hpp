@@ -150,6 +150,7 @@ template <int CH> struct FusedLdsT {
     float2 s_ring[CH][kFS];
     int s_avail[CH];
     int e_span[2][CH];       // 4-channel workgroup: the symbols [first, end) the Costas wave's recurrence lane has just finished
+    float2 e_last[2][CH];    // ... and, by epoch parity, z of the last symbol finished so far (the slicer's "previous symbol")
     // interpolator bank with row 0 repeated in front and row 127 behind: rows max(p-1,0), p, min(p+1,127) of
     // complex_fd.cpp:102-121 are then the 24 contiguous floats at bank[p * 8]
     __attribute__((aligned(16))) float bank[(kInterpPhases + 2) * kInterpTaps];
@@ -555,6 +556,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         st.cfr = p.cfr[chan(c)];
         st.ph2 = p.ph2[chan(c)];
         int S = 0;
+        float2 zlast = make_float2(0.f, 0.f);              // z of the newest finished symbol (none yet: symbol 0 uses prev0)
         constexpr int kFin = 64 / CH;                      // finishing lanes per channel
         const int fc = lane / kFin, fj = lane % kFin;
         uint8_t* brow = p.bits + (long long)chan(fc) * p.bits_stride;
@@ -574,9 +576,13 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                         const float2 v = L.s_ring[c][S & (kFS - 1)];
                         float zr; float zi;
                         k2_costas_rot(k2, st, v.x, v.y, &zr, &zi);
-                        L.s_ring[c][S & (kFS - 1)] = make_float2(zr, zi);
+                        zlast = make_float2(zr, zi);
+                        L.s_ring[c][S & (kFS - 1)] = zlast;
                         S++;
                     }
+                    // The symbol before this epoch's first one is NOT taken from the ring by the finishing lanes: at close to
+                    // one sample per symbol the timing wave, up to a tile ahead, may already be writing into that slot.
+                    L.e_last[e & 1][c] = zlast;
                 }
                 // same wave: its LDS operations execute in order, the fence only keeps the compiler from moving them
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -584,7 +590,9 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                 const int f0 = L.e_span[0][fc], f1 = L.e_span[1][fc];
                 for (int i = f0 + fj; i < f1; i += kFin) {
                     const float2 z = L.s_ring[fc][i & (kFS - 1)];
-                    const float2 zp = L.s_ring[fc][(i - 1) & (kFS - 1)];      // z of the symbol before (an earlier epoch left it there)
+                    // z of the symbol before: this epoch's own (in the ring), or the one the previous epoch ended on
+                    const float2* zpp = i == f0 ? &L.e_last[(e - 1) & 1][fc] : &L.s_ring[fc][(i - 1) & (kFS - 1)];
+                    const float2 zp = *zpp;
                     const int prevq = i == 0 ? prev0 : k2_quadrant(zp.x, zp.y);
                     const int d = k2_dibit(k2_quadrant(z.x, z.y), prevq);
                     if (fwr) {
@@ -599,10 +607,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.cph[ch0 + c] = st.cph;
             p.cfr[ch0 + c] = st.cfr;
             p.ph2[ch0 + c] = st.ph2;
-            if (S > 0) {
-                const float2 zl = L.s_ring[c][(S - 1) & (kFS - 1)];
-                p.prev[ch0 + c] = k2_quadrant(zl.x, zl.y);
-            }
+            if (S > 0) p.prev[ch0 + c] = k2_quadrant(zlast.x, zlast.y);
             p.n_bits[ch0 + c] = 2 * S;
         }
     } else if (wave == kRoleE) {

@@ -897,3 +897,24 @@ def test_matrix_pipe_f32_is_the_contract_fmaf_chain(pkg, oracle, shape):
     _dump("mfma_selftest_%d.json" % shape, report)
     assert not any(report.values()), report
     d.close()
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_close_to_one_sample_per_symbol(pkg, oracle, synth, pipeline):
+    """The slowest timing loop the library accepts: symbolrate 34000 at 36 ksps (omega 1.059, slowest step 1.02 samples per
+    symbol -- almost one symbol per sample: the symbol ring between the timing wave and the Costas wave turns over every two
+    tiles, rows hold ~n bits per... 2 n / 1.02).  Created at that rate (other band-edge filters, another RRC), three calls with
+    carried state, every bit and symbol against the oracle created the same way."""
+    Cn, N = 9, 4000
+    iq, _, _ = synth.gen_batch(Cn, 3 * N, base_seed=3400, sps=36000.0 / 34000.0)
+    d = pkg.Demodulator(Cn, N, flags=PIPELINES[pipeline] & SHAPE, symbolrate=34000.0)
+    oc = oracle.default_cfg()
+    oc.symbolrate = 34000.0
+    orcs = [oracle.Oracle(oc) for _ in range(Cn)]
+    assert d.bits_stride(N) >= 2 * int(N / 1.0377)
+    for k in range(3):
+        _run_vs_oracles(d, orcs, iq[:, k * N:(k + 1) * N])
+    assert d.overruns() == 0
+    nb = d.process(iq[:, :N])[1]
+    assert (nb > 2 * N / 1.09).all()                                     # really ~0.94 symbols per sample
+    d.close()
