@@ -30,13 +30,29 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile the library if missing or older than its sources.  Returns the .so path."""
-    if force or is_stale():
-        # fll_asm.inc is generated (and committed): refuse to build from one that is not what the generator emits
-        import sys
-        subprocess.run([sys.executable, os.path.join(CSRC, "gen_fll_asm.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+    """Compile the library if missing or older than its sources.  Returns the .so path.  Serialised across processes by a
+    lock file (the ranks of a multi-GPU run all import the package at once: one builds, the others find the result), and the
+    library appears atomically (compiled next to its final name, then renamed)."""
+    if not (force or is_stale()):
+        return LIB
+    import fcntl
+    import sys
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or is_stale():
+                # fll_asm.inc is generated (and committed): refuse to build from one that is not what the generator emits
+                subprocess.run([sys.executable, os.path.join(CSRC, "gen_fll_asm.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
+                tmp = LIB + ".tmp.%d" % os.getpid()
+                cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                if verbose:
+                    print(" ".join(cmd))
+                try:
+                    subprocess.run(cmd, check=True)
+                    os.replace(tmp, LIB)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
