@@ -574,6 +574,28 @@ struct K2State {
     int prev;
 };
 
+// Timing recovery step (complex_fd.cpp:101-143), second half: from the three interpolated values v = f(T) (bank row `phase`),
+// a = f(T+1) (row min(phase+1,127)), b = f(T-1) (row max(phase-1,0)) to the loop update.  Advances mu / omega / offset.
+TD_FN void k2_timing_tail(const K2Consts& k, K2State& st, int phase, float vr, float vi, float ar, float ai, float br, float bi) {
+    // complex_fd.cpp:107-123, branch-free: one-sided differences at the bank edges, central difference inside
+    // At the low edge the "row below" IS row `phase` (the caller clamps the neighbour rows), so b equals v bit for bit and a - b
+    // is the reference's one-sided f(T+1) - f(T); likewise a == v at the high edge.
+    const bool edge = phase == 0 || phase == kInterpPhases - 1;
+    const float sc = edge ? 1.0f : 0.5f;                  // x*1.0f is exact, so the edge cases stay `a - b`
+    const float dr = (ar - br) * sc, di = (ai - bi) * sc;
+    // complex_fd.cpp:126,136-137
+    float terr = ((vr > 0 ? 1.0f : -1.0f) * dr) + ((vi > 0 ? 1.0f : -1.0f) * di);
+    terr = v_clamp(terr, -1.0f, 1.0f);
+    // complex_fd.cpp:140-143
+    pcl_advance<float, false>(terr, st.mu, st.omega, k.tr_alpha, k.tr_beta, k.tr_min_freq, k.tr_max_freq);
+    float delta = v_floor(st.mu);
+    // A finite stream always advances by >= 1 sample (omega (1 - rel_limit) - |alpha| >= 1 is a condition of create), so the
+    // max() is neutral there; it guarantees forward progress (loop termination) when NaN/Inf has poisoned mu.
+    const int adv = (int)delta;
+    st.offset += adv > 1 ? adv : 1;
+    st.mu = st.mu - delta;
+}
+
 // Timing recovery step (complex_fd.cpp:101-143).  w[0..7]: the 8 complex samples buffer[offset..offset+7];
 // rows tm1/t0/tp1: interpolator bank rows max(phase-1,0), phase, min(phase+1,127).  Returns the interpolated
 // symbol (vr, vi) and advances mu / omega / offset.  The three 8-tap dots run as packed (re,im) fmaf chains.
@@ -586,27 +608,33 @@ TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float
         a = pk_fma(w[j], Pair<float>(tp1[j], tp1[j]), a);
         b = pk_fma(w[j], Pair<float>(tm1[j], tm1[j]), b);
     }
-    const float vr = v.x(), vi = v.y(), ar = a.x(), ai = a.y(), br = b.x(), bi = b.y();
-    // complex_fd.cpp:107-123, branch-free: one-sided differences at the bank edges, central difference inside
-        // At the low edge tm1 IS row `phase` (the caller clamps the neighbour rows), so b equals v bit for bit and a - b is the
-    // reference's one-sided f(T+1) - f(T); likewise a == v at the high edge.
-    const bool edge = phase == 0 || phase == kInterpPhases - 1;
-    const float sc = edge ? 1.0f : 0.5f;                  // x*1.0f is exact, so the edge cases stay `a - b`
-    const float dr = (ar - br) * sc, di = (ai - bi) * sc;
-    // complex_fd.cpp:126,136-137
-    float terr = ((vr > 0 ? 1.0f : -1.0f) * dr) + ((vi > 0 ? 1.0f : -1.0f) * di);
-    terr = v_clamp(terr, -1.0f, 1.0f);
-    // complex_fd.cpp:140-143
-    pcl_advance<float, false>(terr, st.mu, st.omega, k.tr_alpha, k.tr_beta, k.tr_min_freq, k.tr_max_freq);
-    float delta = v_floor(st.mu);
-    // A finite stream always advances by >= 1 sample (omega >= 2(1 - rel_limit) > 1 + |alpha|), so the max() is
-    // neutral there; it guarantees forward progress (loop termination) when NaN/Inf has poisoned mu.
-    const int adv = (int)delta;
-    st.offset += adv > 1 ? adv : 1;
-    st.mu = st.mu - delta;
+    k2_timing_tail(k, st, phase, v.x(), v.y(), a.x(), a.y(), b.x(), b.y());
+    *out_re = v.x();
+    *out_im = v.y();
+}
+
+#if TD_DEVICE
+// The same step with the three dots on three lanes of a quad (the timing wave of the 16- and 4-channel workgroups spends four
+// lanes on a channel): lane kq of the quad holds ONE bank row -- kq 0: row `phase`, 1: min(phase+1,127), 2: max(phase-1,0)
+// (3: any) -- and runs one 8-tap chain; the three results are then broadcast over the quad and every lane makes the same loop
+// update, so the four lanes carry identical state.  8 packed FMAs and 2 row loads per symbol instead of 24 and 6, at the price
+// of six quad_perm moves; every value is the one k2_timing computes (each dot is the same fmaf chain).
+template <int Q> TD_FN float quad_bcast(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), Q * 0x55, 0xf, 0xf, true));
+}
+TD_FN void k2_timing_quad(const K2Consts& k, K2State& st, int phase, const Pair<float>* w, const float* trow,
+                          float* out_re, float* out_im) {
+    Pair<float> d(0.0f, 0.0f);
+#pragma unroll
+    for (int j = 0; j < kInterpTaps; j++) d = pk_fma(w[j], Pair<float>(trow[j], trow[j]), d);
+    const float vr = quad_bcast<0>(d.x()), vi = quad_bcast<0>(d.y());
+    const float ar = quad_bcast<1>(d.x()), ai = quad_bcast<1>(d.y());
+    const float br = quad_bcast<2>(d.x()), bi = quad_bcast<2>(d.y());
+    k2_timing_tail(k, st, phase, vr, vi, ar, ai, br, bi);
     *out_re = vr;
     *out_im = vi;
 }
+#endif
 
 // complex_fd.cpp:101: interpolator phase of the next symbol.
 TD_FN int k2_phase(float mu) {

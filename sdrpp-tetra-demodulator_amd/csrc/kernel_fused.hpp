@@ -473,9 +473,13 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         )
         if (wave == kRoleC && lane < CH && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
     } else if (wave == kRoleD) {
-        // ---- timing recovery: lane c < 16 owns channel c; consumes y of tiles <= e-3 ---------------------
-        const bool on = lane < CH;
-        const int c = on ? lane : 0;
+        // ---- timing recovery; consumes y of tiles <= e-3 ------------------------------------------------------
+        // 16- and 4-channel workgroups: FOUR lanes per channel (lane = 4 c + kq), each holding one of the symbol's three
+        // interpolator rows (k2_timing_quad; identical loop state in the four lanes); 32-channel workgroup: one lane per channel.
+        constexpr int kDL = CH <= 16 ? 4 : 1;
+        const bool on = lane < CH * kDL;
+        const int c = on ? lane / kDL : 0;
+        const int kq = lane % kDL;
         K2State st;
         st.mu = p.mu[chan(c)];
         st.omega = p.omega[chan(c)];
@@ -489,6 +493,8 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         bool cut = false;
         const unsigned y_base = pin_u32(lds_addr(&L.y_ring[c][0]));
         const unsigned bank_base = pin_u32(lds_addr(&L.bank[0]));
+        const unsigned row_off = kq == 1 ? 64u : kq == 2 ? 0u : 32u;
+        (void)row_off;
         K2Consts k2 = p.k2;
         k2.tr_max_freq = v_pin(k2.tr_max_freq);
         __syncthreads();
@@ -501,22 +507,32 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                     // window buffer[offset .. offset+7] (contiguous thanks to the ring's mirror) and bank rows
                     // max(phase-1,0), phase, min(phase+1,127) = 24 contiguous floats of the padded table
                     lds_cfloat2* yw = (lds_cfloat2*)(size_t)(y_base + (((st.offset - (kInterpTaps - 1)) & (kFY - 1)) << 3));
-                    lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5));
-                    Pair<float> w[kInterpTaps]; float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
+                    Pair<float> w[kInterpTaps];
                     _Pragma("unroll")
                     for (int j = 0; j < kInterpTaps; j++) {
                         const vfloat2 wv = yw[j];
                         w[j] = Pair<float>(wv.x, wv.y);
                     }
-                    vfloat4 q;
-                    q = bk[0]; tm1[0] = q.x; tm1[1] = q.y; tm1[2] = q.z; tm1[3] = q.w;
-                    q = bk[1]; tm1[4] = q.x; tm1[5] = q.y; tm1[6] = q.z; tm1[7] = q.w;
-                    q = bk[2]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
-                    q = bk[3]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
-                    q = bk[4]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
-                    q = bk[5]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
                     float vr; float vi;
-                    k2_timing(k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
+                    vfloat4 q;
+                    if constexpr (kDL == 4) {
+                        // this lane's row of the padded table: kq 0 -> row phase (+32 bytes), 1 -> phase+1 (+64), 2 -> phase-1 (+0)
+                        lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5) + row_off);
+                        float tr[kInterpTaps];
+                        q = bk[0]; tr[0] = q.x; tr[1] = q.y; tr[2] = q.z; tr[3] = q.w;
+                        q = bk[1]; tr[4] = q.x; tr[5] = q.y; tr[6] = q.z; tr[7] = q.w;
+                        k2_timing_quad(k2, st, phase, w, tr, &vr, &vi);
+                    } else {
+                        lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5));
+                        float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
+                        q = bk[0]; tm1[0] = q.x; tm1[1] = q.y; tm1[2] = q.z; tm1[3] = q.w;
+                        q = bk[1]; tm1[4] = q.x; tm1[5] = q.y; tm1[6] = q.z; tm1[7] = q.w;
+                        q = bk[2]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
+                        q = bk[3]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
+                        q = bk[4]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
+                        q = bk[5]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
+                        k2_timing(k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
+                    }
                     L.s_ring[c][S & (kFS - 1)] = make_float2(vr, vi);
                     S++;
                 };
@@ -536,7 +552,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                 L.s_avail[c] = S;
             }
         )
-        if (on && live(c)) {
+        if (on && kq == 0 && live(c)) {
             p.mu[ch0 + c] = st.mu;
             p.omega[ch0 + c] = st.omega;
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
