@@ -43,13 +43,15 @@ class Shape:
     interleaved, so a hop between neighbouring positions is a shift by 16/lanes lanes.  The schedule's period is taps - 1
     steps (the residents of a position), which must divide the tile."""
 
-    def __init__(self, lanes, taps, out, prefix, what, fold_c12=False):
+    def __init__(self, lanes, taps, out, prefix, what, fold_c12=True):
         self.lanes, self.taps, self.out, self.prefix, self.what = lanes, taps, os.path.join(HERE, out), prefix, what
         # the first two Cody-Waite steps as ONE fma with C1 + C2 (the operand %[negc1] then carries -(C1 + C2)): C1 + C2 is a
         # binary32 number, k is -1, 0 or 1 and x - k*C1 is exact (Sterbenz) for every |x| <= pi, so fma(-k, C1 + C2, x) is
         # fma(-k, C2, fma(-k, C1, x)) bit for bit -- checked over all 2 157 060 024 floats of [-pi, pi] in tests/test_oracle.py.
-        # Off for both shipped geometries: one slot less changed neither launch time (profiles/r02/r02_l, r02_q).
-        self.fold_c12 = fold_c12
+        # On for all three geometries since round 3: with the timing wave on four lanes per channel the FLL stream is what
+        # paces every shape, and the slot shows (4096 x 36000: -0.75 %, 8192: -0.5 %, <= 1024 channels: -1.9 %;
+        # profiles/r03/r03_l_exp.log).  In round 2 it changed neither launch (profiles/r02/r02_l, r02_q).
+        self.fold_c12 = fold_c12 and not os.environ.get("TETRA_EXP_NO_FOLD")      # (the environment switch: experiment builds)
         self.hop = 16 // lanes
         self.nres = taps - 1
         assert TILE % self.nres == 0 and self.nres % 2 == 0
@@ -445,6 +447,8 @@ def generate(shape=None):
     k = pk_consts()
     parts.append("#define %s_K1 0x%016xull\n#define %s_K2 0x%016xull\n#define %s_K3 0x%016xull\n#define %s_K4 0x%016xull\n" % (P, k[0], P, k[1], P, k[2], P, k[3]))
     parts.append("#define %s_SLOTS_PER_TILE %d\n" % (P, per_tile))
+    # the block's %[negc1] operand: -C1 of the phasor's Cody-Waite reduction, or -(C1 + C2) when the first two steps are folded
+    parts.append("#define %s_NEGC1 %s\n" % (P, "(-(3.140625f + 9.67502593994140625e-4f))" if G.fold_c12 else "(-3.140625f)"))
     return "".join(parts), E, per_tile
 
 

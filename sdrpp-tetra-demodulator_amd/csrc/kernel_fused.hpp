@@ -339,11 +339,14 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - FllRow::kReplay]);
             const unsigned long long p4 = (unsigned long long)__builtin_bit_cast(unsigned, 0.4f);
             if constexpr (CH == 4) {
+                // (negc1: -C1 of the phasor's Cody-Waite reduction, or -(C1 + C2) for a block generated with the first two steps
+                // folded into one fma -- exact for every phase in [-pi, pi], checked exhaustively in tests/test_oracle.py; the
+                // generator says which in <block>_NEGC1)
                 asm volatile(FLL16_WAVE_ASM
                              : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
                                [maxf] "v"(k1.fll_max_freq),
-                               [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [negc1] "s"(FLL16_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                                [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
                                [k1] "s"(FLL16_WAVE_K1), [k2] "s"(FLL16_WAVE_K2), [k3] "s"(FLL16_WAVE_K3), [k4] "s"(FLL16_WAVE_K4),
                                [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
@@ -353,7 +356,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                              : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
                                [maxf] "v"(k1.fll_max_freq),
-                               [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [negc1] "s"(FLL_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                                [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
                                [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4),
                                [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
@@ -363,7 +366,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                              : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
                                [maxf] "v"(k1.fll_max_freq),
-                               [negc1] "s"(-3.140625f), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [negc1] "s"(FLL4_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                                [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
                                [k1] "s"(FLL4_WAVE_K1), [k2] "s"(FLL4_WAVE_K2), [k3] "s"(FLL4_WAVE_K3), [k4] "s"(FLL4_WAVE_K4),
                                [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
@@ -558,7 +561,10 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
             if (cut) atomicAdd(p.overruns, 1);          // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
         }
-    } else if (wave == kRoleE && CH == kFChSmall) {
+#ifndef TETRA_EXP_TWOPASS
+#define TETRA_EXP_TWOPASS 0        // experiment builds: 1 = the two-pass Costas wave on every shape
+#endif
+    } else if (wave == kRoleE && (CH == kFChSmall || TETRA_EXP_TWOPASS)) {
         // ---- kRoleE, 4-channel workgroup (this wave has a SIMD to itself and sets the pace once the FLL step is short): the
         // recurrence -- Costas loop only -- runs on lanes 0..3 and leaves z in place of v in the symbol ring; then ALL 64 lanes
         // (16 per channel, one symbol each) slice, decode differentially against the symbol before, and store: the part of the
