@@ -220,6 +220,9 @@ template <class LDS, class Row> struct FllDeviceIOT {
         __syncthreads();                                                         \
     }
 
+#ifndef TETRA_EXP_TWOPASS
+#define TETRA_EXP_TWOPASS 0           // experiment builds: 1 = the two-pass Costas wave on every shape (product: the 4-channel shape only)
+#endif
 #ifndef TETRA_EXP_WAVES_PER_EU
 #define TETRA_EXP_WAVES_PER_EU 1      // experiment builds: a larger value caps the VGPRs so that more waves fit a SIMD
 #endif
@@ -561,9 +564,6 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
             if (cut) atomicAdd(p.overruns, 1);          // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
         }
-#ifndef TETRA_EXP_TWOPASS
-#define TETRA_EXP_TWOPASS 0        // experiment builds: 1 = the two-pass Costas wave on every shape
-#endif
     } else if (wave == kRoleE && (CH == kFChSmall || TETRA_EXP_TWOPASS)) {
         // ---- kRoleE, 4-channel workgroup (this wave has a SIMD to itself and sets the pace once the FLL step is short): the
         // recurrence -- Costas loop only -- runs on lanes 0..3 and leaves z in place of v in the symbol ring; then ALL 64 lanes

@@ -26,9 +26,9 @@ using namespace tdm;
 namespace {
 
 constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
-constexpr int kWg16ClocksPerSample = 277;       // measured shader clocks per sample of one workgroup round (profiles/r02)
-constexpr int kWg32ClocksPerSample = 365;       // 32-channel workgroup: 5.3-5.6 ms per 36000 samples (profiles/r02/r02_q)
-constexpr int kWg4ClocksPerSample = 250;        // 4-channel workgroup (profiles/r03)
+constexpr int kWg16ClocksPerSample = 270;       // measured shader clocks per sample of one workgroup round: 4.05 ms per 36000 samples (profiles/r03)
+constexpr int kWg32ClocksPerSample = 357;       // 32-channel workgroup: 5.35 ms per 36000 samples
+constexpr int kWg4ClocksPerSample = 232;        // 4-channel workgroup: 3.47 ms per 36000 samples
 
 __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
     float2 v = *p;
