@@ -197,6 +197,7 @@ assert (R_TA, R_TB, R_R14, R_R32, R_XS, R_HADDR) == (16, 25, 34, 50, (66, 68), 1
 
 # sincos_t constants (demod_core.hpp)
 INV_PI_NEG = f32(-0.318309886183790672)
+WRAP_C = "0x3e22f983"            # binary32 nearest 1 / (2 pi): see the phase wrap in fir_and_hop
 C2N, C3N = -9.67502593994140625e-4, -1.509957990978376432e-7
 S3, S2, S1, S0 = 2.597026877992903e-06, -0.0001980524102691561, 0.008332998491823673, -0.16666656732559204
 C4, C3c, C2c, C1c = -2.604826931928983e-07, 2.476031113474164e-05, -0.0013888374669477344, 0.04166663810610771
@@ -287,13 +288,18 @@ def fir_and_hop(E, s, n, replay):
         E.ins("v_add_f32 v%d, v%d, v%d" % (R_E, R_FR, R_E), "valu", [R_E], [R_FR, R_E])
         E.ins("v_med3_f32 v%d, v%d, %%[minf], v%d" % (R_FR, R_E, R_MAXF), "valu", [R_FR], [R_E, R_MAXF])
         E.ins("v_add_f32 v%d, v%d, v%d" % (R_PH, R_PH, R_FR), "valu", [R_PH], [R_PH, R_FR])
-        E.ins("v_bfi_b32 v%d, %%[absmask], v%d, v%d" % (R_T, R_2PI, R_PH), "valu", [R_T], [R_2PI, R_PH])
-        E.ins("v_sub_f32 v%d, v%d, v%d" % (R_T, R_PH, R_T), "valu", [R_T], [R_PH, R_T])
-        E.ins("v_cmp_gt_f32 vcc, |v%d|, %%[pi]" % R_PH, "valu", [], [R_PH], writes_vcc=True)
+        # the wrap `phase > pi -> phase - 2 pi, phase < -pi -> phase + 2 pi` as w = rint(phase * WRAP_C) in {-1, 0, 1} and
+        # phase = fma(-w, 2 pi, phase): three instructions instead of copysign / subtract / compare / select.  WRAP_C is the
+        # binary32 nearest 1 / (2 pi); rint(x * WRAP_C) is 1 exactly for the floats above FL_M_PI, -1 below -FL_M_PI, and the
+        # fma is the one rounding of the exact x -+ 2 pi like the reference's subtraction: checked for every binary32 x in
+        # [-2 pi, 2 pi] (tests/test_oracle.py::test_rint_phase_wrap_is_exact_for_every_phase; the one difference, x = -0 ->
+        # +0, cannot occur: a phase that starts at +0 never becomes -0, and tetra_demod_set_state stores -0 as +0).
+        E.ins("v_mul_f32 v%d, %s, v%d" % (R_T, WRAP_C, R_PH), "valu", [R_T], [R_PH])
+        E.ins("v_rndne_f32 v%d, v%d" % (R_T, R_T), "valu", [R_T], [R_T])
     E.ins(*fma_op(sh14, n, R_TA, 0, sh14))
     E.ins(*fma_op(sh32, n, R_TB, 0, sh32))
     if not replay:
-        E.ins("v_cndmask_b32 v%d, v%d, v%d, vcc" % (R_PH, R_PH, R_T), "valu", [R_PH], [R_PH, R_T], reads_vcc=True)
+        E.ins("v_fma_f32 v%d, -v%d, v%d, v%d" % (R_PH, R_T, R_2PI, R_PH), "valu", [R_PH], [R_T, R_2PI, R_PH])
 
 
 def real_step(E, s):

@@ -350,7 +350,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
                                [maxf] "v"(k1.fll_max_freq),
                                [negc1] "s"(FLL16_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
-                               [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                               [p4] "s"(p4),
                                [k1] "s"(FLL16_WAVE_K1), [k2] "s"(FLL16_WAVE_K2), [k3] "s"(FLL16_WAVE_K3), [k4] "s"(FLL16_WAVE_K4),
                                [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
                              : "vcc", "scc", "memory", FLL16_WAVE_CLOBBERS);
@@ -360,7 +360,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
                                [maxf] "v"(k1.fll_max_freq),
                                [negc1] "s"(FLL_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
-                               [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                               [p4] "s"(p4),
                                [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4),
                                [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
                              : "vcc", "scc", "memory", FLL_WAVE_CLOBBERS);
@@ -370,7 +370,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
                                [maxf] "v"(k1.fll_max_freq),
                                [negc1] "s"(FLL4_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
-                               [absmask] "s"(0x7fffffff), [pi] "s"(kFlPi), [p4] "s"(p4),
+                               [p4] "s"(p4),
                                [k1] "s"(FLL4_WAVE_K1), [k2] "s"(FLL4_WAVE_K2), [k3] "s"(FLL4_WAVE_K3), [k4] "s"(FLL4_WAVE_K4),
                                [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
                              : "vcc", "scc", "memory", FLL4_WAVE_CLOBBERS);

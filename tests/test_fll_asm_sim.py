@@ -96,8 +96,8 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     f32 = lambda x: int(np.float32(x).view(np.uint32))
     sca = {
         # (a block generated with the first two Cody-Waite steps folded into one fma takes -(C1 + C2) here: <macro>_NEGC1)
-        "negc1": f32(-(np.float32(3.140625) + np.float32(9.67502593994140625e-4))) if folded else f32(-3.140625), "beta": f32(tab.k1.fll_beta), "minf": f32(tab.k1.fll_min_freq), "absmask": 0x7fffffff,
-        "pi": f32(3.1415926535), "p4": (f32(0.4), 0), "toggle": nch * TILE * 8, "base": 0, "tiles": ntiles, "st": 0,
+        "negc1": f32(-(np.float32(3.140625) + np.float32(9.67502593994140625e-4))) if folded else f32(-3.140625), "beta": f32(tab.k1.fll_beta), "minf": f32(tab.k1.fll_min_freq),
+        "p4": (f32(0.4), 0), "toggle": nch * TILE * 8, "base": 0, "tiles": ntiles, "st": 0,
         "k1": consts["K1"], "k2": consts["K2"], "k3": consts["K3"], "k4": consts["K4"],
     }
     sim = gcn_sim.Sim(lines, vec, sca, lds, on_barrier=lambda s, k: put_tile(k))

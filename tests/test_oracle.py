@@ -230,3 +230,45 @@ int main(void) {
     subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", str(src), "-o", str(exe), "-lm"], check=True)
     n, bad = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(n) == 2 * 1078530012 and int(bad) == 0
+
+
+def test_rint_phase_wrap_is_exact_for_every_phase(tmp_path):
+    """The generated FLL blocks wrap the loop phase as w = rint(x * WRAP_C), x = fma(-w, 2 pi, x) (three instructions) instead of
+    PhaseControlLoop's `x > pi -> x - 2 pi, x < -pi -> x + 2 pi` (copysign, subtract, compare, select).  WRAP_C = 0x3e22f983 is
+    the binary32 nearest 1 / (2 pi).  Every binary32 x of [-2 pi, 2 pi] (the loop's sums stay inside 1.5 pi) through both forms:
+    the only difference is x = -0 -> +0, which a phase that starts at +0 can never reach (x + y is -0 only for two -0 operands)
+    and which tetra_demod_set_state canonicalises."""
+    import subprocess
+    src = tmp_path / "wrap.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    const float pi = 3.1415926535f, twopi = pi - (-pi);
+    float c; uint32_t cb = 0x3e22f983u; memcpy(&c, &cb, 4);
+    float lim = 2.0f * pi; uint32_t hi; memcpy(&hi, &lim, 4);
+    long long bad = 0, n = 0, negzero = 0;
+    if (fabs((double)c - 1.0 / (2.0 * 3.14159265358979323846)) > 1e-8) return 1;
+#pragma omp parallel for reduction(+ : bad, n, negzero) schedule(static)
+    for (long long u = 0; u <= (long long)hi; u++) {
+        for (int sgn = 0; sgn < 2; sgn++) {
+            const uint32_t b = (uint32_t)u | (sgn ? 0x80000000u : 0u);
+            float x; memcpy(&x, &b, 4);
+            float ref = x;
+            if (x > pi) ref = x - twopi; else if (x < -pi) ref = x + twopi;
+            const float w = rintf(x * c);
+            const float got = fmaf(-w, twopi, x);
+            n++;
+            if (memcmp(&ref, &got, 4)) { if (b == 0x80000000u) negzero++; else bad++; }
+        }
+    }
+    printf("%lld %lld %lld\n", n, bad, negzero);
+    return 0;
+}
+''')
+    exe = tmp_path / "wrap"
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", str(src), "-o", str(exe), "-lm"], check=True)
+    n, bad, negzero = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(n) > 2100000000 and int(bad) == 0 and int(negzero) == 1
