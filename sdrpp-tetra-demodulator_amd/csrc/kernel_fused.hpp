@@ -221,7 +221,7 @@ template <class LDS, class Row> struct FllDeviceIOT {
     }
 
 #ifndef TETRA_EXP_TWOPASS
-#define TETRA_EXP_TWOPASS 0           // experiment builds: 1 = the two-pass Costas wave on every shape (product: the 4-channel shape only)
+#define TETRA_EXP_TWOPASS 0           // experiment builds: 1 = the two-pass Costas wave on the 32-channel shape too (product: 4 and 16 channels)
 #endif
 #ifndef TETRA_EXP_WAVES_PER_EU
 #define TETRA_EXP_WAVES_PER_EU 1      // experiment builds: a larger value caps the VGPRs so that more waves fit a SIMD
@@ -564,12 +564,14 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
             if (cut) atomicAdd(p.overruns, 1);          // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
         }
-    } else if (wave == kRoleE && (CH == kFChSmall || TETRA_EXP_TWOPASS)) {
-        // ---- kRoleE, 4-channel workgroup (this wave has a SIMD to itself and sets the pace once the FLL step is short): the
-        // recurrence -- Costas loop only -- runs on lanes 0..3 and leaves z in place of v in the symbol ring; then ALL 64 lanes
-        // (16 per channel, one symbol each) slice, decode differentially against the symbol before, and store: the part of the
-        // reference's per-symbol work that is not a recurrence (dqpsk_sym_extr.cpp:32-52, bit_unpacker.cpp:6-7) costs one pass
-        // per epoch instead of ~35 instruction slots per symbol.
+    } else if (wave == kRoleE && (CH != kFChWide || TETRA_EXP_TWOPASS)) {
+        // ---- kRoleE, 4- and 16-channel workgroups: the recurrence -- Costas loop only -- runs on lanes 0..CH-1 and leaves z in
+        // place of v in the symbol ring; then ALL 64 lanes (64 / CH per channel, one symbol each) slice, decode differentially
+        // against the symbol before, and store: the part of the reference's per-symbol work that is not a recurrence
+        // (dqpsk_sym_extr.cpp:32-52, bit_unpacker.cpp:6-7) costs one pass per epoch instead of ~35 instruction slots per symbol.
+        // (4 channels: this wave has a SIMD to itself and would set the pace, -8 %; 16 channels: -1.1 % once the FLL stream was
+        // down to 57 slots, neutral before; 32 channels, where the wave shares its SIMD with the timing wave: +1.8 %, so that
+        // shape keeps the one-pass form below.  profiles/r03/r03_e, r03_l, r03_p.)
         const bool on = lane < CH;
         const int c = on ? lane : 0;
         K2State st;
