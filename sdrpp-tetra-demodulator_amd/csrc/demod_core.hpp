@@ -634,6 +634,27 @@ TD_FN void k2_timing_quad(const K2Consts& k, K2State& st, int phase, const Pair<
     *out_re = vr;
     *out_im = vi;
 }
+// The same with TWO lanes per channel (the timing wave of the 32-channel workgroup: 32 channels on 64 lanes): both lanes run
+// the chain of row `phase` (v), lane 0 also that of row min(phase+1,127) (a), lane 1 that of row max(phase-1,0) (b); a and b
+// are then swapped between the neighbours.  16 packed FMAs and 4 row loads per symbol instead of 24 and 6.
+TD_FN float pair_swap(float x) {      // quad_perm:[1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xb1, 0xf, 0xf, true));
+}
+TD_FN void k2_timing_pair(const K2Consts& k, K2State& st, int phase, const Pair<float>* w, const float* t0, const float* t2,
+                          bool second, float* out_re, float* out_im) {
+    Pair<float> v(0.0f, 0.0f), d(0.0f, 0.0f);
+#pragma unroll
+    for (int j = 0; j < kInterpTaps; j++) {
+        v = pk_fma(w[j], Pair<float>(t0[j], t0[j]), v);
+        d = pk_fma(w[j], Pair<float>(t2[j], t2[j]), d);
+    }
+    const float ox = pair_swap(d.x()), oy = pair_swap(d.y());      // the neighbour's second dot
+    const float ar = second ? ox : d.x(), ai = second ? oy : d.y();
+    const float br = second ? d.x() : ox, bi = second ? d.y() : oy;
+    k2_timing_tail(k, st, phase, v.x(), v.y(), ar, ai, br, bi);
+    *out_re = v.x();
+    *out_im = v.y();
+}
 #endif
 
 // complex_fd.cpp:101: interpolator phase of the next symbol.

@@ -223,6 +223,9 @@ template <class LDS, class Row> struct FllDeviceIOT {
 #ifndef TETRA_EXP_TWOPASS
 #define TETRA_EXP_TWOPASS 0           // experiment builds: 1 = the two-pass Costas wave on the 32-channel shape too (product: 4 and 16 channels)
 #endif
+#ifndef TETRA_EXP_DPAIR
+#define TETRA_EXP_DPAIR 1             // 32-channel shape: timing wave on two lanes per channel (0 = one lane per channel)
+#endif
 #ifndef TETRA_EXP_WAVES_PER_EU
 #define TETRA_EXP_WAVES_PER_EU 1      // experiment builds: a larger value caps the VGPRs so that more waves fit a SIMD
 #endif
@@ -482,7 +485,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         // ---- timing recovery; consumes y of tiles <= e-3 ------------------------------------------------------
         // 16- and 4-channel workgroups: FOUR lanes per channel (lane = 4 c + kq), each holding one of the symbol's three
         // interpolator rows (k2_timing_quad; identical loop state in the four lanes); 32-channel workgroup: one lane per channel.
-        constexpr int kDL = CH <= 16 ? 4 : 1;
+        constexpr int kDL = CH <= 16 ? 4 : TETRA_EXP_DPAIR ? 2 : 1;
         const bool on = lane < CH * kDL;
         const int c = on ? lane / kDL : 0;
         const int kq = lane % kDL;
@@ -499,7 +502,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
         bool cut = false;
         const unsigned y_base = pin_u32(lds_addr(&L.y_ring[c][0]));
         const unsigned bank_base = pin_u32(lds_addr(&L.bank[0]));
-        const unsigned row_off = kq == 1 ? 64u : kq == 2 ? 0u : 32u;
+        const unsigned row_off = kDL == 2 ? (kq ? 0u : 64u) : kq == 1 ? 64u : kq == 2 ? 0u : 32u;      // kDL 2: the lane's SECOND row
         (void)row_off;
         K2Consts k2 = p.k2;
         k2.tr_max_freq = v_pin(k2.tr_max_freq);
@@ -528,6 +531,15 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                         q = bk[0]; tr[0] = q.x; tr[1] = q.y; tr[2] = q.z; tr[3] = q.w;
                         q = bk[1]; tr[4] = q.x; tr[5] = q.y; tr[6] = q.z; tr[7] = q.w;
                         k2_timing_quad(k2, st, phase, w, tr, &vr, &vi);
+                    } else if constexpr (kDL == 2) {
+                        lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5) + 32u);
+                        lds_cfloat4* b2 = (lds_cfloat4*)(size_t)(bank_base + (phase << 5) + row_off);
+                        float t0[kInterpTaps]; float t2[kInterpTaps];
+                        q = bk[0]; t0[0] = q.x; t0[1] = q.y; t0[2] = q.z; t0[3] = q.w;
+                        q = bk[1]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
+                        q = b2[0]; t2[0] = q.x; t2[1] = q.y; t2[2] = q.z; t2[3] = q.w;
+                        q = b2[1]; t2[4] = q.x; t2[5] = q.y; t2[6] = q.z; t2[7] = q.w;
+                        k2_timing_pair(k2, st, phase, w, t0, t2, kq != 0, &vr, &vi);
                     } else {
                         lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5));
                         float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
