@@ -310,24 +310,31 @@ def real_step(E, s):
     a = R_AQ[(s >> 1) & 1] + 2 * (s & 1)
     had = len(E.pending)
     E.comment("---- step %d" % s)
-    # NCO phasor: sincos_t<float, true>(-ph); sine and cosine polynomials as one packed Horner chain
+    # NCO phasor: sincos_t<float, true>(-ph); sine and cosine polynomials as one packed Horner chain.  Every link of that
+    # chain (packed result -> next instruction) needs one instruction in between: the instructions that do not belong to the
+    # chain -- the sign (-1)^k, the sample times that sign, the wait for the AGC samples -- are issued exactly there, so that
+    # the deferred tap FMAs are left for the gaps further down (the 16-lane block has only six of those per step and used to
+    # pad with s_nop).
     E.ins("v_mul_f32 v%d, %s, v%d" % (R_K, INV_PI_NEG, R_PH), "valu", [R_K], [R_PH])
     E.ins("v_rndne_f32 v%d, v%d" % (R_K, R_K), "valu", [R_K], [R_K])
-    E.ins("v_fma_f32 v%d, |v%d|, -2.0, 1.0" % (R_SGN, R_K), "valu", [R_SGN], [R_K])                                     # (-1)^k for |k| <= 1
     E.ins("v_fma_f32 v%d, v%d, %%[negc1], -v%d" % (R_R, R_K, R_PH), "valu", [R_R], [R_K, R_PH])
     if not G.fold_c12:
         E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C2N), R_K), "valu", [R_R], [R_R, R_K])
     E.ins("v_fmac_f32 v%d, %s, v%d" % (R_R, f32(C3N), R_K), "valu", [R_R], [R_R, R_K])
     E.ins("v_mul_f32 v%d, v%d, v%d" % (R_Z, R_R, R_R), "valu", [R_Z], [R_R])
-    if s & 1 == 0:
-        E.ins("s_waitcnt lgkmcnt(0)", "wait")          # this pair of AGC samples (loaded two steps ago)
-    E.ins("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair(R_A2), pair(a), pair(R_SGN)), "pk", [R_A2, R_A2 + 1], [a, a + 1, R_SGN])
     E.ins("v_fmamk_f32 v%d, v%d, %s, v%d" % (R_Q + 1, R_Z, f32(C4), R_CC3), "valu", [R_Q + 1], [R_Z, R_CC3])        # c4*z + c3
     E.ins("v_pk_fma_f32 %s, %s, %s, %%[k1] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_Q), pair(R_Z)), "pk", [R_PP, R_PP + 1],
           [R_Q, R_Q + 1, R_Z])                                                                                        # (s3*z + s2, . *z + c2)
-    for kk in ("k2", "k3", "k4"):                                                                                     # k4: (ps*z - 0, pc*z + 1)
-        E.ins("v_pk_fma_f32 %s, %s, %s, %%[%s] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z), kk), "pk", [R_PP, R_PP + 1],
-              [R_PP, R_PP + 1, R_Z])
+    E.ins("v_fma_f32 v%d, |v%d|, -2.0, 1.0" % (R_SGN, R_K), "valu", [R_SGN], [R_K])                                     # (-1)^k for |k| <= 1
+    E.ins("v_pk_fma_f32 %s, %s, %s, %%[k2] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z)), "pk", [R_PP, R_PP + 1],
+          [R_PP, R_PP + 1, R_Z])
+    if s & 1 == 0:
+        E.ins("s_waitcnt lgkmcnt(0)", "wait")          # this pair of AGC samples (loaded two steps ago)
+    E.ins("v_pk_fma_f32 %s, %s, %s, %%[k3] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z)), "pk", [R_PP, R_PP + 1],
+          [R_PP, R_PP + 1, R_Z])
+    E.ins("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair(R_A2), pair(a), pair(R_SGN)), "pk", [R_A2, R_A2 + 1], [a, a + 1, R_SGN])
+    E.ins("v_pk_fma_f32 %s, %s, %s, %%[k4] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z)), "pk", [R_PP, R_PP + 1],
+          [R_PP, R_PP + 1, R_Z])                                                                                      # k4: (ps*z - 0, pc*z + 1)
     E.ins("v_fmac_f32 v%d, v%d, v%d" % (R_R, R_PP, R_R), "valu", [R_R], [R_PP, R_R])                                   # sin (before the sign)
     # The sign (-1)^k of sincos_t goes onto the SAMPLE instead of onto sine and cosine: a' = a * sgn with sgn = 1 - 2|k|
     # (the loop keeps |ph| <= pi, so k is -1, 0 or 1; tetra_demod_set_state refuses other phases).  Multiplying by +-1 is

@@ -530,7 +530,11 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                         float tr[kInterpTaps];
                         q = bk[0]; tr[0] = q.x; tr[1] = q.y; tr[2] = q.z; tr[3] = q.w;
                         q = bk[1]; tr[4] = q.x; tr[5] = q.y; tr[6] = q.z; tr[7] = q.w;
+#if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 4      // experiment builds only: the timing wave without its arithmetic
+                        vr = w[0].x() + tr[0]; vi = w[0].y(); st.offset += 2;
+#else
                         k2_timing_quad(k2, st, phase, w, tr, &vr, &vi);
+#endif
                     } else if constexpr (kDL == 2) {
                         lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5) + 32u);
                         lds_cfloat4* b2 = (lds_cfloat4*)(size_t)(bank_base + (phase << 5) + row_off);
@@ -611,7 +615,11 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                     while (S < avail) {
                         const float2 v = L.s_ring[c][S & (kFS - 1)];
                         float zr; float zi;
+#if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 1      // experiment builds only: the Costas recurrence without its arithmetic
+                        zr = v.x; zi = v.y;
+#else
                         k2_costas_rot(k2, st, v.x, v.y, &zr, &zi);
+#endif
                         zlast = make_float2(zr, zi);
                         L.s_ring[c][S & (kFS - 1)] = zlast;
                         S++;
