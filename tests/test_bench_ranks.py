@@ -56,3 +56,18 @@ def test_bench_rccl_half_of_the_rank_path_on_one_gpu():
     json.dump(d, open(os.path.join(OUT, "bench_force_dist_nccl.json"), "w"))
     assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_world_size"] == 1
     assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
+
+
+def test_bench_under_the_driver_s_own_launcher():
+    """The driver's command line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- bench.py then runs as ONE of the ranks (it must not start ranks of its own)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    d = _line(r)
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["check"]["bit_errors"] == 0
