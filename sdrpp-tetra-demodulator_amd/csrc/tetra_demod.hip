@@ -194,7 +194,9 @@ struct tetra_demod {
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
     int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones ...
-    bool small = false;         // ... unless every channel runs in 4-channel workgroups (at most 4 channels per CU)
+    bool small = false;         // ... or, when they are at most 4 per CU (or the flag forces it), in 4-channel ones
+    bool force_small = false;   // TETRA_FLAG_SMALL_WORKGROUPS
+    int cus = 256;
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // TETRA_FLAG_KEEP_RRC_OUT: time-major RRC output scratch [(7 + max_samples)][C]
     float2* ybuf = nullptr;     // COMPLEX_FD delay buffer [C][7]
@@ -524,20 +526,21 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         cus = cus > 0 ? cus : 256;
-        // whole rounds of 32-channel workgroups first; what is left takes whichever shape gets it through in less time
+        // whole rounds of 32-channel workgroups first; what is left takes whichever shape gets it through in less time: one
+        // round of 4-channel workgroups (each has a CU to itself and the shortest FLL step: kWg4 clocks per sample) if there
+        // are at most 4 channels per CU, else rounds of 16-channel ones, or one more round of 32-channel ones
+        h->cus = cus;
         const long long per_round32 = (long long)kFChWide * cus;
         const long long full = (h->C / per_round32) * per_round32, rest = h->C - full;
         const long long r16 = ((rest + kFCh - 1) / kFCh + cus - 1) / cus, r32 = ((rest + kFChWide - 1) / kFChWide + cus - 1) / cus;
-        const bool rest_wide = rest > 0 && r32 * kWg32ClocksPerSample < r16 * kWg16ClocksPerSample;
+        const long long t16 = r16 * kWg16ClocksPerSample, t32 = r32 * kWg32ClocksPerSample;
+        const long long t4 = rest <= (long long)kFChSmall * cus ? (long long)kWg4ClocksPerSample : t16 + t32 + 1;
+        const bool rest_wide = rest > 0 && t32 < t16 && t32 < t4;
         h->n_wide = (int)(rest_wide ? h->C : full);
-        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) h->n_wide = h->C;
-        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) h->n_wide = 0;
-        // Up to 4 channels per CU every 4-channel workgroup has a CU to itself, and its FLL wave (a whole DPP row per channel)
-        // has the shortest step of the three shapes: one round of kWg4 clocks per sample against one of kWg16.
-        h->small = (long long)h->C <= (long long)kFChSmall * cus && kWg4ClocksPerSample < kWg16ClocksPerSample;
-        if (cfg->flags & (TETRA_FLAG_WIDE_WORKGROUPS | TETRA_FLAG_NARROW_WORKGROUPS)) h->small = false;
-        if (cfg->flags & TETRA_FLAG_SMALL_WORKGROUPS) h->small = true;
-        if (h->small) h->n_wide = 0;
+        h->small = rest > 0 && !rest_wide && t4 < t16;
+        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) { h->n_wide = h->C; h->small = false; }
+        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) { h->n_wide = 0; h->small = false; }
+        if (cfg->flags & TETRA_FLAG_SMALL_WORKGROUPS) { h->n_wide = 0; h->small = h->force_small = true; }
     }
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
@@ -613,14 +616,17 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.prof = nullptr;
         // channels [0, n_wide) in 32-channel workgroups (see tetra_demod_create; their FLL rows hold 4 x 17 taps), the rest in
         // 16-channel ones: at most two launches, back to back on the stream
+        // (band-edge filters of more than 68 taps do not fit the 32-channel shape's rows: then everything is "the rest")
         const int n_wide = h->design.ntaps_be <= kF4Pad ? h->n_wide : 0;
-        const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh), gs((h->C + kFChSmall - 1) / kFChSmall);
+        const bool rest_small = h->force_small || (h->small && h->C - n_wide <= kFChSmall * h->cus);
+        const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh),
+            gs((h->C - n_wide + kFChSmall - 1) / kFChSmall);
         const bool a0 = pf.k1.fll_alpha == 0.0f;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
         const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
-        if (prof_path && n_wide == 0 && !h->small) {
+        if (prof_path && n_wide == 0 && !rest_small) {
             const size_t nwg = (size_t)gf.x;
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
@@ -633,19 +639,19 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         else if (pf.prof) hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
         else
 #endif
-        if (h->small) {
-            const dim3 ts(fused_threads(kFChSmall));
-            pf.ch_base = 0;
-            if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, pf);
-            else hipLaunchKernelGGL((k_fused<false, false, kFChSmall>), gs, ts, 0, s, pf);
-        } else {
+        {
             if (n_wide > 0) {
                 const dim3 tw(fused_threads(kFChWide));
                 pf.ch_base = 0;
                 if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gw, tw, 0, s, pf);
                 else hipLaunchKernelGGL((k_fused<false, false, kFChWide>), gw, tw, 0, s, pf);
             }
-            if (n_wide < h->C) {
+            if (n_wide < h->C && rest_small) {
+                const dim3 ts(fused_threads(kFChSmall));
+                pf.ch_base = n_wide;
+                if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, pf);
+                else hipLaunchKernelGGL((k_fused<false, false, kFChSmall>), gs, ts, 0, s, pf);
+            } else if (n_wide < h->C) {
                 pf.ch_base = n_wide;
                 if (a0) hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
                 else hipLaunchKernelGGL((k_fused<false>), gf, dim3(kFThreads), 0, s, pf);
