@@ -355,6 +355,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    backend_note = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -366,6 +367,11 @@ def main():
         # RCCL carries only the barrier and the MAX of the elapsed time (no data-path collective).  One rank per GPU: RCCL
         # refuses ranks that share a device ("Duplicate GPU detected") -- a functional run of the N > 1 path on fewer GPUs
         # than ranks takes --backend gloo.  A communicator that cannot be built fails the run at once, loudly.
+        if args.backend == "nccl" and world > torch.cuda.device_count():
+            # more ranks than GPUs (a functional run of the N > 1 path on a smaller box): RCCL needs a GPU per rank, so the ranks
+            # line up over gloo instead -- decided from the device count, the same on every rank, before any communicator exists
+            args.backend = "gloo"
+            backend_note = "gloo: %d ranks on %d GPU(s), RCCL needs one GPU per rank" % (world, torch.cuda.device_count())
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -600,6 +606,8 @@ def main():
         if dist is not None:
             out["rccl_world_size"] = dist.get_world_size() if args.backend == "nccl" else None
             out["dist_backend"] = args.backend
+            if backend_note:
+                out["dist_backend_note"] = backend_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_baseline_fast"] = cpu_baseline(pkg.synth, N)
         if args.chain and world == 1:
