@@ -10,17 +10,20 @@
 // channels.  A CU's 16 channels are therefore split by STAGE, each stage at the widest lane occupancy its recurrence
 // allows:
 //
-//   wave  role                                  lanes/channel   instruction slots / sample       SIMD
-//   F0,F1 FLL: NCO, band-edge FIRs, loop         8 (interleaved) 59 (hand-scheduled, fll_asm.inc) 2, 3: one each, alone
-//   E     Costas + slicer + diff. decoder + out  1               ~46                              0 (older wave)
-//   C     RRC matched filter (time-parallel)     4 x 8 outputs   ~24                              0
-//   D     ML timing recovery                     1               ~45                              1 (older wave)
-//   A     AGC                                    1               ~25                              1
+//   wave  role                                  lanes/channel        instruction slots / sample       SIMD
+//   F0,F1 FLL: NCO, band-edge FIRs, loop         8 (interleaved)      57 (hand-scheduled, fll_asm.inc) 2, 3: one each, alone
+//   E     Costas + slicer + diff. decoder + out  1, then 4 (2 passes) ~42                              0 (older wave)
+//   C     RRC matched filter (time-parallel)     4 x 8 outputs        ~24                              0
+//   D     ML timing recovery                     4 (one row each)     ~35                              1 (older wave)
+//   A     AGC                                    1                    ~25                              1
 //
 // The issue arbiter serves the OLDEST wave of a SIMD first, so the recurrence-bound roles take the lower wave index of
 // their SIMD and the throughput roles fill the slots they leave.  (Cutting the FLL in two -- loop waves plus a helper wave
-// for the far taps -- was built and measured this round: it shortens the longest wave but adds work and a seventh role that
-// does not pack into four SIMDs; profiles/r02/r02_c_fll_split_experiment.md.)
+// for the far taps -- was built and measured in round 2: it shortens the longest wave but adds work and a seventh role that
+// does not pack into four SIMDs, profiles/r02/r02_c_fll_split_experiment.md; round 3 bounded ANY re-homing of the FIR work --
+// helper wave, matrix pipe -- by ablation: nothing to gain, profiles/r03/r03_b_matrix_pipe_and_coresidency.md.)
+// Two more shapes of the same template: 32 channels in eight waves (FLL rows of 4 lanes per channel: more than 16 channels per
+// CU) and 4 channels (FLL rows of 16 lanes: at most 4 channels per CU); see Roles<CH> below and DESIGN.md section 5.
 //
 // Stages are connected by LDS rings (AGC out -> FLL out x -> RRC out y -> symbols) and run as a software pipeline over
 // 32-sample tiles with one workgroup barrier per tile: in epoch e, A works on tile e, F on e-1, C on e-2, D consumes y
