@@ -43,7 +43,7 @@ class Shape:
     interleaved, so a hop between neighbouring positions is a shift by 16/lanes lanes.  The schedule's period is taps - 1
     steps (the residents of a position), which must divide the tile."""
 
-    def __init__(self, lanes, taps, out, prefix, what, fold_c12=True):
+    def __init__(self, lanes, taps, out, prefix, what, fold_c12=True, whole_tile_loads=True):
         self.lanes, self.taps, self.out, self.prefix, self.what = lanes, taps, os.path.join(HERE, out), prefix, what
         # the first two Cody-Waite steps as ONE fma with C1 + C2 (the operand %[negc1] then carries -(C1 + C2)): C1 + C2 is a
         # binary32 number, k is -1, 0 or 1 and x - k*C1 is exact (Sterbenz) for every |x| <= pi, so fma(-k, C1 + C2, x) is
@@ -52,6 +52,11 @@ class Shape:
         # paces every shape, and the slot shows (4096 x 36000: -0.75 %, 8192: -0.5 %, <= 1024 channels: -1.9 %;
         # profiles/r03/r03_l_exp.log).  In round 2 it changed neither launch (profiles/r02/r02_l, r02_q).
         self.fold_c12 = fold_c12 and not os.environ.get("TETRA_EXP_NO_FOLD")      # (the environment switch: experiment builds)
+        # The AGC samples of a WHOLE tile are fetched at the top of the tile (16 ds_read_b128 into 64 registers) with two waits,
+        # instead of two samples at a time with a wait per load: 14 slots less per tile, and the first sample no longer waits for
+        # its load (the 16 issue slots cover the LDS latency).  Costs 56 registers: not for the 4-lane block, whose wave is at
+        # 231 of the 256 VGPRs two waves per SIMD can have.
+        self.whole_tile_loads = whole_tile_loads and not os.environ.get("TETRA_EXP_NO_TILE_LOADS")
         self.hop = 16 // lanes
         self.nres = taps - 1
         assert TILE % self.nres == 0 and self.nres % 2 == 0
@@ -63,7 +68,7 @@ SHAPES = {
     # 16-channel workgroups: two FLL waves of 8 channels, 8 lanes per channel (72 = 8 x 9 padded taps)
     "fll": Shape(8, 9, "fll_asm.inc", "FLL_WAVE", "FLL wave"),
     # 32-channel workgroups: two FLL waves of 16 channels, 4 lanes per channel (68 = 4 x 17 padded taps)
-    "fll4": Shape(4, 17, "fll4_asm.inc", "FLL4_WAVE", "FLL wave, 4 lanes per channel"),
+    "fll4": Shape(4, 17, "fll4_asm.inc", "FLL4_WAVE", "FLL wave, 4 lanes per channel", whole_tile_loads=False),
     # 4-channel workgroups (at most 4 channels per CU): one FLL wave of 4 channels, a whole DPP row per channel (80 = 16 x 5)
     "fll16": Shape(16, 5, "fll16_asm.inc", "FLL16_WAVE", "FLL wave, 16 lanes per channel"),
 }
@@ -189,7 +194,14 @@ def configure(shape):
     R_E, R_T = B + 44, B + 45
     R_CC3, R_2PI, R_MAXF = B + 46, B + 47, B + 48      # constants that must sit in vector registers (constant-bus limit)
     R_AADDR, R_XLANE, R_XROWL, R_TAPADDR, R_HADDR = B + 49, B + 50, B + 51, B + 52, B + 53
-    CLOBBER = list(range(16, B + 54))
+    global R_ASUM
+    R_ASUM = B + 54                 # a_buf[0] row address + a_buf[1] row address of this lane: the other half = sum - this half
+    top = B + 55
+    if G.whole_tile_loads:          # sample s of the tile in v[R_AS + 2 s : +1]
+        global R_AS
+        R_AS = (top + 3) & ~3
+        top = R_AS + 2 * TILE
+    CLOBBER = list(range(16, top))
 
 
 configure(G)
@@ -307,7 +319,7 @@ def real_step(E, s):
     middle FMAs (they read the OLD pipeline registers, which the next step's x overwrites: all must be out by the end
     of this step, and the two on r[ph] before this step's first FMA)."""
     o, n = R_XS[s & 1], R_XS[(s + 1) & 1]
-    a = R_AQ[(s >> 1) & 1] + 2 * (s & 1)
+    a = R_AS + 2 * s if G.whole_tile_loads else R_AQ[(s >> 1) & 1] + 2 * (s & 1)
     had = len(E.pending)
     E.comment("---- step %d" % s)
     # NCO phasor: sincos_t<float, true>(-ph); sine and cosine polynomials as one packed Horner chain.  Every link of that
@@ -328,7 +340,12 @@ def real_step(E, s):
     E.ins("v_fma_f32 v%d, |v%d|, -2.0, 1.0" % (R_SGN, R_K), "valu", [R_SGN], [R_K])                                     # (-1)^k for |k| <= 1
     E.ins("v_pk_fma_f32 %s, %s, %s, %%[k2] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z)), "pk", [R_PP, R_PP + 1],
           [R_PP, R_PP + 1, R_Z])
-    if s & 1 == 0:
+    if G.whole_tile_loads:
+        if s == 0:
+            E.ins("s_waitcnt lgkmcnt(%d)" % (TILE // 2 - 1), "wait")      # the first of the tile's 16 loads (LDS returns in order)
+        elif s == 2:
+            E.ins("s_waitcnt lgkmcnt(0)", "wait")                         # all of them (issued ~130 slots ago: no stall)
+    elif s & 1 == 0:
         E.ins("s_waitcnt lgkmcnt(0)", "wait")          # this pair of AGC samples (loaded two steps ago)
     E.ins("v_pk_fma_f32 %s, %s, %s, %%[k3] op_sel_hi:[1,0,1]" % (pair(R_PP), pair(R_PP), pair(R_Z)), "pk", [R_PP, R_PP + 1],
           [R_PP, R_PP + 1, R_Z])
@@ -346,7 +363,7 @@ def real_step(E, s):
     E.ins("v_pk_mul_f32 %s, %s, %s op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" % (pair(R_T2), pair(R_A2), pair(R_K)), "pk",
           [R_T2, R_T2 + 1], [R_A2, R_A2 + 1, R_R])
     E.ins("v_pk_add_f32 %s, %s, %s" % (pair(n), pair(R_T1), pair(R_T2)), "pk", [n, n + 1], [R_T1, R_T1 + 1, R_T2, R_T2 + 1])
-    if s & 1 == 1 and s + 3 < TILE:
+    if not G.whole_tile_loads and s & 1 == 1 and s + 3 < TILE:
         # both samples of this pair are consumed: the pair after the next one goes into their registers
         nq = R_AQ[(s >> 1) & 1]
         E.ins("ds_read_b128 %s, v%d offset:%d" % (quad(nq), R_AADDR, 8 * (s + 3)), "lds", list(range(nq, nq + 4)), [R_AADDR])
@@ -379,7 +396,7 @@ def gen():
     E = Emitter()
     E.comment("state, constants and addresses into the block's fixed registers; taps from LDS; sums and pipeline start at zero")
     for (reg, opnd) in ((R_PH, "ph"), (R_FR, "fr"), (R_AADDR, "a_addr"), (R_XROWL, "x_rowlane"), (R_TAPADDR, "tap_addr"),
-                        (R_HADDR, "hist_addr"), (R_MAXF, "maxf")):
+                        (R_HADDR, "hist_addr"), (R_MAXF, "maxf"), (R_ASUM, "a_sum")):
         E.ins("v_mov_b32 v%d, %%[%s]" % (reg, opnd), "valu", [reg])
     E.ins("v_mov_b32 v%d, %s" % (R_Q, f32(S3)), "valu", [R_Q])
     E.ins("v_mov_b32 v%d, %s" % (R_CC3, f32(C3c)), "valu", [R_CC3])
@@ -416,14 +433,21 @@ def gen():
     E.ins("s_and_b32 %%[st], %%[base], 0x%x" % (int(os.environ.get("TETRA_EXP_XRING", "256")) - 1), "salu")
     E.ins("s_lshl_b32 %[st], %[st], 3", "salu")
     E.ins("v_add_u32 v%d, %%[st], v%d" % (R_XLANE, R_XROWL), "valu", [R_XLANE], [R_XROWL])
-    E.ins("ds_read_b128 %s, v%d" % (quad(R_AQ[0]), R_AADDR), "lds", list(range(R_AQ[0], R_AQ[0] + 4)), [R_AADDR])
-    E.ins("ds_read_b128 %s, v%d offset:16" % (quad(R_AQ[1]), R_AADDR), "lds", list(range(R_AQ[1], R_AQ[1] + 4)), [R_AADDR])
-    prologue = E.n
+    if G.whole_tile_loads:
+        loads_at = E.n
+        for q in range(TILE // 2):
+            r0 = R_AS + 4 * q
+            E.ins("ds_read_b128 %s, v%d offset:%d" % (quad(r0), R_AADDR, 16 * q), "lds", list(range(r0, r0 + 4)), [R_AADDR])
+    else:
+        loads_at = None
+        E.ins("ds_read_b128 %s, v%d" % (quad(R_AQ[0]), R_AADDR), "lds", list(range(R_AQ[0], R_AQ[0] + 4)), [R_AADDR])
+        E.ins("ds_read_b128 %s, v%d offset:16" % (quad(R_AQ[1]), R_AADDR), "lds", list(range(R_AQ[1], R_AQ[1] + 4)), [R_AADDR])
+    prologue = E.n if loads_at is None else loads_at          # (the per-tile count includes the tile's sample loads either way)
     for s in range(TILE):
         real_step(E, s)
     per_tile = E.n - prologue
     assert [p[0] for p in E.pending] == at_top, "deferred FMAs must line up across the loop's back edge"
-    E.ins("v_xor_b32 v%d, %%[toggle], v%d" % (R_AADDR, R_AADDR), "valu", [R_AADDR], [R_AADDR])   # a_buf[0] <-> a_buf[1]
+    E.ins("v_sub_u32 v%d, v%d, v%d" % (R_AADDR, R_ASUM, R_AADDR), "valu", [R_AADDR], [R_ASUM, R_AADDR])   # a_buf[0] <-> a_buf[1]
     E.ins("s_add_u32 %[base], %[base], 32", "salu")
     E.ins("s_sub_u32 %[tiles], %[tiles], 1", "salu")
     E.ins("s_waitcnt lgkmcnt(0)", "wait")

@@ -38,6 +38,8 @@
 namespace {
 
 constexpr int kFT = 32;                  // samples per tile (pipeline epoch)
+constexpr int kFAS = kFT + 2;            // row stride of the AGC output buffer: 34 float2 = 68 dwords, so that the 8 (16, 4) channels an FLL
+                                         // wave reads with one ds_read_b128 sit 4 banks apart instead of on the same 4 banks
 constexpr int kFCh = 16;                 // channels per workgroup: the benchmark's shape (4096 channels = one workgroup per CU) ...
 constexpr int kFChWide = 32;             // ... the wide shape for more than 16 channels per CU (FLL rows of 4 lanes per channel) ...
 constexpr int kFChSmall = 4;             // ... and the small shape for at most 4 channels per CU (FLL rows of 16 lanes per channel)
@@ -147,7 +149,7 @@ struct FusedParams {
 };
 
 template <int CH> struct FusedLdsT {
-    float2 a_buf[2][CH][kFT];
+    float2 a_buf[2][CH][kFAS];
     float2 x_ring[CH][kFXS];
     float2 y_ring[CH][kFYS];
     float2 s_ring[CH][kFS];
@@ -358,7 +360,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                                [negc1] "s"(FLL16_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                                [p4] "s"(p4),
                                [k1] "s"(FLL16_WAVE_K1), [k2] "s"(FLL16_WAVE_K2), [k3] "s"(FLL16_WAVE_K3), [k4] "s"(FLL16_WAVE_K4),
-                               [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
+                               [a_sum] "v"(2u * a_addr + (unsigned)(sizeof(float2) * CH * kFAS))
                              : "vcc", "scc", "memory", FLL16_WAVE_CLOBBERS);
             } else if constexpr (CH == 16) {
                 asm volatile(FLL_WAVE_ASM
@@ -368,7 +370,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                                [negc1] "s"(FLL_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                                [p4] "s"(p4),
                                [k1] "s"(FLL_WAVE_K1), [k2] "s"(FLL_WAVE_K2), [k3] "s"(FLL_WAVE_K3), [k4] "s"(FLL_WAVE_K4),
-                               [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
+                               [a_sum] "v"(2u * a_addr + (unsigned)(sizeof(float2) * CH * kFAS))
                              : "vcc", "scc", "memory", FLL_WAVE_CLOBBERS);
             } else {
                 asm volatile(FLL4_WAVE_ASM
@@ -378,7 +380,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                                [negc1] "s"(FLL4_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
                                [p4] "s"(p4),
                                [k1] "s"(FLL4_WAVE_K1), [k2] "s"(FLL4_WAVE_K2), [k3] "s"(FLL4_WAVE_K3), [k4] "s"(FLL4_WAVE_K4),
-                               [toggle] "s"((unsigned)(sizeof(float2) * CH * kFT))
+                               [a_sum] "v"(2u * a_addr + (unsigned)(sizeof(float2) * CH * kFAS))
                              : "vcc", "scc", "memory", FLL4_WAVE_CLOBBERS);
             }
         }

@@ -273,6 +273,9 @@ class Sim:
         if op == "v_add_u32":
             V[self._dst(o[0])] = self._src32(o[1], as_float=False) + self._src32(o[2], as_float=False)
             return None
+        if op == "v_sub_u32":
+            V[self._dst(o[0])] = (self._src32(o[1], as_float=False) - self._src32(o[2], as_float=False)) & np.uint32(0xffffffff)
+            return None
         if op == "v_xor_b32":
             V[self._dst(o[0])] = self._src32(o[1], as_float=False) ^ self._src32(o[2], as_float=False)
             return None

@@ -60,7 +60,8 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     be = np.zeros((2, 80), np.float32)
     be[0, 80 - nt:] = np.array(tab.be_re[:nt], np.float32)
     be[1, 80 - nt:] = np.array(tab.be_im[:nt], np.float32)
-    a_bytes = 2 * nch * TILE * 8
+    AROW = (TILE + 2) * 8           # kernel_fused.hpp kFAS: rows of the AGC output buffer are padded by two samples
+    a_bytes = 2 * nch * AROW
     off_a, off_be = 0, a_bytes
     off_x = off_be + 2 * 80 * 4
     row = (KFXP + KFX + 1) * 8
@@ -70,9 +71,10 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     def put_tile(t):
         if t >= ntiles:
             return
-        base = off_a + (t & 1) * nch * TILE * 8
+        base = off_a + (t & 1) * nch * AROW
         blk = np.ascontiguousarray(iq[:, t * TILE:(t + 1) * TILE])          # [nch][32] complex64
-        lds[base:base + nch * TILE * 8] = blk.view(np.uint8).reshape(-1)
+        for c in range(nch):
+            lds[base + c * AROW:base + c * AROW + TILE * 8] = blk[c].view(np.uint8)
 
     put_tile(0)
     if warm:
@@ -87,7 +89,8 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     vec = {
         "ph": np.array([np.float32(start[c][0]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
         "fr": np.array([np.float32(start[c][1]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
-        "a_addr": (off_a + ch * TILE * 8).astype(np.uint32),
+        "a_addr": (off_a + ch * AROW).astype(np.uint32),
+        "a_sum": (2 * (off_a + ch * AROW) + nch * AROW).astype(np.uint32),
         "x_rowlane": (off_x + ch * row + KFXP * 8 - 8 * pos).astype(np.uint32),
         "tap_addr": (off_be + 4 * (tap_off + taps * (lanes - 1 - pos))).astype(np.uint32),
         "hist_addr": (off_x + ch * row + (KFXP + KFX - replay) * 8).astype(np.uint32),
@@ -97,7 +100,7 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     sca = {
         # (a block generated with the first two Cody-Waite steps folded into one fma takes -(C1 + C2) here: <macro>_NEGC1)
         "negc1": f32(-(np.float32(3.140625) + np.float32(9.67502593994140625e-4))) if folded else f32(-3.140625), "beta": f32(tab.k1.fll_beta), "minf": f32(tab.k1.fll_min_freq),
-        "p4": (f32(0.4), 0), "toggle": nch * TILE * 8, "base": 0, "tiles": ntiles, "st": 0,
+        "p4": (f32(0.4), 0), "base": 0, "tiles": ntiles, "st": 0,
         "k1": consts["K1"], "k2": consts["K2"], "k3": consts["K3"], "k4": consts["K4"],
     }
     sim = gcn_sim.Sim(lines, vec, sca, lds, on_barrier=lambda s, k: put_tile(k))
