@@ -1,0 +1,63 @@
+/*
+ * tetra_chan.h -- C ABI of the polyphase channeliser front-end (BASELINE.json config 5).
+ *
+ * The reference plugin has no channeliser: every instance asks SDR++ core for its own VFO/DDC
+ * (src/main.cpp:75, sigpath::vfoManager.createVFO(name, ..., VFO_BANDWIDTH, VFO_SAMPLERATE, ...)) and demodulates
+ * that one 36 ksps stream.  For a wideband capture carrying hundreds of TETRA carriers this front-end replaces the
+ * N VFOs by one analysis filter bank on the GPU and hands the demodulator (include/tetra_demod.h,
+ * TETRA_LAYOUT_TIME_MAJOR) one frame per output instant:
+ *
+ *   out[m][k] = sum_{l<L} h[l] * x[n_m - l] * exp(-j 2 pi k (n_m - l) / M),   n_m = (m+1)*D - 1,  k = 0..M-1
+ *
+ * M channels at spacing Fs/M (channel k centred at k*Fs/M; k > M/2 are the negative frequencies), prototype low-pass
+ * h of L = P*M taps, decimation D (output rate Fs/D per channel; D = M/2 = 2x oversampled is the intended use:
+ * 20 MHz / 800 channels = 25 kHz spacing, 50 ksps per channel, demodulator run with samplerate 50000).
+ * Floating point throughout (float32 DFT): results are held to a tolerance against the double-precision definition
+ * (oracle/chan_oracle.c), see tests/test_chan.py.  Same conventions as tetra_demod.h: extern "C", int status
+ * (TETRA_OK / TETRA_ERR_*), no exceptions, one thread per handle, GPU only.
+ */
+#ifndef TETRA_CHAN_H
+#define TETRA_CHAN_H
+
+#include <stdint.h>
+
+#include "tetra_demod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tetra_chan_config {
+    int32_t n_channels;        /* M: must factor as N1*N2 with N1, N2 <= 64 (e.g. 800 = 25*32, 32 = 4*8) */
+    int32_t taps_per_channel;  /* P: prototype length L = P*M (1..32) */
+    int32_t decimation;        /* D >= 1 */
+    int32_t max_in;            /* largest n_in of one process call */
+    int32_t device;            /* HIP device ordinal, -1 = current */
+    int32_t reserved;
+    double cutoff_rel;         /* prototype cutoff relative to half the channel spacing (1.0 = Fs/(2M)); default 1.2 */
+    const float* prototype;    /* optional caller-supplied prototype [P*M]; NULL = Kaiser(beta 9)-windowed sinc */
+} tetra_chan_config_t;
+
+typedef struct tetra_chan tetra_chan_t;
+
+int tetra_chan_default_config(tetra_chan_config_t* cfg);   /* M 800, P 8, D 400, cutoff 1.2 */
+int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out);
+int tetra_chan_destroy(tetra_chan_t* h);
+/* Frames the next process call with n_in samples will emit (depends on the carried sub-frame phase). */
+int tetra_chan_frames_for(tetra_chan_t* h, int n_in);
+/* x: n_in wideband complex64 samples (device pointer); out: [frames][M] complex64 (device pointer, capacity >=
+ * tetra_chan_frames_for(n_in) frames); *n_frames receives the frame count.  Enqueued on hip_stream, no sync.
+ * The filter history and the sub-frame phase are carried across calls (results independent of the chunking). */
+int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream);
+/* Host-pointer variant: copies in, runs, copies out, synchronises. */
+int tetra_chan_process(tetra_chan_t* h, const float* x, int n_in, float* out, int* n_frames);
+int tetra_chan_reset(tetra_chan_t* h);
+/* Copy of the prototype filter [P*M]. */
+int tetra_chan_get_prototype(tetra_chan_t* h, float* proto);
+/* GPU time (ms) of the channeliser kernel of the most recent process call (HIP events on its stream). */
+int tetra_chan_last_kernel_ms(tetra_chan_t* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,110 @@
+/*
+ * tetra_lmac.h -- C ABI of the batched lower-MAC channel decoding.
+ *
+ * Replaces, for n_blocks logical-channel blocks at once, the channel-decoding half of the reference's
+ *     void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bits, unsigned int len, void *priv)
+ * (src/decoder/src/lower_mac/tetra_lower_mac.c:148-240), i.e. its lines :181-236:
+ *     type5 --tetra_scramb_bits (lower_mac/tetra_scramb.c:34-51, :77-85)--> type4
+ *           --block_deinterleave (lower_mac/tetra_interleave.c:36-39, :51-59)--> type3
+ *           --tetra_rcpc_depunct(TETRA_RCPC_PUNCT_2_3) (lower_mac/tetra_conv_enc.c:229-251)--> mother code, 0xff = punctured
+ *           --viterbi_dec_sb1_wrapper (lower_mac/viterbi.c:6-25 -> viterbi_cch.c:59-67 -> osmo_conv.c osmo_conv_decode_acc,
+ *             K=5 rate-1/4 code of EN 300 392-2 8.2.3.1.1, CONV_TERM_FLUSH)--> type2
+ *           --crc16_ccitt_bits(type2, type1_bits+16) == TETRA_CRC_OK (lower_mac/crc_simple.c:103, tetra_common.h:330)--> crc_ok
+ * with the block parameters of tetra_blk_param[] (tetra_lower_mac.c:58-105).  TPSAP_T_BBK follows the reference's
+ * pass-through (:231-236: descramble only, crc_ok = 1; its Reed-Muller decode is a FIXME there).
+ *
+ * Bit-exact with the reference for ANY input bytes, including its treatment of non-0/1 bytes (after descrambling a byte
+ * 0 is a strong 0, 0xff is an erasure, anything else a strong 1 -- viterbi.c:12-23), the decoder's tie-breaks
+ * (osmo_conv.c:63-95, even predecessor wins) and the four zero-metric flush steps it runs past the block
+ * (osmo_conv.c:678-679 and :727-738, reading the zero-initialised tail of viterbi.c:8).  Parity for this entry point is PINNED: tests compare it with the reference
+ * functions themselves, built from the reference's own source files into oracle/_ref (oracle/build_ref.sh), and with
+ * the reference's encoder primitives as known-answer generator.
+ *
+ * What stays on the host: the SYNC-PDU field extraction (:246-275), TDMA time keeping and everything above the lower MAC.
+ * Same conventions as tetra_demod.h: extern "C", int status (TETRA_OK / TETRA_ERR_*), no exceptions, GPU only.
+ */
+#ifndef TETRA_LMAC_H
+#define TETRA_LMAC_H
+
+#include <stdint.h>
+
+#include "tetra_demod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum tp_sap_data_type of src/decoder/src/phy/tetra_burst.h:9-16 */
+enum {
+    TETRA_TPSAP_T_SB1 = 0,
+    TETRA_TPSAP_T_SB2 = 1,
+    TETRA_TPSAP_T_NDB = 2,
+    TETRA_TPSAP_T_BBK = 3,
+    TETRA_TPSAP_T_SCH_HU = 4,
+    TETRA_TPSAP_T_SCH_F = 5
+};
+
+/* struct tetra_blk_param of tetra_lower_mac.c:48-55 (without the name) */
+typedef struct tetra_lmac_blk_param {
+    int32_t type345_bits;
+    int32_t type2_bits;
+    int32_t type1_bits;
+    int32_t interleave_a;
+    int32_t have_crc16;
+} tetra_lmac_blk_param_t;
+
+int tetra_lmac_blk_param(int type, tetra_lmac_blk_param_t* out);
+/* tetra_scramb_get_init (lower_mac/tetra_scramb.c:87-99): scrambling code of a cell from MCC, MNC and colour code. */
+uint32_t tetra_lmac_scramb_init(uint16_t mcc, uint16_t mnc, uint8_t colour);
+
+/*
+ * type          TETRA_TPSAP_T_x, one block kind per call
+ * d_type5       [n_blocks][in_stride] uint8, one bit per byte: the `bits` argument of tp_sap_udata_ind, type345_bits
+ *               bytes used per row (device pointer, 4-byte aligned, in_stride a multiple of 4 and >= type345_bits)
+ * d_scramb_init [n_blocks] uint32: the cell's scrambling code per block (tcd->scramb_init).  Ignored (may be NULL) for
+ *               TETRA_TPSAP_T_SB1, which the reference always descrambles with SCRAMB_INIT = 3 (tetra_lower_mac.c:185-187)
+ * d_type2       [n_blocks][out_stride] uint8 out: type2_bits decoded bits per row, one per byte; the first type1_bits
+ *               are the type-1 payload the reference hands to the upper MAC (4-byte aligned, out_stride a multiple of
+ *               4 and >= type2_bits)
+ * d_crc_ok      [n_blocks] int32 out: the reference's tup->crc_ok (1/0)
+ * Enqueued on hip_stream of the current device, no synchronisation.  n_blocks == 0 is a no-op.
+ */
+int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_blocks, int in_stride,
+                                   const uint32_t* d_scramb_init, uint8_t* d_type2, int out_stride, int32_t* d_crc_ok,
+                                   void* hip_stream);
+/*
+ * Counted form for rows that come out of tetra_burst_demux_compact_device: n_blocks is the CAPACITY of the row arrays, the
+ * number of rows actually present is read on the device from *d_n_blocks (NULL: all n_blocks), and the scrambling code of
+ * row j is d_scramb_init[d_init_index[j]] (d_init_index = the demultiplexer's d_row_frame, so that the per-frame-slot code
+ * array of tetra_lmac_track_scramb_device is used as it is; NULL: d_scramb_init[j]).  Rows past the count are not touched.
+ */
+int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blocks, const int32_t* d_n_blocks, int in_stride,
+                                     const uint32_t* d_scramb_init, const int32_t* d_init_index, uint8_t* d_type2, int out_stride,
+                                     int32_t* d_crc_ok, void* hip_stream);
+/* Host-pointer variant (copies in/out, synchronises; device = HIP ordinal or -1 for the current one). */
+int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
+                            uint8_t* type2, int out_stride, int32_t* crc_ok, int device);
+
+/*
+ * The one piece of the SYNC-PDU read-out (tetra_lower_mac.c:246-275) that feeds back into the decoding chain: every SB1
+ * block with a good CRC sets the cell's scrambling code, tcd->scramb_init = tetra_scramb_get_init(mcc, mnc, colour code)
+ * with colour code = type2[4..9], mcc = type2[31..40], mnc = type2[41..54] (bits_to_uint, MSB first; :258-266), and every
+ * later block of that receiver -- starting with the BBK and SB2 of the same burst, which tetra_burst_rx_cb hands over
+ * after the SB1 -- is descrambled with it.  The reference keeps one process-global tcd (:116); here every channel has one.
+ *
+ * d_sb1_type2   [n_channels * frames_per_channel][type2_stride] decoded SB1 rows, frame slots in time order per channel
+ *               (the layout tetra_bsync_process_device + tetra_burst_demux_device + tetra_lmac_decode_batch_device produce)
+ * d_crc_ok, d_valid  per row: the decoder's crc_ok, the demultiplexer's valid (row is an SB1 at all)
+ * d_chan_scramb [n_channels] uint32 in/out: the code in force when the call starts / after its last frame (0 for a fresh
+ *               receiver, as the reference's zero-initialised tcd)
+ * d_row_scramb  [n_channels * frames_per_channel] uint32 out: the code in force for the non-SB1 blocks of each frame slot
+ *               -- feed it to tetra_lmac_decode_batch_device as d_scramb_init for SB2 / NDB / SCH-F / BBK rows
+ */
+int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
+                                   int n_channels, int frames_per_channel, uint32_t* d_chan_scramb, uint32_t* d_row_scramb,
+                                   void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

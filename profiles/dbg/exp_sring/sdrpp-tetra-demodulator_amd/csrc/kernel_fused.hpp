@@ -152,8 +152,8 @@ template <int CH> struct FusedLdsT {
     float2 a_buf[2][CH][kFAS];
     float2 x_ring[CH][kFXS];
     float2 y_ring[CH][kFYS];
-    float2 s_ring[CH][kFS];      // (rows 512 bytes apart; padding them by one entry was measured: +1 % / +2 % at 4096 / 1024 channels,
-                                 // -0.6 % at 8192, profiles/r03/r03_y_exp.log -- left as it is)
+    float2 s_ring[CH][kFS + TETRA_EXP_SPAD];   // (+1: rows 2 banks apart -- the timing wave writes, and the Costas wave reads, one entry of
+                                               // every channel per instruction)
     int s_avail[CH];
     int e_span[2][CH];       // 4-channel workgroup: the symbols [first, end) the Costas wave's recurrence lane has just finished
     float2 e_last[2][CH];    // ... and, by epoch parity, z of the last symbol finished so far (the slicer's "previous symbol")
@@ -228,6 +228,9 @@ template <class LDS, class Row> struct FllDeviceIOT {
 
 #ifndef TETRA_EXP_TWOPASS
 #define TETRA_EXP_TWOPASS 0           // experiment builds: 1 = the two-pass Costas wave on the 32-channel shape too (product: 4 and 16 channels)
+#endif
+#ifndef TETRA_EXP_SPAD
+#define TETRA_EXP_SPAD 1              // padding of the symbol ring's rows (0 in experiment builds: rows 512 bytes apart, all on the same banks)
 #endif
 #ifndef TETRA_EXP_DPAIR
 #define TETRA_EXP_DPAIR 1             // 32-channel shape: timing wave on two lanes per channel (0 = one lane per channel)

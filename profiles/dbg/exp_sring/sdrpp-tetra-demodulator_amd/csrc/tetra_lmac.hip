@@ -1,0 +1,250 @@
+// tetra_lmac.hip -- batched lower-MAC channel decoding (include/tetra_lmac.h), bit-exact with the reference's
+// tp_sap_udata_ind() decoding chain (src/decoder/src/lower_mac/tetra_lower_mac.c:181-236).
+//
+// One 64-lane workgroup (one wavefront) decodes 64 blocks, one block per lane (lane-level code: lmac_core.hpp):
+//   1. the 64 rows are read from HBM once, 64 bits per row at a time (coalesced 64-byte segments, 4 rows per load
+//      instruction), into a small LDS stage (row stride 17 dwords = odd, so that "every lane reads the same column of
+//      its own row" is bank-conflict free);
+//   2. each lane descrambles its row chunk (its own LFSR) and packs the soft classes 2 bits per type-4 bit into LDS
+//      words laid out [word][lane];
+//   3. forward recursion: 16 path metrics in registers, the three soft values of a step pair gathered from the class
+//      words at the deinterleaved positions, 16 decision bits per step stored as one ushort to a global scratch laid
+//      out [workgroup][step][lane] (one 128-byte line per step; written once, read once, normally from L2 / MALL);
+//   4. traceback from the scratch (the addresses do not depend on the surviving state, only the bit picked does, so the
+//      loads pipeline), decoded bits packed 16 per ushort into LDS [half][lane], CRC16 over them;
+//   5. the 64 decoded rows are written back with coalesced dword stores, 4 bits -> 4 bytes per lane.
+// LDS per workgroup: 4352 (stage) + 6912 (classes) + 2304 (decoded) = 13568 B, 70 VGPRs -> 11 workgroups per CU (the
+// first version kept the decisions in LDS: 46.6 KB, 3 waves per CU, 3x slower).  The work is integer
+// add/compare/select, VALU-bound.
+#include <hip/hip_runtime.h>
+
+#include "../../include/tetra_lmac.h"
+#include "lmac_core.hpp"
+
+namespace {
+
+using namespace tetra_lmac;
+
+constexpr int kLanes = 64;
+constexpr int kChunkDwords = 16;                       // 64 type-5 bits per row per staging chunk
+constexpr int kSteps = kMaxType2 + kFlush;             // 292
+constexpr int kClsWords = (kMaxType345 + 15) / 16;     // 27
+constexpr int kOutHalves = kMaxType2 / 16;             // 18
+
+struct BlkParam { int type345, type2, type1, a, crc; };
+// tetra_blk_param[], tetra_lower_mac.c:58-105 (values of EN 300 392-2 table 8.x / 8.2.4.1)
+const BlkParam kBlk[6] = {
+    { 120, 80, 60, 11, 1 },     // SB1
+    { 216, 144, 124, 101, 1 },  // SB2
+    { 216, 144, 124, 101, 1 },  // NDB
+    { 30, 30, 14, 0, 0 },       // BBK
+    { 168, 112, 92, 13, 1 },    // SCH/HU
+    { 432, 288, 268, 103, 1 },  // SCH/F
+};
+
+__global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
+                                                        const uint32_t* __restrict__ scramb_init, int fixed_init,
+                                                        int type345, int type2, int type1, int a,
+                                                        uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
+                                                        uint16_t* __restrict__ dec_scratch, int dec_steps,
+                                                        const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index) {
+    __shared__ uint32_t stage[kLanes][kChunkDwords + 1];     // +1: odd row stride, conflict-free column reads
+    __shared__ uint32_t cls[kClsWords][kLanes];
+    __shared__ uint16_t outw[kOutHalves][kLanes];
+    const int lane = threadIdx.x;
+    const int blk0 = blockIdx.x * kLanes;
+    const int blk = blk0 + lane;
+    if (n_blocks_dev) {           // counted form: the number of rows is a device-side result (compacting demultiplexer)
+        const int have = *n_blocks_dev;
+        n_blocks = have < n_blocks ? have : n_blocks;
+        if (blk0 >= n_blocks) return;
+    }
+    const int rows_here = min(kLanes, n_blocks - blk0);
+
+    // 1+2. rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
+    //      descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
+    uint32_t lfsr = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[init_index ? init_index[blk] : blk];
+    const int row_dw = type345 >> 2;
+    for (int c0 = 0; c0 < row_dw; c0 += kChunkDwords) {
+#pragma unroll 4
+        for (int it = 0; it < kLanes * kChunkDwords / kLanes; ++it) {
+            const int q = it * (kLanes / kChunkDwords) + lane / kChunkDwords, d = lane % kChunkDwords;
+            uint32_t v = 0;
+            if (q < rows_here && c0 + d < row_dw)
+                v = reinterpret_cast<const uint32_t*>(type5 + (size_t)(blk0 + q) * in_stride)[c0 + d];
+            stage[q][d] = v;
+        }
+        __syncthreads();
+        lfsr = descramble_chunk(type345 - 4 * c0, lfsr, [&](int d) { return stage[lane][d]; },
+                                [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
+        __syncthreads();
+    }
+
+    // 3. forward recursion: decisions of step t of this workgroup's 64 blocks = one 128-byte line of the scratch
+    uint16_t* dec = dec_scratch + (size_t)blockIdx.x * dec_steps * kLanes + lane;
+    viterbi_forward(type2, type345, a,
+                    [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; },
+                    [&](int t, uint32_t mask) { dec[t * kLanes] = (uint16_t)mask; });
+
+    // 4. traceback + CRC (own lane's data only: program order is enough)
+    viterbi_traceback(type2, [&](int t) { return (uint32_t)dec[t * kLanes]; },
+                      [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; });
+    const uint32_t crc = crc16_bits(type1 + 16, [&](int h) { return (uint32_t)outw[h][lane]; });
+    if (blk < n_blocks) crc_ok[blk] = crc == kCrcOk;
+    __syncthreads();
+
+    // 5. decoded rows -> HBM
+    const int out_dw = type2 >> 2;
+    for (int q = 0; q < rows_here; ++q) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)(blk0 + q) * out_stride);
+        for (int d = lane; d < out_dw; d += kLanes) dst[d] = spread4(((uint32_t)outw[d >> 2][q] >> (4 * (d & 3))) & 0xfu);
+    }
+}
+
+// TPSAP_T_BBK: the reference only descrambles (tetra_lower_mac.c:231-236); 30 bits per block, one lane per block.
+__global__ __launch_bounds__(256) void k_lmac_bbk(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
+                                                  const uint32_t* __restrict__ scramb_init, int nbits,
+                                                  uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
+                                                  const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index) {
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= n_blocks || (n_blocks_dev && blk >= *n_blocks_dev)) return;
+    uint32_t lfsr = scramb_init[init_index ? init_index[blk] : blk];
+    const uint8_t* src = type5 + (size_t)blk * in_stride;
+    uint8_t* dst = out + (size_t)blk * out_stride;
+    for (int j = 0; j < nbits; ++j) dst[j] = src[j] ^ (uint8_t)lfsr_next(lfsr);
+    crc_ok[blk] = 1;
+}
+
+// tetra_lower_mac.c:258-266 per channel: walk the frame slots in time order, a good SB1 replaces the scrambling code
+__global__ __launch_bounds__(256) void k_track_scramb(const uint8_t* __restrict__ sb1, int stride, const int* __restrict__ crc_ok,
+                                                      const int* __restrict__ valid, int n_channels, int frames,
+                                                      uint32_t* __restrict__ chan_scramb, uint32_t* __restrict__ row_scramb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) return;
+    uint32_t cur = chan_scramb[c];
+    for (int f = 0; f < frames; ++f) {
+        const size_t r = (size_t)c * frames + f;
+        if (valid[r] && crc_ok[r]) {
+            const uint8_t* t2 = sb1 + r * stride;
+            auto field = [&](int first, int len) { uint32_t v = 0; for (int i = 0; i < len; ++i) v = (v << 1) | (t2[first + i] & 1u); return v; };
+            const uint32_t cc = field(4, 6), mcc = field(31, 10), mnc = field(41, 14);
+            cur = (((cc & 0x3f) | ((mnc & 0x3fff) << 6) | ((mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1;   // tetra_scramb.c:87-99
+        }
+        row_scramb[r] = cur;
+    }
+    chan_scramb[c] = cur;
+}
+
+int check_args(int type, const void* in, int n_blocks, int in_stride, const void* init, const void* out, int out_stride,
+               const void* ok, bool device_ptrs) {
+    if (type < 0 || type > 5 || n_blocks < 0) return TETRA_ERR_ARG;
+    if (n_blocks == 0) return TETRA_OK;
+    if (!in || !out || !ok) return TETRA_ERR_ARG;
+    if (type != TETRA_TPSAP_T_SB1 && !init) return TETRA_ERR_ARG;
+    const BlkParam& p = kBlk[type];
+    if (in_stride < p.type345 || out_stride < p.type2) return TETRA_ERR_ARG;
+    if ((in_stride & 3) || (out_stride & 3)) return TETRA_ERR_ALIGN;
+    if (device_ptrs && (((uintptr_t)in & 3) || ((uintptr_t)out & 3))) return TETRA_ERR_ALIGN;
+    return TETRA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tetra_lmac_blk_param(int type, tetra_lmac_blk_param_t* out) {
+    if (type < 0 || type > 5 || !out) return TETRA_ERR_ARG;
+    out->type345_bits = kBlk[type].type345;
+    out->type2_bits = kBlk[type].type2;
+    out->type1_bits = kBlk[type].type1;
+    out->interleave_a = kBlk[type].a;
+    out->have_crc16 = kBlk[type].crc;
+    return TETRA_OK;
+}
+
+uint32_t tetra_lmac_scramb_init(uint16_t mcc, uint16_t mnc, uint8_t colour) {
+    // tetra_scramb.c:87-99: colour (6 bits) | MNC (14) << 6 | MCC (10) << 20, then two 1 bits shifted in below
+    const uint32_t v = (uint32_t)(colour & 0x3f) | ((uint32_t)(mnc & 0x3fff) << 6) | ((uint32_t)(mcc & 0x3ff) << 20);
+    return (v << 2) | kScrambInitSb1;
+}
+
+int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_blocks, int in_stride, const uint32_t* d_scramb_init,
+                                   uint8_t* d_type2, int out_stride, int32_t* d_crc_ok, void* hip_stream) {
+    return tetra_lmac_decode_counted_device(type, d_type5, n_blocks, nullptr, in_stride, d_scramb_init, nullptr, d_type2, out_stride,
+                                            d_crc_ok, hip_stream);
+}
+
+int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blocks, const int32_t* d_n_blocks, int in_stride,
+                                     const uint32_t* d_scramb_init, const int32_t* d_init_index, uint8_t* d_type2, int out_stride,
+                                     int32_t* d_crc_ok, void* hip_stream) {
+    const int rc = check_args(type, d_type5, n_blocks, in_stride, d_scramb_init, d_type2, out_stride, d_crc_ok, true);
+    if (rc != TETRA_OK || n_blocks == 0) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const BlkParam& p = kBlk[type];
+    if (type == TETRA_TPSAP_T_BBK) {
+        hipLaunchKernelGGL(k_lmac_bbk, dim3((n_blocks + 255) / 256), dim3(256), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
+                           p.type345, d_type2, out_stride, d_crc_ok, d_n_blocks, d_init_index);
+    } else {
+        // decision scratch: (type2 + 4) steps x 64 lanes x u16 per workgroup, from the stream-ordered allocator (pooled:
+        // after the first call it is a free-list hit), released in stream order right behind the kernel
+        const int groups = (n_blocks + kLanes - 1) / kLanes;
+        const int dec_steps = p.type2 + kFlush;
+        uint16_t* scratch = nullptr;
+        if (hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)groups * dec_steps * kLanes * sizeof(uint16_t), s) != hipSuccess)
+            return TETRA_ERR_NOMEM;
+        hipLaunchKernelGGL(k_lmac_decode, dim3(groups), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
+                           type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride, d_crc_ok,
+                           scratch, dec_steps, d_n_blocks, d_init_index);
+        const hipError_t launch = hipGetLastError();
+        if (hipFreeAsync(scratch, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
+        return TETRA_OK;
+    }
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
+                                   int n_channels, int frames_per_channel, uint32_t* d_chan_scramb, uint32_t* d_row_scramb,
+                                   void* hip_stream) {
+    if (!d_sb1_type2 || !d_crc_ok || !d_valid || !d_chan_scramb || !d_row_scramb) return TETRA_ERR_ARG;
+    if (n_channels < 1 || frames_per_channel < 0 || type2_stride < 60) return TETRA_ERR_ARG;
+    hipLaunchKernelGGL(k_track_scramb, dim3((n_channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2,
+                       type2_stride, d_crc_ok, d_valid, n_channels, frames_per_channel, d_chan_scramb, d_row_scramb);
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
+                            uint8_t* type2, int out_stride, int32_t* crc_ok, int device) {
+    int rc = check_args(type, type5, n_blocks, in_stride, scramb_init, type2, out_stride, crc_ok, false);
+    if (rc != TETRA_OK || n_blocks == 0) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TETRA_ERR_NO_DEVICE;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return TETRA_ERR_HIP;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint32_t* d_init = nullptr;
+    int32_t* d_ok = nullptr;
+    const size_t in_bytes = (size_t)n_blocks * in_stride, out_bytes = (size_t)n_blocks * out_stride;
+    rc = TETRA_ERR_HIP;
+    do {
+        if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess ||
+            hipMalloc(&d_ok, sizeof(int32_t) * n_blocks) != hipSuccess) { rc = TETRA_ERR_NOMEM; break; }
+        if (scramb_init) {
+            if (hipMalloc(&d_init, sizeof(uint32_t) * n_blocks) != hipSuccess) { rc = TETRA_ERR_NOMEM; break; }
+            if (hipMemcpy(d_init, scramb_init, sizeof(uint32_t) * n_blocks, hipMemcpyHostToDevice) != hipSuccess) break;
+        }
+        if (hipMemcpy(d_in, type5, in_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+        const int krc = tetra_lmac_decode_batch_device(type, d_in, n_blocks, in_stride, d_init, d_out, out_stride, d_ok, nullptr);
+        if (krc != TETRA_OK) { rc = krc; break; }
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        // only the type2_bits columns: the caller's row padding is left alone
+        if (hipMemcpy2D(type2, out_stride, d_out, out_stride, kBlk[type].type2, n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(crc_ok, d_ok, sizeof(int32_t) * n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = TETRA_OK;
+    } while (false);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipFree(d_init);
+    (void)hipFree(d_ok);
+    return rc;
+}
+
+}  // extern "C"
