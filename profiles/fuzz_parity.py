@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Time-bounded parity fuzzer: GPU (through the C ABI) against the oracle on random draws over everything the pytest cases vary
+one or two at a time -- rates (1.06 ... 4 samples per symbol, at create), RRC tap count and roll-off, every loop constant, the
+three workgroup shapes and the automatic plan, input layout, symbol output, the quality statistic, TETRA_FLAG_REFERENCE_QUIRKS
+with resets, call lengths 0 ... 3000 with carried state, a loop setter in the middle of the stream, and inputs the synthetic
+TETRA channels do not contain (silence, noise only, amplitudes 1e-6 and 2).  Bits, bit counts, symbols (bit patterns) and
+the loop state after the last call must equal the oracle's for every channel.
+
+    python profiles/fuzz_parity.py --seconds 240 [--seed 1] > gpurun_out/fuzz.json
+
+One JSON line: cases run, channel-calls compared, bits compared, the first failures (empty = all equal).  Test infrastructure:
+uses oracle/ as the checker, like tests/."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tetra_amd  # noqa: E402
+
+from oracle import binding as oracle  # noqa: E402
+
+pkg = tetra_amd.pkg
+B = pkg.binding
+LOOP_PARAMS = ["agc_rate", "costas_bandwidth", "fll_bandwidth", "omega_gain", "mu_gain", "omega_rel_limit"]
+
+
+def _u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def draw_params(rng):
+    sps = float(rng.choice([2.0, 2.0, 50000 / 18000, 40000 / 18000, 1.4, 1.06, 3.0, 4.0, 1.8]))
+    p = dict(symbolrate=18000.0, samplerate=18000.0 * sps)
+    if rng.integers(0, 2):
+        p["rrc_tap_count"] = int(rng.integers(2, 73))
+    if rng.integers(0, 2):
+        p["rrc_beta"] = float(rng.uniform(0.2, 0.5))
+    if rng.integers(0, 2):
+        p["agc_rate"] = float(10 ** rng.uniform(-2.5, -1))
+    if rng.integers(0, 2):
+        p["costas_bandwidth"] = float(10 ** rng.uniform(-2.7, -1.3))
+    if rng.integers(0, 2):
+        p["fll_bandwidth"] = float(10 ** rng.uniform(-3, -1.7))
+    if rng.integers(0, 2):
+        p["omega_rel_limit"] = float(rng.uniform(0.002, 0.03))
+    if rng.integers(0, 3) == 0:
+        p["mu_gain"] = float(rng.uniform(0.005, 0.03))
+        p["omega_gain"] = float(10 ** rng.uniform(-4.5, -3.5))
+    return sps, p
+
+
+def oracle_cfg(p):
+    cfg = oracle.default_cfg()
+    for k, v in p.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def special_channel(rng, kind, n):
+    z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    if kind == 0:
+        return np.zeros(n, np.complex64)
+    if kind == 1:
+        return z * np.float32(0.3)
+    if kind == 2:
+        return z * np.float32(1e-6)
+    return z * np.float32(2.0)      # (FastAGC diverges to Inf/NaN once rate x amplitude reaches 2: the reference's UB, not a parity case)
+
+
+DRY = False      # --dry: the oracle side only (checks the script's own mechanics where there is no GPU)
+
+
+def one_case(rng, stats):
+    sps, p = draw_params(rng)
+    Cn = int(rng.integers(1, 71))
+    tm = bool(rng.integers(0, 2))
+    shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS, B.FLAG_SMALL_WORKGROUPS]))
+    quality = bool(rng.integers(0, 3) == 0)
+    quirks = bool(rng.integers(0, 3) == 0)
+    chunks = [int(rng.choice([0, 1, 5, 31, 32, 33, 63, 64, 65, 180, 255, 700, 1500, 3000])) for _ in range(5)]
+    N = max(sum(chunks), 1)
+    seed = int(rng.integers(0, 1 << 30))
+    iq, _, _ = pkg.synth.gen_batch(Cn, N, base_seed=seed, sps=sps)
+    for c in range(Cn):
+        if rng.integers(0, 8) == 0:
+            iq[c] = special_channel(rng, int(rng.integers(0, 4)), N)
+    desc = dict(params=p, C=Cn, time_major=tm, shape=shape, quality=quality, quirks=quirks, chunks=chunks, seed=seed)
+    try:
+        orcs = [oracle.Oracle(oracle_cfg(p)) for _ in range(Cn)]
+    except ValueError:
+        orcs = None      # outside the oracle's own limits (it mirrors the library's): the library must refuse it too
+    if DRY:
+        if orcs is None:
+            stats["refused"] += 1
+            return None
+        pos = 0
+        for n in chunks:
+            for c in range(Cn):
+                stats["bits"] += int(orcs[c].process(iq[c, pos:pos + n], stages=True)["bits"].size)
+                stats["channel_calls"] += 1
+            pos += n
+        return None
+    try:
+        d = pkg.Demodulator(Cn, 3000, layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR,
+                            flags=shape | (B.FLAG_QUALITY if quality else 0) | (B.FLAG_REFERENCE_QUIRKS if quirks else 0), **p)
+    except B.TetraDemodError as e:
+        stats["refused"] += 1
+        # what the library refuses, the oracle's design must not be asked to run either: only the documented limits
+        assert e.status == -2, (desc, str(e))
+        return None
+    if orcs is None:
+        return dict(desc, what="the library accepted parameters the oracle refuses")
+    pos = 0
+    for k, n in enumerate(chunks):
+        blk = iq[:, pos:pos + n]
+        want_sym = bool(rng.integers(0, 2))
+        bits, nb, sym = d.process(np.ascontiguousarray(blk.T) if tm else blk, want_sym=want_sym)
+        for c in range(Cn):
+            r = orcs[c].process(blk[c], stages=True)
+            stats["channel_calls"] += 1
+            stats["bits"] += int(r["bits"].size)
+            if nb[c] != r["bits"].size:
+                return dict(desc, call=k, ch=c, what="n_bits", gpu=int(nb[c]), ref=int(r["bits"].size))
+            if not np.array_equal(bits[c][:nb[c]], r["bits"]):
+                return dict(desc, call=k, ch=c, what="bits", first=int(np.flatnonzero(bits[c][:nb[c]] != r["bits"])[0]))
+            if want_sym and not np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])):
+                return dict(desc, call=k, ch=c, what="sym")
+        if quality:
+            err, _ = d.quality()
+            for c in range(Cn):
+                e0 = float(orcs[c].st.standarderr)
+                if not (abs(float(err[c]) - e0) < 2e-6 or (np.isnan(err[c]) and np.isnan(e0))):
+                    return dict(desc, call=k, ch=c, what="standarderr", gpu=float(err[c]), ref=e0)
+        if k == 1:      # a loop setter in the middle of the stream, both sides
+            name = LOOP_PARAMS[int(rng.integers(0, len(LOOP_PARAMS)))]
+            cur = getattr(orcs[0].cfg, name)
+            val = float(cur * rng.uniform(0.5, 1.5))
+            try:
+                d.set_param(name, val)
+            except B.TetraDemodError as e:
+                assert e.status == -2, (desc, name, val, str(e))
+            else:
+                for o in orcs:
+                    o.set_param(B.PARAMS[name], val, quirks=quirks)
+        if k == 2:
+            c = int(rng.integers(0, Cn))
+            d.reset(c)
+            if quirks:
+                orcs[c].reset_reference()
+            else:
+                orcs[c].reset()
+        pos += n
+    for c in range(0, Cn, max(1, Cn // 6)):
+        st, o = d.get_state(c), orcs[c].st
+        for f in ("agc_gain", "fll_phase", "fll_freq", "mu", "omega", "costas_phase", "costas_freq", "ph2"):
+            if np.float32(getattr(st, f)).tobytes() != np.float32(getattr(o, f)).tobytes():
+                return dict(desc, ch=c, what="state." + f, gpu=float(getattr(st, f)), ref=float(getattr(o, f)))
+        if st.offset != o.offset or st.prev != o.prev:
+            return dict(desc, ch=c, what="state.offset/prev")
+    if d.overruns() != 0:
+        return dict(desc, what="overruns", n=d.overruns())
+    d.close()
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-cases", type=int, default=1 << 30)
+    ap.add_argument("--dry", action="store_true")
+    a = ap.parse_args()
+    global DRY
+    DRY = a.dry
+    rng = np.random.default_rng(a.seed)
+    stats = dict(cases=0, refused=0, channel_calls=0, bits=0)
+    failures = []
+    t0 = time.time()
+    kinds = {}
+    while time.time() - t0 < a.seconds and stats["cases"] < a.max_cases and len(failures) < 12:
+        f = one_case(rng, stats)
+        stats["cases"] += 1
+        if f is not None:
+            kinds[f["what"]] = kinds.get(f["what"], 0) + 1
+            if kinds[f["what"]] <= 3:          # at most three examples of a kind; the run goes on to find other kinds
+                failures.append(f)
+    stats["failed_cases_by_kind"] = kinds
+    stats["seconds"] = round(time.time() - t0, 1)
+    stats["seed"] = a.seed
+    stats["failures"] = failures
+    print(json.dumps(stats, default=str))
+    return 1 if kinds else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -720,7 +720,7 @@ TD_FN float quality_distance(float zr, float zi) {
 #else
     const float inv = 1.0f / hi;
 #endif
-    const float r = hi > 0.0f ? lo * inv : 0.0f;     // atan2f(0, 0) = 0 in the reference -> distance pi/4
+    const float r = hi > 0.0f ? lo * inv : 0.0f;     // atan2f(+0, +0) = 0 -> distance pi/4 (the other zeros: below)
     const float z = r * r;
     float p = v_fma(0.0028662257f, z, -0.0161657367f);
     p = v_fma(p, z, 0.0429096138f);
@@ -730,6 +730,13 @@ TD_FN float quality_distance(float zr, float zi) {
     p = v_fma(p, z, 0.1999355085f);
     p = v_fma(p, z, -0.3333314528f);
     p = v_fma(p, z, 1.0f);
+    // atan2f's signed zeros (symbols with an exactly-zero component: digital silence).  The slicer files both zeros under
+    // "positive" (x < 0 is false), atan2f does not: an imaginary part of -0 beside a negative (or -0) real part is the angle
+    // -pi, +0 beside -0 is +pi -- |ideal - angle| = 3pi/4 + pi, pi/4 + pi, pi - pi/4 (the floats atan2f returns)
+    const unsigned ui = __builtin_bit_cast(unsigned, zi), ur = __builtin_bit_cast(unsigned, zr);
+    if (ui == 0x80000000u && zr < 0.0f) return 2.3561945f + 3.14159274f;
+    if (ui == 0x80000000u && ur == 0x80000000u) return 0.785398185f + 3.14159274f;
+    if (ui == 0u && ur == 0x80000000u) return 3.14159274f - 0.785398185f;
     return 0.785398163397448f - p * r;
 }
 

@@ -413,6 +413,7 @@ const char* tetra_demod_strerror(int status) {
     case TETRA_ERR_NOMEM: return "out of memory";
     case TETRA_ERR_SIZE: return "size out of range";
     case TETRA_ERR_ALIGN: return "misaligned output buffer";
+    case TETRA_ERR_OVERRUN: return "a channel filled its output row and was cut off (outputs delivered)";
     default: return "unknown status";
     }
 }
@@ -688,6 +689,11 @@ int tetra_demod_process_resident(tetra_demod_t* h, const float* d_iq, int n_samp
     if (!h) return TETRA_ERR_ARG;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    if (h->as.ready) {      // like tetra_demod_process: asynchronous calls still in flight finish first (state order)
+        HIP_TRY(h, hipStreamSynchronize(h->as.s_in));
+        HIP_TRY(h, hipStreamSynchronize(h->as.s_k));
+        HIP_TRY(h, hipStreamSynchronize(h->as.s_out));
+    }
     if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     const int rc = tetra_demod_process_device(h, d_iq, n_samples, d_bits, bits_stride, d_n_bits, d_sym, h->own_stream);
     if (rc != TETRA_OK) return rc;
@@ -835,13 +841,20 @@ int async_enqueue(tetra_demod* h, const void* iq, int iq_format, int n_samples, 
     if (want_iq > a.iq_bytes || want_raw > a.raw_bytes || want_cbits > a.cbits_bytes || want_out > a.out_bytes) {
         HIP_TRY(h, hipDeviceSynchronize());          // buffers may be in use by calls still in flight
         for (int i = 0; i < 2; i++) {
-            int rc;
+            int rc = TETRA_OK;
             size_t t;
-            t = a.iq_bytes; if ((rc = grow(h, (void**)&a.d_iq[i], &t, want_iq))) return rc;
-            if (want_raw) { t = a.raw_bytes; if ((rc = grow(h, &a.d_raw[i], &t, want_raw))) return rc; }
-            t = a.cbits_bytes; if ((rc = grow(h, (void**)&a.d_cbits[i], &t, want_cbits))) return rc;
-            t = a.out_bytes; if ((rc = grow(h, (void**)&a.d_out[i], &t, want_out))) return rc;
-            if (want_out > a.out_bytes) HIP_TRY(h, hipMemset(a.d_out[i], 0, want_out));      // once; a call defines bits[c][0 .. n_bits[c])
+            t = a.iq_bytes; rc = grow(h, (void**)&a.d_iq[i], &t, want_iq);
+            if (rc == TETRA_OK && want_raw) { t = a.raw_bytes; rc = grow(h, &a.d_raw[i], &t, want_raw); }
+            if (rc == TETRA_OK) { t = a.cbits_bytes; rc = grow(h, (void**)&a.d_cbits[i], &t, want_cbits); }
+            if (rc == TETRA_OK) { t = a.out_bytes; rc = grow(h, (void**)&a.d_out[i], &t, want_out); }
+            if (rc == TETRA_OK && want_out > a.out_bytes) {      // once; a call defines bits[c][0 .. n_bits[c])
+                const hipError_t e = hipMemset(a.d_out[i], 0, want_out);
+                if (e != hipSuccess) { h->last_hip = (int)e; rc = TETRA_ERR_HIP; }
+            }
+            if (rc != TETRA_OK) {      // a buffer may be gone: forget every size, the next call allocates all of them again
+                a.iq_bytes = a.raw_bytes = a.cbits_bytes = a.out_bytes = 0;
+                return rc;
+            }
         }
         a.iq_bytes = a.iq_bytes > want_iq ? a.iq_bytes : want_iq;
         if (want_raw) a.raw_bytes = a.raw_bytes > want_raw ? a.raw_bytes : want_raw;

@@ -275,4 +275,10 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
     return emul_fused_shape(t, st, C, n, iq, y_out, bits, bits_stride, n_bits, sym, 8);
 }
 
+// DQPSKSymbolExtractor's per-symbol angular distance as k_quality computes it (demod_core.hpp quality_distance): n symbols
+// z[2i], z[2i+1] -> out[i]
+void emul_quality_distance(int n, const float* z, float* out) {
+    for (int i = 0; i < n; i++) out[i] = quality_distance(z[2 * i], z[2 * i + 1]);
+}
+
 }  // extern "C"

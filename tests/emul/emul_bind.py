@@ -65,6 +65,8 @@ def lib():
         L.emul_fused_shape.restype = C.c_int
         L.emul_bits_stride_for.argtypes = [C.POINTER(Config), C.c_longlong]
         L.emul_bits_stride_for.restype = C.c_longlong
+        L.emul_quality_distance.argtypes = [C.c_int, vp, vp]
+        L.emul_quality_distance.restype = None
         _lib = L
     return _lib
 
@@ -91,6 +93,15 @@ def bits_stride_for(cfg, n):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def quality_distance(z):
+    """k_quality's per-symbol distance (demod_core.hpp quality_distance) for complex64 symbols z[n]."""
+    import numpy as np
+    z = np.ascontiguousarray(z, np.complex64)
+    out = np.zeros(z.size, np.float32)
+    lib().emul_quality_distance(int(z.size), _p(z), _p(out))
+    return out
 
 
 def bits_stride(n):

@@ -203,3 +203,27 @@ def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, fll_lanes, l
         assert np.array_equal(_u32(q["y"][0]), _u32(r["y"])), (lanes, nt)
         nb = int(q["n_bits"][0])
         assert np.array_equal(q["bits"][0][:nb], r["bits"]), (lanes, nt)
+
+
+def test_quality_distance_is_the_reference_expression_including_signed_zeros(emul):
+    """DQPSKSymbolExtractor's per-symbol distance (dqpsk_sym_extr.cpp:8-12): |atan2f(ideal) - atan2f(symbol)| with the ideal
+    point chosen by `x < 0` tests.  The kernel's polynomial form equals it to float rounding for symbols inside a quadrant,
+    and -- found by profiles/fuzz_parity.py on digitally silent channels -- has to follow atan2f's signed zeros where a
+    component is exactly zero: the slicer files -0 under "positive", atan2f(-0, x < 0) is -pi."""
+    rng = np.random.default_rng(77)
+    z = (rng.standard_normal(20000) + 1j * rng.standard_normal(20000)).astype(np.complex64)
+    z[:2000] *= np.float32(1e-20)
+    z[2000:4000] *= np.float32(1e15)
+    vals = [0.0, -0.0, 0.5, -0.5, 1e-30, -1e-30]
+    edge = np.array([complex(a, b) for a in vals for b in vals], np.complex64)
+    # (numpy's complex(a, b) keeps the zero signs in both parts)
+    z = np.concatenate([z, edge])
+    re, im = z.real.astype(np.float32), z.imag.astype(np.float32)
+    assert np.signbit(re[-36:]).sum() == 18 and np.signbit(im[-36:]).sum() == 18
+    ideal_re = np.where(re < 0, np.float32(-0.7071), np.float32(0.7071))
+    ideal_im = np.where(im < 0, np.float32(-0.7071), np.float32(0.7071))
+    want = np.abs(np.arctan2(ideal_im, ideal_re).astype(np.float32) - np.arctan2(im, re).astype(np.float32))
+    got = emul.quality_distance(z)
+    assert np.abs(got - want).max() < 1e-6, (np.abs(got - want).argmax(), z[np.abs(got - want).argmax()])
+    # the three sign-of-zero cases are really in the set
+    assert (want > 5.0).any() and (np.abs(want - 3.9269908) < 1e-6).any() and (np.abs(want - 2.3561945) < 1e-6).any()
