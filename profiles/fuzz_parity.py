@@ -168,12 +168,135 @@ def one_case(rng, stats):
     return None
 
 
+_POOL = {}
+
+
+def plan_case(rng, stats):
+    """The launch plan over the channel axis: C log-uniform in 1 ... 20000 on the automatic plan (whole rounds of 32-channel
+    workgroups, the rest in 32-, 16- or 4-channel ones: tetra_demod_create), two short calls with carried state, against the
+    oracle's batch entry (OpenMP over channels)."""
+    sps = float(rng.choice([2.0, 2.0, 50000 / 18000]))
+    if sps not in _POOL:
+        _POOL[sps] = pkg.synth.gen_batch(256, 800, base_seed=4242, sps=sps)[0]
+    pool = _POOL[sps]
+    Cn = int(np.exp(rng.uniform(0, np.log(20000.0))))
+    tm = bool(rng.integers(0, 2))
+    n1, n2 = int(rng.integers(1, 401)), int(rng.integers(1, 401))
+    idx = rng.integers(0, 256, Cn)
+    scale = (rng.uniform(0.2, 1.5, Cn) * np.exp(1j * rng.uniform(-np.pi, np.pi, Cn))).astype(np.complex64)
+    iq = np.ascontiguousarray(pool[idx, :n1 + n2] * scale[:, None])
+    p = dict(symbolrate=18000.0, samplerate=18000.0 * sps)
+    desc = dict(mode="plan", C=Cn, sps=sps, time_major=tm, n=[n1, n2])
+    d = pkg.Demodulator(Cn, 400, layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR, **p)
+    states = None
+    pos = 0
+    for k, n in enumerate((n1, n2)):
+        blk = np.ascontiguousarray(iq[:, pos:pos + n])
+        bits, nb, _ = d.process(np.ascontiguousarray(blk.T) if tm else blk)
+        rb, rnb, _, states = oracle.process_batch(blk, cfg=oracle_cfg(p), states=states, stride=bits.shape[1])
+        stats["channel_calls"] += Cn
+        stats["bits"] += int(rnb.sum())
+        if not np.array_equal(nb, rnb):
+            c = int(np.flatnonzero(nb != rnb)[0])
+            return dict(desc, call=k, ch=c, what="n_bits", gpu=int(nb[c]), ref=int(rnb[c]))
+        m = np.arange(bits.shape[1])[None, :] < nb[:, None]
+        if not np.array_equal(bits[m], rb[m]):
+            c = int(np.flatnonzero(((bits != rb) & m).any(axis=1))[0])
+            return dict(desc, call=k, ch=c, what="bits")
+        pos += n
+    d.close()
+    return None
+
+
+class Pinned:
+    """Page-locked host arrays from tetra_demod_host_alloc (no torch in this script)."""
+
+    def __init__(self):
+        self.lib = B.load_library()
+        self.ptrs = []
+
+    def array(self, shape, dtype):
+        import ctypes as C
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.lib.tetra_demod_host_alloc(max(n, 1))
+        assert ptr
+        self.ptrs.append(ptr)
+        return np.frombuffer((C.c_uint8 * max(n, 1)).from_address(ptr), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        for ptr in self.ptrs:
+            self.lib.tetra_demod_host_free(ptr)
+        self.ptrs = []
+
+
+def async_case(rng, stats):
+    """tetra_demod_process_async: call lengths around its time-chunk boundaries (n / 4096 chunks, at most 8, lengths rounded to
+    32), float / int16 / int8 input, both layouts, three calls of which two are in flight together, rates that change the row
+    length -- against the oracle on the values the GPU converts to."""
+    sps = float(rng.choice([2.0, 50000 / 18000, 1.4]))
+    Cn = int(rng.integers(1, 65))
+    tm = bool(rng.integers(0, 2))
+    fmt = int(rng.choice([B.IQ_CF32, B.IQ_CS16, B.IQ_CS8]))
+    def length():
+        k = int(rng.integers(0, 10))
+        return max(1, min(40000, k * 4096 + int(rng.choice([-33, -32, -1, 0, 1, 31, 32, 33, 100, 2000]))))
+    sizes = [length() for _ in range(3)]
+    iq, _, _ = pkg.synth.gen_batch(Cn, sum(sizes), base_seed=int(rng.integers(0, 1 << 30)), sps=sps, amp=0.5)
+    f = iq.view(np.float32)
+    if fmt == B.IQ_CS16:
+        raw = np.clip(np.round(f * 32768.0), -32768, 32767).astype(np.int16)
+        val = (raw.astype(np.float32) / np.float32(32768.0)).view(np.complex64)
+    elif fmt == B.IQ_CS8:
+        raw = np.clip(np.round(f * 128.0), -128, 127).astype(np.int8)
+        val = (raw.astype(np.float32) / np.float32(128.0)).view(np.complex64)
+    else:
+        raw, val = f, iq
+    raw = raw.reshape(Cn, -1, 2)
+    p = dict(symbolrate=18000.0, samplerate=18000.0 * sps)
+    desc = dict(mode="async", C=Cn, sps=sps, time_major=tm, fmt=fmt, sizes=sizes)
+    d = pkg.Demodulator(Cn, max(sizes), layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR, **p)
+    pin = Pinned()
+    keep, pos = [], 0
+    for k, n in enumerate(sizes):
+        blk = raw[:, pos:pos + n]
+        src = np.swapaxes(blk, 0, 1) if tm else blk
+        host_in = pin.array(src.shape, raw.dtype)
+        host_in[...] = src
+        stride = d.bits_stride(n)
+        bits = pin.array((Cn, stride), np.uint8)
+        bits[...] = 7
+        nb = pin.array((Cn,), np.int32)
+        nb[...] = -1
+        d.process_async(host_in.ctypes.data, fmt, n, bits.ctypes.data, stride, nb.ctypes.data)
+        keep.append((bits, nb, pos, n, stride))
+        pos += n
+        if k == 0:
+            d.wait()                # calls 1 and 2 are then in flight together
+    d.wait()
+    states = None
+    for k, (bits, nb, p0, n, stride) in enumerate(keep):
+        rb, rnb, _, states = oracle.process_batch(np.ascontiguousarray(val[:, p0:p0 + n]), cfg=oracle_cfg(p), states=states, stride=stride)
+        stats["channel_calls"] += Cn
+        stats["bits"] += int(rnb.sum())
+        if not np.array_equal(nb, rnb):
+            c = int(np.flatnonzero(nb != rnb)[0])
+            return dict(desc, call=k, ch=c, what="n_bits", gpu=int(nb[c]), ref=int(rnb[c]))
+        m = np.arange(stride)[None, :] < rnb[:, None]
+        if not np.array_equal(bits[m], rb[m]):
+            c = int(np.flatnonzero(((bits != rb) & m).any(axis=1))[0])
+            return dict(desc, call=k, ch=c, what="bits")
+    d.close()
+    pin.free()
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cases", type=int, default=1 << 30)
     ap.add_argument("--dry", action="store_true")
+    ap.add_argument("--mode", choices=["chain", "plan", "async"], default="chain")
     a = ap.parse_args()
     global DRY
     DRY = a.dry
@@ -183,7 +306,7 @@ def main():
     t0 = time.time()
     kinds = {}
     while time.time() - t0 < a.seconds and stats["cases"] < a.max_cases and len(failures) < 12:
-        f = one_case(rng, stats)
+        f = plan_case(rng, stats) if a.mode == "plan" else async_case(rng, stats) if a.mode == "async" else one_case(rng, stats)
         stats["cases"] += 1
         if f is not None:
             kinds[f["what"]] = kinds.get(f["what"], 0) + 1
@@ -192,6 +315,7 @@ def main():
     stats["failed_cases_by_kind"] = kinds
     stats["seconds"] = round(time.time() - t0, 1)
     stats["seed"] = a.seed
+    stats["mode"] = a.mode
     stats["failures"] = failures
     print(json.dumps(stats, default=str))
     return 1 if kinds else 0
