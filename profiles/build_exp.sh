@@ -15,6 +15,11 @@ cp -r "$HERE/../sdrpp-tetra-demodulator_amd/csrc" "$D/sdrpp-tetra-demodulator_am
 cp -r "$HERE/../include" "$D/include"
 env "$@" python3 "$D/sdrpp-tetra-demodulator_amd/csrc/gen_fll_asm.py" > /dev/null
 C="$D/sdrpp-tetra-demodulator_amd/csrc"
+# EXP_ABLATE_MASK=1 (environment of this script): TETRA_EXP_ABLATE becomes a bit mask in the copy, so that several roles can be
+# ablated together: 1 Costas (E), 2 RRC (C), 4 AGC (A), 8 timing (D)
+if [ -n "$EXP_ABLATE_MASK" ]; then
+    sed -i 's/TETRA_EXP_ABLATE == 1/(TETRA_EXP_ABLATE \& 1)/; s/TETRA_EXP_ABLATE == 2/(TETRA_EXP_ABLATE \& 2)/; s/TETRA_EXP_ABLATE == 3/(TETRA_EXP_ABLATE \& 4)/; s/TETRA_EXP_ABLATE == 4/(TETRA_EXP_ABLATE \& 8)/' "$C/kernel_fused.hpp"
+fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $FLAGS \
     -fPIC -shared -o "$HERE/dbg/lib_$NAME.so" "$C/tetra_demod.hip" "$C/tetra_chan.hip" "$C/tetra_burst_scan.hip" "$C/tetra_lmac.hip" "$C/tetra_burst_sync.hip"
 rm -rf "$D"

@@ -73,12 +73,15 @@ static_assert(kF16Pad == 80 && kF16Taps == 5, "fll16_asm.inc is generated for 16
 
 // Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
 // the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
-//   SIMD0 {E (wave 0), C (wave 4)}   SIMD1 {D (wave 1), A (wave 5)}   SIMD2 {F0}   SIMD3 {F1}
-// The symbol-rate recurrences (E, D) keep priority; the packed-FP32-heavy RRC wave sits beside the lighter of the two.
-// Measured A/B on one box (profiles/r02/r02_j_role_placement.md): this placement 4.41 ms; {E,A}{D,C} 4.49; the same pairs with
-// priorities flipped 5.23; {E,D}{A,C} 5.02.
+//   SIMD0 {E (wave 0), A (wave 4)}   SIMD1 {D (wave 1), C (wave 5)}   SIMD2 {F0}   SIMD3 {F1}
+// The symbol-rate recurrences (E, D) keep priority.  Which of the two gets the packed-FP32-heavy RRC wave for a neighbour was
+// measured twice on one box: in round 2 (Costas wave 52 slots per sample in one pass, timing wave 45 on one lane per channel:
+// profiles/r02/r02_j_role_placement.md) {E,C}{D,A} 4.41 ms, {E,A}{D,C} 4.49, the pairs with priorities flipped 5.23,
+// {E,D}{A,C} 5.02; on round 3's waves (Costas 42 in two passes, timing 35 on four lanes per channel) the RRC wave fits beside
+// the lightened timing wave and the Costas wave keeps SIMD0 nearly to itself: {E,A}{D,C} 3.86 ms, {E,C}{D,A} 3.98
+// (profiles/r03/r03_p2_exp.log) -- the launch then runs at the FLL waves' own pace.
 #ifndef TETRA_ROLE_IDS
-#define TETRA_ROLE_IDS 0, 1, 2, 3, 5, 4
+#define TETRA_ROLE_IDS 0, 1, 2, 3, 4, 5
 #endif
 namespace role_ids { constexpr int v[6] = { TETRA_ROLE_IDS }; }
 // The wide workgroup (32 channels): the two FLL waves carry 16 channels each on rows of 4 lanes per channel (75 slots per
