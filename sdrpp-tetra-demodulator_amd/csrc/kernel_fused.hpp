@@ -46,7 +46,10 @@ constexpr int kFChSmall = 4;             // ... and the small shape for at most 
 #ifndef TETRA_WIDE_WAVES
 #define TETRA_WIDE_WAVES 8
 #endif
-constexpr int fused_threads(int ch) { return ch == 16 ? 6 * 64 : ch == 4 ? 8 * 64 : TETRA_WIDE_WAVES * 64; }   // 16: six roles; 32, 4: see Roles
+#ifndef TETRA_NARROW_WAVES
+#define TETRA_NARROW_WAVES 6             // (experiment builds: 8 = two more waves without a role, so that the role table can leave SIMD slots empty)
+#endif
+constexpr int fused_threads(int ch) { return ch == 16 ? TETRA_NARROW_WAVES * 64 : ch == 4 ? 8 * 64 : TETRA_WIDE_WAVES * 64; }   // 16: six roles; 32, 4: see Roles
 constexpr int kFThreads = fused_threads(kFCh);       // 384 = 6 waves
 // Ring depths.  The TETRA_EXP_* overrides exist for TIMING-ONLY experiment builds (profiles/build_exp.sh: rings too short to
 // hold the data, output garbage, same instruction streams); the product is built without them.

@@ -26,9 +26,9 @@ using namespace tdm;
 namespace {
 
 constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
-constexpr int kWg16ClocksPerSample = 270;       // measured shader clocks per sample of one workgroup round: 4.05 ms per 36000 samples (profiles/r03)
-constexpr int kWg32ClocksPerSample = 357;       // 32-channel workgroup: 5.35 ms per 36000 samples
-constexpr int kWg4ClocksPerSample = 232;        // 4-channel workgroup: 3.47 ms per 36000 samples
+constexpr int kWg16ClocksPerSample = 258;       // measured shader clocks per sample of one workgroup round: 3.86 ms per 36000 samples (profiles/r03)
+constexpr int kWg32ClocksPerSample = 348;       // 32-channel workgroup: 5.21 ms per 36000 samples
+constexpr int kWg4ClocksPerSample = 223;        // 4-channel workgroup: 3.33 ms per 36000 samples
 
 __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
     float2 v = *p;
