@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Container-only EVIDENCE sweep (not a pin, see tests/test_reference_shim.py): the reference's own src/dsp/*.cpp compiled against
+tests/refshim/ versus oracle/tetra_oracle.c over RANDOM parameter sets (profiles/fuzz_parity.draw_params: rates 1.06 ... 4 samples
+per symbol, tap counts 2 ... 72, roll-off, every loop constant) and random channels.  Reports how many cases have all bits equal and,
+for the rest, whether the FIRST differing decision is a boundary decision (the flipped component below 3e-2 in both, streams
+within the documented symbol tolerance up to there): the two differ in float rounding by design (libm sine / plain sums there,
+polynomial / fmaf chains here), and a decision-directed loop amplifies a flipped sign.
+    python profiles/fuzz_refshim_cpu.py <seed> <seconds>"""
+import sys, time
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, 'tests'), os.path.join(R, 'profiles')]
+import numpy as np
+import test_reference_shim as S
+import fuzz_parity as F
+from oracle import binding as oracle
+L=S.load_reference_build()
+rng=np.random.default_rng(int(sys.argv[1])); secs=float(sys.argv[2])
+t0=time.time(); cases=0; equal=0; boundary=0; other=[]; bits=0
+while time.time()-t0<secs:
+    sps,p=F.draw_params(rng)
+    cfg=F.oracle_cfg(p)
+    try: o=oracle.Oracle(cfg)
+    except ValueError: continue
+    if sps*(1-cfg.omega_rel_limit)-abs(cfg.mu_gain) < 1.0: continue
+    r=S.RefChain(L,cfg)
+    n=int(rng.choice([3000,8000,20000]))
+    seed=int(rng.integers(0,1<<30))
+    iq,_,_=F.pkg.synth.gen_channel(n,seed,sps=sps)
+    rs,rb=r.process(iq); oo=o.process(iq)
+    cases+=1; bits+=rb.size
+    if rb.size==oo['bits'].size and np.array_equal(rb,oo['bits']):
+        equal+=1; continue
+    m=min(rs.size,oo['sym'].size)
+    # first symbol whose quadrant differs
+    qa=(rs[:m].real<0).astype(int)*2+(rs[:m].imag<0); qb=(oo['sym'][:m].real<0).astype(int)*2+(oo['sym'][:m].imag<0)
+    w=np.flatnonzero(qa!=qb)
+    if w.size==0:
+        other.append(dict(p=p,seed=seed,what='no quadrant difference but bits differ',sizes=(rs.size,oo['sym'].size))); continue
+    i=int(w[0])
+    # up to there the two streams agree within the documented tolerance, and the flipped component is on the boundary
+    d=float(np.abs(rs[:i]-oo['sym'][:i]).max()) if i else 0.0
+    a,b=rs[i],oo['sym'][i]
+    comp=min(abs(a.real),abs(b.real)) if (a.real<0)!=(b.real<0) else min(abs(a.imag),abs(b.imag))
+    if d<3e-2 and comp<3e-2: boundary+=1
+    else: other.append(dict(p=p,seed=seed,i=i,maxdiff_before=d,comp=float(comp),a=complex(a),b=complex(b)))
+print(dict(cases=cases,bits=bits,all_bits_equal=equal,first_difference_is_a_boundary_decision=boundary,other=len(other),seconds=round(time.time()-t0,1)))
+for x in other[:8]: print(x)
