@@ -25,6 +25,7 @@ using namespace tdm;
 
 namespace {
 
+constexpr int kTinyCallSamples = 768;           // tetra_demod_process: calls of at most this many samples per channel run in place (below)
 constexpr int kYHist = kInterpTaps - 1;         // COMPLEX_FD's delay buffer: 7 RRC outputs in front of the new ones
 constexpr int kWg16ClocksPerSample = 258;       // measured shader clocks per sample of one workgroup round: 3.86 ms per 36000 samples (profiles/r03)
 constexpr int kWg32ClocksPerSample = 348;       // 32-channel workgroup: 5.21 ms per 36000 samples
@@ -202,6 +203,8 @@ struct tetra_demod {
     float2* ybuf = nullptr;     // COMPLEX_FD delay buffer [C][7]
     int* d_overruns = nullptr;  // [1] channels cut off at their row capacity, counted by the kernels since create
     long long overruns_seen = 0;   // ... and what the host entry points have already reported of it
+    long long overruns_tiny = 0;   // ... plus what the in-place calls counted in their own page-locked counter (below)
+    int* overruns_override = nullptr;   // set around an in-place call's launch: the kernels count into this address instead
     float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state (k_quality)
     int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
     float* q_err = nullptr;
@@ -221,6 +224,8 @@ struct tetra_demod {
     // small synchronous calls (the single-channel drop-in's 180-sample chunks): page-locked host staging, one packed output
     uint8_t *pk_dev = nullptr, *pk_host = nullptr, *pk_in = nullptr;
     size_t pk_bytes = 0, pk_in_bytes = 0;
+    // the smallest synchronous calls: page-locked, mapped, coherent blocks the kernels read / write in place (no copy engine)
+    uint8_t *tn_out = nullptr, *tn_in = nullptr, *tn_out_dev = nullptr, *tn_in_dev = nullptr;
     // ring of HIP-event pairs (before / after the call's launches), one slot per process call
     static constexpr int kEvSlots = 64;
     hipEvent_t ev[kEvSlots][2] = {};
@@ -362,6 +367,8 @@ void free_all(tetra_demod* h) {
     if (h->pk_dev) (void)hipFree(h->pk_dev);
     if (h->pk_host) (void)hipHostFree(h->pk_host);
     if (h->pk_in) (void)hipHostFree(h->pk_in);
+    if (h->tn_out) (void)hipHostFree(h->tn_out);
+    if (h->tn_in) (void)hipHostFree(h->tn_in);
     hipStream_t ss[] = { a.s_in, a.s_k, a.s_out, h->own_stream };
     for (hipStream_t st : ss)
         if (st) (void)hipStreamDestroy(st);
@@ -610,7 +617,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
-        pf.overruns = h->d_overruns;
+        pf.overruns = h->overruns_override ? h->overruns_override : h->d_overruns;
         pf.sym_stride = bits_stride / 2;
         if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
@@ -725,6 +732,46 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
     constexpr size_t kSmallCall = 256 * 1024;
     const size_t nb_bytes = (sizeof(int) * C + 15) / 16 * 16;
     const size_t pack_bytes = nb_bytes + bits_bytes + sym_bytes + 16;      // + the overrun counter, so that it rides along
+#ifdef TETRA_EXP_TINY_ENV      // experiment builds: the in-place limit from the environment (profiles/measure_tiny_calls.py)
+    static const int kTiny = std::getenv("TETRA_TINY_SAMPLES") ? std::atoi(std::getenv("TETRA_TINY_SAMPLES")) : kTinyCallSamples;
+#else
+    constexpr int kTiny = kTinyCallSamples;
+#endif
+    if (n_samples > 0 && n_samples <= kTiny && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall) {
+        // The shortest calls use no copy engine at all: the CPU copies the samples into a page-locked, mapped, coherent block
+        // that the AGC wave reads in place over PCIe (a tile ahead, as always), the kernels write n_bits | bits | symbols | this
+        // call's overrun counter straight into a second such block, ONE synchronisation, plain memcpys out.  Measured
+        // (profiles/r03/r03_ad_tiny_calls.json): 1 x 180 samples 67.7 -> 59.9 us per call, 16 x 180 77.6 -> 62.7, 64 x 180
+        // 88.0 -> 65.9, 64 x 500 128.7 -> 109.4; the launch itself gets ~10 % slower per sample (the AGC wave's loads cross
+        // PCIe), which is why calls of more than kTinyCallSamples keep the copy engines (1 x 1024: 144 vs 147 us).
+        if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        if (!h->tn_out) {
+            HIP_TRY(h, hipHostMalloc((void**)&h->tn_out, kSmallCall, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(h->tn_out, 0, kSmallCall);
+            HIP_TRY(h, hipHostGetDevicePointer((void**)&h->tn_out_dev, h->tn_out, 0));
+        }
+        if (!h->tn_in) {
+            HIP_TRY(h, hipHostMalloc((void**)&h->tn_in, kSmallCall, hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(h, hipHostGetDevicePointer((void**)&h->tn_in_dev, h->tn_in, 0));
+        }
+        std::memcpy(h->tn_in, iq, iq_bytes);
+        volatile int* cnt = reinterpret_cast<volatile int*>(h->tn_out + pack_bytes - 16);
+        *cnt = 0;
+        uint8_t* d_bits = h->tn_out_dev + nb_bytes;
+        h->overruns_override = reinterpret_cast<int*>(h->tn_out_dev + pack_bytes - 16);
+        const int rc = tetra_demod_process_device(h, reinterpret_cast<const float*>(h->tn_in_dev), n_samples, d_bits, bits_stride,
+                                                  reinterpret_cast<int32_t*>(h->tn_out_dev),
+                                                  sym ? reinterpret_cast<float*>(d_bits + bits_bytes) : nullptr, h->own_stream);
+        h->overruns_override = nullptr;
+        if (rc != TETRA_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+        std::memcpy(n_bits, h->tn_out, sizeof(int) * C);
+        std::memcpy(bits, h->tn_out + nb_bytes, bits_bytes);
+        if (sym) std::memcpy(sym, h->tn_out + nb_bytes + bits_bytes, sym_bytes);
+        const int fresh = *cnt;
+        h->overruns_tiny += fresh;
+        return fresh > 0 ? TETRA_ERR_OVERRUN : TETRA_OK;
+    }
     if (n_samples > 0 && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall) {
         if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
         if (pack_bytes > h->pk_bytes) {
@@ -970,7 +1017,7 @@ int tetra_demod_get_overruns(tetra_demod_t* h, long long* total) {
     HIP_TRY(h, hipDeviceSynchronize());
     int v = 0;
     HIP_TRY(h, hipMemcpy(&v, h->d_overruns, sizeof(int), hipMemcpyDeviceToHost));
-    *total = v;
+    *total = (long long)v + h->overruns_tiny;
     return TETRA_OK;
 }
 

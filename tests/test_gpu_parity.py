@@ -918,3 +918,40 @@ def test_close_to_one_sample_per_symbol(pkg, oracle, synth, pipeline):
     nb = d.process(iq[:, :N])[1]
     assert (nb > 2 * N / 1.09).all()                                     # really ~0.94 symbols per sample
     d.close()
+
+
+@pytest.mark.gpu
+def test_short_calls_run_in_place_and_still_report(pkg, oracle, synth):
+    """tetra_demod_process with at most 768 samples per channel reads its samples from, and writes its results into, page-locked
+    host blocks directly from the kernels (no copy engine).  Same bits, symbols and statistic as the oracle over a stream cut
+    into such calls -- alternating with longer ones, which take the copy-engine paths, on the same handle -- and a channel cut
+    off at its row's capacity is reported by the short call itself (counter in the same host block) and in the total."""
+    Cn = 5
+    sizes = [180, 768, 769, 1, 500, 3000, 180, 64]
+    iq, _, _ = synth.gen_batch(Cn, sum(sizes), base_seed=4711)
+    d = pkg.Demodulator(Cn, max(sizes), flags=pkg.binding.FLAG_QUALITY)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    pos = 0
+    for k, n in enumerate(sizes):
+        blk = iq[:, pos:pos + n]
+        bits, nb, sym = d.process(blk, want_sym=bool(k & 1))
+        for c in range(Cn):
+            r = orcs[c].process(blk[c], stages=True)
+            assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (k, c)
+            if sym is not None:
+                assert np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])), (k, c)
+        err, _ = d.quality()
+        assert all(abs(err[c] - orcs[c].st.standarderr) < 2e-6 for c in range(Cn)), k
+        pos += n
+    assert d.overruns() == 0
+    st = d.get_state(2)
+    st.mu = float("nan")
+    d.set_state(2, st)
+    with pytest.raises(pkg.TetraDemodError) as ei:
+        d.process(iq[:, :300])
+    assert ei.value.status == pkg.binding.ERR_OVERRUN and d.overruns() == 1
+    bits, nb, _ = d.process(iq[:, 300:600], allow_overrun=True)
+    assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 2 and nb[2] >= bits.shape[1] - 32
+    bits, nb, _ = d.process(iq[:, :3000], allow_overrun=True)                 # a copy-engine call: the device counter
+    assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 3
+    d.close()
