@@ -680,7 +680,16 @@ TD_FN void k2_costas_rot(const K2Consts& k, K2State& st, float vr, float vi, flo
     const float zr = zz.x(), zi = zz.y();
     float cerr = ((zr > 0 ? 1.0f : -1.0f) * zi) - ((zi > 0 ? 1.0f : -1.0f) * zr);
     cerr = v_clamp(cerr, -1.0f, 1.0f);
-    pcl_advance<float, true>(cerr, st.cph, st.cfr, k.costas_alpha, k.costas_beta, k.costas_min_freq, k.costas_max_freq);
+    // pcl.advance (PhaseControlLoop<float, true>): the frequency and the sum as pcl_advance writes them; the wrap to [-pi, pi]
+    // as a rounding, w = rint(x / 2 pi) in {-1, 0, 1} and x - w 2 pi in one fma -- three instructions and no compare / select
+    // pair on VCC instead of copysign, subtract, compare, select.  Bit for bit the reference's `x > pi -> x - 2 pi, x < -pi ->
+    // x + 2 pi` for every binary32 x of [-2 pi, 2 pi] (this sum stays inside 1.2 pi) except x = -0 -> +0, which a phase that
+    // starts at +0 never reaches and tetra_demod_set_state stores as +0: the FLL blocks' wrap (gen_fll_asm.py),
+    // tests/test_oracle.py::test_rint_phase_wrap_is_exact_for_every_phase.
+    st.cfr = v_clamp(st.cfr + k.costas_beta * cerr, k.costas_min_freq, k.costas_max_freq);
+    const float x = st.cph + (st.cfr + k.costas_alpha * cerr);
+    const float w = v_rint(x * __builtin_bit_cast(float, 0x3e22f983u));      // the binary32 nearest 1 / (2 pi)
+    st.cph = v_fma(-w, kFlPi - (-kFlPi), x);
     *zr_out = zr;
     *zi_out = zi;
 }

@@ -1156,9 +1156,10 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     // a phase of -0 is stored as +0: the loops never produce one (a sum is -0 only for two -0 operands, and the chain starts at
     // +0), and the FLL blocks' rint-based phase wrap (gen_fll_asm.py) would turn it into +0 one step later than the reference
     const float fll_phase = in->fll_phase == 0.0f ? 0.0f : in->fll_phase;
+    const float costas_phase = in->costas_phase == 0.0f ? 0.0f : in->costas_phase;      // (the Costas wave wraps the same way)
     SET1(h->agc_g, in->agc_gain); SET1(h->fll_ph, fll_phase); SET1(h->fll_fr, in->fll_freq);
     SET1(h->mu, in->mu); SET1(h->omega, in->omega); SET1(h->offset, in->offset);
-    SET1(h->cph, in->costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
+    SET1(h->cph, costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
     const int rv = in->rrc_valid < 0 ? 0 : in->rrc_valid > (int)kHist ? (int)kHist : in->rrc_valid;
     SET1(h->rrc_valid, rv);
 #undef SET1
