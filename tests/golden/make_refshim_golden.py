@@ -84,6 +84,33 @@ def main():
     out["rrcp_iq"] = iq6
     out["rrcp_sym0"], out["rrcp_bits0"] = a6
     out["rrcp_sym1"], out["rrcp_bits1"] = b6
+    # 7. random parameter sets (rates 1.8 ... 4 samples per symbol at create, tap counts 2 ... 72, roll-off, every loop constant;
+    #    the draw of profiles/fuzz_parity.py): eight sets on which the reference code and the oracle make the same decisions
+    #    throughout -- on ~3 % of random draws their float recipes (libm sine and plain sums / polynomial and fmaf chains) part
+    #    ways at a boundary decision, profiles/fuzz_refshim_cpu.py; those are skipped here, and the skip is counted
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import fuzz_parity as F  # noqa: E402
+    rng = np.random.default_rng(20260927)
+    k = skipped = 0
+    while k < 8:
+        sps, prm = F.draw_params(rng)
+        cfg = F.oracle_cfg(prm)
+        seed = int(rng.integers(0, 1 << 30))
+        if sps < 1.8 or sps * (1 - cfg.omega_rel_limit) - abs(cfg.mu_gain) < 1.0:
+            continue
+        iq7, _, _ = synth.gen_channel(6000, seed, sps=sps)
+        r = T.RefChain(L, cfg)
+        sym7, bits7 = r.process(iq7)
+        r.close()
+        o = ob.Oracle(cfg).process(iq7)
+        if len(o["bits"]) != len(bits7) or not np.array_equal(o["bits"], bits7):
+            skipped += 1
+            continue
+        out["rand%d_cfg" % k] = np.array([cfg.symbolrate, cfg.samplerate, cfg.rrc_tap_count, cfg.rrc_beta, cfg.agc_rate,
+                                          cfg.costas_bandwidth, cfg.fll_bandwidth, cfg.omega_gain, cfg.mu_gain, cfg.omega_rel_limit], np.float64)
+        out["rand%d_iq" % k], out["rand%d_sym" % k], out["rand%d_bits" % k] = iq7, sym7, bits7
+        k += 1
+    out["rand_skipped"] = np.array([skipped], np.int32)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim_vectors.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")

@@ -140,3 +140,44 @@ def test_gpu_equals_reference_code_outputs(vec, pkg, shape):
         bits, nb, sym = d.process(iq[None, cuts[k]:cuts[k + 1]], want_sym=True)
         _close(sym[0][:nb[0] // 2], vec["ctl_sym%d" % k], bits[0][:nb[0]], vec["ctl_bits%d" % k], "control %d" % k)
     d.close()
+
+
+CFG_FIELDS = ("symbolrate", "samplerate", "rrc_tap_count", "rrc_beta", "agc_rate", "costas_bandwidth", "fll_bandwidth", "omega_gain",
+              "mu_gain", "omega_rel_limit")
+
+
+def _rand_cases(vec):
+    k = 0
+    while "rand%d_cfg" % k in vec.files:
+        yield k, dict(zip(CFG_FIELDS, vec["rand%d_cfg" % k].tolist()))
+        k += 1
+
+
+def test_oracle_equals_reference_code_outputs_for_random_parameter_sets(vec, oracle):
+    """Eight random parameter sets at create (rates 1.8 ... 2.2 samples per symbol here, tap counts 18 ... 65, roll-off, loop
+    constants; tests/golden/make_refshim_golden.py section 7, the draw of profiles/fuzz_parity.py): the oracle designs its own
+    filters and loops from the ten numbers and makes the reference code's decisions."""
+    n = 0
+    for k, prm in _rand_cases(vec):
+        cfg = oracle.default_cfg()
+        for f, v in prm.items():
+            setattr(cfg, f, int(v) if f == "rrc_tap_count" else v)
+        r = oracle.Oracle(cfg).process(vec["rand%d_iq" % k])
+        _close(r["sym"], vec["rand%d_sym" % k], r["bits"], vec["rand%d_bits" % k], "random set %d" % k)
+        n += 1
+    assert n == 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["narrow", "wide", "small"])
+def test_gpu_equals_reference_code_outputs_for_random_parameter_sets(vec, pkg, shape):
+    """The same eight sets through tetra_demod_create on the GPU: the library's own design (csrc/design.hpp) and kernels against
+    the reference code's outputs, no oracle in between."""
+    B = pkg.binding
+    shape_flag = {"wide": B.FLAG_WIDE_WORKGROUPS, "narrow": B.FLAG_NARROW_WORKGROUPS, "small": B.FLAG_SMALL_WORKGROUPS}[shape]
+    for k, prm in _rand_cases(vec):
+        prm["rrc_tap_count"] = int(prm["rrc_tap_count"])
+        d = pkg.Demodulator(1, 6000, flags=B.FLAG_REFERENCE_QUIRKS | shape_flag, **prm)
+        bits, nb, sym = d.process(vec["rand%d_iq" % k][None, :], want_sym=True)
+        _close(sym[0][:nb[0] // 2], vec["rand%d_sym" % k], bits[0][:nb[0]], vec["rand%d_bits" % k], "random set %d (%s)" % (k, shape))
+        d.close()
