@@ -119,7 +119,11 @@ def test_no_cpu_fallback(pkg):
     with pytest.raises(pkg.TetraDemodError) as e:
         pkg.Demodulator(4, 1024)
     assert e.value.status == -3
-    assert b"HIP" in pkg.load_library().tetra_demod_strerror(-3) or True
+    L = pkg.load_library()
+    assert b"no usable HIP device" in L.tetra_demod_strerror(-3)
+    # every status of include/tetra_demod.h has its own text (TETRA_ERR_OVERRUN = -8 was missing until round 3)
+    texts = [L.tetra_demod_strerror(st) for st in range(0, -9, -1)]
+    assert len(set(texts)) == 9 and b"unknown" not in b" ".join(texts) and b"unknown" in L.tetra_demod_strerror(-9)
     src = open(os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "binding.py")).read()
     assert "oracle" not in src.replace("oracle's", "")
 
