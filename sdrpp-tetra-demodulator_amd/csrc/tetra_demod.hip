@@ -744,6 +744,8 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
         // (profiles/r03/r03_ad_tiny_calls.json): 1 x 180 samples 67.7 -> 59.9 us per call, 16 x 180 77.6 -> 62.7, 64 x 180
         // 88.0 -> 65.9, 64 x 500 128.7 -> 109.4; the launch itself gets ~10 % slower per sample (the AGC wave's loads cross
         // PCIe), which is why calls of more than kTinyCallSamples keep the copy engines (1 x 1024: 144 vs 147 us).
+        // (The call's overrun counter sits in the same host block: the kernels' atomicAdd on it crosses PCIe as an atomic
+        // operation, which every platform ROCm runs on provides -- and it executes only when a poisoned channel fills its row.)
         if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
         if (!h->tn_out) {
             HIP_TRY(h, hipHostMalloc((void**)&h->tn_out, kSmallCall, hipHostMallocMapped | hipHostMallocCoherent));
