@@ -292,13 +292,11 @@ def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command under
     torch.distributed.run (one process per GPU; on a box with fewer GPUs than ranks they share -- functional runs only) and
     pass the line rank 0 prints through.  Under a launcher (WORLD_SIZE set) main() runs the rank itself."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: the launcher picks the rendezvous port itself (c10d store on port 0), so there is no window between "found a
+    # free port" and "bound it" for another process to take it; --local-addr keeps the rendezvous on 127.0.0.1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -351,7 +349,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the demodulator has no CPU path")
-    local_rank %= max(1, torch.cuda.device_count())     # more ranks than GPUs (functional test of the N > 1 path on one GPU, --backend gloo)
+    # More ranks than GPUs (a functional run of the N > 1 path on a smaller box): ranks are folded onto the GPUs there are, and
+    # the line says so where no parser can miss it -- "functional_only": true, "value": null, "n_gpus" = the GPUs that really
+    # ran ("n_ranks" = the ranks), the folded throughput only as "value_functional".
+    gpus_physical = torch.cuda.device_count()
+    folded = world > gpus_physical
+    local_rank %= max(1, gpus_physical)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -360,10 +363,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            if world > 1:
+                raise SystemExit("bench.py: WORLD_SIZE %d without MASTER_PORT -- start the ranks with torch.distributed.run (or let "
+                                 "`python bench.py --gpus N` start them)" % world)
+            os.environ["MASTER_PORT"] = "0"          # a one-rank group (--force-dist): the store binds a free port itself
         # RCCL carries only the barrier and the MAX of the elapsed time (no data-path collective).  One rank per GPU: RCCL
         # refuses ranks that share a device ("Duplicate GPU detected") -- a functional run of the N > 1 path on fewer GPUs
         # than ranks takes --backend gloo.  A communicator that cannot be built fails the run at once, loudly.
@@ -571,7 +574,8 @@ def main():
                 "cycles_note": "launch time x %.0f MHz / samples per channel / %d workgroup round(s) per CU" % (clk_hz / 1e6, rounds)}
         out = {
             "metric": "IQ Msamples/s demodulated to bits, batched TETRA channels",
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value": None if folded else round(value, 3), "unit": "Msamples/s", "n_gpus": min(world, gpus_physical),
+            "n_ranks": world, "gpus_physical": gpus_physical, "functional_only": folded, "steps": args.steps,
             "warmup": args.warmup, "ramp_steps": RAMP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -594,6 +598,10 @@ def main():
             "ramp_note": "%d untimed launches + a state reset precede the %d warm-up steps: after an idle second the shader clock "
                          "needs ~5 launches to reach its steady value (profiles/r02/r02_f_clock_ramp.md)" % (RAMP_STEPS, args.warmup),
         }
+        if folded:
+            out["value_functional"] = round(value, 3)
+            out["functional_note"] = ("%d ranks shared %d GPU(s): a functional run of the N > 1 path, NOT an %d-GPU measurement"
+                                      % (world, gpus_physical, world))
         if tmaj is not None:
             out["time_major"] = tmaj
         out.update(host)

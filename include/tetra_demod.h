@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TETRA_DEMOD_ABI_VERSION 3
+#define TETRA_DEMOD_ABI_VERSION 4
 #define TETRA_DEMOD_MAX_TAPS 80 /* capacity every tap table of this ABI is sized for (filters are 2..72 taps) */
 
 enum {
@@ -299,6 +299,10 @@ const char* tetra_demod_strerror(int status);
 /* hipError_t of the last failing HIP call on this handle (0 if none). */
 int tetra_demod_last_hip_error(tetra_demod_t* h);
 int tetra_demod_abi_version(void);
+/* 64 hex digits: sha256 of the sources and compile flags this library was built from (sdrpp-tetra-demodulator_amd/build.py
+ * source_hash()).  The Python binding, the tests and smoke() refuse a library whose id is not the tree's: a stale .so is never
+ * tested or benchmarked as if it were current. */
+const char* tetra_demod_build_id(void);
 /* Shader clock (kHz) and compute-unit count of a device, for callers that price a launch in clocks (either may be NULL). */
 int tetra_demod_device_info(int device, int* clock_khz, int* compute_units);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "tetra_demod_last_hip_error", "tetra_demod_abi_version", "tetra_demod_debug_selftest", "tetra_demod_kernel_ms_history", "tetra_demod_get_quality",
     "tetra_demod_bandedge_tap_count", "tetra_demod_process_async", "tetra_demod_wait", "tetra_demod_host_alloc",
     "tetra_demod_host_free", "tetra_demod_device_info", "tetra_demod_bits_stride_for", "tetra_demod_get_overruns",
-    "tetra_demod_set_rrc_params", "tetra_demod_process_resident", "tetra_demod_debug_mfma_selftest",
+    "tetra_demod_set_rrc_params", "tetra_demod_process_resident", "tetra_demod_debug_mfma_selftest", "tetra_demod_build_id",
 ]
 ERR_OVERRUN = -8
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
@@ -87,8 +87,14 @@ def load_library(rebuild_if_stale=True):
         path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("HIP library %s is missing; run __graft_entry__.build() (no CPU fallback exists)" % path)
+    if not override and _build.lib_build_id(path) != _build.source_hash():
+        # never run (or measure) a library built from other sources than the tree holds
+        raise RuntimeError("HIP library %s was built from other sources than this tree holds (build id %s, sources %s); run "
+                           "__graft_entry__.build()" % (path, _build.lib_build_id(path), _build.source_hash()))
     L = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int
+    L.tetra_demod_build_id.argtypes = []
+    L.tetra_demod_build_id.restype = C.c_char_p
     L.tetra_demod_default_config.argtypes = [C.POINTER(Config)]
     L.tetra_demod_device_count.argtypes = []
     L.tetra_demod_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -122,7 +128,7 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_host_alloc.argtypes = [C.c_size_t]
     L.tetra_demod_host_free.argtypes = [vp]
     for name in EXPORTS:
-        if name not in ("tetra_demod_strerror", "tetra_demod_host_alloc", "tetra_demod_host_free"):
+        if name not in ("tetra_demod_strerror", "tetra_demod_host_alloc", "tetra_demod_host_free", "tetra_demod_build_id"):
             getattr(L, name).restype = i32
     L.tetra_demod_host_alloc.restype = vp
     L.tetra_demod_host_free.restype = None

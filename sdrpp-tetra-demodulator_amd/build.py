@@ -22,15 +22,53 @@ def hipcc_path():
     return p
 
 
+BUILD_ID_MARKER = b"TETRA_BUILD_ID="
+
+
+def source_hash():
+    """sha256 over every source the library is compiled from (file names + contents, DEPS order de-duplicated) and the
+    compile flags.  The library carries the value it was built from (tetra_demod_build_id(), the string behind
+    BUILD_ID_MARKER in the file): a library is current exactly when the two agree -- file times say nothing after a checkout
+    or a copy to another machine."""
+    import hashlib
+    hsh = hashlib.sha256()
+    seen = set()
+    for d in DEPS:
+        path = os.path.normpath(os.path.join(CSRC, d))
+        if path in seen:
+            continue
+        seen.add(path)
+        with open(path, "rb") as f:
+            hsh.update(os.path.basename(path).encode() + b"\0" + f.read() + b"\0")
+    hsh.update(" ".join(HIPCC_FLAGS).encode())
+    return hsh.hexdigest()
+
+
+def lib_build_id(path=None):
+    """The build id embedded in a built library, read from the file itself (no dlopen: a stale library must not end up in the
+    process that is about to replace it).  None if the file is missing or carries none."""
+    path = path or LIB
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    at = blob.find(BUILD_ID_MARKER)
+    if at < 0:
+        return None
+    hexid = blob[at + len(BUILD_ID_MARKER): at + len(BUILD_ID_MARKER) + 64]
+    try:
+        return hexid.decode("ascii") if len(hexid) == 64 and int(hexid, 16) >= 0 else None
+    except ValueError:
+        return None
+
+
 def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return lib_build_id() != source_hash()
 
 
 def build(force=False, verbose=False):
-    """Compile the library if missing or older than its sources.  Returns the .so path.  Serialised across processes by a
+    """Compile the library if missing or built from other sources than the tree holds (build id, see source_hash).  Returns the .so path.  Serialised across processes by a
     lock file (the ranks of a multi-GPU run all import the package at once: one builds, the others find the result), and the
     library appears atomically (compiled next to its final name, then renamed)."""
     if not (force or is_stale()):
@@ -44,7 +82,7 @@ def build(force=False, verbose=False):
                 # fll_asm.inc is generated (and committed): refuse to build from one that is not what the generator emits
                 subprocess.run([sys.executable, os.path.join(CSRC, "gen_fll_asm.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
                 tmp = LIB + ".tmp.%d" % os.getpid()
-                cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                cmd = [hipcc_path()] + HIPCC_FLAGS + ["-DTETRA_BUILD_ID=\"%s\"" % source_hash(), "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
                 if verbose:
                     print(" ".join(cmd))
                 try:

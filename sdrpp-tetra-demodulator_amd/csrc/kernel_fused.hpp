@@ -147,6 +147,8 @@ struct FusedParams {
     float2* sym;         // optional [C][sym_stride]
     long long sym_stride;
     int* overruns;       // [1] channels whose output row filled up in this launch (the rest of their samples were dropped)
+    int* cut_flag;       // optional [1]: a cut-off channel also leaves a plain store of 1 here (the in-place host path points it
+                         // into its mapped host block: a store crosses PCIe on every platform, an atomic may not)
     float2* y_dbg;       // optional: time-major scratch [(7+n)][C], row 7+i = y_i
     K1Consts k1;
     K2Consts k2;
@@ -590,7 +592,10 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             p.mu[ch0 + c] = st.mu;
             p.omega[ch0 + c] = st.omega;
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
-            if (cut) atomicAdd(p.overruns, 1);          // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
+            if (cut) {                                  // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
+                atomicAdd(p.overruns, 1);
+                if (p.cut_flag) *(volatile int*)p.cut_flag = 1;
+            }
         }
     } else if (wave == kRoleE && (CH != kFChWide || TETRA_EXP_TWOPASS)) {
         // ---- kRoleE, 4- and 16-channel workgroups: the recurrence -- Costas loop only -- runs on lanes 0..CH-1 and leaves z in

@@ -1,8 +1,10 @@
 // tetra_demod.hip -- HIP kernels (gfx950) + C ABI of the batched TETRA pi/4-DQPSK demodulator.
 //
 // The whole chain runs in ONE kernel, k_fused (kernel_fused.hpp): AGC -> band-edge FLL -> RRC matched filter -> ML timing
-// recovery -> pi/4 Costas -> slicer -> differential decoder -> bit unpacker, sixteen channels per workgroup, six specialised
-// waves, all intermediate streams in LDS rings.  (The two-kernel pipeline of round 1 -- k1_agc_fll_rrc / k2_sync_slice with an
+// recovery -> pi/4 Costas -> slicer -> differential decoder -> bit unpacker, as specialised waves connected by LDS rings.  Three
+// workgroup shapes of the one template: 16 channels in six waves (one workgroup per CU up to 4096 channels), 32 channels in
+// eight waves (more than 16 channels per CU) and 4 channels (at most 4 channels per CU); tetra_demod_create plans which
+// channels take which shape, the results are identical bit for bit.  (The two-kernel pipeline of round 1 -- k1_agc_fll_rrc / k2_sync_slice with an
 // HBM scratch in between -- was retired in ABI 2; `git log` has it.)
 // Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
 // src/dsp/bit_unpacker.cpp:4-10 (see include/tetra_demod.h).
@@ -203,8 +205,8 @@ struct tetra_demod {
     float2* ybuf = nullptr;     // COMPLEX_FD delay buffer [C][7]
     int* d_overruns = nullptr;  // [1] channels cut off at their row capacity, counted by the kernels since create
     long long overruns_seen = 0;   // ... and what the host entry points have already reported of it
-    long long overruns_tiny = 0;   // ... plus what the in-place calls counted in their own page-locked counter (below)
-    int* overruns_override = nullptr;   // set around an in-place call's launch: the kernels count into this address instead
+    int* cut_flag = nullptr;    // set around an in-place call's launch: a cut-off channel also stores 1 here (mapped host memory)
+    bool tn_disabled = false;   // the platform refused the mapped, coherent host blocks: short calls keep the copy-engine path
     float* q_ring = nullptr;    // TETRA_FLAG_QUALITY: [C][4096] distance ring + per-channel state (k_quality)
     int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
     float* q_err = nullptr;
@@ -394,6 +396,16 @@ template <class T> int dalloc(tetra_demod* h, T** p, size_t count) {
 extern "C" {
 
 int tetra_demod_abi_version(void) { return TETRA_DEMOD_ABI_VERSION; }
+
+// sha256 of the sources + flags this library was compiled from (build.py: source_hash() -> -DTETRA_BUILD_ID); the marker in
+// front lets build.py read it from the file without loading it.
+#ifndef TETRA_BUILD_ID
+#define TETRA_BUILD_ID "0000000000000000000000000000000000000000000000000000000000000000"
+#endif
+const char* tetra_demod_build_id(void) {
+    static const char id[] = "TETRA_BUILD_ID=" TETRA_BUILD_ID;
+    return id + 15;
+}
 
 int tetra_demod_device_info(int device, int* clock_khz, int* compute_units) {
     int ndev = 0;
@@ -617,7 +629,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.bank = h->d_bank;
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
-        pf.overruns = h->overruns_override ? h->overruns_override : h->d_overruns;
+        pf.overruns = h->d_overruns;
+        pf.cut_flag = h->cut_flag;
         pf.sym_stride = bits_stride / 2;
         if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
@@ -713,7 +726,8 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
                         int32_t* n_bits, float* sym) {
     if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
     if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
-    if (bits_stride < stride_for(h->design, n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
+    if (bits_stride < stride_for(h->design, n_samples)) return TETRA_ERR_SIZE;
+    if (bits_stride & 7) return TETRA_ERR_ALIGN;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     if (h->as.ready) {      // asynchronous calls still in flight run on their own streams: let them finish first (state order)
@@ -737,42 +751,47 @@ int tetra_demod_process(tetra_demod_t* h, const float* iq, int n_samples, uint8_
 #else
     constexpr int kTiny = kTinyCallSamples;
 #endif
-    if (n_samples > 0 && n_samples <= kTiny && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall) {
+    if (n_samples > 0 && n_samples <= kTiny && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall && !h->tn_disabled) {
         // The shortest calls use no copy engine at all: the CPU copies the samples into a page-locked, mapped, coherent block
-        // that the AGC wave reads in place over PCIe (a tile ahead, as always), the kernels write n_bits | bits | symbols | this
-        // call's overrun counter straight into a second such block, ONE synchronisation, plain memcpys out.  Measured
+        // that the AGC wave reads in place over PCIe (a tile ahead, as always), the kernels write n_bits | bits | symbols | a
+        // "some channel was cut off" flag straight into a second such block, ONE synchronisation, plain memcpys out.  Measured
         // (profiles/r03/r03_ad_tiny_calls.json): 1 x 180 samples 67.7 -> 59.9 us per call, 16 x 180 77.6 -> 62.7, 64 x 180
         // 88.0 -> 65.9, 64 x 500 128.7 -> 109.4; the launch itself gets ~10 % slower per sample (the AGC wave's loads cross
         // PCIe), which is why calls of more than kTinyCallSamples keep the copy engines (1 x 1024: 144 vs 147 us).
-        // (The call's overrun counter sits in the same host block: the kernels' atomicAdd on it crosses PCIe as an atomic
-        // operation, which every platform ROCm runs on provides -- and it executes only when a poisoned channel fills its row.)
+        // The overrun COUNTER stays in device memory (an atomic across PCIe is not something every platform routes); a channel
+        // that is cut off additionally leaves a plain store in the host block, and only then is the counter read back.
+        // A platform that refuses mapped + coherent host memory (or its device pointer) loses nothing but this shortcut: the
+        // blocks are only kept once BOTH calls succeeded, otherwise the path is switched off and the call continues below.
         if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-        if (!h->tn_out) {
-            HIP_TRY(h, hipHostMalloc((void**)&h->tn_out, kSmallCall, hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(h->tn_out, 0, kSmallCall);
-            HIP_TRY(h, hipHostGetDevicePointer((void**)&h->tn_out_dev, h->tn_out, 0));
-        }
-        if (!h->tn_in) {
-            HIP_TRY(h, hipHostMalloc((void**)&h->tn_in, kSmallCall, hipHostMallocMapped | hipHostMallocCoherent));
-            HIP_TRY(h, hipHostGetDevicePointer((void**)&h->tn_in_dev, h->tn_in, 0));
-        }
+        auto mapped_block = [&](uint8_t** host_p, uint8_t** dev_p) {
+            if (*host_p) return true;
+            uint8_t *hp = nullptr, *dp = nullptr;
+            if (hipHostMalloc((void**)&hp, kSmallCall, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipHostGetDevicePointer((void**)&dp, hp, 0) != hipSuccess || !dp) { (void)hipGetLastError(); (void)hipHostFree(hp); return false; }
+            std::memset(hp, 0, kSmallCall);
+            *host_p = hp; *dev_p = dp;
+            return true;
+        };
+        if (!mapped_block(&h->tn_out, &h->tn_out_dev) || !mapped_block(&h->tn_in, &h->tn_in_dev)) h->tn_disabled = true;
+    }
+    if (n_samples > 0 && n_samples <= kTiny && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall && !h->tn_disabled) {
         std::memcpy(h->tn_in, iq, iq_bytes);
-        volatile int* cnt = reinterpret_cast<volatile int*>(h->tn_out + pack_bytes - 16);
-        *cnt = 0;
+        volatile int* flag = reinterpret_cast<volatile int*>(h->tn_out + pack_bytes - 16);
+        *flag = 0;
         uint8_t* d_bits = h->tn_out_dev + nb_bytes;
-        h->overruns_override = reinterpret_cast<int*>(h->tn_out_dev + pack_bytes - 16);
+        h->cut_flag = reinterpret_cast<int*>(h->tn_out_dev + pack_bytes - 16);
         const int rc = tetra_demod_process_device(h, reinterpret_cast<const float*>(h->tn_in_dev), n_samples, d_bits, bits_stride,
                                                   reinterpret_cast<int32_t*>(h->tn_out_dev),
                                                   sym ? reinterpret_cast<float*>(d_bits + bits_bytes) : nullptr, h->own_stream);
-        h->overruns_override = nullptr;
+        h->cut_flag = nullptr;
         if (rc != TETRA_OK) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->own_stream));
         std::memcpy(n_bits, h->tn_out, sizeof(int) * C);
         std::memcpy(bits, h->tn_out + nb_bytes, bits_bytes);
         if (sym) std::memcpy(sym, h->tn_out + nb_bytes + bits_bytes, sym_bytes);
-        const int fresh = *cnt;
-        h->overruns_tiny += fresh;
-        return fresh > 0 ? TETRA_ERR_OVERRUN : TETRA_OK;
+        if (*flag == 0) return TETRA_OK;
+        const int cut = new_overruns(h);          // rare: a poisoned channel filled its row
+        return cut < 0 ? cut : TETRA_ERR_OVERRUN;
     }
     if (n_samples > 0 && iq_bytes <= kSmallCall && pack_bytes <= kSmallCall) {
         if (!h->own_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -962,7 +981,8 @@ int tetra_demod_process_async(tetra_demod_t* h, const void* iq, int iq_format, i
     if (!h || !iq || !bits || !n_bits) return TETRA_ERR_ARG;
     if (iq_format != TETRA_IQ_CF32 && iq_format != TETRA_IQ_CS16 && iq_format != TETRA_IQ_CS8) return TETRA_ERR_ARG;
     if (n_samples < 0 || n_samples > h->max_samples) return TETRA_ERR_SIZE;
-    if (bits_stride < stride_for(h->design, n_samples) || (bits_stride & 7)) return TETRA_ERR_SIZE;
+    if (bits_stride < stride_for(h->design, n_samples)) return TETRA_ERR_SIZE;
+    if (bits_stride & 7) return TETRA_ERR_ALIGN;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     auto& a = h->as;
@@ -1019,7 +1039,7 @@ int tetra_demod_get_overruns(tetra_demod_t* h, long long* total) {
     HIP_TRY(h, hipDeviceSynchronize());
     int v = 0;
     HIP_TRY(h, hipMemcpy(&v, h->d_overruns, sizeof(int), hipMemcpyDeviceToHost));
-    *total = (long long)v + h->overruns_tiny;
+    *total = (long long)v;
     return TETRA_OK;
 }
 

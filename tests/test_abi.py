@@ -22,7 +22,8 @@ def test_header_symbols_all_exported(pkg):
     for n in names:
         assert hasattr(L, n), "declared in include/tetra_demod.h but not exported: " + n
     assert set(pkg.binding.EXPORTS) == set(names)
-    assert L.tetra_demod_abi_version() == 3
+    assert L.tetra_demod_abi_version() == 4
+    assert L.tetra_demod_build_id().decode() == pkg.build.source_hash() == pkg.build.lib_build_id()
 
 
 def test_channeliser_header_symbols_all_exported(pkg):
@@ -188,6 +189,8 @@ int main(void) {
       cfg.flags = TETRA_FLAG_WIDE_WORKGROUPS | TETRA_FLAG_NARROW_WORKGROUPS;       /* contradictory: refused before any device work */
       { tetra_demod_t* hh = NULL; if (tetra_demod_create(&cfg, &hh) != TETRA_ERR_ARG || hh != NULL) return 19; } }
     tetra_demod_host_free(NULL);
+    /* ABI 4: the library says what sources it was built from */
+    { const char* id = tetra_demod_build_id(); int i; if (!id) return 20; for (i = 0; i < 64; i++) if (!id[i]) return 21; if (id[64]) return 22; }
     printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
     return 0;
 }
@@ -196,7 +199,7 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), lib, "-Wl,-rpath," + os.path.dirname(lib),
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["65", "800", "3"]
+    assert out == ["65", "800", "4"]
 
 
 def test_generated_fll_assembly_is_current():

@@ -58,7 +58,9 @@ def test_gpus_flag_launches_that_many_ranks(monkeypatch):
     assert bench.launch_ranks(4, ["--gpus", "4", "--steps", "3"]) == 0
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    # the launcher picks the rendezvous port itself (no find-a-port-then-bind race), on 127.0.0.1
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
+    assert "--master-port" not in cmd
     assert cmd[-5:] == [os.path.abspath(bench.__file__), "--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 

@@ -1,5 +1,6 @@
 """bench.py's N > 1 path on real hardware: `python bench.py --gpus 2` by itself starts two ranks (here both mapped onto the
-one GPU of the box), once over gloo and once over RCCL; the line says n_gpus 2 and the known-answer check is green."""
+one GPU of the box), once over gloo and once over RCCL; on a box with fewer GPUs than ranks the line is marked functional_only
+(value null, n_gpus = the GPUs that ran) and the known-answer check is green."""
 import json
 import os
 import subprocess
@@ -29,13 +30,19 @@ def _line(r):
 def test_bench_gpus_2_runs_two_ranks(backend):
     """`python bench.py --gpus 2 ...` alone.  With a GPU per rank the default backend is RCCL; on a box with fewer GPUs than ranks
     (both ranks on the one GPU here) RCCL would refuse the communicator ("Duplicate GPU detected"), so bench.py lines the ranks up
-    over gloo and says so in the line -- either way two ranks run and the line says n_gpus 2."""
+    over gloo and says so in the line -- either way two ranks run; a folded run can not be mistaken for a 2-GPU measurement."""
     import torch
     r = _run(backend)
     d = _line(r)
     os.makedirs(OUT, exist_ok=True)
     json.dump(d, open(os.path.join(OUT, "bench_gpus2_%s.json" % backend), "w"))
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["ramp_steps"] == 8
+    assert d["n_ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["ramp_steps"] == 8
+    ngpu = torch.cuda.device_count()
+    assert d["gpus_physical"] == ngpu and d["n_gpus"] == min(2, ngpu) and d["functional_only"] == (ngpu < 2)
+    value = d["value"]
+    if ngpu < 2:
+        assert d["value"] is None and "NOT an" in d["functional_note"]
+        value = d["value_functional"]
     if backend == "nccl" and torch.cuda.device_count() >= 2:
         assert d["dist_backend"] == "nccl" and d["rccl_world_size"] == 2
     else:
@@ -43,7 +50,7 @@ def test_bench_gpus_2_runs_two_ranks(backend):
         assert ("dist_backend_note" in d) == (backend == "nccl")
     assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
     # two ranks of 4096 channels each: the whole-job value counts both
-    assert abs(d["value"] - 2 * 4096 * 36000 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    assert abs(value - 2 * 4096 * 36000 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * value
 
 
 def test_bench_rccl_half_of_the_rank_path_on_one_gpu():
@@ -72,4 +79,6 @@ def test_bench_under_the_driver_s_own_launcher():
            "--no-cpu-baseline", "--backend", "gloo"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     d = _line(r)
-    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["check"]["bit_errors"] == 0
+    import torch
+    assert d["n_ranks"] == 2 and d["n_gpus"] == min(2, torch.cuda.device_count()) and d["dist_backend"] == "gloo"
+    assert d["functional_only"] == (torch.cuda.device_count() < 2) and d["check"]["bit_errors"] == 0

@@ -27,7 +27,7 @@ def _build(pkg):
 def test_block_mirror_builds_and_links(pkg):
     exe = _build(pkg)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "abi 3" in out and "default taps 65" in out
+    assert "abi 4" in out and "default taps 65" in out
 
 
 @pytest.mark.gpu
@@ -84,3 +84,99 @@ def test_multibank_two_shards_two_threads_one_device(pkg, oracle, synth, tmp_pat
             assert nb[k, c] == want.size and np.array_equal(bits[k, c, :want.size], want), (c, k)
             if k == calls // 2:
                 o.set_param(4, 0.02)
+
+
+EXE4 = os.path.join(ROOT, "tests", "host", "test_config4")
+CONFIG4_AMPS = (1.0, 0.37, 0.81, 0.052, 0.6, 0.23, 0.95, 0.11)          # test_config4.hip: amps[]
+
+
+def _build_config4(pkg):
+    pkg.build.build()
+    drv = os.path.join(ROOT, "tests", "host", "test_config4.hip")
+    mirror = os.path.join(PK, "host", "pi4dqpsk_gpu.cpp")
+    deps = [drv, mirror, os.path.join(PK, "host", "pi4dqpsk_gpu.h"), os.path.join(PK, "host", "dsp_compat.h"),
+            os.path.join(ROOT, "include", "tetra_demod.h")]
+    if not os.path.exists(EXE4) or any(os.path.getmtime(d) > os.path.getmtime(EXE4) for d in deps):
+        obj = EXE4 + ".mirror.o"
+        # the product side stays plain C++ (g++); only the driver -- it generates its input on the GPU -- is HIP
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-c", mirror, "-o", obj], check=True)
+        dobj = EXE4 + ".driver.o"
+        subprocess.run([pkg.build.hipcc_path(), "--offload-arch=gfx950", "-std=c++17", "-O2", "-c", drv, "-o", dobj], check=True)
+        subprocess.run([pkg.build.hipcc_path(), "--offload-arch=gfx950", "-pthread", dobj, obj, "-L", PK, "-ltetra_demod_hip",
+                        "-Wl,-rpath," + PK, "-o", EXE4], check=True)
+        os.remove(obj)
+        os.remove(dobj)
+    return EXE4
+
+
+def config4_channel_input(base, c):
+    """Channel c of test_config4.hip's bank, rebuilt bit for bit: base[c % B] x amp[(c / B) % 8] x j^((c / B) % 4)."""
+    B = base.shape[0]
+    k = c // B
+    v = (base[c % B].view(np.float32) * np.float32(CONFIG4_AMPS[k % 8])).reshape(-1, 2)
+    re, im = v[:, 0], v[:, 1]
+    re, im = ((re, im), (-im, re), (-re, -im), (im, -re))[k & 3]
+    out = np.empty((v.shape[0], 2), np.float32)
+    out[:, 0], out[:, 1] = re, im
+    return out.reshape(-1).view(np.complex64)
+
+
+def test_config4_input_rule_is_exact():
+    """The bank rule above uses only exact float operations besides one multiply per component (CPU check of the helper)."""
+    rng = np.random.default_rng(3)
+    base = (rng.standard_normal((4, 64)) + 1j * rng.standard_normal((4, 64))).astype(np.complex64)
+    for c in range(4 * 8 * 2):
+        k = c // 4
+        want = base[c % 4].astype(np.complex128) * float(np.float32(CONFIG4_AMPS[k % 8])) * (1j ** (k & 3))
+        got = config4_channel_input(base, c)
+        assert np.allclose(got, want, rtol=1e-6, atol=0) and got.dtype == np.complex64
+    assert np.array_equal(config4_channel_input(base, 1), config4_channel_input(base, 1 + 4 * 8))          # the period
+
+
+@pytest.mark.gpu
+def test_config4_32768_channels_eight_shards(pkg, oracle, synth, tmp_path):
+    """BASELINE config 4 at full size: 32768 channels = 8 shards x 4096 (SURVEY.md 8(e): per-GPU channel ranges, no collective;
+    /root/reference src/main.cpp:51: one chain per instance, any number of instances), 36000 samples per channel, ONE
+    PI4DQPSKMultiBank, input generated on the GPU, processDevice.  A GPU per shard where the box has eight; on the one-GPU box
+    all eight handles share it, each driven by its own thread on its own stream.
+      * 80 channels -- both sides of every shard boundary, the bank's first and last channel, and others spread over all
+        shards -- against the oracle on the bit-identical input: counts and every bit;
+      * the first 512 channels (one period of the input rule): transmitted bits come back after lock;
+      * ALL other channels: row and count identical to the channel one period earlier, which received the same samples."""
+    exe = _build_config4(pkg)
+    B, n, Cn, G = 64, 36000, 32768, 8
+    base, txb, _ = synth.gen_batch(B, n, base_seed=4400, amp=1.0)
+    f_base = tmp_path / "base.f32"
+    np.ascontiguousarray(base).view(np.float32).tofile(f_base)
+    P = B * 8
+    edges = [pkg.shard.channel_range(Cn, G, g) for g in range(G)]
+    assert all(hi - lo == 4096 for lo, hi in edges)
+    oracle_ch = sorted({0, Cn - 1} | {lo - 1 for lo, _ in edges[1:]} | {lo for lo, _ in edges[1:]} |
+                       {int(c) for c in np.random.default_rng(44).integers(0, Cn, 64)})
+    assert len(oracle_ch) >= 64
+    sel = list(range(P)) + [c for c in oracle_ch if c >= P]
+    f_sel = tmp_path / "sel.txt"
+    f_sel.write_text("\n".join(str(c) for c in sel))
+    f_rows, f_nb = tmp_path / "rows.u8", tmp_path / "nb.i32"
+    r = subprocess.run([exe, str(f_base), str(B), str(n), str(Cn), str(G), str(f_rows), str(f_nb), str(f_sel)],
+                       timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    import torch
+    ngpu = torch.cuda.device_count()
+    for g, (lo, hi) in enumerate(edges):
+        assert "shard %d: channels [%d, %d) on device %d" % (g, lo, hi, g % ngpu) in r.stdout
+    assert "period_check %d mismatches 0" % P in r.stdout, r.stdout[-500:]
+    stride = int(r.stdout.split("stride ")[1].split()[0])
+    rows = np.fromfile(f_rows, np.uint8).reshape(len(sel), stride)
+    nb = np.fromfile(f_nb, np.int32)
+    assert nb.shape == (Cn,) and nb.min() > 2 * n // 2 - 400 and nb.max() <= stride
+    row_of = {c: i for i, c in enumerate(sel)}
+    for c in oracle_ch:
+        want = oracle.Oracle().process(config4_channel_input(base, c))["bits"]
+        assert nb[c] == want.size and np.array_equal(rows[row_of[c], :want.size], want), c
+    errs = ncmp = 0
+    for c in range(P):
+        lag, e, m = synth.align_and_count_errors(rows[c][: nb[c]], txb[c % B], skip=3 * nb[c] // 4)
+        errs += e
+        ncmp += m
+    assert ncmp > 8000 * P and errs <= 1e-4 * ncmp, (errs, ncmp)
