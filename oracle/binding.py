@@ -101,6 +101,8 @@ def lib():
         vp = C.c_void_p
         L.tetra_oracle_process.argtypes = [C.POINTER(Tables), C.POINTER(State), C.c_int, vp, vp, vp, vp, vp, vp]
         L.tetra_oracle_process.restype = C.c_int
+        L.tetra_oracle_process_mode.argtypes = [C.POINTER(Tables), C.POINTER(State), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.tetra_oracle_process_mode.restype = C.c_int
         L.tetra_oracle_process_batch.argtypes = [C.POINTER(Tables), C.POINTER(State), C.c_int, C.c_int,
                                                  C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
         L.tetra_oracle_process_batch.restype = C.c_int
@@ -124,7 +126,10 @@ def _ptr(a):
 class Oracle:
     """One channel of the reference chain: PI4DQPSK -> DQPSKSymbolExtractor -> BitUnpacker."""
 
-    def __init__(self, cfg=None):
+    def __init__(self, cfg=None, reference_floats=False):
+        """reference_floats: compute with the reference's own float recipe (libm phasors, plain sums, two complex band-edge
+        dots: tetra_oracle.h TETRA_ORACLE_REFERENCE_FLOATS) instead of the arithmetic contract the kernels implement."""
+        self.mode = 1 if reference_floats else 0
         self.cfg = cfg if cfg is not None else default_cfg()
         self.tab = Tables()
         rc = lib().tetra_oracle_design(C.byref(self.cfg), C.byref(self.tab))
@@ -172,14 +177,20 @@ class Oracle:
         """iq: complex64[count].  Returns dict(sym, dibits, bits[, x, y])."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         n = iq.shape[0]
-        cap = n + 16          # every symbol advances by >= 1 sample for the parameter sets the tests use
+        # symbols one call can emit: every symbol moves mu by at least tr_min_freq - |tr_alpha| (complex_fd.cpp:136-143); below one
+        # sample per symbol the reference emits several symbols from one offset (floor(mu) = 0), so the bound exceeds n there
+        step = float(self.tab.tr_min_freq) - abs(float(self.tab.tr_alpha))
+        if not step > 0.01:
+            raise ValueError("timing loop may stall (omega_min - |mu_gain| = %g): the reference would never leave the call" % step)
+        cap = int((n + 1) / min(step, 1.0)) + 16
         sym = np.zeros(cap, np.complex64)
         dib = np.zeros(cap, np.uint8)
         bits = np.zeros(2 * cap, np.uint8)
         x = np.zeros(n, np.complex64) if stages else None
         y = np.zeros(n, np.complex64) if stages else None
-        S = lib().tetra_oracle_process(C.byref(self.tab), C.byref(self.st), n, _ptr(iq), _ptr(x), _ptr(y),
-                                       _ptr(sym), _ptr(dib), _ptr(bits))
+        S = lib().tetra_oracle_process_mode(C.byref(self.tab), C.byref(self.st), self.mode, n, _ptr(iq), _ptr(x), _ptr(y),
+                                            _ptr(sym), _ptr(dib), _ptr(bits))
+        assert S >= 0
         out = dict(sym=sym[:S], dibits=dib[:S], bits=bits[: 2 * S])
         if stages:
             out["x"] = x

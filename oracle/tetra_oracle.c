@@ -301,7 +301,19 @@ static inline float fast_amplitude(float re, float im) {
     return (r > i) ? (r + 0.4f * i) : (i + 0.4f * r);
 }
 
-int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st,
+/* Run-time phasor math::phasor(x) = { cosf(x), sinf(x) } (SDR++ core): the contract's polynomial, or -- reference-float
+ * mode -- the host libm the reference itself calls. */
+static inline __attribute__((always_inline)) void phasor_m(const int mode, float x, float* s, float* c) {
+    if (mode == TETRA_ORACLE_REFERENCE_FLOATS) { *c = cosf(x); *s = sinf(x); }
+    else tetra_oracle_sincosf(x, s, c);
+}
+/* One step of a dot product: the contract's fmaf chain, or -- reference-float mode -- the plain `acc += a * b` of a scalar
+ * VOLK kernel (two roundings). */
+static inline __attribute__((always_inline)) float mac_m(const int mode, float a, float b, float acc) {
+    return mode == TETRA_ORACLE_REFERENCE_FLOATS ? acc + a * b : fmaf(a, b, acc);
+}
+
+static inline __attribute__((always_inline)) int process_impl(const int mode, const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st,
                          int count, const float* iq,
                          float* x_out, float* y_out, float* sym_out,
                          uint8_t* dibits, uint8_t* bits) {
@@ -332,23 +344,38 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
         if (g > tab->agc_max_gain) g = tab->agc_max_gain;
         /* FLL: x = in * phasor(-phase)  fll.cpp:137-138 */
         float s, c;
-        tetra_oracle_sincosf(-ph, &s, &c);
+        phasor_m(mode, -ph, &s, &c);
         float xr = ar * c - ai * s;
         float xi = ai * c + ar * s;
         wr[H + i] = xr;
         wi[H + i] = xi;
         /* two band-edge FIRs over the same delay line, fll.cpp:141-142 */
-        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
         const float* pr = wr + i + (H - (nb - 1));
         const float* pi = wi + i + (H - (nb - 1));
-        for (int k = 0; k < nb; k++) {
-            s1 = fmaf(pr[k], tab->be_a[k], s1);
-            s2 = fmaf(pi[k], tab->be_b[k], s2);
-            s3 = fmaf(pr[k], tab->be_b[k], s3);
-            s4 = fmaf(pi[k], tab->be_a[k], s4);
+        float lre, lim, hre, him;
+        if (mode == TETRA_ORACLE_REFERENCE_FLOATS) {
+            /* FIR<complex_t, complex_t>::process(1, ..) x 2 -> volk_32fc_x2_dot_prod_32fc in ascending tap order, each product
+             * a full complex multiply added to the running sum: re += x.re t.re - x.im t.im, im += x.im t.re + x.re t.im.
+             * Lower taps t = (a, b), upper taps t = (a, -b) (fll.cpp:89-93); y * (-b) == -(y * b) exactly. */
+            lre = lim = hre = him = 0.0f;
+            for (int k = 0; k < nb; k++) {
+                const float a = tab->be_a[k], b = tab->be_b[k];
+                lre += pr[k] * a - pi[k] * b;
+                lim += pi[k] * a + pr[k] * b;
+                hre += pr[k] * a - pi[k] * -b;
+                him += pi[k] * a + pr[k] * -b;
+            }
+        } else {
+            float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
+            for (int k = 0; k < nb; k++) {
+                s1 = fmaf(pr[k], tab->be_a[k], s1);
+                s2 = fmaf(pi[k], tab->be_b[k], s2);
+                s3 = fmaf(pr[k], tab->be_b[k], s3);
+                s4 = fmaf(pi[k], tab->be_a[k], s4);
+            }
+            lre = s1 - s2; lim = s4 + s3;     /* x * (a + jb) */
+            hre = s1 + s2; him = s4 - s3;     /* x * (a - jb) */
         }
-        float lre = s1 - s2, lim = s4 + s3;     /* x * (a + jb) */
-        float hre = s1 + s2, him = s4 - s3;     /* x * (a - jb) */
         float err = fast_amplitude(hre, him) - fast_amplitude(lre, lim); /* fll.cpp:143 */
         /* pcl.advance(err) fll.cpp:145 (PhaseControlLoop<float>, alpha forced 0) */
         fr += tab->fll_beta * err;
@@ -375,8 +402,8 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
         const int k0 = have >= nt ? 0 : (int)(nt - have);   /* older ones are zeros in the reference's RRC delay line;
                                                              * fmaf(0, tap, acc) == acc, so they are skipped */
         for (int k = k0; k < nt; k++) {
-            ar = fmaf(pr[k], tab->rrc[k], ar);
-            ai = fmaf(pi[k], tab->rrc[k], ai);
+            ar = mac_m(mode, pr[k], tab->rrc[k], ar);
+            ai = mac_m(mode, pi[k], tab->rrc[k], ai);
         }
         yr[7 + i] = ar;
         yi[7 + i] = ai;
@@ -404,26 +431,26 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
         const float* bi = yi + offset;
         const float* tp = tab->bank[phase];
         float vr = 0.0f, vi = 0.0f;
-        for (int k = 0; k < 8; k++) { vr = fmaf(br[k], tp[k], vr); vi = fmaf(bi[k], tp[k], vi); }
+        for (int k = 0; k < 8; k++) { vr = mac_m(mode, br[k], tp[k], vr); vi = mac_m(mode, bi[k], tp[k], vi); }
         /* derivative, complex_fd.cpp:107-123 (_outSps == 1: every output is a symbol) */
         float dr, di;
         if (phase == 0) {
             const float* t1 = tab->bank[phase + 1];
             float fr1 = 0.0f, fi1 = 0.0f;
-            for (int k = 0; k < 8; k++) { fr1 = fmaf(br[k], t1[k], fr1); fi1 = fmaf(bi[k], t1[k], fi1); }
+            for (int k = 0; k < 8; k++) { fr1 = mac_m(mode, br[k], t1[k], fr1); fi1 = mac_m(mode, bi[k], t1[k], fi1); }
             dr = fr1 - vr; di = fi1 - vi;
         } else if (phase == TETRA_ORACLE_INTERP_PHASES - 1) {
             const float* t0 = tab->bank[phase - 1];
             float fr0 = 0.0f, fi0 = 0.0f;
-            for (int k = 0; k < 8; k++) { fr0 = fmaf(br[k], t0[k], fr0); fi0 = fmaf(bi[k], t0[k], fi0); }
+            for (int k = 0; k < 8; k++) { fr0 = mac_m(mode, br[k], t0[k], fr0); fi0 = mac_m(mode, bi[k], t0[k], fi0); }
             dr = vr - fr0; di = vi - fi0;
         } else {
             const float* t1 = tab->bank[phase + 1];
             const float* t0 = tab->bank[phase - 1];
             float fr1 = 0.0f, fi1 = 0.0f, fr0 = 0.0f, fi0 = 0.0f;
             for (int k = 0; k < 8; k++) {
-                fr1 = fmaf(br[k], t1[k], fr1); fi1 = fmaf(bi[k], t1[k], fi1);
-                fr0 = fmaf(br[k], t0[k], fr0); fi0 = fmaf(bi[k], t0[k], fi0);
+                fr1 = mac_m(mode, br[k], t1[k], fr1); fi1 = mac_m(mode, bi[k], t1[k], fi1);
+                fr0 = mac_m(mode, br[k], t0[k], fr0); fi0 = mac_m(mode, bi[k], t0[k], fi0);
             }
             dr = (fr1 - fr0) * 0.5f; di = (fi1 - fi0) * 0.5f;
         }
@@ -442,13 +469,13 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
 
         /* Costas, pi4dqpsk_costas.cpp:7-19 */
         float s, c;
-        tetra_oracle_sincosf(-cph, &s, &c);
+        phasor_m(mode, -cph, &s, &c);
         float xr = vr * c - vi * s;
         float xi = vi * c + vr * s;
         ph2 += -FL_M_PI / 4.0f;
         if (ph2 >= 2 * FL_M_PI) ph2 -= 2 * FL_M_PI;
         else if (ph2 <= -2 * FL_M_PI) ph2 += 2 * FL_M_PI;
-        tetra_oracle_sincosf(ph2, &s, &c);
+        phasor_m(mode, ph2, &s, &c);
         float zr = xr * c - xi * s;
         float zi = xi * c + xr * s;
         /* errorFunction pi4dqpsk_costas.cpp:23-28 (math::step: x>0 ? 1 : -1) */
@@ -500,6 +527,19 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
     free(wr);
     free(yr);
     return S;
+}
+
+int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st, int count, const float* iq,
+                         float* x_out, float* y_out, float* sym_out, uint8_t* dibits, uint8_t* bits) {
+    return process_impl(TETRA_ORACLE_CONTRACT, tab, st, count, iq, x_out, y_out, sym_out, dibits, bits);
+}
+
+int tetra_oracle_process_mode(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st, int mode, int count, const float* iq,
+                              float* x_out, float* y_out, float* sym_out, uint8_t* dibits, uint8_t* bits) {
+    if (mode == TETRA_ORACLE_REFERENCE_FLOATS)
+        return process_impl(TETRA_ORACLE_REFERENCE_FLOATS, tab, st, count, iq, x_out, y_out, sym_out, dibits, bits);
+    if (mode != TETRA_ORACLE_CONTRACT) return -1;
+    return process_impl(TETRA_ORACLE_CONTRACT, tab, st, count, iq, x_out, y_out, sym_out, dibits, bits);
 }
 
 int tetra_oracle_max_threads(void) {

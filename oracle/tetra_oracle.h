@@ -154,6 +154,27 @@ int tetra_oracle_process(const tetra_oracle_tables_t* tab, tetra_oracle_state_t*
                          uint8_t* dibits, uint8_t* bits);
 
 /*
+ * The same call with the float recipe chosen:
+ *   TETRA_ORACLE_CONTRACT          the arithmetic contract above (what tetra_oracle_process computes and the HIP kernels
+ *                                  reproduce bit for bit);
+ *   TETRA_ORACLE_REFERENCE_FLOATS  the reference's own recipe as an x86 build without VOLK SIMD kernels executes it: host libm
+ *                                  cosf / sinf for every math::phasor (fll.cpp:137, pi4dqpsk_costas.cpp:7,16), the FLL's two
+ *                                  band-edge FIRs as two separate complex x complex dot products (fll.cpp:141-142 ->
+ *                                  volk_32fc_x2_dot_prod_32fc), every dot product a plain `acc += a * b` in ascending tap order,
+ *                                  no fmaf anywhere.  Same tables, same state, same control flow.
+ * Purpose: in this mode the restatement must equal the reference's src/dsp objects -- compiled from
+ * /root/reference against the stand-in SDR++ core headers of tests/refshim -- in every symbol FLOAT, every bit and the
+ * final loop state, bit for bit (tests/test_reference_shim.py), which turns "bits equal, symbols within 3e-3" into an
+ * exact statement about the transcription; the contract mode then differs from it only by the documented recipe.
+ * Returns S, or -1 for an unknown mode.
+ */
+enum { TETRA_ORACLE_CONTRACT = 0, TETRA_ORACLE_REFERENCE_FLOATS = 1 };
+int tetra_oracle_process_mode(const tetra_oracle_tables_t* tab, tetra_oracle_state_t* st, int mode,
+                              int count, const float* iq,
+                              float* x_out, float* y_out, float* sym_out,
+                              uint8_t* dibits, uint8_t* bits);
+
+/*
  * Batched driver used for the CPU baseline and for big parity tests: C channels,
  * channel-major iq[C][n_samples] (interleaved re,im), processed in `chunk`-sample
  * process() calls (chunk<=0: one call), channels split over `threads` OpenMP

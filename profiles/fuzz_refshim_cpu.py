@@ -5,6 +5,11 @@ per symbol, tap counts 2 ... 72, roll-off, every loop constant) and random chann
 for the rest, whether the FIRST differing decision is a boundary decision (the flipped component below 3e-2 in both, streams
 within the documented symbol tolerance up to there): the two differ in float rounding by design (libm sine / plain sums there,
 polynomial / fmaf chains here), and a decision-directed loop amplifies a flipped sign.
+Round 4: every case also runs the oracle's REFERENCE-FLOAT mode (oracle/tetra_oracle.h: libm phasors, plain sums, two complex
+band-edge dots), cut into three calls, and that one must reproduce the reference objects' symbol floats, bits and loop state BIT FOR
+BIT after every call -- `reference_float_mode_exact` has to equal `cases`.  The draw is widened below one sample per symbol step
+(rates 0.9 ... 1.06 samples per symbol, where COMPLEX_FD emits several symbols from one offset) for that comparison; the
+contract-mode decision statistics keep the old domain (`contract_cases`).
     python profiles/fuzz_refshim_cpu.py <seed> <seconds>"""
 import sys, time
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, 'tests'), os.path.join(R, 'profiles')]
@@ -14,18 +19,33 @@ import fuzz_parity as F
 from oracle import binding as oracle
 L=S.load_reference_build()
 rng=np.random.default_rng(int(sys.argv[1])); secs=float(sys.argv[2])
-t0=time.time(); cases=0; equal=0; boundary=0; other=[]; bits=0
+t0=time.time(); cases=0; equal=0; boundary=0; other=[]; bits=0; exact=0; inexact=[]; allcases=0; multi_cases=0
 while time.time()-t0<secs:
     sps,p=F.draw_params(rng)
+    if rng.integers(0,6)==0:      # widened: at and below one sample per symbol (floor(mu) = 0 events)
+        sps=float(rng.choice([0.9,0.95,1.0,1.02])); p["samplerate"]=18000.0*sps
     cfg=F.oracle_cfg(p)
     try: o=oracle.Oracle(cfg)
     except ValueError: continue
-    if sps*(1-cfg.omega_rel_limit)-abs(cfg.mu_gain) < 1.0: continue
-    r=S.RefChain(L,cfg)
     n=int(rng.choice([3000,8000,20000]))
     seed=int(rng.integers(0,1<<30))
-    iq,_,_=F.pkg.synth.gen_channel(n,seed,sps=sps)
+    iq,_,_=F.pkg.synth.gen_channel(n,seed,sps=max(sps,1.02))
+    # reference-float mode: exact, call by call (three ragged calls), state included
+    allcases+=1
+    r=S.RefChain(L,cfg); of=oracle.Oracle(cfg,reference_floats=True)
+    cuts=sorted({0,n,int(rng.integers(1,n)),int(rng.integers(1,n))}); ok=True; nsym=0
+    for a,b in zip(cuts[:-1],cuts[1:]):
+        rs,rb=r.process(iq[a:b]); oo=of.process(iq[a:b]); nsym+=rs.size
+        if not (rs.size==oo['sym'].size and np.array_equal(rb,oo['bits']) and np.array_equal(rs.view(np.uint32),oo['sym'].view(np.uint32))
+                and S.state_bits(r.state())==S.state_bits(of.st)):
+            ok=False; inexact.append(dict(p=p,seed=seed,n=n,cut=(a,b))); break
+    r.close()
+    exact+=ok
+    multi_cases+= nsym>n*0.97
+    if sps*(1-cfg.omega_rel_limit)-abs(cfg.mu_gain) < 1.0: continue
+    r=S.RefChain(L,cfg)
     rs,rb=r.process(iq); oo=o.process(iq)
+    r.close()
     cases+=1; bits+=rb.size
     if rb.size==oo['bits'].size and np.array_equal(rb,oo['bits']):
         equal+=1; continue
@@ -42,5 +62,9 @@ while time.time()-t0<secs:
     comp=min(abs(a.real),abs(b.real)) if (a.real<0)!=(b.real<0) else min(abs(a.imag),abs(b.imag))
     if d<3e-2 and comp<3e-2: boundary+=1
     else: other.append(dict(p=p,seed=seed,i=i,maxdiff_before=d,comp=float(comp),a=complex(a),b=complex(b)))
-print(dict(cases=cases,bits=bits,all_bits_equal=equal,first_difference_is_a_boundary_decision=boundary,other=len(other),seconds=round(time.time()-t0,1)))
+import json
+print(json.dumps(dict(cases=allcases,reference_float_mode_exact=exact,cases_at_or_below_one_sample_per_symbol=multi_cases,
+                      contract_cases=cases,contract_bits=bits,contract_all_bits_equal=equal,
+                      contract_first_difference_is_a_boundary_decision=boundary,contract_other=len(other),seconds=round(time.time()-t0,1))))
+for x in inexact[:8]: print("INEXACT",x)
 for x in other[:8]: print(x)

@@ -70,4 +70,24 @@ void ref_set_rrc_params(void* h, int taps, double beta) { ((Chain*)h)->demod.set
 void ref_reset(void* h) { ((Chain*)h)->demod.reset(); }
 
 int ref_sync(void* h) { return ((Chain*)h)->extractor.sync ? 1 : 0; }
+
+// The loop state of the reference's objects, for the bit-exact comparison with the oracle's reference-float mode.  The members
+// are protected / private in the reference's headers; this file (and only this file) is compiled with g++ -fno-access-control
+// so that they can be READ without touching or wrapping the reference's sources.
+// out[0..8] = FastAGC gain, FLL pcl.phase, pcl.freq, COMPLEX_FD pcl.phase (mu), pcl.freq (omega), PLL pcl.phase, pcl.freq, ph2,
+// DQPSKSymbolExtractor::standarderr; iout[0..1] = COMPLEX_FD offset, DQPSKSymbolExtractor prev.
+void ref_get_state(void* h, float* out, int* iout) {
+    Chain* c = (Chain*)h;
+    out[0] = c->demod.agc._gain;
+    out[1] = c->demod.fll.pcl.phase;
+    out[2] = c->demod.fll.pcl.freq;
+    out[3] = c->demod.recov.pcl.phase;
+    out[4] = c->demod.recov.pcl.freq;
+    out[5] = c->demod.costas.pcl.phase;
+    out[6] = c->demod.costas.pcl.freq;
+    out[7] = c->demod.costas.ph2;
+    out[8] = c->extractor.standarderr;
+    iout[0] = c->demod.recov.offset;
+    iout[1] = c->extractor.prev;
+}
 }

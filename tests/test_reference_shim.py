@@ -6,8 +6,14 @@ and VOLK, which are NOT under /root/reference; tests/refshim/ holds our own rest
 (SURVEY.md Appendix A).  So this is EVIDENCE, NOT A PIN: it shows the reference's per-sample loop code, fed the
 primitives as we understand them, makes the bit decisions oracle/tetra_oracle.c makes.  Float results differ by
 design (libm cosf/sinf and plain multiply-add sums there; the oracle's own sincos polynomial and fmaf chains here),
-so symbols are compared with the tolerance SURVEY.md Appendix B.4/B.5 measured for reduction-order changes:
-rms <= 3e-3, max <= 3e-2, and ALL bits equal.
+so in the oracle's CONTRACT mode symbols are compared with the tolerance SURVEY.md Appendix B.4/B.5 measured for
+reduction-order changes: rms <= 3e-3, max <= 3e-2, and ALL bits equal.
+
+The second half of the file (test_exact_*) removes that slack: with the oracle in its REFERENCE-FLOAT mode (libm phasors, two
+separate complex band-edge dots, plain `acc += a * b` sums, no fmaf: oracle/tetra_oracle.h) every symbol FLOAT, every bit and
+the final loop state of the reference's objects must be reproduced BIT FOR BIT -- any transcription slip in fll.cpp:135-149,
+complex_fd.cpp:89-151, pi4dqpsk_costas.cpp:5-28 or pi4dqpsk.cpp:32-140 would show as a differing bit pattern.  What is left
+between the two oracle modes is exactly the documented recipe (polynomial sincos, fmaf chains, conjugate-pair FLL sums).
 """
 import ctypes as C
 import os
@@ -37,7 +43,8 @@ def load_reference_build():
     deps = srcs + [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(SHIM, "dsp")) for f in fs]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         # -ffp-contract=off: the reference's expressions as written (an x86 build never fuses them)
-        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-I", SHIM,
+        # -fno-access-control: ref_driver.cpp reads the objects' protected / private loop state (ref_get_state)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-access-control", "-fPIC", "-shared", "-w", "-I", SHIM,
                         "-I", os.path.join(REF, "src"), "-o", so] + srcs, check=True)
     L = C.CDLL(so)
     L.ref_create.restype = C.c_void_p
@@ -50,6 +57,8 @@ def load_reference_build():
     L.ref_reset.argtypes = [C.c_void_p]
     L.ref_set_rrc_params.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.ref_set_rrc_params.restype = None
+    L.ref_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_get_state.restype = None
     return L
 
 
@@ -69,12 +78,20 @@ class RefChain:
     def process(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)
         n = len(iq)
-        sym = np.zeros(n, np.complex64)
-        bits = np.zeros(2 * n, np.uint8)
+        sym = np.zeros(2 * n + 64, np.complex64)          # below one sample per symbol a call emits more symbols than samples
+        bits = np.zeros(4 * n + 128, np.uint8)
         ns = self.L.ref_process(self.h, n, iq.ctypes.data_as(C.c_void_p), sym.ctypes.data_as(C.c_void_p),
                                 bits.ctypes.data_as(C.c_void_p))
         assert ns >= 0
         return sym[:ns], bits[: 2 * ns]
+
+    def state(self):
+        """Loop state of the reference's objects: dict of np.float32 / int in the oracle State's field names."""
+        f = np.zeros(9, np.float32)
+        i = np.zeros(2, np.int32)
+        self.L.ref_get_state(self.h, f.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p))
+        return dict(agc_gain=f[0], fll_phase=f[1], fll_freq=f[2], mu=f[3], omega=f[4], costas_phase=f[5], costas_freq=f[6],
+                    ph2=f[7], standarderr=f[8], offset=int(i[0]), prev=int(i[1]))
 
     def set_param(self, pid, v):
         assert self.L.ref_set_param(self.h, pid, float(v)) == 0
@@ -233,3 +250,135 @@ def test_other_sample_rate_and_several_chains(ref, oracle, synth):
         r.close()
         rms, mx, nbad = _compare(sym, bits, oracle.Oracle().process(x))
         assert nbad == 0 and rms <= RMS_TOL and mx <= MAX_TOL, (c, rms, mx, nbad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Bit-exact: the oracle's reference-float mode against the reference's objects (symbol floats, bits, final loop state)
+# ---------------------------------------------------------------------------------------------------------------------
+STATE_FLOATS = ("agc_gain", "fll_phase", "fll_freq", "mu", "omega", "costas_phase", "costas_freq", "ph2", "standarderr")
+STATE_INTS = ("offset", "prev")
+
+
+def state_bits(st):
+    """A loop state (RefChain.state() dict or an oracle State) as comparable bit patterns."""
+    get = (lambda k: st[k]) if isinstance(st, dict) else (lambda k: getattr(st, k))
+    return ([int(np.float32(get(k)).view(np.uint32)) for k in STATE_FLOATS], [int(get(k)) for k in STATE_INTS])
+
+
+def _exact(r, o, sym, bits, oo, what=""):
+    assert len(sym) == len(oo["sym"]) and len(bits) == len(oo["bits"]), what
+    assert np.array_equal(bits, oo["bits"]), what
+    bad = np.flatnonzero((sym.view(np.uint32) != oo["sym"].view(np.uint32)).reshape(-1, 2).any(axis=1))
+    assert bad.size == 0, (what, "first differing symbol", int(bad[0]), sym[bad[0]], oo["sym"][bad[0]])
+    assert state_bits(r.state()) == state_bits(o.st), (what, r.state(), {k: getattr(o.st, k) for k in STATE_FLOATS + STATE_INTS})
+
+
+def test_exact_probe_and_baseline_channels(ref, oracle, synth):
+    """One call each: the survey's probe scenario and channels of the BASELINE generator (36000 samples)."""
+    cases = [synth.gen_channel(40060, 7, cfo=0.03, tau=5 / 16.0, amp=0.2, esn0_db=25.0)[0]]
+    cases += [synth.gen_channel(36000, seed)[0] for seed in (1234, 1235, 1240, 1299, 77)]
+    for k, iq in enumerate(cases):
+        r = RefChain(ref, oracle.default_cfg())
+        o = oracle.Oracle(reference_floats=True)
+        sym, bits = r.process(iq)
+        _exact(r, o, sym, bits, o.process(iq), "case %d" % k)
+        r.close()
+
+
+def test_exact_chunked_streaming(ref, oracle, synth):
+    """Carried state call after call (7 / 180 / 4001 samples): exact after EVERY call, not only at the end."""
+    iq, _, _ = synth.gen_channel(12000, 42, cfo=-0.02, tau=1.3, amp=0.5)
+    for chunk in (7, 180, 4001):
+        r = RefChain(ref, oracle.default_cfg())
+        o = oracle.Oracle(reference_floats=True)
+        for i in range(0, len(iq), chunk):
+            sym, bits = r.process(iq[i:i + chunk])
+            _exact(r, o, sym, bits, o.process(iq[i:i + chunk]), "chunk %d at %d" % (chunk, i))
+        r.close()
+
+
+def test_exact_reset_and_setters(ref, oracle, synth):
+    """reset() and every loop setter mid-stream, then setRRCBeta(int)'s truncation (pi4dqpsk.cpp:72-74, pi4dqpsk.h:56)."""
+    iq, _, _ = synth.gen_channel(30000, 77, cfo=0.01, tau=0.4, amp=0.3)
+    a, b, c = iq[:9001], iq[9001:20000], iq[20000:]
+    r = RefChain(ref, oracle.default_cfg())
+    o = oracle.Oracle(reference_floats=True)
+    sym, bits = r.process(a); _exact(r, o, sym, bits, o.process(a), "before reset")
+    r.reset(); o.reset_reference()
+    assert state_bits(r.state()) == state_bits(o.st)
+    sym, bits = r.process(b); _exact(r, o, sym, bits, o.process(b), "after reset")
+    for pid, v in ((4, 0.03), (5, 0.004), (6, 0.008), (7, 2e-4), (8, 0.02), (9, 0.02)):
+        r.set_param(pid, v); o.set_param(pid, v, quirks=True)
+    sym, bits = r.process(c); _exact(r, o, sym, bits, o.process(c), "after the loop setters")
+    r.set_param(3, 0.35); o.set_param(3, 0.35, quirks=True)
+    sym, bits = r.process(iq[:4000]); _exact(r, o, sym, bits, o.process(iq[:4000]), "after setRRCBeta(int)")
+    r.close()
+
+
+def test_exact_tap_count_setters_and_set_rrc_params(ref, oracle, synth):
+    """setRRCTapCount shrinking / growing / growing again mid-stream (FIR::setTaps' history rule, rrc_valid) and
+    setRRCParams(49, 0.35) (the double roll-off survives)."""
+    iq, _, _ = synth.gen_channel(20000, 78, cfo=-0.015, tau=1.1, amp=0.6)
+    cuts = [0, 5000, 5020, 9000, 20000]
+    taps = [None, 33, 49, 65]
+    r = RefChain(ref, oracle.default_cfg())
+    o = oracle.Oracle(reference_floats=True)
+    for k in range(4):
+        if taps[k]:
+            r.set_param(2, taps[k]); o.set_param(2, taps[k], quirks=True)
+        blk = iq[cuts[k]:cuts[k + 1]]
+        sym, bits = r.process(blk)
+        _exact(r, o, sym, bits, o.process(blk), "tap count step %d" % k)
+    r.close()
+    iq, _, _ = synth.gen_channel(14000, 79, cfo=0.012, tau=0.9, amp=0.4)
+    r = RefChain(ref, oracle.default_cfg())
+    o = oracle.Oracle(reference_floats=True)
+    sym, bits = r.process(iq[:7000]); _exact(r, o, sym, bits, o.process(iq[:7000]), "before setRRCParams")
+    r.set_rrc_params(49, 0.35)
+    o.set_param(2, 49, quirks=True); o.set_param(3, 0.35, quirks=False)
+    sym, bits = r.process(iq[7000:]); _exact(r, o, sym, bits, o.process(iq[7000:]), "after setRRCParams")
+    r.close()
+
+
+def test_exact_other_rates_and_rate_setters(ref, oracle, synth):
+    """50 ksps at create (config 5's rate), then setSamplerate / setSymbolrate mid-stream (pi4dqpsk.cpp:32-54: RRC re-designed,
+    timing loop reset by COMPLEX_FD::setOmega, band-edge filters untouched)."""
+    cfg = oracle.default_cfg()
+    cfg.samplerate = 50000.0
+    iq, _, _ = synth.gen_channel(30000, 321, sps=50000.0 / 18000.0, cfo=0.015)
+    r = RefChain(ref, cfg)
+    o = oracle.Oracle(cfg, reference_floats=True)
+    sym, bits = r.process(iq[:20000]); _exact(r, o, sym, bits, o.process(iq[:20000]), "50 ksps")
+    r.set_param(1, 48000.0); o.set_param(1, 48000.0, quirks=True)
+    sym, bits = r.process(iq[20000:26000]); _exact(r, o, sym, bits, o.process(iq[20000:26000]), "after setSamplerate")
+    r.set_param(0, 17000.0); o.set_param(0, 17000.0, quirks=True)
+    sym, bits = r.process(iq[26000:]); _exact(r, o, sym, bits, o.process(iq[26000:]), "after setSymbolrate")
+    r.close()
+
+
+def test_exact_below_one_sample_per_symbol_step(ref, oracle, synth):
+    """The part of COMPLEX_FD::process's domain where floor(mu) can be 0 -- several symbols from one offset
+    (complex_fd.cpp:98-145: `offset += delta` with delta == 0): 1.0 and 0.9 samples per symbol (omega_min - |mu gain| =
+    0.96 / 0.86).  Cut into ONE-sample calls on both sides, so a call that returns two symbols IS such an event; the run has
+    to contain many.  (At 2 samples per symbol no muGain short of ~2 stalls the loop: the detector's error is a difference
+    of neighbouring interpolator rows, a few 1e-2 -- measured, so rates are what reaches this code.)"""
+    for rate, seed in ((18000.0, 555), (16200.0, 557)):
+        cfg = oracle.default_cfg()
+        cfg.samplerate = rate
+        iq, _, _ = synth.gen_channel(3000, seed, sps=1.02)
+        r = RefChain(ref, cfg)
+        o = oracle.Oracle(cfg, reference_floats=True)
+        multi = 0
+        for i in range(len(iq)):
+            sym, bits = r.process(iq[i:i + 1])
+            _exact(r, o, sym, bits, o.process(iq[i:i + 1]), "rate %g sample %d" % (rate, i))
+            multi += len(sym) >= 2
+        r.close()
+        assert multi > 50, (rate, multi)
+        # and as one call
+        r = RefChain(ref, cfg)
+        o = oracle.Oracle(cfg, reference_floats=True)
+        sym, bits = r.process(iq)
+        assert len(sym) > len(iq) * 0.99
+        _exact(r, o, sym, bits, o.process(iq), "rate %g, one call" % rate)
+        r.close()
