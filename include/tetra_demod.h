@@ -40,7 +40,8 @@ enum {
     TETRA_ERR_SIZE = -6,        /* n_samples > max_samples, or an output stride too small */
     TETRA_ERR_ALIGN = -7,       /* output pointer / stride not 8-byte aligned */
     TETRA_ERR_OVERRUN = -8      /* a channel's output row filled up and the rest of its samples were dropped (only a NaN/Inf-poisoned
-                                   channel can do that: rows are sized for the slowest finite timing loop, tetra_demod_bits_stride_for).
+                                   channel can do that: rows are sized for the slowest finite timing loop, tetra_demod_bits_stride_for;
+                                   with min_step < 1 such a channel stops advancing and fills its row from one offset).
                                    The outputs of every other channel are valid and were delivered; see tetra_demod_get_overruns */
 };
 
@@ -97,9 +98,12 @@ typedef struct tetra_demod_config {
     double fll_bandwidth;    /* 0.006 */
     double omega_gain;       /* timing loop beta, src/main.cpp:82 */
     double mu_gain;          /* timing loop alpha, src/main.cpp:81 */
-    double omega_rel_limit;  /* 0.02.  Accepted: 0 <= limit < 1 with samplerate / symbolrate x (1 - limit) - |mu_gain| >= 1, i.e. a
-                              * timing loop whose every symbol advances by at least one sample (the reference below that emits
-                              * several symbols from one offset; not implemented: TETRA_ERR_UNSUPPORTED, also from the setters) */
+    double omega_rel_limit;  /* 0.02.  Accepted: 0 <= limit < 1 with min_step = samplerate / symbolrate x (1 - limit) - |mu_gain| >= 0.27
+                              * samples per symbol.  Below min_step = 1 the reference emits several symbols from one offset
+                              * (floor(mu) = 0, complex_fd.cpp:141-143) and so do the kernels (ABI 4; such handles run in 16- and
+                              * 4-channel workgroups with a deeper symbol ring).  Refused (TETRA_ERR_UNSUPPORTED, also from the
+                              * setters): min_step < 0.27 -- at <= 0 the reference's own loop may never leave process(), and up to
+                              * 0.27 (more than 3.7 symbols per input sample) the kernels' LDS symbol ring is the limit */
     /* Optional caller-supplied tables (NULL = design them like the reference does).  In an SDR++
      * build the host may pass SDR++'s own tap generators' output here. */
     const float* rrc_taps;        /* [rrc_tap_count]                 taps::rootRaisedCosine, pi4dqpsk.cpp:18 */

@@ -565,7 +565,11 @@ int tetra_oracle_process_batch(const tetra_oracle_tables_t* tab, tetra_oracle_st
         uint8_t* bo = bits + (size_t)c * (size_t)bits_stride;
         float* so = sym ? sym + (size_t)c * (size_t)(bits_stride / 2) * 2 : NULL;
         int nb = 0;
-        int maxs = chunk + 8;      /* every symbol advances >= 1 sample for the parameter sets the tests use */
+        /* symbols one call can emit: every symbol moves mu by at least tr_min_freq - |tr_alpha| (complex_fd.cpp:136-143) */
+        double step = (double)tab->tr_min_freq - fabs((double)tab->tr_alpha);
+        if (!(step > 0.01)) step = 0.01;
+        if (step > 1.0) step = 1.0;
+        int maxs = (int)((double)(chunk + 1) / step) + 16;
         uint8_t* tb = (uint8_t*)malloc((size_t)maxs * 2);
         float* ts = (float*)malloc(sizeof(float) * (size_t)maxs * 2);
         for (int pos = 0; pos < n_samples; pos += chunk) {

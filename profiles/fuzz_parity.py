@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time-bounded parity fuzzer: GPU (through the C ABI) against the oracle on random draws over everything the pytest cases vary
-one or two at a time -- rates (1.06 ... 4 samples per symbol, at create), RRC tap count and roll-off, every loop constant, the
+one or two at a time -- rates (0.35 ... 4 samples per symbol, at create; below ~1 several symbols leave one offset), RRC tap count and roll-off, every loop constant, the
 three workgroup shapes and the automatic plan, input layout, symbol output, the quality statistic, TETRA_FLAG_REFERENCE_QUIRKS
 with resets, call lengths 0 ... 3000 with carried state, a loop setter in the middle of the stream, and inputs the synthetic
 TETRA channels do not contain (silence, noise only, amplitudes 1e-6 and 2).  Bits, bit counts, symbols (bit patterns) and
@@ -77,6 +77,9 @@ DRY = False      # --dry: the oracle side only (checks the script's own mechanic
 
 def one_case(rng, stats):
     sps, p = draw_params(rng)
+    if rng.integers(0, 6) == 0:          # round 4: at and below one sample per symbol step (several symbols from one offset, floor(mu) = 0)
+        sps = float(rng.choice([1.02, 1.0, 0.9, 0.6, 0.35]))
+        p["samplerate"] = 18000.0 * sps
     Cn = int(rng.integers(1, 71))
     tm = bool(rng.integers(0, 2))
     shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS, B.FLAG_SMALL_WORKGROUPS]))
@@ -85,7 +88,7 @@ def one_case(rng, stats):
     chunks = [int(rng.choice([0, 1, 5, 31, 32, 33, 63, 64, 65, 180, 255, 700, 1500, 3000])) for _ in range(5)]
     N = max(sum(chunks), 1)
     seed = int(rng.integers(0, 1 << 30))
-    iq, _, _ = pkg.synth.gen_batch(Cn, N, base_seed=seed, sps=sps)
+    iq, _, _ = pkg.synth.gen_batch(Cn, N, base_seed=seed, sps=max(sps, 1.02))
     for c in range(Cn):
         if rng.integers(0, 8) == 0:
             iq[c] = special_channel(rng, int(rng.integers(0, 4)), N)

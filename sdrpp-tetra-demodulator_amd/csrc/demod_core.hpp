@@ -576,6 +576,12 @@ struct K2State {
 
 // Timing recovery step (complex_fd.cpp:101-143), second half: from the three interpolated values v = f(T) (bank row `phase`),
 // a = f(T+1) (row min(phase+1,127)), b = f(T-1) (row max(phase-1,0)) to the loop update.  Advances mu / omega / offset.
+// MINADV = the smallest offset advance a symbol may make: 1 for parameter sets whose every symbol moves at least one sample
+// (omega_min - |alpha| >= 1: the clamp is then neutral and guarantees loop termination when NaN/Inf has poisoned mu), 0 for the
+// rest of the reference's domain, where floor(mu) = 0 makes COMPLEX_FD emit several symbols from ONE offset
+// (complex_fd.cpp:141-143: `offset += delta` with delta == 0) -- there a poisoned loop stops advancing and is cut off at its
+// row's capacity by the caller's per-symbol check.
+template <int MINADV = 1>
 TD_FN void k2_timing_tail(const K2Consts& k, K2State& st, int phase, float vr, float vi, float ar, float ai, float br, float bi) {
     // complex_fd.cpp:107-123, branch-free: one-sided differences at the bank edges, central difference inside
     // At the low edge the "row below" IS row `phase` (the caller clamps the neighbour rows), so b equals v bit for bit and a - b
@@ -589,16 +595,18 @@ TD_FN void k2_timing_tail(const K2Consts& k, K2State& st, int phase, float vr, f
     // complex_fd.cpp:140-143
     pcl_advance<float, false>(terr, st.mu, st.omega, k.tr_alpha, k.tr_beta, k.tr_min_freq, k.tr_max_freq);
     float delta = v_floor(st.mu);
-    // A finite stream always advances by >= 1 sample (omega (1 - rel_limit) - |alpha| >= 1 is a condition of create), so the
-    // max() is neutral there; it guarantees forward progress (loop termination) when NaN/Inf has poisoned mu.
+    // MINADV 1: a finite stream always advances by >= 1 sample there, so the max() is neutral; it guarantees forward progress
+    // (loop termination) when NaN/Inf has poisoned mu.  MINADV 0: mu >= 0 for every finite stream (omega_min - |alpha| > 0), so
+    // this max() is neutral too and only keeps a poisoned offset from running backwards.
     const int adv = (int)delta;
-    st.offset += adv > 1 ? adv : 1;
+    st.offset += adv > MINADV ? adv : MINADV;
     st.mu = st.mu - delta;
 }
 
 // Timing recovery step (complex_fd.cpp:101-143).  w[0..7]: the 8 complex samples buffer[offset..offset+7];
 // rows tm1/t0/tp1: interpolator bank rows max(phase-1,0), phase, min(phase+1,127).  Returns the interpolated
 // symbol (vr, vi) and advances mu / omega / offset.  The three 8-tap dots run as packed (re,im) fmaf chains.
+template <int MINADV = 1>
 TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float>* w,
                      const float* tm1, const float* t0, const float* tp1, float* out_re, float* out_im) {
     Pair<float> v(0.0f, 0.0f), a(0.0f, 0.0f), b(0.0f, 0.0f);
@@ -608,7 +616,7 @@ TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float
         a = pk_fma(w[j], Pair<float>(tp1[j], tp1[j]), a);
         b = pk_fma(w[j], Pair<float>(tm1[j], tm1[j]), b);
     }
-    k2_timing_tail(k, st, phase, v.x(), v.y(), a.x(), a.y(), b.x(), b.y());
+    k2_timing_tail<MINADV>(k, st, phase, v.x(), v.y(), a.x(), a.y(), b.x(), b.y());
     *out_re = v.x();
     *out_im = v.y();
 }
@@ -622,6 +630,7 @@ TD_FN void k2_timing(const K2Consts& k, K2State& st, int phase, const Pair<float
 template <int Q> TD_FN float quad_bcast(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), Q * 0x55, 0xf, 0xf, true));
 }
+template <int MINADV = 1>
 TD_FN void k2_timing_quad(const K2Consts& k, K2State& st, int phase, const Pair<float>* w, const float* trow,
                           float* out_re, float* out_im) {
     Pair<float> d(0.0f, 0.0f);
@@ -630,7 +639,7 @@ TD_FN void k2_timing_quad(const K2Consts& k, K2State& st, int phase, const Pair<
     const float vr = quad_bcast<0>(d.x()), vi = quad_bcast<0>(d.y());
     const float ar = quad_bcast<1>(d.x()), ai = quad_bcast<1>(d.y());
     const float br = quad_bcast<2>(d.x()), bi = quad_bcast<2>(d.y());
-    k2_timing_tail(k, st, phase, vr, vi, ar, ai, br, bi);
+    k2_timing_tail<MINADV>(k, st, phase, vr, vi, ar, ai, br, bi);
     *out_re = vr;
     *out_im = vi;
 }
@@ -640,6 +649,7 @@ TD_FN void k2_timing_quad(const K2Consts& k, K2State& st, int phase, const Pair<
 TD_FN float pair_swap(float x) {      // quad_perm:[1,0,3,2]
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xb1, 0xf, 0xf, true));
 }
+template <int MINADV = 1>
 TD_FN void k2_timing_pair(const K2Consts& k, K2State& st, int phase, const Pair<float>* w, const float* t0, const float* t2,
                           bool second, float* out_re, float* out_im) {
     Pair<float> v(0.0f, 0.0f), d(0.0f, 0.0f);
@@ -651,7 +661,7 @@ TD_FN void k2_timing_pair(const K2Consts& k, K2State& st, int phase, const Pair<
     const float ox = pair_swap(d.x()), oy = pair_swap(d.y());      // the neighbour's second dot
     const float ar = second ? ox : d.x(), ai = second ? oy : d.y();
     const float br = second ? d.x() : ox, bi = second ? d.y() : oy;
-    k2_timing_tail(k, st, phase, v.x(), v.y(), ar, ai, br, bi);
+    k2_timing_tail<MINADV>(k, st, phase, v.x(), v.y(), ar, ai, br, bi);
     *out_re = v.x();
     *out_im = v.y();
 }

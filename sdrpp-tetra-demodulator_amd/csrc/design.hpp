@@ -158,16 +158,20 @@ inline void design_bandedge(const DesignParams& p, Design& d, int count) {
     bandedge_filters(count, (float)p.rrc_beta, (double)(int)p.symbolrate, (double)(int)p.samplerate, d.be_re.data(), d.be_im.data());
 }
 // What the kernels cover.  The timing loop moves floor(mu) samples per symbol with mu = frac + freq + alpha * err,
-// freq >= omega (1 - rel_limit), |err| <= 1 (complex_fd.cpp:136-143).  While omega (1 - rel_limit) - |mu_gain| >= 1 every
-// symbol advances by at least one sample, which the kernel's forward-progress clamp relies on (it is then neutral); below
-// that the reference emits several symbols from one offset -- not implemented, refused.  Output rows are sized from the
-// same bound (tetra_demod_bits_stride_for), so any accepted parameter set fits its rows.
+// freq >= omega (1 - rel_limit), |err| <= 1 (complex_fd.cpp:136-143): min_step = omega (1 - rel_limit) - |mu_gain| samples per
+// symbol at least.  While min_step >= 1 every symbol advances by at least one sample (the kernel's forward-progress clamp is
+// then neutral).  Below that the reference emits several symbols from one offset (floor(mu) = 0, complex_fd.cpp:141-143): the
+// kernels' "deep" variant (kernel_fused.hpp: DEEP) does the same, with a symbol ring sized for min_step >= kMinStepDeep.
+// Still refused: min_step < kMinStepDeep -- at min_step <= 0 the reference's own loop may never leave process() or walk
+// backwards out of its buffer, and between 0 and kMinStepDeep (more than 3.7 symbols per sample) the LDS ring is the limit.
+// Output rows are sized from the same bound (tetra_demod_bits_stride_for), so any accepted parameter set fits its rows.
+constexpr double kMinStepDeep = 0.27;
 inline bool params_ok(const DesignParams& p) {
     if (p.rrc_tap_count < 2 || p.rrc_tap_count > kPadTaps) return false;
     if (!(p.symbolrate > 0) || !(p.samplerate > 0)) return false;
     if (!(p.omega_rel_limit >= 0.0) || !(p.omega_rel_limit < 1.0)) return false;
     const float omega_min = (float)(p.samplerate / p.symbolrate * (1.0 - p.omega_rel_limit));
-    if (!((double)omega_min - std::fabs((double)(float)p.mu_gain) >= 1.0)) return false;
+    if (!((double)omega_min - std::fabs((double)(float)p.mu_gain) >= kMinStepDeep)) return false;
     return true;
 }
 
@@ -175,6 +179,8 @@ inline bool params_ok(const DesignParams& p) {
 // Smallest advance of the timing loop per symbol, in samples: every step adds freq + alpha * err to mu with
 // freq >= omega (1 - rel_limit) and |err| <= 1 (complex_fd.cpp:136-143), and floor(mu) of it moves the offset.
 inline double min_step(const Design& d) { return (double)d.k2.tr_min_freq - std::fabs((double)d.k2.tr_alpha); }
+// several symbols may share an offset: the launch takes the kernels' DEEP variant
+inline bool needs_deep(const Design& d) { return min_step(d) < 1.0; }
 inline long long bits_stride_for(const Design& d, long long n) {
     // K symbols are emitted only while (K - 1) min_step - 1 < n (the offsets of a call start at >= 0 and the fractional
     // parts of mu telescope to less than one sample):  K <= (n + 1) / min_step + 1; two symbols of margin for the float

@@ -69,7 +69,11 @@ constexpr int kFXS = kFXP + kFX + 1;     // row stride (odd: spreads channels ov
 constexpr int kFY = TETRA_EXP_YRING;     // y ring (RRC output) per channel ...
 constexpr int kFYM = 8;                  // ... plus a mirror of the first slots so the interpolator window never wraps
 constexpr int kFYS = kFY + kFYM + 1;
-constexpr int kFS = TETRA_EXP_SRING;     // symbol ring per channel
+constexpr int kFS = TETRA_EXP_SRING;     // symbol ring per channel: two epochs' worth of symbols while every symbol advances >= 1 sample
+constexpr int kFSDeep = 256;             // ... and for timing loops that may emit several symbols from one offset (floor(mu) = 0,
+                                         // complex_fd.cpp:141-143): an epoch's 32 samples then carry up to 33 / min_step + 1 symbols, the
+                                         // Costas wave runs one epoch behind, so the ring holds 2 (33 / min_step + 1) <= 256 for
+                                         // min_step >= kMinStepDeep (design.hpp: 0.27 samples per symbol).  16- and 4-channel shapes only.
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
 static_assert(kF16Pad == 80 && kF16Taps == 5, "fll16_asm.inc is generated for 16 positions x 5 taps");
@@ -156,11 +160,12 @@ struct FusedParams {
                          // bodies (barrier waits excluded), [7] = clocks from kernel entry to exit of wave 0; null = off
 };
 
-template <int CH> struct FusedLdsT {
+template <int CH, bool DEEP = false> struct FusedLdsT {
+    static constexpr int kS = DEEP ? kFSDeep : kFS;
     float2 a_buf[2][CH][kFAS];
     float2 x_ring[CH][kFXS];
     float2 y_ring[CH][kFYS];
-    float2 s_ring[CH][kFS];      // (rows 512 bytes apart; padding them by one entry was measured: +1 % / +2 % at 4096 / 1024 channels,
+    float2 s_ring[CH][kS];      // (rows 512 bytes apart; padding them by one entry was measured: +1 % / +2 % at 4096 / 1024 channels,
                                  // -0.6 % at 8192, profiles/r03/r03_y_exp.log -- left as it is)
     int s_avail[CH];
     int e_span[2][CH];       // 4-channel workgroup: the symbols [first, end) the Costas wave's recurrence lane has just finished
@@ -173,7 +178,7 @@ template <int CH> struct FusedLdsT {
 };
 typedef FusedLdsT<kFCh> FusedLds;
 static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256 &&
-              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024, "LDS budget of a CU");
+              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024 && sizeof(FusedLdsT<kFCh, true>) <= 104 * 1024, "LDS budget of a CU");
 
 // Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
 // register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
@@ -243,8 +248,13 @@ template <class LDS, class Row> struct FllDeviceIOT {
 #ifndef TETRA_EXP_WAVES_PER_EU
 #define TETRA_EXP_WAVES_PER_EU 1      // experiment builds: a larger value caps the VGPRs so that more waves fit a SIMD
 #endif
-template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParams p) {
-    typedef FusedLdsT<CH> Lds;
+// DEEP: the timing loop may emit several symbols from one offset (min_step < 1, see kFSDeep): deeper symbol ring, no forward-
+// progress clamp in the timing step, the output-row check on every symbol.  Everything else is the same code.
+template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParams p) {
+    typedef FusedLdsT<CH, DEEP> Lds;
+    constexpr int kSR = Lds::kS;          // symbol ring depth
+    constexpr int kMinAdv = DEEP ? 0 : 1;
+    static_assert(!DEEP || CH != kFChWide, "the deep symbol ring is instantiated for the 16- and 4-channel shapes");
     typedef FllRowT<float, Roles<CH>::FL, Roles<CH>::FT> FllRow;
     typedef FllDeviceIOT<Lds, FllRow> FllDeviceIO;
     typedef Roles<CH> R_;
@@ -547,7 +557,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
 #if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 4      // experiment builds only: the timing wave without its arithmetic
                         vr = w[0].x() + tr[0]; vi = w[0].y(); st.offset += 2;
 #else
-                        k2_timing_quad(k2, st, phase, w, tr, &vr, &vi);
+                        k2_timing_quad<kMinAdv>(k2, st, phase, w, tr, &vr, &vi);
 #endif
                     } else if constexpr (kDL == 2) {
                         lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5) + 32u);
@@ -557,7 +567,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                         q = bk[1]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
                         q = b2[0]; t2[0] = q.x; t2[1] = q.y; t2[2] = q.z; t2[3] = q.w;
                         q = b2[1]; t2[4] = q.x; t2[5] = q.y; t2[6] = q.z; t2[7] = q.w;
-                        k2_timing_pair(k2, st, phase, w, t0, t2, kq != 0, &vr, &vi);
+                        k2_timing_pair<kMinAdv>(k2, st, phase, w, t0, t2, kq != 0, &vr, &vi);
                     } else {
                         lds_cfloat4* bk = (lds_cfloat4*)(size_t)(bank_base + (phase << 5));
                         float t0[kInterpTaps]; float tm1[kInterpTaps]; float tp1[kInterpTaps];
@@ -567,17 +577,18 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                         q = bk[3]; t0[4] = q.x; t0[5] = q.y; t0[6] = q.z; t0[7] = q.w;
                         q = bk[4]; tp1[0] = q.x; tp1[1] = q.y; tp1[2] = q.z; tp1[3] = q.w;
                         q = bk[5]; tp1[4] = q.x; tp1[5] = q.y; tp1[6] = q.z; tp1[7] = q.w;
-                        k2_timing(k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
+                        k2_timing<kMinAdv>(k2, st, phase, w, tm1, t0, tp1, &vr, &vi);
                     }
-                    L.s_ring[c][S & (kFS - 1)] = make_float2(vr, vi);
+                    L.s_ring[c][S & (kSR - 1)] = make_float2(vr, vi);
                     S++;
                 };
-                // Output capacity guard.  Every symbol advances the offset by >= 1 sample (k2_timing), so this
+                // Output capacity guard.  (DEEP: always the per-symbol check -- several symbols may share an offset.)  Otherwise
+                // every symbol advances the offset by >= 1 sample (k2_timing), so this
                 // epoch adds at most limit - offset symbols.  If even that fits the output row the loop runs
                 // unchecked (always the case for a finite stream except near the end of very short calls);
                 // otherwise it checks per symbol, and a NaN/Inf-poisoned channel whose loop has stopped advancing
                 // properly is cut off at the row capacity instead of overrunning it.
-                if (S + (limit - st.offset) <= sym_cap) {
+                if (!DEEP && S + (limit - st.offset) <= sym_cap) {
                     while (st.offset < limit) one_symbol();
                 } else {
                     while (st.offset < limit) {
@@ -630,7 +641,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                     L.e_span[0][c] = S;
                     L.e_span[1][c] = avail;
                     while (S < avail) {
-                        const float2 v = L.s_ring[c][S & (kFS - 1)];
+                        const float2 v = L.s_ring[c][S & (kSR - 1)];
                         float zr; float zi;
 #if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 1      // experiment builds only: the Costas recurrence without its arithmetic
                         zr = v.x; zi = v.y;
@@ -638,7 +649,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                         k2_costas_rot(k2, st, v.x, v.y, &zr, &zi);
 #endif
                         zlast = make_float2(zr, zi);
-                        L.s_ring[c][S & (kFS - 1)] = zlast;
+                        L.s_ring[c][S & (kSR - 1)] = zlast;
                         S++;
                     }
                     // The symbol before this epoch's first one is NOT taken from the ring by the finishing lanes: at close to
@@ -650,9 +661,9 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
                 __builtin_amdgcn_wave_barrier();
                 const int f0 = L.e_span[0][fc], f1 = L.e_span[1][fc];
                 for (int i = f0 + fj; i < f1; i += kFin) {
-                    const float2 z = L.s_ring[fc][i & (kFS - 1)];
+                    const float2 z = L.s_ring[fc][i & (kSR - 1)];
                     // z of the symbol before: this epoch's own (in the ring), or the one the previous epoch ended on
-                    const float2* zpp = i == f0 ? &L.e_last[(e - 1) & 1][fc] : &L.s_ring[fc][(i - 1) & (kFS - 1)];
+                    const float2* zpp = i == f0 ? &L.e_last[(e - 1) & 1][fc] : &L.s_ring[fc][(i - 1) & (kSR - 1)];
                     const float2 zp = *zpp;
                     const int prevq = i == 0 ? prev0 : k2_quadrant(zp.x, zp.y);
                     const int d = k2_dibit(k2_quadrant(z.x, z.y), prevq);
@@ -692,7 +703,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh> __global__ __launch_bou
             if (e >= 4 && on) {
                 const int avail = L.s_avail[c];
                 while (S < avail) {
-                    const float2 v = L.s_ring[c][S & (kFS - 1)];
+                    const float2 v = L.s_ring[c][S & (kSR - 1)];
                     float zr; float zi;
 #if defined(TETRA_EXP_ABLATE) && TETRA_EXP_ABLATE == 1      // experiment builds only (profiles/r02): E without its arithmetic
                     zr = v.x; zi = v.y;

@@ -638,11 +638,15 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         // channels [0, n_wide) in 32-channel workgroups (see tetra_demod_create; their FLL rows hold 4 x 17 taps), the rest in
         // 16-channel ones: at most two launches, back to back on the stream
         // (band-edge filters of more than 68 taps do not fit the 32-channel shape's rows: then everything is "the rest")
-        const int n_wide = h->design.ntaps_be <= kF4Pad ? h->n_wide : 0;
+        // (the same for a timing loop that may emit several symbols from one offset: the deep symbol ring exists for the 16-
+        // and 4-channel shapes)
+        const bool deep = host::needs_deep(h->design);
+        const int n_wide = h->design.ntaps_be <= kF4Pad && !deep ? h->n_wide : 0;
         const bool rest_small = h->force_small || (h->small && h->C - n_wide <= kFChSmall * h->cus);
         const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh),
             gs((h->C - n_wide + kFChSmall - 1) / kFChSmall);
-        const bool a0 = pf.k1.fll_alpha == 0.0f;
+        // the FLL's loop filter runs with alpha = 0 (fll.cpp:25; design.hpp never produces anything else): only those kernels exist
+        if (pf.k1.fll_alpha != 0.0f) return TETRA_ERR_UNSUPPORTED;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
@@ -656,26 +660,24 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
 #endif
         HIP_TRY(h, hipEventRecord(ev[0], s));
 #ifdef TETRA_DEMOD_DEBUG
-        if (pf.prof && a0) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
-        else if (pf.prof) hipLaunchKernelGGL((k_fused<false, true>), gf, dim3(kFThreads), 0, s, pf);
+        if (pf.prof && !deep) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
         else
 #endif
         {
             if (n_wide > 0) {
                 const dim3 tw(fused_threads(kFChWide));
                 pf.ch_base = 0;
-                if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gw, tw, 0, s, pf);
-                else hipLaunchKernelGGL((k_fused<false, false, kFChWide>), gw, tw, 0, s, pf);
+                hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gw, tw, 0, s, pf);
             }
             if (n_wide < h->C && rest_small) {
                 const dim3 ts(fused_threads(kFChSmall));
                 pf.ch_base = n_wide;
-                if (a0) hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, pf);
-                else hipLaunchKernelGGL((k_fused<false, false, kFChSmall>), gs, ts, 0, s, pf);
+                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true>), gs, ts, 0, s, pf);
+                else hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, pf);
             } else if (n_wide < h->C) {
                 pf.ch_base = n_wide;
-                if (a0) hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
-                else hipLaunchKernelGGL((k_fused<false>), gf, dim3(kFThreads), 0, s, pf);
+                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true>), gf, dim3(kFThreads), 0, s, pf);
+                else hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
             }
         }
         if (h->q_ring)

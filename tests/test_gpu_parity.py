@@ -311,7 +311,8 @@ def test_setter_sequences_keep_what_they_do_not_own(pkg, oracle, synth):
     assert d.tables()["be_re"].size == 49 and np.array_equal(d.tables()["be_re"], orcs[0].bandedge_taps()[0])
     _run_vs_oracles(d, orcs, iq[:, 4000:])
     with pytest.raises(pkg.TetraDemodError):
-        d.set_param("omega_rel_limit", 0.6)                           # 2.22 x 0.4 - mu_gain < 1: symbols would stop advancing
+        d.set_param("omega_rel_limit", 0.9)                           # 2.22 x 0.1 - mu_gain < 0.27: below what the symbol ring holds
+    d.set_param("omega_rel_limit", 0.6)                               # 2.22 x 0.4 - mu_gain = 0.87: several symbols per offset, accepted (ABI 4)
     d.close()
 
 
@@ -790,7 +791,8 @@ def test_symbol_rate_setter_outside_two_samples_per_symbol(pkg, oracle, synth, p
     """set_param(SYMBOLRATE, 20000) at 36 ksps (omega 1.8, omega_min 1.764: up to 1.15 n bits per call).
     Rows are sized from the handle (tetra_demod_bits_stride_for), a call with the handle-free row length is refused loudly
     (TETRA_ERR_SIZE), and with the right rows every bit and symbol equals the oracle's driven through the same setter; a
-    symbol rate whose symbols could stop advancing is refused (TETRA_ERR_UNSUPPORTED) and changes nothing."""
+    symbol rate beyond what the kernels' symbol ring holds (min_step < 0.27 samples per symbol) is refused
+    (TETRA_ERR_UNSUPPORTED) and changes nothing; one sample per symbol is accepted since ABI 4 (test_below_one_sample_per_symbol_step)."""
     import ctypes as C
     Cn, N = 20, 9000
     iq, _, _ = synth.gen_batch(Cn, 2 * N, base_seed=2020, sps=1.8)
@@ -813,7 +815,7 @@ def test_symbol_rate_setter_outside_two_samples_per_symbol(pkg, oracle, synth, p
     nbits = d.process(np.ascontiguousarray(iq[:, :N]))[1]
     assert (nbits > small - 32).any() or (nbits > 2 * N / 1.9).all()      # more bits than the 2-samples-per-symbol row holds
     with pytest.raises(pkg.TetraDemodError) as ei:
-        d.set_param("symbolrate", 36000.0)                                 # omega 1: symbols could stop advancing
+        d.set_param("symbolrate", 150000.0)                                # omega 0.24: more than 3.7 symbols per sample
     assert ei.value.status == -2
     assert d.bits_stride(N) == need                                        # nothing changed
     d.close()
@@ -954,4 +956,63 @@ def test_short_calls_run_in_place_and_still_report(pkg, oracle, synth):
     assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 2 and nb[2] >= bits.shape[1] - 32
     bits, nb, _ = d.process(iq[:, :3000], allow_overrun=True)                 # a copy-engine call: the device counter
     assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 3
+    d.close()
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+@pytest.mark.parametrize("rate", [18360.0, 18000.0, 16200.0, 9000.0])
+def test_below_one_sample_per_symbol_step(pkg, oracle, synth, pipeline, rate):
+    """VERDICT r3 item 5 / missing 1: the part of COMPLEX_FD::process's domain where floor(mu) can be 0 and several symbols
+    leave ONE offset (/root/reference src/dsp/complex_fd.cpp:98-145: `offset += delta`, delta == 0) -- 1.02, 1.0, 0.9 and 0.5
+    samples per symbol at create (min_step 0.98 / 0.96 / 0.86 / 0.47).  Ragged calls with carried state (one of ONE sample: a
+    call that returns two symbols is such an event), every bit, symbol bit pattern, count and the loop state against the
+    oracle; rows sized by the handle (more bits than samples); no overrun reported.  The 32-channel shape has no deep symbol
+    ring: a handle forced to it runs these parameter sets in 16-channel workgroups (same results)."""
+    Cn = 21
+    cuts = [0, 1, 2, 700, 701, 3000, 6500]
+    iq, _, _ = synth.gen_batch(Cn, cuts[-1], base_seed=5100, sps=1.02)
+    d = pkg.Demodulator(Cn, 3500, flags=PIPELINES[pipeline] & SHAPE, samplerate=rate)
+    cfg = oracle.default_cfg()
+    cfg.samplerate = rate
+    orcs = [oracle.Oracle(cfg) for _ in range(Cn)]
+    assert d.bits_stride(3500) > 2 * 3500 * (18000.0 / rate) * 0.95
+    multi = total = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        blk = np.ascontiguousarray(iq[:, a:b])
+        bits, nb, sym = d.process(blk, want_sym=True)
+        for c, o in enumerate(orcs):
+            r = o.process(blk[c])
+            assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (c, a, b)
+            assert np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])), (c, a, b)
+            if b - a == 1:
+                multi += nb[c] >= 4
+            total += nb[c] // 2
+    assert total > 0.97 * Cn * cuts[-1] * (18000.0 / rate) and (multi > 0 or rate > 18000.0)
+    for c in range(Cn):
+        st, o = d.get_state(c), orcs[c].st
+        for f in ("agc_gain", "fll_phase", "fll_freq", "mu", "omega", "offset", "costas_phase", "costas_freq", "ph2", "prev"):
+            assert getattr(st, f) == getattr(o, f), (c, f)
+    assert d.overruns() == 0
+    d.close()
+
+
+def test_below_one_sample_per_symbol_a_poisoned_channel_is_cut_off_and_reported(pkg, oracle, synth):
+    """With min_step < 1 there is no forward-progress clamp in the timing step (the reference has none): a channel whose mu
+    is NaN stops advancing and fills its row from one offset -- it is cut off at the row and reported (TETRA_ERR_OVERRUN),
+    its neighbours equal the oracle."""
+    Cn, N = 9, 2000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=5200, sps=1.02)
+    d = pkg.Demodulator(Cn, N, samplerate=18000.0)
+    st = d.get_state(4)
+    st.mu = float("nan")
+    d.set_state(4, st)
+    cfg = oracle.default_cfg()
+    cfg.samplerate = 18000.0
+    bits, nb, _ = d.process(iq)
+    assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 1
+    assert nb[4] >= d.bits_stride(N) - 32
+    for c in range(Cn):
+        if c != 4:
+            r = oracle.Oracle(cfg).process(iq[c])
+            assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), c
     d.close()
