@@ -7,6 +7,44 @@
 namespace dsp {
 namespace demod {
 
+void DecisionTap::push(const uint8_t* bits, int nBits) {
+    std::lock_guard<std::mutex> l(m_);
+    bits_.insert(bits_.end(), bits, bits + nBits);
+}
+void DecisionTap::mark(long long pos, float err, bool sync) {
+    std::lock_guard<std::mutex> l(m_);
+    marks_.push_back(Mark{ pos, err, sync });
+}
+int DecisionTap::pop(int nSym, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync) {
+    std::lock_guard<std::mutex> l(m_);
+    const long long have = (long long)(bits_.size() / 2);
+    const int n = have < nSym ? (int)have : nSym;
+    for (int i = 0; i < n; i++) {
+        const uint8_t b1 = bits_[2 * (size_t)i], b0 = bits_[2 * (size_t)i + 1];
+        if (dibits) dibits[i] = (uint8_t)((b1 << 1) | b0);      // re-packing of the GPU's decisions, no arithmetic on samples
+        if (bits) { bits[2 * i] = b1; bits[2 * i + 1] = b0; }
+    }
+    bits_.erase(bits_.begin(), bits_.begin() + 2 * (size_t)n);
+    consumed_ += n;
+    while (!marks_.empty() && marks_.front().pos <= consumed_) {
+        if (standarderr) *standarderr = marks_.front().err;
+        if (sync) *sync = marks_.front().sync;
+        marks_.pop_front();
+    }
+    return n;
+}
+void DecisionTap::clear() {
+    std::lock_guard<std::mutex> l(m_);
+    bits_.clear();
+    marks_.clear();
+}
+
+std::shared_ptr<DecisionTap> PI4DQPSK::openTap() {
+    std::lock_guard<std::mutex> l(tapMtx_);
+    taps_.push_back(std::make_shared<DecisionTap>());
+    return taps_.back();
+}
+
 PI4DQPSK::~PI4DQPSK() {
     if (base_type::_block_init) base_type::stop();
     if (h_) tetra_demod_destroy(h_);
@@ -30,6 +68,8 @@ void PI4DQPSK::init(stream<complex_t>* in, double symbolrate, double samplerate,
     cfg.mu_gain = muGain;
     cfg.omega_rel_limit = omegaRelLimit;
     cfg.flags |= TETRA_FLAG_REFERENCE_QUIRKS;   // this class IS the reference's block: reset() and the RRC setters behave like pi4dqpsk.cpp
+    cfg.flags |= TETRA_FLAG_QUALITY;            // DQPSKSymbolExtractor's statistic is kept on the GPU for the mirror of that block (dqpsk_sym_extr_gpu.h)
+    symbols_ = 0;
     if (h_) { tetra_demod_destroy(h_); h_ = nullptr; }
     status_ = tetra_demod_create(&cfg, &h_);
     maxStride_ = 0;
@@ -101,6 +141,23 @@ int PI4DQPSK::process(int count, const complex_t* in, complex_t* out) {
     const int nsym = nb / 2;
     std::memcpy(out, symbuf_.data(), sizeof(complex_t) * (size_t)nsym);
     bits_.assign(bitbuf_.begin(), bitbuf_.begin() + nb);
+    // the downstream mirrors: the decisions of these symbols, and -- when the call crossed a 256-symbol boundary, where the
+    // reference publishes its statistic (dqpsk_sym_extr.cpp:17-30) -- the statistic the GPU has brought up to that boundary
+    {
+        std::lock_guard<std::mutex> l(tapMtx_);
+        const long long before = symbols_;
+        symbols_ += nsym;
+        if (!taps_.empty()) {
+            const long long boundary = symbols_ / 256 * 256;
+            float err = 0.f;
+            uint8_t sy = 0;
+            const bool fresh = boundary > before && tetra_demod_get_quality(h_, &err, &sy) == TETRA_OK;
+            for (auto& t : taps_) {
+                t->push(bitbuf_.data(), nb);
+                if (fresh) t->mark(boundary, err, sy != 0);
+            }
+        }
+    }
     return nsym;
 }
 

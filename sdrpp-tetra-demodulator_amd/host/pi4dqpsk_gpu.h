@@ -15,6 +15,7 @@
 #pragma once
 #include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -25,6 +26,34 @@
 
 namespace dsp {
 namespace demod {
+
+// The GPU's per-symbol decisions on their way to the blocks downstream of PI4DQPSK.  In the reference the symbols leave
+// PI4DQPSK through a stream and DQPSKSymbolExtractor / BitUnpacker -- separate blocks with their own worker threads -- slice
+// and unpack them on the CPU (src/main.cpp:84-91).  The kernels have already made those decisions for the very same symbols
+// (and keep DQPSKSymbolExtractor's statistic), so the GPU-backed mirrors of the two blocks (dqpsk_sym_extr_gpu.h,
+// bit_unpacker_gpu.h) take them from here instead of recomputing: a thread-safe FIFO written by PI4DQPSK::process (the
+// demodulator's worker thread), read by one consumer block's process() (that block's worker thread).  Bits are stored as the
+// kernels deliver them (one bit per byte, MSB of each dibit first); the statistic as (symbol position, value) marks that a
+// consumer applies once it has passed the position -- the reference updates standarderr / sync inside process() every 256
+// symbols (dqpsk_sym_extr.cpp:17-30).
+class DecisionTap {
+public:
+    void push(const uint8_t* bits, int nBits);
+    void mark(long long symbolPosition, float standarderr, bool sync);
+    // Takes the decisions of the next nSym symbols: dibits[nSym] (bit 1 = first bit; what DQPSKSymbolExtractor writes) and/or
+    // bits[2 nSym] (what BitUnpacker writes); applies every statistic mark passed on the way to *standarderr / *sync.
+    // Returns nSym, or the (smaller) number available if the source has not produced that many -- a wiring error.
+    int pop(int nSym, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync);
+    long long consumedSymbols() const { return consumed_; }
+    void clear();
+
+private:
+    struct Mark { long long pos; float err; bool sync; };
+    std::mutex m_;
+    std::deque<uint8_t> bits_;
+    std::deque<Mark> marks_;
+    long long consumed_ = 0;
+};
 
 class PI4DQPSK : public Processor<complex_t, complex_t> {
     using base_type = Processor<complex_t, complex_t>;
@@ -80,6 +109,10 @@ public:
     // TETRA_OK, or the status of the last failing C-ABI call.  TETRA_ERR_OVERRUN after process() means the call delivered
     // its symbols but a NaN/Inf-poisoned stream filled the output row and the rest of the call's samples were dropped.
     int lastStatus() const { return status_; }
+    // A FIFO of this demodulator's decisions for ONE downstream block (DQPSKSymbolExtractor::attach / BitUnpacker::attach call
+    // this); every process() from then on feeds it.  Open taps before start().
+    std::shared_ptr<DecisionTap> openTap();
+    tetra_demod_t* handle() { return h_; }
 
 private:
     void set(int id, double v);
@@ -89,6 +122,9 @@ private:
     int status_ = TETRA_ERR_ARG;
     std::vector<uint8_t> bitbuf_, bits_;
     std::vector<float> symbuf_;
+    std::vector<std::shared_ptr<DecisionTap>> taps_;
+    std::mutex tapMtx_;
+    long long symbols_ = 0;      // symbols produced since init (the statistic's 256-symbol boundaries are counted from there)
 };
 
 class PI4DQPSKBank {

@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
+#include "../../sdrpp-tetra-demodulator_amd/host/dqpsk_sym_extr_gpu.h"
+#include "../../sdrpp-tetra-demodulator_amd/host/bit_unpacker_gpu.h"
 
 // test_block multibank|multibank-cs16|multibank-device <iq.f32 [C][n]> <C> <n> <calls> <out_bits.u8> <out_nbits.i32> [dev0 dev1 ...]
 // PI4DQPSKMultiBank over the given devices (default: 0 0 = two shards, two host threads, two handles on ONE GPU), the
@@ -113,8 +115,103 @@ static int multibank_main(int argc, char** argv) {
     return 0;
 }
 
+// test_block chain3 <iq.f32> <chunk> <out_bits.u8> <out_dibits.u8> <out_symbols.f32>
+// The plugin's three blocks as src/main.cpp:84-91 wires them, all three GPU-backed mirrors, each with its own worker thread:
+//   source thread -> PI4DQPSK -> relay thread (stands where SDR++'s splitter is, src/main.cpp:85-87) -> DQPSKSymbolExtractor
+//   -> BitUnpacker -> sink (this thread).  No DSP arithmetic on the host anywhere: the sink only stores what arrives.
+// Prints "standarderr <float> sync <0|1>" = the extractor's public members after the last chunk.
+static int chain3_main(int argc, char** argv) {
+    (void)argc;
+    tetra_demod_config_t cfg;
+    tetra_demod_default_config(&cfg);
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f) return 2;
+    std::vector<float> iq;
+    float tmp[4096];
+    size_t r;
+    while ((r = std::fread(tmp, sizeof(float), 4096, f)) > 0) iq.insert(iq.end(), tmp, tmp + r);
+    std::fclose(f);
+    const int n = (int)(iq.size() / 2), chunk = std::atoi(argv[3]);
+
+    dsp::stream<dsp::complex_t> src, demodStream;
+    dsp::demod::PI4DQPSK mainDemodulator;
+    dsp::DQPSKSymbolExtractor symbolExtractor;
+    dsp::BitUnpacker bitsUnpacker;
+    mainDemodulator.init(&src, cfg.symbolrate, cfg.samplerate, cfg.rrc_tap_count, cfg.rrc_beta, cfg.agc_rate, cfg.costas_bandwidth,
+                         cfg.fll_bandwidth, cfg.omega_gain, cfg.mu_gain, cfg.omega_rel_limit);
+    if (mainDemodulator.lastStatus() != TETRA_OK) { std::fprintf(stderr, "init failed: %s\n", tetra_demod_strerror(mainDemodulator.lastStatus())); return 3; }
+    symbolExtractor.init(&demodStream);                // src/main.cpp:90
+    bitsUnpacker.init(&symbolExtractor.out);           // src/main.cpp:91
+    symbolExtractor.attach(&mainDemodulator);          // the one added line per block of the GPU drop-in
+    bitsUnpacker.attach(&mainDemodulator);
+    mainDemodulator.start();
+    symbolExtractor.start();
+    bitsUnpacker.start();
+    const int chunks = (n + chunk - 1) / chunk;
+    std::vector<float> syms;
+    std::thread feeder([&] {
+        for (int pos = 0; pos < n; pos += chunk) {
+            const int c = n - pos < chunk ? n - pos : chunk;
+            std::memcpy(src.writeBuf, iq.data() + 2 * (size_t)pos, sizeof(float) * 2 * (size_t)c);
+            if (!src.swap(c)) return;
+        }
+    });
+    std::thread relay([&] {                            // the splitter's place: every symbol chunk goes on unchanged
+        for (int k = 0; k < chunks; k++) {
+            const int c = mainDemodulator.out.read();
+            if (c < 0) return;
+            const float* p = reinterpret_cast<const float*>(mainDemodulator.out.readBuf);
+            syms.insert(syms.end(), p, p + 2 * (size_t)c);
+            std::memcpy(demodStream.writeBuf, mainDemodulator.out.readBuf, sizeof(dsp::complex_t) * (size_t)c);
+            mainDemodulator.out.flush();
+            if (!demodStream.swap(c)) return;
+        }
+    });
+    std::vector<uint8_t> bits;
+    for (int got = 0; got < chunks; got++) {
+        const int c = bitsUnpacker.out.read();
+        if (c < 0) break;
+        bits.insert(bits.end(), bitsUnpacker.out.readBuf, bitsUnpacker.out.readBuf + c);
+        bitsUnpacker.out.flush();
+    }
+    feeder.join();
+    relay.join();
+    std::printf("standarderr %.9g sync %d status %d %d %d\n", (double)symbolExtractor.standarderr, symbolExtractor.sync ? 1 : 0,
+                mainDemodulator.lastStatus(), symbolExtractor.lastStatus(), bitsUnpacker.lastStatus());
+    bitsUnpacker.stop();
+    symbolExtractor.stop();
+    mainDemodulator.stop();
+    FILE* fb = std::fopen(argv[4], "wb");
+    std::fwrite(bits.data(), 1, bits.size(), fb);
+    std::fclose(fb);
+    FILE* fs = std::fopen(argv[6], "wb");
+    std::fwrite(syms.data(), sizeof(float), syms.size(), fs);
+    std::fclose(fs);
+    // the extractor's own process() signature, called directly the way a unit test of the reference's block would: dibits of a
+    // second, short stream through the same demodulator
+    {
+        std::vector<dsp::complex_t> out((size_t)chunk);
+        std::vector<uint8_t> dib((size_t)chunk);
+        const int ns = mainDemodulator.process(chunk, reinterpret_cast<const dsp::complex_t*>(iq.data()), out.data());
+        if (ns < 0) return 4;
+        uint8_t ub[4096];
+        const int nd = symbolExtractor.process(ns, out.data(), dib.data());
+        const int nbit = bitsUnpacker.process(nd, dib.data(), ub);
+        if (nd != ns || nbit != 2 * ns || symbolExtractor.lastStatus() != TETRA_OK || bitsUnpacker.lastStatus() != TETRA_OK) return 5;
+        FILE* fd = std::fopen(argv[5], "wb");
+        std::fwrite(dib.data(), 1, (size_t)nd, fd);
+        std::fwrite(ub, 1, (size_t)nbit, fd);
+        std::fclose(fd);
+        // a stream that does NOT come from the attached demodulator is flagged, not silently sliced
+        if (symbolExtractor.process(3, out.data(), dib.data()) != 3 || symbolExtractor.lastStatus() != TETRA_ERR_ARG) return 6;
+    }
+    std::printf("symbols %zu bits %zu\n", syms.size() / 2, bits.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 8 && !std::strncmp(argv[1], "multibank", 9)) return multibank_main(argc, argv);
+    if (argc >= 7 && !std::strcmp(argv[1], "chain3")) return chain3_main(argc, argv);
     tetra_demod_config_t cfg;
     tetra_demod_default_config(&cfg);
     if (argc < 5) {

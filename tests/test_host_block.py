@@ -13,9 +13,10 @@ EXE = os.path.join(ROOT, "tests", "host", "test_block")
 
 def _build(pkg):
     pkg.build.build()
-    srcs = [os.path.join(ROOT, "tests", "host", "test_block.cpp"), os.path.join(PK, "host", "pi4dqpsk_gpu.cpp")]
-    deps = srcs + [os.path.join(PK, "host", "pi4dqpsk_gpu.h"), os.path.join(PK, "host", "dsp_compat.h"),
-                   os.path.join(ROOT, "include", "tetra_demod.h")]
+    srcs = [os.path.join(ROOT, "tests", "host", "test_block.cpp")] + [os.path.join(PK, "host", f) for f in
+                                                                       ("pi4dqpsk_gpu.cpp", "dqpsk_sym_extr_gpu.cpp", "bit_unpacker_gpu.cpp")]
+    deps = srcs + [os.path.join(PK, "host", f) for f in ("pi4dqpsk_gpu.h", "dqpsk_sym_extr_gpu.h", "bit_unpacker_gpu.h", "dsp_compat.h")] + \
+        [os.path.join(ROOT, "include", "tetra_demod.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         # libamdhip64 only for the test driver's own device buffers ("multibank-device"); the mirror itself needs just the C ABI
         subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + srcs +
@@ -46,6 +47,39 @@ def test_block_mirror_streams_like_the_plugin(pkg, oracle, synth, tmp_path):
     r = oracle.Oracle().process(iq)
     assert np.array_equal(sym.view(np.uint32), r["sym"].view(np.uint32))
     assert np.array_equal(bits, r["bits"])
+
+
+@pytest.mark.gpu
+def test_three_mirrored_blocks_stream_like_the_plugin(pkg, oracle, synth, tmp_path):
+    """PI4DQPSK -> DQPSKSymbolExtractor -> BitUnpacker, all three the GPU-backed mirrors
+    (/root/reference src/dsp/dqpsk_sym_extr.h:19-46, bit_unpacker.h:16-34; wired as src/main.cpp:84-91), each on its own worker
+    thread, 180-sample chunks from a file as SDR++ delivers them (BASELINE config 1's shape).  The sink's bits equal the
+    oracle's, the extractor's public standarderr / sync (the GUI's meter, src/main.cpp:211,215) equal the oracle's faithful
+    restatement of the statistic within 2e-6 -- and no DSP arithmetic ran on the host (the mirrors only move the kernels'
+    decisions).  The blocks' own process() signatures called directly give the same dibits / bits."""
+    exe = _build(pkg)
+    N = 36000
+    iq, _, _ = synth.gen_channel(N, 78)
+    f_in = tmp_path / "iq.f32"
+    iq.view(np.float32).tofile(f_in)
+    f_bits, f_dib, f_sym = tmp_path / "bits.u8", tmp_path / "dib.u8", tmp_path / "sym.f32"
+    r = subprocess.run([exe, "chain3", str(f_in), "180", str(f_bits), str(f_dib), str(f_sym)], timeout=300, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    o = oracle.Oracle()
+    want = o.process(iq)
+    bits = np.fromfile(f_bits, np.uint8)
+    sym = np.fromfile(f_sym, np.float32).view(np.complex64)
+    assert np.array_equal(bits, want["bits"]) and np.array_equal(sym.view(np.uint32), want["sym"].view(np.uint32))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("standarderr")][0].split()
+    err, sync, statuses = float(line[1]), int(line[3]), [int(x) for x in line[5:8]]
+    assert statuses == [0, 0, 0]
+    assert want["sym"].size >= 4096 + 256                                   # the ring is full of real distances by the end
+    assert abs(err - float(o.st.standarderr)) < 2e-6 and sync == int(o.st.sync) == 1, (err, float(o.st.standarderr))
+    # direct calls of the two blocks' process() on a further 180 samples
+    w2 = o.process(iq[:180])
+    raw = np.fromfile(f_dib, np.uint8)
+    ns = w2["dibits"].size
+    assert raw.size == 3 * ns and np.array_equal(raw[:ns], w2["dibits"]) and np.array_equal(raw[ns:], w2["bits"])
 
 
 @pytest.mark.gpu
