@@ -272,13 +272,30 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         check = dict(carriers=len(tx), bits_compared_second_half=int(ncmp), bit_errors=int(errs), idle_channels=len(idle))
         if ncmp < 2000 * len(tx) or errs > 1e-3 * ncmp:
             raise SystemExit("config 5 known-answer check failed: %d bit errors in %d bits of %d carriers" % (errs, ncmp, len(tx)))
+    # Rooflines of the leg's two kernels.  Channeliser: algorithmic bytes = the capture read once + the frames written once
+    # (8 B per wideband sample in, 8 B per channel-sample out); algorithmic flops = the weighted overlap-add (L = P M taps, 4 flop
+    # each) + the 25 x 32 DFT's 57 complex multiply-adds per output (8 flop each), per frame.  Demodulator: 9 B per channel-sample.
+    ch_bytes = 8.0 * n_in + 8.0 * frames * M
+    ch_flop = frames * (4.0 * P * M + 8.0 * M * (25 + 32))
+    dm_bytes = ALGO_BYTES_PER_SAMPLE * frames * M
+    roof = {"channeliser": {"kernel": "k_channelise_mfma", "kernel_ms": round(ch_ms, 4),
+                            "hbm": {"achieved": round(ch_bytes / (ch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(ch_bytes / (ch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": ch_bytes},
+                            "fp32": {"achieved": round(ch_flop / (ch_ms * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(ch_flop / (ch_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), "algorithmic_flop": ch_flop,
+                                     "note": "FP32 matrix peak = FP32 vector peak on gfx950 (157.3 TFLOP/s); the DFT stages run as "
+                                             "v_mfma_f32_16x16x4_f32 on the 2x2 block form, which spends 1.25x the algorithmic flops on padding"}},
+            "demodulator": {"kernel": "k_fused<.., 4>", "kernel_ms": round(float(k1[0]), 4),
+                            "hbm": {"achieved": round(dm_bytes / (float(k1[0]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(dm_bytes / (float(k1[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                            "note": "800 channels = 200 four-channel workgroups: 200 of the 256 CUs, each at the per-sample recurrence's pace"}}
     res = {"metric": "wideband IQ Msamples/s channelised and demodulated to bits (BASELINE config 5)",
            "value": round(args.steps * n_in / el / 1e6, 2), "unit": "Msamples/s (20 MHz capture)",
            "ms_per_step": round(el / args.steps * 1e3, 3), "realtime_factor": round(args.steps * n_in / el / 20e6, 1),
            "channeliser_kernel_ms": round(ch_ms, 3), "demod_kernel_ms": round(float(k1[0]), 3),
            "two_streams_ms_per_step": round(el2 / args.steps * 1e3, 3),
            "two_streams_realtime_factor": round(args.steps * n_in / el2 / 20e6, 1),
-           "check": check,
+           "check": check, "roofline": roof,
            "config": {"workload": "5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> bits",
                       "channels": M, "taps_per_channel": P, "decimation": D}}
     del outs

@@ -33,10 +33,17 @@ typedef struct tetra_chan_config {
     int32_t decimation;        /* D >= 1 */
     int32_t max_in;            /* largest n_in of one process call */
     int32_t device;            /* HIP device ordinal, -1 = current */
-    int32_t reserved;
+    int32_t reserved;          /* flags: TETRA_CHAN_FLAG_* (0 = default) */
     double cutoff_rel;         /* prototype cutoff relative to half the channel spacing (1.0 = Fs/(2M)); default 1.2 */
     const float* prototype;    /* optional caller-supplied prototype [P*M]; NULL = Kaiser(beta 9)-windowed sinc */
 } tetra_chan_config_t;
+
+/* tetra_chan_config_t.reserved */
+enum {
+    TETRA_CHAN_FLAG_VALU_DFT = 1 /* keep the direct-sum DFT kernel even where the matrix-pipe form exists (M = 800 = 25 x 32 runs its
+                                    two DFT stages as chained v_mfma_f32_16x16x4_f32 by default); same results within the
+                                    documented float32 tolerance.  For A/B measurements and tests. */
+};
 
 typedef struct tetra_chan tetra_chan_t;
 

@@ -354,6 +354,9 @@ def chan_lib():
         L.chan_oracle_process.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                           C.c_int, vp, vp]
         L.chan_oracle_process.restype = C.c_int
+        L.chan_oracle_process_channels.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                                                   C.c_int, vp, vp, C.c_int, vp]
+        L.chan_oracle_process_channels.restype = C.c_int
         _chan = L
     return _chan
 
@@ -369,12 +372,16 @@ class ChanOracle:
         self.phase = C.c_int(0)
         self.frame = C.c_int64(0)
 
-    def process(self, x):
+    def process(self, x, channels=None):
+        """All M channels, or -- channels = a list of channel indices -- only those (columns in that order): the definition is
+        evaluated per channel, so a subset costs proportionally less."""
         x = np.ascontiguousarray(x, np.complex64)
         nf = (self.phase.value + x.shape[0]) // self.D
-        out = np.zeros((max(nf, 1), self.M), np.complex64)
-        got = chan_lib().chan_oracle_process(self.M, self.P, self.D, _ptr(self.h), _ptr(self.hist), C.byref(self.phase),
-                                             C.byref(self.frame), x.shape[0], _ptr(x), _ptr(out))
+        sel = None if channels is None else np.ascontiguousarray(channels, np.int32)
+        ncol = self.M if sel is None else int(sel.size)
+        out = np.zeros((max(nf, 1), ncol), np.complex64)
+        got = chan_lib().chan_oracle_process_channels(self.M, self.P, self.D, _ptr(self.h), _ptr(self.hist), C.byref(self.phase),
+                                                      C.byref(self.frame), x.shape[0], _ptr(x), _ptr(out), ncol, _ptr(sel))
         return out[:got]
 
 

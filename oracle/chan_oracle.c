@@ -57,8 +57,17 @@ void chan_oracle_prototype(int M, int P, double cutoff_rel, float* h) {
  * Emits frames m = 0 .. n_frames-1 with n_frames = floor((phase + n_in) / D) where `phase` in [0, D) is the number of
  * samples already consumed towards the next frame (carried in *phase).  Frame j of this call is aligned so that its
  * newest sample is x[(j+1)*D - 1 - phase0].  out: [n_frames][M] complex (re,im).  Returns n_frames. */
+/* The same, for the n_sel channels sel[] only (out: [n_frames][n_sel]); sel == NULL: all M channels (out: [n_frames][M]). */
+int chan_oracle_process_channels(int M, int P, int D, const float* h, float* hist, int* phase, int64_t* frame_index,
+                                 int n_in, const float* x, float* out, int n_sel, const int32_t* sel);
+
 int chan_oracle_process(int M, int P, int D, const float* h, float* hist, int* phase, int64_t* frame_index,
                         int n_in, const float* x, float* out) {
+    return chan_oracle_process_channels(M, P, D, h, hist, phase, frame_index, n_in, x, out, M, NULL);
+}
+
+int chan_oracle_process_channels(int M, int P, int D, const float* h, float* hist, int* phase, int64_t* frame_index,
+                                 int n_in, const float* x, float* out, int n_sel, const int32_t* sel) {
     const int L = M * P;
     const int ph0 = *phase;
     const int n_frames = (ph0 + n_in) / D;
@@ -67,27 +76,35 @@ int chan_oracle_process(int M, int P, int D, const float* h, float* hist, int* p
     for (int i = 0; i < L - 1; i++) { br[2 * i] = hist[2 * i]; br[2 * i + 1] = hist[2 * i + 1]; }
     for (int i = 0; i < n_in; i++) { br[2 * (L - 1 + i)] = x[2 * i]; br[2 * (L - 1 + i) + 1] = x[2 * i + 1]; }
     const int64_t f0 = *frame_index;
+    /* exp(-j 2 pi q / M) for q = 0 .. M-1: the phasor of the definition depends on k n mod M only, so it is evaluated once per
+     * residue instead of once per (frame, channel, tap) -- the same double-precision values, memoised */
+    double* ct = (double*)malloc(sizeof(double) * (size_t)M * 2);
+    for (int q = 0; q < M; q++) {
+        const double ang = -2.0 * CH_PI * (double)q / (double)M;
+        ct[2 * q] = cos(ang);
+        ct[2 * q + 1] = sin(ang);
+    }
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (int j = 0; j < n_frames; j++) {
         const int newest = (j + 1) * D - 1 - ph0;            /* index into x of this frame's newest sample */
         /* absolute sample time of the newest sample: n_abs = (f0 + j + 1)*D - 1  (stream starts at n = 0) */
         const int64_t n_abs = (f0 + j + 1) * (int64_t)D - 1;
-        for (int k = 0; k < M; k++) {
+        for (int ks = 0; ks < n_sel; ks++) {
+            const int k = sel ? sel[ks] : ks;
             double ar = 0.0, ai = 0.0;
             for (int l = 0; l < L; l++) {
                 const int bi = (L - 1) + newest - l;          /* >= 0 */
                 const int64_t n = n_abs - l;
                 const int64_t kn = ((int64_t)k * (n % M + M)) % M; /* k*n mod M */
-                const double ang = -2.0 * CH_PI * (double)kn / (double)M;
-                const double c = cos(ang), s = sin(ang);
+                const double c = ct[2 * kn], s = ct[2 * kn + 1];
                 const double xr = br[2 * bi], xi = br[2 * bi + 1];
                 ar += (double)h[l] * (xr * c - xi * s);
                 ai += (double)h[l] * (xr * s + xi * c);
             }
-            out[((size_t)j * M + k) * 2] = (float)ar;
-            out[((size_t)j * M + k) * 2 + 1] = (float)ai;
+            out[((size_t)j * n_sel + ks) * 2] = (float)ar;
+            out[((size_t)j * n_sel + ks) * 2 + 1] = (float)ai;
         }
     }
     /* carry */
@@ -95,6 +112,7 @@ int chan_oracle_process(int M, int P, int D, const float* h, float* hist, int* p
     for (int i = 0; i < L - 1; i++) { hist[2 * i] = (float)br[2 * (consumed + i)]; hist[2 * i + 1] = (float)br[2 * (consumed + i) + 1]; }
     *phase = (ph0 + n_in) % D;
     *frame_index = f0 + n_frames;
+    free(ct);
     free(br);
     return n_frames;
 }

@@ -64,7 +64,26 @@ for sec in range(SEC):
     locked = sum(1 for st in bs.states() if st[0] == bb.RX_S_LOCKED)
     nf = d_nf.cpu().numpy()
     ft = d_ft.cpu().numpy()
+    # Rooflines: algorithmic HBM bytes of every stage against 8 TB/s, and -- the decoder's add-compare-select
+    # recursion is integer VALU work -- its vector-instruction rate against the chip's issue peak (256 CUs x 4 SIMDs x one wave
+    # instruction per 4 clocks at 2.4 GHz = 614 G wave-instructions/s; 68 instructions per trellis step per 64-block wave,
+    # DESIGN.md 8.3).  Bytes: demodulator 9 B per sample; synchroniser = the bit rows it scans + the 512-byte frames it writes;
+    # a demux launch = frame types + the frames that carry the kind (read) + every row slot (written); a decode launch = every
+    # row slot read + type-1 bits, CRC flag and scrambling code per slot.
+    n_bits_total = int(d_nbits.sum().item())
+    frames_total = int(nf.sum())
+    by = {"demod": 9.0 * C * N, "burst_sync": n_bits_total + 512.0 * frames_total + 8.0 * C * F}
+    by["demux_x4"] = sum(4.0 * C * F + float(rs) * int((bufs[name][1] != 0).sum().item()) + float(rs) * C * F for name, _, _, rs, _ in kinds)
+    by["lmac_x4"] = sum((float(rs) + os_ + 8.0) * C * F for _, _, _, rs, os_ in kinds)
+    steps = {"SB1": 80 + 4, "SB2": 144 + 4, "SCH/F": 288 + 4}          # trellis steps per block incl. the flush (BBK: no Viterbi)
+    wave_instr = sum(68.0 * steps[k[0]] * (C * F / 64.0) for k in kinds if k[0] in steps)
+    roof = {st_: {"bytes": round(b), "GBps": round(b / (ms * 1e-3) / 1e9, 1), "frac_hbm_8TBps": round(b / (ms * 1e-3) / 8e12, 4)}
+            for st_, b, ms in (("demod", by["demod"], t[0]), ("burst_sync", by["burst_sync"], t[1]), ("demux_x4", by["demux_x4"], t[2]),
+                               ("lmac_x4", by["lmac_x4"], t[3]))}
+    roof["lmac_x4"]["valu_wave_instr_per_s"] = round(wave_instr / (t[3] * 1e-3) / 1e9, 1)
+    roof["lmac_x4"]["frac_valu_issue_614G"] = round(wave_instr / (t[3] * 1e-3) / 614.4e9, 4)
+    roof["lmac_x4"]["bound"] = "valu-issue (integer add-compare-select)"
     print(json.dumps({"second": sec, "channels": C, "samples_per_channel": N, "ms_demod": round(t[0], 3), "ms_burst_sync": round(t[1], 3),
                       "ms_demux_x4": round(t[2], 3), "ms_lmac_x4": round(t[3], 3), "ms_total": round(sum(t), 3),
                       "x_real_time": round(1000.0 / sum(t), 1), "channels_locked": locked, "frames": int(nf.sum()),
-                      "bursts_with_callback": int((ft >= 0).sum()), "frame_slots_decoded_per_kind": C * F}))
+                      "bursts_with_callback": int((ft >= 0).sum()), "frame_slots_decoded_per_kind": C * F, "roofline": roof}))

@@ -42,8 +42,10 @@ def _lib():
 class Channeliser:
     """M-channel analysis filter bank on one GPU; emits time-major frames [frames][M] complex64."""
 
+    FLAG_VALU_DFT = 1      # TETRA_CHAN_FLAG_VALU_DFT: keep the direct-sum DFT kernel where the matrix-pipe form exists (M = 800)
+
     def __init__(self, n_channels=800, taps_per_channel=8, decimation=None, max_in=1 << 20, device=-1, cutoff_rel=1.2,
-                 prototype=None):
+                 prototype=None, flags=0):
         self._lib = _lib()
         cfg = ChanConfig()
         self._lib.tetra_chan_default_config(C.byref(cfg))
@@ -53,6 +55,7 @@ class Channeliser:
         cfg.max_in = max_in
         cfg.device = device
         cfg.cutoff_rel = cutoff_rel
+        cfg.reserved = flags
         keep = None
         if prototype is not None:
             keep = np.ascontiguousarray(prototype, np.float32)

@@ -6,6 +6,13 @@
 // length N2 (direct sums: N1, N2 <= 64; for M = 800 that is 25 + 32 complex MACs per output instead of 800).  Frames go
 // out time-major, out[m][k] -- exactly the TETRA_LAYOUT_TIME_MAJOR input of the demodulator.  Per second of a 20 MHz
 // capture this is ~2.3 G complex MACs and 160 MB in / 320 MB out: a small fraction of the demodulator's time.
+//
+// M = 800 = 25 x 32 (BASELINE config 5) runs the two DFT stages on the MATRIX pipe instead (k_channelise_mfma below): a complex
+// DFT stage is a real matrix product with the 2 x 2 block form of the twiddle matrix, so 104 + 128 chained
+// v_mfma_f32_16x16x4_f32 per frame (exact f32 fma chains, MI355X_MICROARCH.md) replace 800 x 57 complex multiply-adds issued
+// as 8 VALU + 3 integer + 2 LDS instructions each (this file is compiled with -ffp-contract=off: the direct form cannot even
+// contract its products).  The twiddle blocks are CONSTANT operands and stay in registers for the workgroup's whole life; the
+// data operands make one trip through LDS per stage.  TETRA_CHAN_FLAG_VALU_DFT keeps the direct-sum kernel (A/B, other sizes).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -97,6 +104,126 @@ __global__ __launch_bounds__(kThreads) void k_channelise(ChanParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Matrix-pipe form for M = N1 x N2 = 25 x 32.  One workgroup = four waves, looping over frames; per frame:
+//   fold       v[r] as before, written to LDS as the A operand of stage 1:  At[k][n2],  k = n1 (real parts) | N1 + n1 (imaginary)
+//   stage 1    Bt[n2][k1] = sum_n1 V[n1][n2] W_N1^(n1 k1)        as  [n2 x 52] . [52 x 64]: columns k1 (re) | 32 + k1 (im);
+//              constant operand Bc = [[Wr, Wi], [-Wi, Wr]] (zero-padded), 13 k-steps; then the twiddle W_M^(n2 k1) (four
+//              constants per lane) and the result goes to LDS as the B operand of stage 2:  Bo[k][k1], k = n2 (re) | 32 + n2 (im)
+//   stage 2    Xt[k2][k1] = sum_n2 W_N2^(n2 k2) Bt[n2][k1]        as  [64 x 64] . [64 x 32]: rows k2 (re) | 32 + k2 (im);
+//              constant operand Ac = [[Wr, -Wi], [Wi, Wr]], 16 k-steps; lane (g = l >> 4, c = l & 15) ends up with re and im of
+//              X[k1 + N1 k2] for k2 = 16 mt + 4 g + r, k1 = 16 nt + c: 16 consecutive bins per store = 128-byte runs.
+// Wave w owns two output tiles per stage that share their data operand (stage 1: n2 rows 16 (w & 1) .., columns re / im of k1
+// 16 (w >> 1) ..; stage 2: rows re / im of k2 16 (w & 1) .., columns k1 16 (w >> 1) ..), so a stage costs a wave 13 (16) LDS
+// reads and 26 (32) MFMAs.  v_mfma_f32_16x16x4_f32 operand layout: a = A[row l & 15][k l >> 4], b = B[k l >> 4][col l & 15],
+// acc[r] = D[row 4 (l >> 4) + r][col l & 15] (checked by tetra_demod_debug_mfma_selftest).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float chan_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMN1 = 25, kMN2 = 32;
+constexpr int kMK1 = (2 * kMN1 + 3) / 4;          // 13 k-steps of stage 1 (K = 50 -> 52)
+constexpr int kMK2 = 2 * kMN2 / 4;                // 16 k-steps of stage 2 (K = 64)
+constexpr int kMAtStride = 48;                    // floats per At row (32 used): rows 16 banks apart -> the four k of a fragment read hit 2 x 16 banks
+constexpr int kMBoStride = 36;                    // floats per Bo row (32 used)
+
+struct ChanMfmaParams {
+    const float2* xbuf;
+    float2* out;
+    const float* h;
+    const float* bc;       // [4 kMK1][64] stage-1 constant operand
+    const float* ac;       // [64][64]     stage-2 constant operand
+    const float2* wm;      // exp(-j 2 pi i / M)
+    int P, D, frames;
+    int ph0;
+    long long abs0;
+};
+
+__global__ __launch_bounds__(kThreads) void k_channelise_mfma(ChanMfmaParams p) {
+    constexpr int M = kMN1 * kMN2;
+    __shared__ float At[4 * kMK1][kMAtStride];
+    __shared__ float Bo[2 * kMN2][kMBoStride];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int wlo = w & 1, whi = w >> 1;
+    // constant operands of this wave's tiles (registers for the workgroup's life)
+    float b1re[kMK1], b1im[kMK1], a2re[kMK2], a2im[kMK2];
+#pragma unroll
+    for (int s = 0; s < kMK1; s++) {
+        b1re[s] = p.bc[(4 * s + g) * 64 + 16 * whi + c];
+        b1im[s] = p.bc[(4 * s + g) * 64 + 32 + 16 * whi + c];
+    }
+#pragma unroll
+    for (int s = 0; s < kMK2; s++) {
+        a2re[s] = p.ac[(16 * wlo + c) * 64 + 4 * s + g];
+        a2im[s] = p.ac[(32 + 16 * wlo + c) * 64 + 4 * s + g];
+    }
+    // W_M^(n2 k1) for this lane's four stage-1 results: n2 = 16 wlo + 4 g + r, k1 = 16 whi + c
+    float2 tw[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int n2 = 16 * wlo + 4 * g + r, k1 = 16 * whi + c;
+        tw[r] = k1 < kMN1 ? p.wm[(n2 * k1) % M] : make_float2(0.f, 0.f);
+    }
+    // padding rows of the stage-1 data operand (k = 50, 51) are zero for ever
+    if (tid < 2 * kMAtStride) At[2 * kMN1 + tid / kMAtStride][tid % kMAtStride] = 0.f;
+    const int L = M * p.P;
+    for (int j = blockIdx.x; j < p.frames; j += gridDim.x) {
+        const int newest = (j + 1) * p.D - 1 - p.ph0;
+        const long long n_abs = p.abs0 + newest;
+        const int nm = (int)(n_abs % M);
+        const float2* xn = p.xbuf + (L - 1) + newest;
+        for (int r = tid; r < M; r += kThreads) {
+            int l0 = nm - r;
+            if (l0 < 0) l0 += M;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int q = 0; q < p.P; q++) {
+                const int l = l0 + q * M;
+                const float hv = p.h[l];
+                const float2 xv = xn[-l];
+                acc.x = fmaf(hv, xv.x, acc.x);
+                acc.y = fmaf(hv, xv.y, acc.y);
+            }
+            const int n1 = r / kMN2, n2 = r % kMN2;
+            At[n1][n2] = acc.x;
+            At[kMN1 + n1][n2] = acc.y;
+        }
+        __syncthreads();
+        {   // stage 1
+            chan_f32x4 dre = { 0.f, 0.f, 0.f, 0.f }, dim_ = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < kMK1; s++) {
+                const float a = At[4 * s + g][16 * wlo + c];
+                dre = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1re[s], dre, 0, 0, 0);
+                dim_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1im[s], dim_, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float2 t = cmul(make_float2(dre[r], dim_[r]), tw[r]);
+                const int n2 = 16 * wlo + 4 * g + r;
+                Bo[n2][16 * whi + c] = t.x;
+                Bo[kMN2 + n2][16 * whi + c] = t.y;
+            }
+        }
+        __syncthreads();
+        {   // stage 2
+            chan_f32x4 xre = { 0.f, 0.f, 0.f, 0.f }, xim = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < kMK2; s++) {
+                const float b = Bo[4 * s + g][16 * whi + c];
+                xre = __builtin_amdgcn_mfma_f32_16x16x4f32(a2re[s], b, xre, 0, 0, 0);
+                xim = __builtin_amdgcn_mfma_f32_16x16x4f32(a2im[s], b, xim, 0, 0, 0);
+            }
+            const int k1 = 16 * whi + c;
+            if (k1 < kMN1) {
+                float2* dst = p.out + (long long)j * M + k1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[kMN1 * (16 * wlo + 4 * g + r)] = make_float2(xre[r], xim[r]);
+            }
+        }
+        // no third barrier: the next frame's fold rewrites At, which every wave finished reading before the barrier above;
+        // its stage 1 rewrites Bo only behind the next frame's first barrier, which every wave passes after its stage-2 reads
+    }
+}
+
 }  // namespace
 
 struct tetra_chan {
@@ -108,6 +235,9 @@ struct tetra_chan {
     float2* xalt = nullptr;     // same size: receives the next call's history (one copy, then the two swap roles)
     float* d_h = nullptr;
     float2 *d_w1 = nullptr, *d_w2 = nullptr, *d_wm = nullptr;
+    float *d_bc = nullptr, *d_ac = nullptr;   // matrix-pipe form: the two constant block-twiddle operands (k_channelise_mfma)
+    bool mfma = false;
+    int cus = 256;
     float2* st_out = nullptr;   // host-path staging
     size_t st_out_frames = 0;
     int phase = 0;              // samples consumed towards the next frame
@@ -187,11 +317,32 @@ int upload_twiddles(tetra_chan* h) {
     CH_TRY(h, hipMemcpy(h->d_w2, w2.data(), sizeof(float2) * w2.size(), hipMemcpyHostToDevice));
     CH_TRY(h, hipMemcpy(h->d_wm, wm.data(), sizeof(float2) * wm.size(), hipMemcpyHostToDevice));
     CH_TRY(h, hipMemcpy(h->d_h, h->proto.data(), sizeof(float) * h->proto.size(), hipMemcpyHostToDevice));
+    if (h->mfma) {
+        // stage 1: Bc[k][col], k = n1 | N1 + n1, col = k1 | 32 + k1:  re = Vr Wr - Vi Wi, im = Vr Wi + Vi Wr, W = W_N1^(n1 k1)
+        std::vector<float> bc((size_t)4 * kMK1 * 64, 0.f), ac((size_t)64 * 64, 0.f);
+        for (int n1 = 0; n1 < kMN1; n1++)
+            for (int k1 = 0; k1 < kMN1; k1++) {
+                const double a = -2.0 * pi * (double)((n1 * k1) % kMN1) / kMN1;
+                const float wr = (float)std::cos(a), wi = (float)std::sin(a);
+                bc[(size_t)n1 * 64 + k1] = wr;            bc[(size_t)n1 * 64 + 32 + k1] = wi;
+                bc[(size_t)(kMN1 + n1) * 64 + k1] = -wi;  bc[(size_t)(kMN1 + n1) * 64 + 32 + k1] = wr;
+            }
+        // stage 2: Ac[row][k], row = k2 | 32 + k2, k = n2 | 32 + n2:  re = Wr Br - Wi Bi, im = Wi Br + Wr Bi, W = W_N2^(n2 k2)
+        for (int k2 = 0; k2 < kMN2; k2++)
+            for (int n2 = 0; n2 < kMN2; n2++) {
+                const double a = -2.0 * pi * (double)((n2 * k2) % kMN2) / kMN2;
+                const float wr = (float)std::cos(a), wi = (float)std::sin(a);
+                ac[(size_t)k2 * 64 + n2] = wr;            ac[(size_t)k2 * 64 + 32 + n2] = -wi;
+                ac[(size_t)(32 + k2) * 64 + n2] = wi;     ac[(size_t)(32 + k2) * 64 + 32 + n2] = wr;
+            }
+        CH_TRY(h, hipMemcpy(h->d_bc, bc.data(), sizeof(float) * bc.size(), hipMemcpyHostToDevice));
+        CH_TRY(h, hipMemcpy(h->d_ac, ac.data(), sizeof(float) * ac.size(), hipMemcpyHostToDevice));
+    }
     return TETRA_OK;
 }
 
 void free_all(tetra_chan* h) {
-    void* ptrs[] = { h->xbuf, h->xalt, h->d_h, h->d_w1, h->d_w2, h->d_wm, h->st_out };
+    void* ptrs[] = { h->xbuf, h->xalt, h->d_h, h->d_w1, h->d_w2, h->d_wm, h->d_bc, h->d_ac, h->st_out };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
 }
@@ -232,6 +383,7 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
     h->device = dev;
     h->M = cfg->n_channels; h->P = cfg->taps_per_channel; h->D = cfg->decimation; h->L = h->M * h->P;
     h->N1 = n1; h->N2 = n2; h->max_in = cfg->max_in;
+    h->mfma = n1 == kMN1 && n2 == kMN2 && !(cfg->reserved & TETRA_CHAN_FLAG_VALU_DFT);
     if (cfg->prototype) h->proto.assign(cfg->prototype, cfg->prototype + h->L);
     else design_prototype(h->M, h->P, cfg->cutoff_rel, h->proto);
     Guard g(dev);
@@ -242,7 +394,10 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
               hipMalloc((void**)&h->d_w1, sizeof(float2) * h->N1) == hipSuccess &&
               hipMalloc((void**)&h->d_w2, sizeof(float2) * h->N2) == hipSuccess &&
               hipMalloc((void**)&h->d_wm, sizeof(float2) * h->M) == hipSuccess &&
+              (!h->mfma || (hipMalloc((void**)&h->d_bc, sizeof(float) * 4 * kMK1 * 64) == hipSuccess &&
+                            hipMalloc((void**)&h->d_ac, sizeof(float) * 64 * 64) == hipSuccess)) &&
               hipEventCreate(&h->ev[0]) == hipSuccess && hipEventCreate(&h->ev[1]) == hipSuccess;
+    if (ok && hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) h->cus = 256;
     int rc = ok ? upload_twiddles(h) : TETRA_ERR_NOMEM;
     if (rc == TETRA_OK && hipMemset(h->xbuf, 0, sizeof(float2) * ((size_t)h->L - 1)) != hipSuccess) rc = TETRA_ERR_HIP;
     if (rc != TETRA_OK) { free_all(h); delete h; return rc; }
@@ -275,7 +430,16 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     const size_t hist = (size_t)h->L - 1;
     if (n_in > 0) CH_TRY(h, hipMemcpyAsync(h->xbuf + hist, d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
     CH_TRY(h, hipEventRecord(h->ev[0], s));
-    if (frames > 0) {
+    if (frames > 0 && h->mfma) {
+        ChanMfmaParams p;
+        p.xbuf = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_h; p.bc = h->d_bc; p.ac = h->d_ac; p.wm = h->d_wm;
+        p.P = h->P; p.D = h->D; p.frames = frames; p.ph0 = h->phase; p.abs0 = h->consumed;
+        // workgroups loop over frames (the constant operands are loaded once per workgroup): a few per CU keep the matrix pipe,
+        // the fold's loads and the stores of different frames overlapping
+        const int grid = frames < 6 * h->cus ? frames : 6 * h->cus;
+        hipLaunchKernelGGL(k_channelise_mfma, dim3(grid), dim3(kThreads), 0, s, p);
+        CH_TRY(h, hipGetLastError());
+    } else if (frames > 0) {
         ChanParams p;
         p.xbuf = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_h;
         p.w1 = h->d_w1; p.w2 = h->d_w2; p.wm = h->d_wm;
