@@ -104,6 +104,37 @@ int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride,
                                    int n_channels, int frames_per_channel, uint32_t* d_chan_scramb, uint32_t* d_row_scramb,
                                    void* hip_stream);
 
+/*
+ * The whole SYNC-PDU read-out and the PHY's TDMA clock for every channel at once -- what labels a frame with its TDMA time.
+ * Reference: tp_sap_udata_ind's SB1 case (src/decoder/src/lower_mac/tetra_lower_mac.c:246-275: colour code, TN/FN/MN, MCC,
+ * MNC of a SYNC PDU with a good CRC go to tcd; tcd->time is then copied to t_phy_state.time WHATEVER the CRC was, :268-269),
+ * the per-frame increment of the LOCKED receiver (src/decoder/src/phy/tetra_burst_sync.c:113: tetra_tdma_time_add_tn before
+ * the callback) and its normalisation (src/decoder/src/tetra_tdma.c:28-78, reproduced to the letter including the wrap
+ * thresholds tn > 4, fn > 18, mn > 60).  The reference keeps ONE process-global tcd / t_phy_state (tetra_lower_mac.c:116,
+ * tetra_burst_sync.c:34); here every channel has its own, device-resident.
+ */
+typedef struct tetra_lmac_cell_state {
+    uint32_t scramb_init;              /* tcd->scramb_init (0 for a fresh receiver) */
+    uint32_t colour_code, mcc, mnc;    /* tcd->colour_code / mcc / mnc of the last SYNC PDU with a good CRC */
+    uint32_t tcd_tn, tcd_fn, tcd_mn;   /* tcd->time */
+    uint32_t phy_tn, phy_fn, phy_mn;   /* t_phy_state.time */
+} tetra_lmac_cell_state_t;
+/*
+ * d_sb1_type2, d_crc_ok, d_valid   as tetra_lmac_track_scramb_device: decoded SB1 rows per frame slot, the decoder's crc_ok,
+ *               the demultiplexer's valid (the slot's frame is a SYNC burst)
+ * d_n_frames    [n_channels] int32: frame slots of each channel that hold a consumed frame in this call
+ *               (tetra_bsync_process_device's d_n_frames; NULL: all frames_per_channel) -- only those advance the clock
+ * d_cell        [n_channels] in/out (all zero for fresh receivers, like the reference's zero-initialised globals)
+ * d_row_scramb  [n_channels * frames_per_channel] uint32 out: the code in force for the slot's non-SB1 blocks
+ * d_row_time_rx [..] uint32 out, may be NULL: t_phy_state.time when tetra_burst_rx_cb is entered for the slot's frame
+ *               (t_display_st->curr_multiframe / curr_frame, tetra_burst.c:349-350), packed tn | fn << 8 | mn << 16
+ * d_row_time    [..] uint32 out, may be NULL: t_phy_state.time after the slot's SB1 block (if it has one), i.e. the time
+ *               every later block of the burst is handled under; unused slots get 0 in both.
+ */
+int tetra_lmac_track_sync_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
+                                 const int32_t* d_n_frames, int n_channels, int frames_per_channel, tetra_lmac_cell_state_t* d_cell,
+                                 uint32_t* d_row_scramb, uint32_t* d_row_time_rx, uint32_t* d_row_time, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

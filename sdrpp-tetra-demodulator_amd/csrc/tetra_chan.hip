@@ -137,13 +137,15 @@ struct ChanMfmaParams {
     long long abs0;
 };
 
-__global__ __launch_bounds__(kThreads) void k_channelise_mfma(ChanMfmaParams p) {
-    constexpr int M = kMN1 * kMN2;
+template <int P> __global__ __launch_bounds__(kThreads, 3) void k_channelise_mfma(ChanMfmaParams p) {      // 3 waves per SIMD: <= 168 VGPRs
+    constexpr int M = kMN1 * kMN2, L = M * P;
     __shared__ float At[4 * kMK1][kMAtStride];
     __shared__ float Bo[2 * kMN2][kMBoStride];
+    __shared__ float hs[L];              // the prototype: every frame reads all of it (rotated by the frame's time mod M)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int wlo = w & 1, whi = w >> 1;
+    for (int i = tid; i < L; i += kThreads) hs[i] = p.h[i];
     // constant operands of this wave's tiles (registers for the workgroup's life)
     float b1re[kMK1], b1im[kMK1], a2re[kMK2], a2im[kMK2];
 #pragma unroll
@@ -165,27 +167,48 @@ __global__ __launch_bounds__(kThreads) void k_channelise_mfma(ChanMfmaParams p) 
     }
     // padding rows of the stage-1 data operand (k = 50, 51) are zero for ever
     if (tid < 2 * kMAtStride) At[2 * kMN1 + tid / kMAtStride][tid % kMAtStride] = 0.f;
-    const int L = M * p.P;
-    for (int j = blockIdx.x; j < p.frames; j += gridDim.x) {
+    constexpr int kRounds = (M + kThreads - 1) / kThreads;      // bins per thread (the last round is partial)
+    // fold, v[r] = sum_q h[l0 + q M] x[n_abs - l0 - q M] with l0 = (n_abs - r) mod M.  ALL of a thread's samples of a frame are
+    // requested at once (kRounds x P loads in flight), and a frame's samples are requested while the frame before it is still in
+    // its DFT stages: the memory latency of the fold hides behind the matrix pipe.
+    float2 xv[kRounds][P];
+    int l0s[kRounds];
+    auto request = [&](int j) {
         const int newest = (j + 1) * p.D - 1 - p.ph0;
         const long long n_abs = p.abs0 + newest;
         const int nm = (int)(n_abs % M);
         const float2* xn = p.xbuf + (L - 1) + newest;
-        for (int r = tid; r < M; r += kThreads) {
+#pragma unroll
+        for (int i = 0; i < kRounds; i++) {
+            const int r = tid + kThreads * i;
             int l0 = nm - r;
-            if (l0 < 0) l0 += M;
-            float2 acc = make_float2(0.f, 0.f);
-            for (int q = 0; q < p.P; q++) {
-                const int l = l0 + q * M;
-                const float hv = p.h[l];
-                const float2 xv = xn[-l];
-                acc.x = fmaf(hv, xv.x, acc.x);
-                acc.y = fmaf(hv, xv.y, acc.y);
-            }
-            const int n1 = r / kMN2, n2 = r % kMN2;
-            At[n1][n2] = acc.x;
-            At[kMN1 + n1][n2] = acc.y;
+            l0 += l0 < 0 ? M : 0;
+            l0 = r < M ? l0 : 0;
+            l0s[i] = l0;
+#pragma unroll
+            for (int q = 0; q < P; q++) xv[i][q] = xn[-(l0 + q * M)];
         }
+    };
+    if ((int)blockIdx.x < p.frames) request(blockIdx.x);
+    __syncthreads();              // hs and the zero rows of At are in place
+    for (int j = blockIdx.x; j < p.frames; j += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < kRounds; i++) {
+            const int r = tid + kThreads * i;
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                const float hv = hs[l0s[i] + q * M];
+                acc.x = fmaf(hv, xv[i][q].x, acc.x);
+                acc.y = fmaf(hv, xv[i][q].y, acc.y);
+            }
+            if (r < M) {
+                const int n1 = r / kMN2, n2 = r % kMN2;
+                At[n1][n2] = acc.x;
+                At[kMN1 + n1][n2] = acc.y;
+            }
+        }
+        if (j + (int)gridDim.x < p.frames) request(j + gridDim.x);
         __syncthreads();
         {   // stage 1
             chan_f32x4 dre = { 0.f, 0.f, 0.f, 0.f }, dim_ = { 0.f, 0.f, 0.f, 0.f };
@@ -219,8 +242,8 @@ __global__ __launch_bounds__(kThreads) void k_channelise_mfma(ChanMfmaParams p) 
                 for (int r = 0; r < 4; r++) dst[kMN1 * (16 * wlo + 4 * g + r)] = make_float2(xre[r], xim[r]);
             }
         }
-        // no third barrier: the next frame's fold rewrites At, which every wave finished reading before the barrier above;
-        // its stage 1 rewrites Bo only behind the next frame's first barrier, which every wave passes after its stage-2 reads
+        __syncthreads();      // the next frame's fold rewrites At (read in stage 1, behind the barrier above) -- and its stage 1 rewrites
+                              // Bo, which this barrier puts behind every wave's stage-2 reads
     }
 }
 
@@ -383,7 +406,8 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
     h->device = dev;
     h->M = cfg->n_channels; h->P = cfg->taps_per_channel; h->D = cfg->decimation; h->L = h->M * h->P;
     h->N1 = n1; h->N2 = n2; h->max_in = cfg->max_in;
-    h->mfma = n1 == kMN1 && n2 == kMN2 && !(cfg->reserved & TETRA_CHAN_FLAG_VALU_DFT);
+    h->mfma = n1 == kMN1 && n2 == kMN2 && (cfg->taps_per_channel == 8 || cfg->taps_per_channel == 6 || cfg->taps_per_channel == 4) &&
+              !(cfg->reserved & TETRA_CHAN_FLAG_VALU_DFT);
     if (cfg->prototype) h->proto.assign(cfg->prototype, cfg->prototype + h->L);
     else design_prototype(h->M, h->P, cfg->cutoff_rel, h->proto);
     Guard g(dev);
@@ -436,8 +460,10 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
         p.P = h->P; p.D = h->D; p.frames = frames; p.ph0 = h->phase; p.abs0 = h->consumed;
         // workgroups loop over frames (the constant operands are loaded once per workgroup): a few per CU keep the matrix pipe,
         // the fold's loads and the stores of different frames overlapping
-        const int grid = frames < 6 * h->cus ? frames : 6 * h->cus;
-        hipLaunchKernelGGL(k_channelise_mfma, dim3(grid), dim3(kThreads), 0, s, p);
+        const int grid = frames < 3 * h->cus ? frames : 3 * h->cus;      // three workgroups fit a CU (registers, LDS); each loops over its frames
+        if (h->P == 8) hipLaunchKernelGGL(k_channelise_mfma<8>, dim3(grid), dim3(kThreads), 0, s, p);
+        else if (h->P == 6) hipLaunchKernelGGL(k_channelise_mfma<6>, dim3(grid), dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL(k_channelise_mfma<4>, dim3(grid), dim3(kThreads), 0, s, p);
         CH_TRY(h, hipGetLastError());
     } else if (frames > 0) {
         ChanParams p;

@@ -135,6 +135,57 @@ __global__ __launch_bounds__(256) void k_track_scramb(const uint8_t* __restrict_
     chan_scramb[c] = cur;
 }
 
+// The whole SYNC-PDU read-out of tp_sap_udata_ind's SB1 case (tetra_lower_mac.c:246-275) plus the PHY's TDMA clock
+// (tetra_burst_sync.c:113, tetra_tdma.c:28-78), per channel, frame slots in time order:
+//   every frame the LOCKED receiver consumes      t_phy_state.time += one timeslot (tetra_tdma_time_add_tn, before the callback)
+//   a SYNC burst's SB1 block, good CRC            tcd-> colour code, time (tn = bits + 1, fn, mn), mcc, mnc, scramb_init
+//   a SYNC burst's SB1 block, any CRC             t_phy_state.time = tcd->time   (:268-269: copied whatever the CRC said)
+// Outputs per frame slot: the scrambling code in force for the slot's other blocks, the TDMA time tetra_burst_rx_cb sees on
+// entry (t_display_st->curr_multiframe / curr_frame, tetra_burst.c:349-350) and the time after the slot's SB1 (what every
+// later block of the burst and the next slot's increment start from).  Times are packed tn | fn << 8 | mn << 16.
+__device__ __forceinline__ void tdma_add_tn(uint32_t& tn, uint32_t& fn, uint32_t& mn) {
+    tn += 1;                                                  // tetra_tdma_time_add_tn(tm, 1) -> normalize_tn -> _fn -> _mn
+    if (tn > 4) { const uint32_t d = tn / 4; tn = tn % 4; fn += d; }
+    if (fn > 18) { const uint32_t d = fn / 18; fn = fn % 18; mn += d; }
+    if (mn > 60) mn = mn % 60;
+}
+__global__ __launch_bounds__(256) void k_track_sync(const uint8_t* __restrict__ sb1, int stride, const int* __restrict__ crc_ok,
+                                                    const int* __restrict__ valid, const int* __restrict__ n_frames, int n_channels,
+                                                    int frames, tetra_lmac_cell_state_t* __restrict__ cell,
+                                                    uint32_t* __restrict__ row_scramb, uint32_t* __restrict__ row_time_rx,
+                                                    uint32_t* __restrict__ row_time) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) return;
+    tetra_lmac_cell_state_t st = cell[c];
+    const int nf = n_frames ? (n_frames[c] < frames ? n_frames[c] : frames) : frames;
+    for (int f = 0; f < frames; ++f) {
+        const size_t r = (size_t)c * frames + f;
+        if (f < nf) {
+            tdma_add_tn(st.phy_tn, st.phy_fn, st.phy_mn);
+            if (row_time_rx) row_time_rx[r] = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
+            if (valid[r]) {
+                if (crc_ok[r]) {
+                    const uint8_t* t2 = sb1 + r * stride;
+                    auto field = [&](int first, int len) { uint32_t v = 0; for (int i = 0; i < len; ++i) v = (v << 1) | (t2[first + i] & 1u); return v; };
+                    st.colour_code = field(4, 6);
+                    st.tcd_tn = field(10, 2) + 1;
+                    st.tcd_fn = field(12, 5);
+                    st.tcd_mn = field(17, 6);
+                    st.mcc = field(31, 10);
+                    st.mnc = field(41, 14);
+                    st.scramb_init = (((st.colour_code & 0x3f) | ((st.mnc & 0x3fff) << 6) | ((st.mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1;
+                }
+                st.phy_tn = st.tcd_tn; st.phy_fn = st.tcd_fn; st.phy_mn = st.tcd_mn;
+            }
+        } else if (row_time_rx) {
+            row_time_rx[r] = 0;
+        }
+        row_scramb[r] = st.scramb_init;
+        if (row_time) row_time[r] = f < nf ? (st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16)) : 0u;
+    }
+    cell[c] = st;
+}
+
 int check_args(int type, const void* in, int n_blocks, int in_stride, const void* init, const void* out, int out_stride,
                const void* ok, bool device_ptrs) {
     if (type < 0 || type > 5 || n_blocks < 0) return TETRA_ERR_ARG;
@@ -209,6 +260,17 @@ int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride,
     if (n_channels < 1 || frames_per_channel < 0 || type2_stride < 60) return TETRA_ERR_ARG;
     hipLaunchKernelGGL(k_track_scramb, dim3((n_channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2,
                        type2_stride, d_crc_ok, d_valid, n_channels, frames_per_channel, d_chan_scramb, d_row_scramb);
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_track_sync_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
+                                 const int32_t* d_n_frames, int n_channels, int frames_per_channel, tetra_lmac_cell_state_t* d_cell,
+                                 uint32_t* d_row_scramb, uint32_t* d_row_time_rx, uint32_t* d_row_time, void* hip_stream) {
+    if (!d_sb1_type2 || !d_crc_ok || !d_valid || !d_cell || !d_row_scramb) return TETRA_ERR_ARG;
+    if (n_channels < 1 || frames_per_channel < 0 || type2_stride < 60) return TETRA_ERR_ARG;
+    hipLaunchKernelGGL(k_track_sync, dim3((n_channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2,
+                       type2_stride, d_crc_ok, d_valid, d_n_frames, n_channels, frames_per_channel, d_cell, d_row_scramb, d_row_time_rx,
+                       d_row_time);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 

@@ -6,7 +6,7 @@ import numpy as np
 from .binding import TetraDemodError, load_library
 
 LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch",
-                "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device"]
+                "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device", "tetra_lmac_track_sync_device"]
 # enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
 TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
 
@@ -111,3 +111,23 @@ def track_scramb_device(d_sb1_type2, type2_stride, d_crc_ok, d_valid, n_channels
                                                vp(d_chan_scramb.data_ptr()), vp(d_row_scramb.data_ptr()), s)
     if rc:
         raise TetraDemodError(rc, "tetra_lmac_track_scramb_device")
+
+
+def track_sync_device(d_sb1_type2, type2_stride, d_crc_ok, d_valid, d_n_frames, n_channels, frames_per_channel, d_cell, d_row_scramb,
+                      d_row_time_rx=None, d_row_time=None, stream=None):
+    """tetra_lmac_track_sync_device: d_cell = torch int32 / uint32 tensor [n_channels][10] (tetra_lmac_cell_state_t: scramb_init,
+    colour_code, mcc, mnc, tcd tn / fn / mn, phy tn / fn / mn)."""
+    s = None
+    if stream is not None:
+        s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+    vp = C.c_void_p
+
+    def p(t):
+        return vp(t.data_ptr()) if t is not None else None
+    L = _lib()
+    L.tetra_lmac_track_sync_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.tetra_lmac_track_sync_device.restype = C.c_int
+    rc = L.tetra_lmac_track_sync_device(p(d_sb1_type2), int(type2_stride), p(d_crc_ok), p(d_valid), p(d_n_frames), int(n_channels),
+                                        int(frames_per_channel), p(d_cell), p(d_row_scramb), p(d_row_time_rx), p(d_row_time), s)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_track_sync_device")

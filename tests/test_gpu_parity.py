@@ -1011,7 +1011,7 @@ def test_below_one_sample_per_symbol_a_poisoned_channel_is_cut_off_and_reported(
     d.set_state(4, st)
     cfg = oracle.default_cfg()
     cfg.samplerate = 18000.0
-    bits, nb, _ = d.process(iq)
+    bits, nb, _ = d.process(iq, allow_overrun=True)
     assert d.last_status == pkg.binding.ERR_OVERRUN and d.overruns() == 1
     assert nb[4] >= d.bits_stride(N) - 32
     for c in range(Cn):

@@ -283,3 +283,69 @@ def test_gpu_track_scramb_equals_reference_rule(pkg, lref):
         torch.cuda.synchronize()
         assert np.array_equal(d_rows.cpu().numpy().view(np.uint32), want_rows), call
         assert np.array_equal(d_chan.cpu().numpy().view(np.uint32), want_chan), call
+
+
+class _TdmaTime(__import__("ctypes").Structure):
+    """struct tetra_tdma_time (src/decoder/src/tetra_tdma.h:6-12)"""
+    import ctypes as _C
+    _fields_ = [("hn", _C.c_uint16), ("sn", _C.c_uint32), ("tn", _C.c_uint32), ("fn", _C.c_uint32), ("mn", _C.c_uint32)]
+
+
+@pytest.mark.gpu
+def test_gpu_track_sync_equals_the_reference_rule_and_clock(pkg, lref, ref):
+    """tetra_lmac_track_sync_device == tp_sap_udata_ind's SB1 case (tetra_lower_mac.c:246-275) + the LOCKED receiver's clock
+    (tetra_burst_sync.c:113), walked per channel in frame order with the REFERENCE'S OWN tetra_tdma_time_add_tn
+    (oracle/_ref: src/decoder/src/tetra_tdma.c compiled where it lies) and tetra_scramb_get_init: a SYNC PDU with a good CRC
+    sets colour code / TN / FN / MN / MCC / MNC and the scrambling code; the PHY time takes tcd's after EVERY SB1, good CRC or
+    not; every consumed frame advances it by one timeslot with the reference's wrap thresholds.  Three calls, state carried,
+    ragged frame counts; arbitrary field values (FN up to 31, MN up to 63 as the bit fields allow) exercise the normalisation."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(9)
+    Cn, F = 41, 29
+    dev = torch.device("cuda", 0)
+    add_tn = ref.lib().tetra_tdma_time_add_tn
+    add_tn.argtypes = [C.POINTER(_TdmaTime), C.c_uint32]
+    add_tn.restype = None
+    cell = np.zeros((Cn, 10), np.uint32)
+    d_cell = torch.from_numpy(cell.view(np.int32).copy()).to(dev)
+    want = [dict(scr=0, cc=0, mcc=0, mnc=0, tcd=(0, 0, 0), phy=_TdmaTime()) for _ in range(Cn)]
+    for call in range(3):
+        t2 = rng.integers(0, 2, (Cn * F, 80), dtype=np.uint8)
+        ok = (rng.random(Cn * F) < 0.5).astype(np.int32)
+        valid = (rng.random(Cn * F) < 0.3).astype(np.int32)
+        nfr = rng.integers(0, F + 1, Cn).astype(np.int32)
+        w_scr = np.zeros(Cn * F, np.uint32)
+        w_rx = np.zeros(Cn * F, np.uint32)
+        w_t = np.zeros(Cn * F, np.uint32)
+        for c in range(Cn):
+            w = want[c]
+            for f in range(F):
+                r = c * F + f
+                if f < nfr[c]:
+                    add_tn(C.byref(w["phy"]), 1)
+                    w_rx[r] = w["phy"].tn | (w["phy"].fn << 8) | (w["phy"].mn << 16)
+                    if valid[r]:
+                        bits = t2[r]
+                        val = lambda a, n: int("".join(map(str, bits[a:a + n])), 2)
+                        if ok[r]:
+                            w["cc"], w["mcc"], w["mnc"] = val(4, 6), val(31, 10), val(41, 14)
+                            w["tcd"] = (val(10, 2) + 1, val(12, 5), val(17, 6))
+                            w["scr"] = int(lref.scramb_get_init(w["mcc"], w["mnc"], w["cc"]))
+                        w["phy"].tn, w["phy"].fn, w["phy"].mn = w["tcd"]
+                    w_t[r] = w["phy"].tn | (w["phy"].fn << 8) | (w["phy"].mn << 16)
+                w_scr[r] = w["scr"]
+        d_scr = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
+        d_rx = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
+        d_t = torch.zeros(Cn * F, dtype=torch.int32, device=dev)
+        pkg.lmac_binding.track_sync_device(torch.from_numpy(t2).to(dev), 80, torch.from_numpy(ok).to(dev), torch.from_numpy(valid).to(dev),
+                                           torch.from_numpy(nfr).to(dev), Cn, F, d_cell, d_scr, d_rx, d_t)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_scr.cpu().numpy().view(np.uint32), w_scr), call
+        assert np.array_equal(d_rx.cpu().numpy().view(np.uint32), w_rx), call
+        assert np.array_equal(d_t.cpu().numpy().view(np.uint32), w_t), call
+        got = d_cell.cpu().numpy().view(np.uint32)
+        for c in range(Cn):
+            w = want[c]
+            assert list(got[c]) == [w["scr"], w["cc"], w["mcc"], w["mnc"], *w["tcd"], w["phy"].tn, w["phy"].fn, w["phy"].mn], (call, c)
+    assert max(w["phy"].mn for w in want) > 0 and any(w["scr"] for w in want)
