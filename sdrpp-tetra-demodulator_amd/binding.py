@@ -93,8 +93,9 @@ def load_library(rebuild_if_stale=True):
                            "__graft_entry__.build()" % (path, _build.lib_build_id(path), _build.source_hash()))
     L = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int
-    L.tetra_demod_build_id.argtypes = []
-    L.tetra_demod_build_id.restype = C.c_char_p
+    if hasattr(L, "tetra_demod_build_id"):          # (an override may be an older experimental build without it)
+        L.tetra_demod_build_id.argtypes = []
+        L.tetra_demod_build_id.restype = C.c_char_p
     L.tetra_demod_default_config.argtypes = [C.POINTER(Config)]
     L.tetra_demod_device_count.argtypes = []
     L.tetra_demod_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]

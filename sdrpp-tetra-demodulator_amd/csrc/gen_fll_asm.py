@@ -428,6 +428,8 @@ def gen():
     E.ins("s_cmp_lg_u32 %[st], 0", "salu")
     E.ins("s_cbranch_scc1 .Lreplay_%=", "br")
     # ---- the tiles
+    if os.environ.get("TETRA_EXP_ALIGN"):          # experiment builds: the tile loop's head on a 2^k-byte boundary
+        E.label(".p2align %d" % int(os.environ["TETRA_EXP_ALIGN"]))
     E.label(".Ltile_%=:")
     # x ring address of this lane for the tile: row + 8*(8 + (base & 255) - pos) (front padding of 8 slots, see FusedLds)
     E.ins("s_and_b32 %%[st], %%[base], 0x%x" % (int(os.environ.get("TETRA_EXP_XRING", "256")) - 1), "salu")

@@ -151,14 +151,26 @@ struct FusedParams {
     float2* sym;         // optional [C][sym_stride]
     long long sym_stride;
     int* overruns;       // [1] channels whose output row filled up in this launch (the rest of their samples were dropped)
-    int* cut_flag;       // optional [1]: a cut-off channel also leaves a plain store of 1 here (the in-place host path points it
-                         // into its mapped host block: a store crosses PCIe on every platform, an atomic may not)
     float2* y_dbg;       // optional: time-major scratch [(7+n)][C], row 7+i = y_i
     K1Consts k1;
     K2Consts k2;
-    long long* prof;     // TETRA_DEMOD_DEBUG builds only: [workgroups][8] = busy clocks of waves 0..5 inside their epoch
-                         // bodies (barrier waits excluded), [7] = clocks from kernel entry to exit of wave 0; null = off
+    long long* prof;     // instrumented (PROF) kernels of TETRA_DEMOD_DEBUG builds: [workgroups][8] = busy clocks of waves 0..5 inside
+                         // their epoch bodies (barrier waits excluded), [7] = clocks from kernel entry to exit of wave 0; null = off.
+                         // Every other kernel of the 16- and 32-channel shapes reads it as the CUT FLAG (below): one pointer, no new member
 };
+// The cut flag: optional int[1]; a cut-off channel also leaves a plain store of 1 there (the in-place host path points it into its
+// mapped host block: a store crosses PCIe on every platform, an atomic may not).  Where it lives in the kernel arguments was
+// chosen by measurement (profiles/r04/r04_f_param_layout.md): ANY member added in front of the loop constants k1 / k2 costs the
+// 4-channel shape 2 % (3.40 against 3.33 ms per 36000 samples; same instruction counts, another register assignment); a member
+// appended behind `prof` is the 4-channel shape's best (3.31) but costs the 16-channel shape 0.3-0.5 %; the 16- and 32-channel
+// shapes are at their best with round 3's argument block unchanged.  So: the 4-channel kernels get the appended member, the
+// others carry the pointer in `prof` (unused by every non-instrumented kernel).
+template <int CH> struct FusedParamsT : FusedParams {};
+template <> struct FusedParamsT<kFChSmall> : FusedParams { int* cut_flag4; };
+template <int CH, bool PROF> __device__ __forceinline__ int* fused_cut_flag(const FusedParamsT<CH>& p) {
+    if constexpr (CH == kFChSmall) return p.cut_flag4;
+    else return PROF ? nullptr : reinterpret_cast<int*>(p.prof);
+}
 
 template <int CH, bool DEEP = false> struct FusedLdsT {
     static constexpr int kS = DEEP ? kFSDeep : kFS;
@@ -250,7 +262,7 @@ template <class LDS, class Row> struct FllDeviceIOT {
 #endif
 // DEEP: the timing loop may emit several symbols from one offset (min_step < 1, see kFSDeep): deeper symbol ring, no forward-
 // progress clamp in the timing step, the output-row check on every symbol.  Everything else is the same code.
-template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParams p) {
+template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParamsT<CH> p) {
     typedef FusedLdsT<CH, DEEP> Lds;
     constexpr int kSR = Lds::kS;          // symbol ring depth
     constexpr int kMinAdv = DEEP ? 0 : 1;
@@ -605,7 +617,8 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
             p.offset[ch0 + c] = st.offset - n;          // complex_fd.cpp:145
             if (cut) {                                  // never silently: tetra_demod_get_overruns / TETRA_ERR_OVERRUN
                 atomicAdd(p.overruns, 1);
-                if (p.cut_flag) *(volatile int*)p.cut_flag = 1;
+                int* const flag = fused_cut_flag<CH, PROF>(p);
+                if (flag) *(volatile int*)flag = 1;
             }
         }
     } else if (wave == kRoleE && (CH != kFChWide || TETRA_EXP_TWOPASS)) {

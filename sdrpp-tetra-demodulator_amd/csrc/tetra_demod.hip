@@ -630,11 +630,10 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.bits = d_bits; pf.bits_stride = bits_stride; pf.n_bits = d_n_bits; pf.sym = reinterpret_cast<float2*>(d_sym);
         pf.y_dbg = h->keep_y ? h->y : nullptr;
         pf.overruns = h->d_overruns;
-        pf.cut_flag = h->cut_flag;
         pf.sym_stride = bits_stride / 2;
         if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
-        pf.prof = nullptr;
+        pf.prof = reinterpret_cast<long long*>(h->cut_flag);      // the non-instrumented 16- / 32-channel kernels read it as the cut flag (kernel_fused.hpp)
         // channels [0, n_wide) in 32-channel workgroups (see tetra_demod_create; their FLL rows hold 4 x 17 taps), the rest in
         // 16-channel ones: at most two launches, back to back on the stream
         // (band-edge filters of more than 68 taps do not fit the 32-channel shape's rows: then everything is "the rest")
@@ -647,6 +646,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
             gs((h->C - n_wide + kFChSmall - 1) / kFChSmall);
         // the FLL's loop filter runs with alpha = 0 (fll.cpp:25; design.hpp never produces anything else): only those kernels exist
         if (pf.k1.fll_alpha != 0.0f) return TETRA_ERR_UNSUPPORTED;
+        bool profiling = false;
+        (void)profiling;
 #ifdef TETRA_DEMOD_DEBUG
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
@@ -656,28 +657,34 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
             pf.prof = h->d_prof;
+            profiling = true;
         }
 #endif
         HIP_TRY(h, hipEventRecord(ev[0], s));
 #ifdef TETRA_DEMOD_DEBUG
-        if (pf.prof && !deep) hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pf);
+        if (profiling && !deep) { FusedParamsT<kFCh> pp; static_cast<FusedParams&>(pp) = pf; hipLaunchKernelGGL((k_fused<true, true>), gf, dim3(kFThreads), 0, s, pp); }
         else
 #endif
         {
             if (n_wide > 0) {
                 const dim3 tw(fused_threads(kFChWide));
                 pf.ch_base = 0;
-                hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gw, tw, 0, s, pf);
+                { FusedParamsT<kFChWide> pw; static_cast<FusedParams&>(pw) = pf; hipLaunchKernelGGL((k_fused<true, false, kFChWide>), gw, tw, 0, s, pw); }
             }
             if (n_wide < h->C && rest_small) {
                 const dim3 ts(fused_threads(kFChSmall));
                 pf.ch_base = n_wide;
-                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true>), gs, ts, 0, s, pf);
-                else hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, pf);
+                FusedParamsT<kFChSmall> ps;
+                static_cast<FusedParams&>(ps) = pf;
+                ps.cut_flag4 = h->cut_flag;
+                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true>), gs, ts, 0, s, ps);
+                else hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, ps);
             } else if (n_wide < h->C) {
                 pf.ch_base = n_wide;
-                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true>), gf, dim3(kFThreads), 0, s, pf);
-                else hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pf);
+                FusedParamsT<kFCh> pn;
+                static_cast<FusedParams&>(pn) = pf;
+                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true>), gf, dim3(kFThreads), 0, s, pn);
+                else hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pn);
             }
         }
         if (h->q_ring)
@@ -687,7 +694,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         HIP_TRY(h, hipEventRecord(ev[1], s));
         h->n_calls++;
 #ifdef TETRA_DEMOD_DEBUG
-        if (pf.prof) {
+        if (profiling) {
             const size_t nwg = (size_t)gf.x;
             std::vector<long long> host(8 * nwg);
             HIP_TRY(h, hipStreamSynchronize(s));
