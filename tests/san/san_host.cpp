@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
+#include "../../sdrpp-tetra-demodulator_amd/host/dqpsk_sym_extr_gpu.h"
+#include "../../sdrpp-tetra-demodulator_amd/host/bit_unpacker_gpu.h"
 
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "san_host: check failed line %d: %s\n", __LINE__, #c); return 1; } } while (0)
 
@@ -231,9 +233,27 @@ int gpu_paths() {
         CHECK(d2.lastStatus() == TETRA_OK);
         d2.setRRCBeta(1);
         CHECK(d2.lastStatus() == TETRA_OK);
-        d2.setSymbolrate(36000);                      // one sample per symbol: symbols could stop advancing
+        {   // the GPU-backed extractor / unpacker mirrors behind this demodulator: decisions flow through their taps
+            dsp::DQPSKSymbolExtractor ex;
+            dsp::BitUnpacker un;
+            ex.attach(&d2);
+            un.attach(&d2);
+            std::vector<uint8_t> dib(5000), ub(10000);
+            for (int k = 0; k < 3; k++) {
+                const int m = d2.process(700, in.data(), out.data());
+                CHECK(m > 0 && ex.process(m, out.data(), dib.data()) == m && ex.lastStatus() == TETRA_OK);
+                CHECK(un.process(m, dib.data(), ub.data()) == 2 * m && un.lastStatus() == TETRA_OK);
+                for (int i = 0; i < m; i++) CHECK(dib[i] == ((ub[2 * i] << 1) | ub[2 * i + 1]) && ub[2 * i] == d2.lastBits()[2 * i]);
+            }
+            CHECK(ex.process(5, out.data(), dib.data()) == 5 && ex.lastStatus() == TETRA_ERR_ARG);      // nothing queued: flagged
+        }
+        d2.setSymbolrate(150000);                     // 0.24 samples per symbol: beyond what the kernels' symbol ring holds
         CHECK(d2.lastStatus() == TETRA_ERR_UNSUPPORTED);
         CHECK(d2.process(100, in.data(), out.data()) > 0);      // nothing changed: the block still runs at 20 ksymbols/s
+        d2.setSymbolrate(36000);                      // one sample per symbol: several symbols may leave one offset (ABI 4: accepted)
+        CHECK(d2.lastStatus() == TETRA_OK);
+        const int n1 = d2.process(2000, in.data(), out.data());
+        CHECK(n1 > 1900 && n1 < 2200 && (int)d2.lastBits().size() == 2 * n1);
     }
     return 0;
 }

@@ -33,9 +33,10 @@ def test_oracles_are_clean_under_asan_and_ubsan():
 def _build_host(pkg):
     pkg.build.build()
     exe = os.path.join(SAN, "san_host")
-    srcs = [os.path.join(SAN, "san_host.cpp"), os.path.join(PK, "host", "pi4dqpsk_gpu.cpp")]
-    deps = srcs + [os.path.join(PK, "host", "pi4dqpsk_gpu.h"), os.path.join(PK, "host", "dsp_compat.h"),
-                   os.path.join(ROOT, "include", "tetra_demod.h")]
+    srcs = [os.path.join(SAN, "san_host.cpp")] + [os.path.join(PK, "host", f) for f in ("pi4dqpsk_gpu.cpp", "dqpsk_sym_extr_gpu.cpp",
+                                                                                         "bit_unpacker_gpu.cpp")]
+    deps = srcs + [os.path.join(PK, "host", f) for f in ("pi4dqpsk_gpu.h", "dqpsk_sym_extr_gpu.h", "bit_unpacker_gpu.h", "dsp_compat.h")] + \
+        [os.path.join(ROOT, "include", "tetra_demod.h")]
     if _stale(exe, deps):
         subprocess.run(["g++", "-std=c++17", "-Wall", "-pthread"] + FLAGS + srcs +
                        ["-L", PK, "-ltetra_demod_hip", "-Wl,-rpath," + PK, "-o", exe], check=True)
