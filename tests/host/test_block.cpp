@@ -218,6 +218,26 @@ int main(int argc, char** argv) {
         dsp::demod::PI4DQPSKBank bank;
         std::printf("abi %d, devices %d, default taps %d, bank channels %d\n", tetra_demod_abi_version(),
                     tetra_demod_device_count(), cfg.rrc_tap_count, bank.channels());
+        // the decision FIFO between the demodulator mirror and the extractor / unpacker mirrors (host logic only, no GPU):
+        // stream order, dibit packing, statistic marks applied when the consumer has passed their symbol position, underflow
+        {
+            dsp::demod::DecisionTap tap;
+            const uint8_t b0[8] = { 0, 1, 1, 0, 1, 1, 0, 0 };          // dibits 1, 2, 3, 0
+            tap.push(b0, 8);
+            tap.mark(3, 0.25f, true);                                  // published when 3 symbols have been consumed
+            uint8_t dib[8], bits[16];
+            float err = -1.f;
+            bool sync = false;
+            int ok = tap.pop(2, dib, bits, &err, &sync) == 2 && dib[0] == 1 && dib[1] == 2 && bits[0] == 0 && bits[1] == 1 && bits[2] == 1 &&
+                     bits[3] == 0 && err == -1.f && !sync;             // two symbols consumed: the mark at 3 is not yet due
+            ok = ok && tap.pop(1, dib, nullptr, &err, &sync) == 1 && dib[0] == 3 && err == 0.25f && sync && tap.consumedSymbols() == 3;
+            ok = ok && tap.pop(5, dib, bits, &err, &sync) == 1 && dib[0] == 0;          // only one symbol left: the caller sees the shortfall
+            tap.push(b0, 4);
+            tap.clear();
+            ok = ok && tap.pop(1, dib, bits, nullptr, nullptr) == 0;
+            std::printf("decision tap %s\n", ok ? "ok" : "FAILED");
+            if (!ok) return 1;
+        }
         return 0;
     }
     FILE* f = std::fopen(argv[1], "rb");

@@ -28,7 +28,7 @@ def _build(pkg):
 def test_block_mirror_builds_and_links(pkg):
     exe = _build(pkg)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "abi 4" in out and "default taps 65" in out
+    assert "abi 4" in out and "default taps 65" in out and "decision tap ok" in out
 
 
 @pytest.mark.gpu
