@@ -28,12 +28,12 @@ extern "C" {
 #endif
 
 #define TETRA_DEMOD_ABI_VERSION 4
-#define TETRA_DEMOD_MAX_TAPS 80 /* capacity every tap table of this ABI is sized for (filters are 2..72 taps) */
+#define TETRA_DEMOD_MAX_TAPS 129 /* longest filter of this ABI and capacity every tap table handed across it is sized for */
 
 enum {
     TETRA_OK = 0,
     TETRA_ERR_ARG = -1,         /* NULL / out-of-range argument */
-    TETRA_ERR_UNSUPPORTED = -2, /* parameter outside what the kernel implements (e.g. > 72 RRC taps) */
+    TETRA_ERR_UNSUPPORTED = -2, /* parameter outside what the library implements (> 129 taps; a timing loop that may stall: min_step <= 0) */
     TETRA_ERR_NO_DEVICE = -3,   /* no HIP device / bad ordinal */
     TETRA_ERR_HIP = -4,         /* a HIP runtime call failed (see tetra_demod_last_hip_error) */
     TETRA_ERR_NOMEM = -5,
@@ -48,7 +48,7 @@ enum {
 /* tetra_demod_config_t.flags */
 enum {
     TETRA_FLAG_RETIRED_TWO_KERNEL = 1, /* ABI 1's two-kernel pipeline was retired in ABI 2: tetra_demod_create refuses the flag
-                                    (TETRA_ERR_UNSUPPORTED).  With it went tap counts 73..80: rrc_tap_count is 2..72. */
+                                    (TETRA_ERR_UNSUPPORTED). */
     TETRA_FLAG_KEEP_RRC_OUT = 2, /* also keep the RRC output in an HBM scratch for tetra_demod_debug_read_rrc_out */
     TETRA_FLAG_QUALITY = 4,      /* also compute DQPSKSymbolExtractor's sync/quality statistic (tetra_demod_get_quality) */
     TETRA_FLAG_WIDE_WORKGROUPS = 16,   /* force 32-channel workgroups / ... */
@@ -90,7 +90,8 @@ typedef struct tetra_demod_config {
     int32_t device;          /* HIP device ordinal; -1 = current device */
     double symbolrate;       /* 18000 */
     double samplerate;       /* 36000 */
-    int32_t rrc_tap_count;   /* 65; 2..72 supported (the reference builds with RRC_TAP_COUNT 65, src/main.cpp:36) */
+    int32_t rrc_tap_count;   /* 65 (the reference builds with RRC_TAP_COUNT 65, src/main.cpp:36); 2..129.  Up to 72 taps run in the fused
+                              * kernel; 73..129 in the generic one (one lane per channel: correct to the bit, not fast) */
     int32_t flags;           /* TETRA_FLAG_* */
     double rrc_beta;         /* 0.35 */
     double agc_rate;         /* 0.02 */
@@ -98,12 +99,12 @@ typedef struct tetra_demod_config {
     double fll_bandwidth;    /* 0.006 */
     double omega_gain;       /* timing loop beta, src/main.cpp:82 */
     double mu_gain;          /* timing loop alpha, src/main.cpp:81 */
-    double omega_rel_limit;  /* 0.02.  Accepted: 0 <= limit < 1 with min_step = samplerate / symbolrate x (1 - limit) - |mu_gain| >= 0.27
+    double omega_rel_limit;  /* 0.02.  Accepted: 0 <= limit < 1 with min_step = samplerate / symbolrate x (1 - limit) - |mu_gain| > 0
                               * samples per symbol.  Below min_step = 1 the reference emits several symbols from one offset
-                              * (floor(mu) = 0, complex_fd.cpp:141-143) and so do the kernels (ABI 4; such handles run in 16- and
-                              * 4-channel workgroups with a deeper symbol ring).  Refused (TETRA_ERR_UNSUPPORTED, also from the
-                              * setters): min_step < 0.27 -- at <= 0 the reference's own loop may never leave process(), and up to
-                              * 0.27 (more than 3.7 symbols per input sample) the kernels' LDS symbol ring is the limit */
+                              * (floor(mu) = 0, complex_fd.cpp:141-143) and so do the kernels (ABI 4): down to 0.27 in the fused
+                              * kernel (16- and 4-channel workgroups with a deeper symbol ring), below that in the generic one.
+                              * Refused (TETRA_ERR_UNSUPPORTED, also from the setters): min_step <= 0, where the reference's own
+                              * loop may never leave process() */
     /* Optional caller-supplied tables (NULL = design them like the reference does).  In an SDR++
      * build the host may pass SDR++'s own tap generators' output here. */
     const float* rrc_taps;        /* [rrc_tap_count]                 taps::rootRaisedCosine, pi4dqpsk.cpp:18 */
@@ -122,10 +123,14 @@ typedef struct tetra_demod_channel_state {
     int32_t prev;                    /* DQPSKSymbolExtractor prev (src/dsp/dqpsk_sym_extr.h:42) */
     float hist[2 * 80];              /* last 80 FLL outputs (re,im), newest last: FIR delay lines (only the last taps-1 matter) */
     float ybuf[2 * 7];               /* COMPLEX_FD delay buffer: last 7 RRC outputs */
-    int32_t rrc_valid;               /* how many of the newest hist[] samples the RRC FIR may see, 0..80 (80 = all; older ones are
-                                      * zeros to it).  The reference keeps a delay line per FIR object; rrc.reset()
-                                      * (pi4dqpsk.cpp:125) and a growing FIR::setTaps clear/zero-fill the RRC's only.  Below 80
-                                      * only after a TETRA_FLAG_REFERENCE_QUIRKS reset or tap-count growth. */
+    int32_t rrc_valid;               /* how many of the newest delay-line samples the RRC FIR may see, 0..128 (>= taps - 1 = all; older
+                                      * ones are zeros to it).  The reference keeps a delay line per FIR object; rrc.reset()
+                                      * (pi4dqpsk.cpp:125) and a growing FIR::setTaps clear/zero-fill the RRC's only.  The fused
+                                      * kernel keeps 80 samples and saturates the count at 80. */
+    float hist_far[2 * 48];          /* the 48 FLL outputs BEFORE hist[] (oldest first): only filters of more than 81 taps look that
+                                      * far back.  Kept by the generic kernel; a launch of the fused kernel (<= 72 taps) does not
+                                      * carry them, after it they read as zeros -- to tetra_demod_get_state and to a filter that a
+                                      * setter grows beyond 81 taps. */
 } tetra_demod_channel_state_t;
 
 /* IDs for tetra_demod_set_param: the setters of PI4DQPSK (src/dsp/pi4dqpsk.h:52-63). */
@@ -260,7 +265,7 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
 /* Copies of the designed tables (any pointer may be NULL): rrc[*taps], be_re[*be_taps], be_im[*be_taps] (lower band-edge
  * filter), bank[128*8].  The two lengths differ after a tap-count change under TETRA_FLAG_REFERENCE_QUIRKS (the FLL keeps its
  * construction-time filters), so a caller cannot size be_re / be_im from *taps: every tap buffer handed in must hold
- * TETRA_DEMOD_MAX_TAPS (80) floats, or call once with NULL buffers to learn both lengths first. */
+ * TETRA_DEMOD_MAX_TAPS (129) floats, or call once with NULL buffers to learn both lengths first. */
 int tetra_demod_get_tables(tetra_demod_t* h, int* taps, float* rrc, int* be_taps, float* be_re, float* be_im, float* bank);
 int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
 

@@ -141,6 +141,17 @@ class Oracle:
     def reset(self):
         lib().tetra_oracle_reset(C.byref(self.tab), C.byref(self.st))
 
+    def forget_far_history(self, keep=80):
+        """What a launch of the product's FUSED kernel does to the delay line: only the newest `keep` = 80 FLL outputs are carried
+        (its filters have at most 72 taps); the samples before them read as zeros afterwards -- to filters a setter grows beyond
+        81 taps and to the RRC's visibility count.  Tests that switch a handle between the fused and the generic kernel call this
+        at the same points."""
+        n = 2 * ((MAX_TAPS - 1) - keep)
+        for i in range(n):
+            self.st.hist[i] = 0.0
+        if self.st.rrc_valid > keep:
+            self.st.rrc_valid = keep
+
     def reset_reference(self):
         """PI4DQPSK::reset as the reference does it (ph2, COMPLEX_FD's delay buffer and the slicer keep their values)."""
         lib().tetra_oracle_reset_reference(C.byref(self.tab), C.byref(self.st))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time-bounded parity fuzzer: GPU (through the C ABI) against the oracle on random draws over everything the pytest cases vary
-one or two at a time -- rates (0.35 ... 4 samples per symbol, at create; below ~1 several symbols leave one offset), RRC tap count and roll-off, every loop constant, the
+one or two at a time -- rates (0.12 ... 4 samples per symbol, at create; below ~1 several symbols leave one offset), tap counts 2 ... 129, RRC tap count and roll-off, every loop constant, the
 three workgroup shapes and the automatic plan, input layout, symbol output, the quality statistic, TETRA_FLAG_REFERENCE_QUIRKS
 with resets, call lengths 0 ... 3000 with carried state, a loop setter in the middle of the stream, and inputs the synthetic
 TETRA channels do not contain (silence, noise only, amplitudes 1e-6 and 2).  Bits, bit counts, symbols (bit patterns) and
@@ -78,8 +78,10 @@ DRY = False      # --dry: the oracle side only (checks the script's own mechanic
 def one_case(rng, stats):
     sps, p = draw_params(rng)
     if rng.integers(0, 6) == 0:          # round 4: at and below one sample per symbol step (several symbols from one offset, floor(mu) = 0)
-        sps = float(rng.choice([1.02, 1.0, 0.9, 0.6, 0.35]))
+        sps = float(rng.choice([1.02, 1.0, 0.9, 0.6, 0.35, 0.2, 0.12]))          # (below 0.27 + 0.0176: the generic kernel)
         p["samplerate"] = 18000.0 * sps
+    if rng.integers(0, 10) == 0:         # filters beyond the fused kernel's 72 taps: the generic kernel
+        p["rrc_tap_count"] = int(rng.integers(73, 130))
     Cn = int(rng.integers(1, 71))
     tm = bool(rng.integers(0, 2))
     shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS, B.FLAG_SMALL_WORKGROUPS]))

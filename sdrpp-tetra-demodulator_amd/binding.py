@@ -56,6 +56,7 @@ class ChannelState(C.Structure):
         ("mu", C.c_float), ("omega", C.c_float), ("offset", C.c_int32),
         ("costas_phase", C.c_float), ("costas_freq", C.c_float), ("ph2", C.c_float), ("prev", C.c_int32),
         ("hist", C.c_float * 160), ("ybuf", C.c_float * 14), ("rrc_valid", C.c_int32),
+        ("hist_far", C.c_float * 96),
     ]
 
 
@@ -310,9 +311,9 @@ class Demodulator:
 
     def tables(self):
         nt, nbe = C.c_int(0), C.c_int(0)
-        rrc = np.zeros(80, np.float32)
-        re = np.zeros(80, np.float32)
-        im = np.zeros(80, np.float32)
+        rrc = np.zeros(129, np.float32)          # TETRA_DEMOD_MAX_TAPS
+        re = np.zeros(129, np.float32)
+        im = np.zeros(129, np.float32)
         bank = np.zeros((128, 8), np.float32)
         self._check(self._lib.tetra_demod_get_tables(self._h, C.byref(nt), _np_ptr(rrc), C.byref(nbe), _np_ptr(re), _np_ptr(im),
                                                      _np_ptr(bank)), "tetra_demod_get_tables")

@@ -161,17 +161,20 @@ inline void design_bandedge(const DesignParams& p, Design& d, int count) {
 // freq >= omega (1 - rel_limit), |err| <= 1 (complex_fd.cpp:136-143): min_step = omega (1 - rel_limit) - |mu_gain| samples per
 // symbol at least.  While min_step >= 1 every symbol advances by at least one sample (the kernel's forward-progress clamp is
 // then neutral).  Below that the reference emits several symbols from one offset (floor(mu) = 0, complex_fd.cpp:141-143): the
-// kernels' "deep" variant (kernel_fused.hpp: DEEP) does the same, with a symbol ring sized for min_step >= kMinStepDeep.
-// Still refused: min_step < kMinStepDeep -- at min_step <= 0 the reference's own loop may never leave process() or walk
-// backwards out of its buffer, and between 0 and kMinStepDeep (more than 3.7 symbols per sample) the LDS ring is the limit.
-// Output rows are sized from the same bound (tetra_demod_bits_stride_for), so any accepted parameter set fits its rows.
+// kernels' "deep" variant (kernel_fused.hpp: DEEP) does the same, with a symbol ring sized for min_step >= kMinStepDeep; below
+// that (more than 3.7 symbols per sample) and for filters of more than 72 taps the launch takes the generic kernel
+// (kernel_generic.hpp: one lane per channel, HBM scratch instead of LDS rings).  Refused: min_step <= 0 -- the reference's own loop
+// may then never leave process() or walk backwards out of its buffer -- and more than kMaxTaps taps (the delay line this
+// library and its checker keep).  Output rows are sized from min_step (tetra_demod_bits_stride_for), so any accepted parameter
+// set fits its rows.
 constexpr double kMinStepDeep = 0.27;
+constexpr int kMaxTaps = 129;          // = kernel_generic.hpp kGenMaxTaps = TETRA_DEMOD_MAX_TAPS = the oracle's TETRA_ORACLE_MAX_TAPS
 inline bool params_ok(const DesignParams& p) {
-    if (p.rrc_tap_count < 2 || p.rrc_tap_count > kPadTaps) return false;
+    if (p.rrc_tap_count < 2 || p.rrc_tap_count > kMaxTaps) return false;
     if (!(p.symbolrate > 0) || !(p.samplerate > 0)) return false;
     if (!(p.omega_rel_limit >= 0.0) || !(p.omega_rel_limit < 1.0)) return false;
     const float omega_min = (float)(p.samplerate / p.symbolrate * (1.0 - p.omega_rel_limit));
-    if (!((double)omega_min - std::fabs((double)(float)p.mu_gain) >= kMinStepDeep)) return false;
+    if (!((double)omega_min - std::fabs((double)(float)p.mu_gain) > 0.0)) return false;
     return true;
 }
 
@@ -181,6 +184,8 @@ inline bool params_ok(const DesignParams& p) {
 inline double min_step(const Design& d) { return (double)d.k2.tr_min_freq - std::fabs((double)d.k2.tr_alpha); }
 // several symbols may share an offset: the launch takes the kernels' DEEP variant
 inline bool needs_deep(const Design& d) { return min_step(d) < 1.0; }
+// beyond the fused kernel's rings and FLL rows: the generic kernel (kernel_generic.hpp)
+inline bool needs_generic(const Design& d) { return d.ntaps > kF8Pad || d.ntaps_be > kF8Pad || min_step(d) < kMinStepDeep; }
 inline long long bits_stride_for(const Design& d, long long n) {
     // K symbols are emitted only while (K - 1) min_step - 1 < n (the offsets of a call start at >= 0 and the fractional
     // parts of mu telescope to less than one sample):  K <= (n + 1) / min_step + 1; two symbols of margin for the float

@@ -4,7 +4,8 @@
 // recovery -> pi/4 Costas -> slicer -> differential decoder -> bit unpacker, as specialised waves connected by LDS rings.  Three
 // workgroup shapes of the one template: 16 channels in six waves (one workgroup per CU up to 4096 channels), 32 channels in
 // eight waves (more than 16 channels per CU) and 4 channels (at most 4 channels per CU); tetra_demod_create plans which
-// channels take which shape, the results are identical bit for bit.  (The two-kernel pipeline of round 1 -- k1_agc_fll_rrc / k2_sync_slice with an
+// channels take which shape, the results are identical bit for bit.  Parameter sets beyond that kernel's rings and FLL rows (73 ..
+// 129 taps, timing loops below 0.27 samples per symbol) run in k_generic (kernel_generic.hpp): one lane per channel, same arithmetic.  (The two-kernel pipeline of round 1 -- k1_agc_fll_rrc / k2_sync_slice with an
 // HBM scratch in between -- was retired in ABI 2; `git log` has it.)
 // Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
 // src/dsp/bit_unpacker.cpp:4-10 (see include/tetra_demod.h).
@@ -41,6 +42,7 @@ __device__ __forceinline__ Pair<float> ld_pair(const float2* p) {
 }  // namespace
 
 #include "kernel_fused.hpp"
+#include "kernel_generic.hpp"
 
 namespace {
 
@@ -194,6 +196,10 @@ struct tetra_demod {
     // device memory
     float *agc_g = nullptr, *fll_ph = nullptr, *fll_fr = nullptr;
     float2* hist = nullptr;
+    float2* hist_far = nullptr;     // [C][48]: the delay-line samples before hist's 80 (generic kernel only, kernel_generic.hpp)
+    bool far_valid = true;          // false once the fused kernel has run since hist_far was written: it then reads as zeros
+    float2 *g_xs = nullptr, *g_ys = nullptr;      // generic kernel's scratch: [C][128 + max_samples] FLL outputs, [C][7 + max_samples] RRC outputs
+    float *d_g_be_a = nullptr, *d_g_be_b = nullptr, *d_g_rrc = nullptr;   // un-padded tap tables for it, [kGenMaxTaps] each
     float *mu = nullptr, *omega = nullptr, *cph = nullptr, *cfr = nullptr, *ph2 = nullptr;
     int *offset = nullptr, *prev = nullptr;
     int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones ...
@@ -277,6 +283,14 @@ struct DeviceGuard {
 int upload_tables(tetra_demod* h) {
     HIP_TRY(h, hipMemcpy(h->d_bank, h->design.bank.data(), sizeof(float) * kInterpPhases * kInterpTaps,
                          hipMemcpyHostToDevice));
+    {   // the generic kernel's un-padded tables (any accepted tap count)
+        std::vector<float> a(kGenMaxTaps, 0.f), b(kGenMaxTaps, 0.f), r(kGenMaxTaps, 0.f);
+        for (int k = 0; k < h->design.ntaps_be; k++) { a[k] = h->design.be_re[k]; b[k] = h->design.be_im[k]; }
+        for (int k = 0; k < h->design.ntaps; k++) r[k] = h->design.rrc[k];
+        HIP_TRY(h, hipMemcpy(h->d_g_be_a, a.data(), sizeof(float) * kGenMaxTaps, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_g_be_b, b.data(), sizeof(float) * kGenMaxTaps, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_g_rrc, r.data(), sizeof(float) * kGenMaxTaps, hipMemcpyHostToDevice));
+    }
     if (h->design.ntaps <= kF8Pad && h->design.ntaps_be <= kF8Pad) {
         std::vector<float> re72(kBePad, 0.f), im72(kBePad, 0.f), rrx(kRrcExt, 0.f);
         const int o72 = kBePad - h->design.ntaps_be;
@@ -322,6 +336,7 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
     // letter (quirks, fused pipeline) the shared line therefore stays and the RRC is told to see none of it.
     if (fresh) {
         HIP_TRY(h, hipMemsetAsync(h->hist + (size_t)first * kHist, 0, sizeof(float2) * kHist * (size_t)count, 0));
+        HIP_TRY(h, hipMemsetAsync(h->hist_far + (size_t)first * (kGenHist - kHist), 0, sizeof(float2) * (kGenHist - kHist) * (size_t)count, 0));
         hipLaunchKernelGGL(k_fill_i32, dim3((count + 255) / 256), dim3(256), 0, 0, h->rrc_valid + first, (int)kHist, count);
         HIP_TRY(h, hipGetLastError());
     } else {
@@ -349,6 +364,9 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
 }
 
 void free_all(tetra_demod* h) {
+    void* gen[] = { h->hist_far, h->g_xs, h->g_ys, h->d_g_be_a, h->d_g_be_b, h->d_g_rrc };
+    for (void* p : gen)
+        if (p) (void)hipFree(p);
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
                      h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_overruns, h->d_bank, h->d_be_re80, h->d_be_im80,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
@@ -516,7 +534,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     h->dp.mu_gain = cfg->mu_gain;
     h->dp.omega_rel_limit = cfg->omega_rel_limit;
     if (!host::make_design(h->dp, cfg->rrc_taps, cfg->bandedge_taps, cfg->interp_bank, h->design) ||
-        h->design.ntaps > kF8Pad || (cfg->flags & TETRA_FLAG_RETIRED_TWO_KERNEL)) {      // the kernel covers 2..72 taps
+        stride_for(h->design, cfg->max_samples) > 0x7ffffff0ll || (cfg->flags & TETRA_FLAG_RETIRED_TWO_KERNEL)) {
         delete h;
         return TETRA_ERR_UNSUPPORTED;
     }
@@ -530,6 +548,8 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     auto A = [&](int r) { if (rc == TETRA_OK) rc = r; };
     A(dalloc(h, &h->agc_g, C)); A(dalloc(h, &h->fll_ph, C)); A(dalloc(h, &h->fll_fr, C));
     A(dalloc(h, &h->hist, C * kHist));
+    A(dalloc(h, &h->hist_far, C * (size_t)(kGenHist - kHist)));
+    A(dalloc(h, &h->d_g_be_a, (size_t)kGenMaxTaps)); A(dalloc(h, &h->d_g_be_b, (size_t)kGenMaxTaps)); A(dalloc(h, &h->d_g_rrc, (size_t)kGenMaxTaps));
     A(dalloc(h, &h->mu, C)); A(dalloc(h, &h->omega, C)); A(dalloc(h, &h->cph, C)); A(dalloc(h, &h->cfr, C));
     A(dalloc(h, &h->ph2, C)); A(dalloc(h, &h->offset, C)); A(dalloc(h, &h->prev, C));
     A(dalloc(h, &h->rrc_valid, C));
@@ -615,6 +635,42 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         return TETRA_OK;
     }
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
+    if (host::needs_generic(h->design)) {
+        // filters of more than 72 taps / timing loops slower than 0.27 samples per symbol: one lane per channel, delay lines in an
+        // HBM scratch that is allocated on the first such call (kernel_generic.hpp)
+        const size_t xs_stride = (size_t)kGenHist + (size_t)h->max_samples, ys_stride = (size_t)kYHist + (size_t)h->max_samples;
+        if (!h->g_xs) HIP_TRY(h, hipMalloc((void**)&h->g_xs, sizeof(float2) * xs_stride * (size_t)h->C));
+        if (!h->g_ys) HIP_TRY(h, hipMalloc((void**)&h->g_ys, sizeof(float2) * ys_stride * (size_t)h->C));
+        GenericParams pg;
+        pg.iq = reinterpret_cast<const float2*>(d_iq);
+        if (h->cfg.layout == TETRA_LAYOUT_CHANNEL_MAJOR) { pg.in_ch_stride = n_samples; pg.in_t_stride = 1; }
+        else { pg.in_ch_stride = 1; pg.in_t_stride = h->C; }
+        pg.n = n_samples; pg.n_channels = h->C;
+        pg.agc_g = h->agc_g; pg.fll_ph = h->fll_ph; pg.fll_fr = h->fll_fr; pg.hist = h->hist; pg.hist_far = h->hist_far;
+        pg.far_valid = h->far_valid ? 1 : 0;
+        pg.rrc_valid = h->rrc_valid; pg.mu = h->mu; pg.omega = h->omega; pg.offset = h->offset;
+        pg.cph = h->cph; pg.cfr = h->cfr; pg.ph2 = h->ph2; pg.prev = h->prev; pg.ybuf = h->ybuf;
+        pg.be_a = h->d_g_be_a; pg.be_b = h->d_g_be_b; pg.rrc = h->d_g_rrc; pg.ntaps = h->design.ntaps; pg.ntaps_be = h->design.ntaps_be;
+        pg.bank = h->d_bank;
+        pg.xs = h->g_xs; pg.ys = h->g_ys; pg.xs_stride = (long long)xs_stride; pg.ys_stride = (long long)ys_stride;
+        pg.bits = d_bits; pg.bits_stride = bits_stride; pg.n_bits = d_n_bits;
+        pg.sym = reinterpret_cast<float2*>(d_sym); pg.sym_stride = bits_stride / 2;
+        if (h->q_ring && !pg.sym) { pg.sym = h->q_sym; pg.sym_stride = h->q_sym_stride; }
+        pg.overruns = h->d_overruns; pg.cut_flag = h->cut_flag;
+        pg.y_dbg = h->keep_y ? h->y : nullptr;
+        pg.k1 = h->design.k1; pg.k2 = h->design.k2;
+        HIP_TRY(h, hipEventRecord(ev[0], s));
+        hipLaunchKernelGGL(k_generic, dim3((h->C + 63) / 64), dim3(64), 0, s, pg);
+        if (h->q_ring)
+            hipLaunchKernelGGL(k_quality, dim3(h->C), dim3(64), 0, s, pg.sym, pg.sym_stride, d_n_bits, h->q_ring, h->q_ptr, h->q_disp,
+                               h->q_err, h->q_sync);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(ev[1], s));
+        h->n_calls++;
+        h->far_valid = true;
+        return TETRA_OK;
+    }
+    h->far_valid = false;          // the fused kernel carries the newest 80 delay-line samples only
     {
         FusedParams pf;
         pf.iq = reinterpret_cast<const float2*>(d_iq);
@@ -1083,7 +1139,7 @@ int apply_params(tetra_demod* h, const host::DesignParams& np, bool tables, bool
             if (h->user_be) return TETRA_ERR_UNSUPPORTED;
             host::design_bandedge(np, nd, np.rrc_tap_count);           // documented deviation: one length for the three FIRs
         }
-        if (nd.ntaps > kF8Pad || nd.ntaps_be > kF8Pad) return TETRA_ERR_UNSUPPORTED;   // the kernel covers <= 72 taps
+        if (nd.ntaps > kGenMaxTaps || nd.ntaps_be > kGenMaxTaps) return TETRA_ERR_UNSUPPORTED;   // (params_ok has said so already)
     }
     host::design_loops(np, nd);
     host::design_timing_limits(np, nd);
@@ -1170,6 +1226,10 @@ int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_sta
     GET1(out->rrc_valid, h->rrc_valid);
 #undef GET1
     HIP_TRY(h, hipMemcpy(out->hist, h->hist + (size_t)c * kHist, sizeof(float2) * kHist, hipMemcpyDeviceToHost));
+    if (h->far_valid)
+        HIP_TRY(h, hipMemcpy(out->hist_far, h->hist_far + (size_t)c * (kGenHist - kHist), sizeof(float2) * (kGenHist - kHist), hipMemcpyDeviceToHost));
+    else
+        std::memset(out->hist_far, 0, sizeof(out->hist_far));
     HIP_TRY(h, hipMemcpy(out->ybuf, h->ybuf + (size_t)c * kYHist, sizeof(float2) * kYHist, hipMemcpyDeviceToHost));
     return TETRA_OK;
 }
@@ -1191,10 +1251,15 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     SET1(h->agc_g, in->agc_gain); SET1(h->fll_ph, fll_phase); SET1(h->fll_fr, in->fll_freq);
     SET1(h->mu, in->mu); SET1(h->omega, in->omega); SET1(h->offset, in->offset);
     SET1(h->cph, costas_phase); SET1(h->cfr, in->costas_freq); SET1(h->ph2, in->ph2); SET1(h->prev, in->prev);
-    const int rv = in->rrc_valid < 0 ? 0 : in->rrc_valid > (int)kHist ? (int)kHist : in->rrc_valid;
+    const int rv = in->rrc_valid < 0 ? 0 : in->rrc_valid > (int)kGenHist ? (int)kGenHist : in->rrc_valid;
     SET1(h->rrc_valid, rv);
 #undef SET1
     HIP_TRY(h, hipMemcpy(h->hist + (size_t)c * kHist, in->hist, sizeof(float2) * kHist, hipMemcpyHostToDevice));
+    if (!h->far_valid) {      // the far delay line of EVERY channel reads as zeros right now: make that literal, then this channel's is current
+        HIP_TRY(h, hipMemset(h->hist_far, 0, sizeof(float2) * (kGenHist - kHist) * (size_t)h->C));
+        h->far_valid = true;
+    }
+    HIP_TRY(h, hipMemcpy(h->hist_far + (size_t)c * (kGenHist - kHist), in->hist_far, sizeof(float2) * (kGenHist - kHist), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->ybuf + (size_t)c * kYHist, in->ybuf, sizeof(float2) * kYHist, hipMemcpyHostToDevice));
     return TETRA_OK;
 }

@@ -108,15 +108,16 @@ def emul_fast_clock(N, sps):
 
 def test_product_refuses_timing_loops_that_can_stall(emul):
     """min_step = omega (1 - limit) - |mu_gain|.  Below 1 the reference emits several symbols from one offset (floor(mu) = 0) and
-    so do the kernels since ABI 4; below 0.27 (more than 3.7 symbols per sample: the LDS symbol ring's limit; at <= 0 the
-    reference's own loop may never return) the product says so (TETRA_ERR_UNSUPPORTED from create and from the setters)
-    instead of dropping samples.  Everything above is accepted -- there is no other limit on the rates."""
+    so do the kernels since ABI 4 (fused kernel down to 0.27, the generic one below).  At min_step <= 0 the reference's own loop
+    may never return: the product says so (TETRA_ERR_UNSUPPORTED from create and from the setters).  Everything above is
+    accepted -- there is no other limit on the rates."""
     cfg = emul.default_cfg()
     for sym, samp, lim, ok in ((18000.0, 36000.0, 0.02, True), (20000.0, 36000.0, 0.02, True), (30000.0, 36000.0, 0.1, True),
                                (34000.0, 36000.0, 0.02, True), (36000.0, 36000.0, 0.02, True), (18000.0, 36000.0, 0.5, True),
                                (18000.0, 36000.0, 0.49, True), (18000.0, 100000.0, 0.02, True), (18000.0, 36000.0, 1.0, False),
-                               (40000.0, 36000.0, 0.02, True), (18000.0, 36000.0, 0.86, False), (18000.0, 9000.0, 0.02, True),
-                               (18000.0, 5000.0, 0.02, False), (18000.0, 36000.0, 0.85, True)):
+                               (40000.0, 36000.0, 0.02, True), (18000.0, 36000.0, 0.86, True), (18000.0, 9000.0, 0.02, True),
+                               (18000.0, 5000.0, 0.02, True), (18000.0, 36000.0, 0.85, True), (18000.0, 36000.0, 0.995, False),
+                               (18000.0, 300.0, 0.02, False)):
         cfg.symbolrate, cfg.samplerate, cfg.omega_rel_limit = sym, samp, lim
         assert (emul.bits_stride_for(cfg, 1000) > 0) == ok, (sym, samp, lim)
 
