@@ -72,14 +72,18 @@ class RefChain:
 
     def __init__(self, L, cfg):
         self.L = L
+        # smallest advance of the timing loop per symbol (complex_fd.cpp:136-143): bounds the symbols one call can emit
+        self.step = min(1.0, cfg.samplerate / cfg.symbolrate * (1.0 - cfg.omega_rel_limit) - abs(cfg.mu_gain))
         self.h = L.ref_create(cfg.symbolrate, cfg.samplerate, cfg.rrc_tap_count, cfg.rrc_beta, cfg.agc_rate,
                               cfg.costas_bandwidth, cfg.fll_bandwidth, cfg.omega_gain, cfg.mu_gain, cfg.omega_rel_limit)
 
     def process(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)
         n = len(iq)
-        sym = np.zeros(2 * n + 64, np.complex64)          # below one sample per symbol a call emits more symbols than samples
-        bits = np.zeros(4 * n + 128, np.uint8)
+        cap = int((n + 1) / self.step) + 64               # below one sample per symbol a call emits more symbols than samples
+        assert cap <= 1000000                             # (the reference's own stream buffers: STREAM_BUFFER_SIZE)
+        sym = np.zeros(cap, np.complex64)
+        bits = np.zeros(2 * cap, np.uint8)
         ns = self.L.ref_process(self.h, n, iq.ctypes.data_as(C.c_void_p), sym.ctypes.data_as(C.c_void_p),
                                 bits.ctypes.data_as(C.c_void_p))
         assert ns >= 0
@@ -382,3 +386,29 @@ def test_exact_below_one_sample_per_symbol_step(ref, oracle, synth):
         assert len(sym) > len(iq) * 0.99
         _exact(r, o, sym, bits, o.process(iq), "rate %g, one call" % rate)
         r.close()
+
+
+def test_exact_long_filters_and_very_slow_timing_loops(ref, oracle, synth):
+    """The rest of the domain the product's generic kernel covers: 73 / 100 / 129 taps (PI4DQPSK::init takes any count,
+    pi4dqpsk.cpp:11-30) and 0.12 samples per symbol (~8 symbols from every offset), incl. setRRCTapCount(101) mid-stream."""
+    for prm, sps in ((dict(rrc_tap_count=73), 2.0), (dict(rrc_tap_count=100), 2.0), (dict(rrc_tap_count=129, rrc_beta=0.3), 2.0),
+                     (dict(samplerate=18000.0 * 0.12), 1.02), (dict(samplerate=18000.0 * 0.2, rrc_tap_count=90), 1.02)):
+        cfg = oracle.default_cfg()
+        for k, v in prm.items():
+            setattr(cfg, k, v)
+        iq, _, _ = synth.gen_channel(2500, 7100 + len(prm), sps=sps)
+        r = RefChain(ref, cfg)
+        o = oracle.Oracle(cfg, reference_floats=True)
+        for a, b in ((0, 1), (1, 800), (800, 2500)):
+            if "samplerate" in prm:          # the reference's stream buffer holds STREAM_BUFFER_SIZE symbols: keep calls short
+                b = min(b, a + 600)
+            sym, bits = r.process(iq[a:b])
+            _exact(r, o, sym, bits, o.process(iq[a:b]), str(prm))
+        r.close()
+    iq, _, _ = synth.gen_channel(6000, 7200)
+    r = RefChain(ref, oracle.default_cfg())
+    o = oracle.Oracle(reference_floats=True)
+    sym, bits = r.process(iq[:3000]); _exact(r, o, sym, bits, o.process(iq[:3000]), "before growth")
+    r.set_param(2, 101); o.set_param(2, 101, quirks=True)
+    sym, bits = r.process(iq[3000:]); _exact(r, o, sym, bits, o.process(iq[3000:]), "after setRRCTapCount(101)")
+    r.close()
