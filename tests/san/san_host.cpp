@@ -247,7 +247,7 @@ int gpu_paths() {
             }
             CHECK(ex.process(5, out.data(), dib.data()) == 5 && ex.lastStatus() == TETRA_ERR_ARG);      // nothing queued: flagged
         }
-        d2.setSymbolrate(150000);                     // 0.24 samples per symbol: beyond what the kernels' symbol ring holds
+        d2.setSymbolrate(3000000);                    // 0.012 samples per symbol < |mu gain|: the timing loop could stall
         CHECK(d2.lastStatus() == TETRA_ERR_UNSUPPORTED);
         CHECK(d2.process(100, in.data(), out.data()) > 0);      // nothing changed: the block still runs at 20 ksymbols/s
         d2.setSymbolrate(36000);                      // one sample per symbol: several symbols may leave one offset (ABI 4: accepted)

@@ -313,7 +313,7 @@ def test_setter_sequences_keep_what_they_do_not_own(pkg, oracle, synth):
     assert d.tables()["be_re"].size == 49 and np.array_equal(d.tables()["be_re"], orcs[0].bandedge_taps()[0])
     _run_vs_oracles(d, orcs, iq[:, 4000:])
     with pytest.raises(pkg.TetraDemodError):
-        d.set_param("omega_rel_limit", 0.9)                           # 2.22 x 0.1 - mu_gain < 0.27: below what the symbol ring holds
+        d.set_param("omega_rel_limit", 0.995)                         # 2.22 x 0.005 - mu_gain < 0: the timing loop could stall
     d.set_param("omega_rel_limit", 0.6)                               # 2.22 x 0.4 - mu_gain = 0.87: several symbols per offset, accepted (ABI 4)
     d.close()
 
@@ -793,7 +793,7 @@ def test_symbol_rate_setter_outside_two_samples_per_symbol(pkg, oracle, synth, p
     """set_param(SYMBOLRATE, 20000) at 36 ksps (omega 1.8, omega_min 1.764: up to 1.15 n bits per call).
     Rows are sized from the handle (tetra_demod_bits_stride_for), a call with the handle-free row length is refused loudly
     (TETRA_ERR_SIZE), and with the right rows every bit and symbol equals the oracle's driven through the same setter; a
-    symbol rate beyond what the kernels' symbol ring holds (min_step < 0.27 samples per symbol) is refused
+    symbol rate at which the loop could stall (min_step <= 0: the reference itself may never return) is refused
     (TETRA_ERR_UNSUPPORTED) and changes nothing; one sample per symbol is accepted since ABI 4 (test_below_one_sample_per_symbol_step)."""
     import ctypes as C
     Cn, N = 20, 9000
@@ -817,7 +817,7 @@ def test_symbol_rate_setter_outside_two_samples_per_symbol(pkg, oracle, synth, p
     nbits = d.process(np.ascontiguousarray(iq[:, :N]))[1]
     assert (nbits > small - 32).any() or (nbits > 2 * N / 1.9).all()      # more bits than the 2-samples-per-symbol row holds
     with pytest.raises(pkg.TetraDemodError) as ei:
-        d.set_param("symbolrate", 150000.0)                                # omega 0.24: more than 3.7 symbols per sample
+        d.set_param("symbolrate", 3000000.0)                               # omega 0.012 < |mu gain|: the loop could stall
     assert ei.value.status == -2
     assert d.bits_stride(N) == need                                        # nothing changed
     d.close()
