@@ -10,6 +10,16 @@ namespace demod {
 void DecisionTap::push(const uint8_t* bits, int nBits) {
     std::lock_guard<std::mutex> l(m_);
     bits_.insert(bits_.end(), bits, bits + nBits);
+    // A consumer that was attached but is not running would let the queue grow for ever (SDR++'s streams block their writer
+    // instead; this side channel must not).  Beyond kMaxQueuedBits the OLDEST decisions are dropped and counted as consumed,
+    // so positions (statistic marks) stay aligned; a consumer that comes back late finds the newest decisions.
+    if (bits_.size() > kMaxQueuedBits) {
+        const size_t drop = (bits_.size() - kMaxQueuedBits + 1) & ~(size_t)1;
+        bits_.erase(bits_.begin(), bits_.begin() + drop);
+        consumed_ += (long long)(drop / 2);
+        dropped_ += (long long)(drop / 2);
+        while (!marks_.empty() && marks_.front().pos <= consumed_) marks_.pop_front();
+    }
 }
 void DecisionTap::mark(long long pos, float err, bool sync) {
     std::lock_guard<std::mutex> l(m_);

@@ -45,14 +45,16 @@ public:
     // Returns nSym, or the (smaller) number available if the source has not produced that many -- a wiring error.
     int pop(int nSym, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync);
     long long consumedSymbols() const { return consumed_; }
+    long long droppedSymbols() const { return dropped_; }      // decisions discarded because nobody took them (see push)
     void clear();
+    static constexpr size_t kMaxQueuedBits = (size_t)1 << 24;   // 8 Mi symbols = 7.8 minutes of one TETRA channel
 
 private:
     struct Mark { long long pos; float err; bool sync; };
     std::mutex m_;
     std::deque<uint8_t> bits_;
     std::deque<Mark> marks_;
-    long long consumed_ = 0;
+    long long consumed_ = 0, dropped_ = 0;
 };
 
 class PI4DQPSK : public Processor<complex_t, complex_t> {
