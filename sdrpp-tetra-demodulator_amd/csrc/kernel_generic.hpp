@@ -45,10 +45,13 @@ struct GenericParams {
     float2* y_dbg;         // optional: time-major [(7 + n)][C], row 7 + i = y_i (TETRA_FLAG_KEEP_RRC_OUT)
     K1Consts k1;
     K2Consts k2;
+    int lanes;             // channels per wave (1 .. 64): every channel is one serial walk, so a launch of few channels spreads them
+                           // over MANY waves (the latency of one walk is what it is; more waves per CU hide it)
 };
 
 __global__ __launch_bounds__(64) void k_generic(GenericParams p) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    if ((int)threadIdx.x >= p.lanes) return;
+    const int c = blockIdx.x * p.lanes + threadIdx.x;
     if (c >= p.n_channels) return;
     const int n = p.n, H = kGenHist;
     float2* xs = p.xs + (long long)c * p.xs_stride;
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(64) void k_generic(GenericParams p) {
             // the two band-edge FIRs over the newest nb samples as four fmaf chains, oldest sample first (conjugate tap pair)
             const float2* w = xs + H + i - (nb - 1);
             float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll 16          // sixteen window loads in flight per trip: the chains stay in tap order, the memory latency overlaps
             for (int k = 0; k < nb; k++) {
                 const float2 xv = w[k];
                 const float ta = p.be_a[k], tb = p.be_b[k];
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(64) void k_generic(GenericParams p) {
             const long long have = (long long)valid0 + i + 1;
             const int k0 = have >= nt ? 0 : (int)(nt - have);
             float ar = 0.f, ai = 0.f;
+#pragma unroll 16
             for (int k = k0; k < nt; k++) {
                 const float2 xv = w[k];
                 const float t = p.rrc[k];

@@ -660,7 +660,12 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pg.y_dbg = h->keep_y ? h->y : nullptr;
         pg.k1 = h->design.k1; pg.k2 = h->design.k2;
         HIP_TRY(h, hipEventRecord(ev[0], s));
-        hipLaunchKernelGGL(k_generic, dim3((h->C + 63) / 64), dim3(64), 0, s, pg);
+        {   // about eight waves per CU when there are enough channels, never more than 64 channels per wave
+            int lanes = h->C / (8 * h->cus);
+            lanes = lanes < 1 ? 1 : lanes > 64 ? 64 : lanes;
+            pg.lanes = lanes;
+            hipLaunchKernelGGL(k_generic, dim3((h->C + lanes - 1) / lanes), dim3(64), 0, s, pg);
+        }
         if (h->q_ring)
             hipLaunchKernelGGL(k_quality, dim3(h->C), dim3(64), 0, s, pg.sym, pg.sym_stride, d_n_bits, h->q_ring, h->q_ptr, h->q_disp,
                                h->q_err, h->q_sync);
