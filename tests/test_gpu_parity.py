@@ -1115,3 +1115,66 @@ def test_setters_move_a_handle_between_the_fused_and_the_generic_kernel(pkg, ora
         assert not np.any(np.array(st.hist_far[:]))                        # after a fused launch: zeros
         assert np.array_equal(_u32(np.array(st.hist[:], np.float32)), _u32(np.array(o.st.hist[:], np.float32)[-160:])), c
     d.close()
+
+
+@pytest.mark.parametrize("prm", [dict(samplerate=18000.0), dict(rrc_tap_count=100), dict(samplerate=18000.0 * 0.2)],
+                         ids=["deep_1sps", "generic_100taps", "generic_0.2sps"])
+def test_every_host_entry_point_on_the_wider_parameter_domain(pkg, oracle, synth, prm):
+    """The entry points around the launch -- the in-place short call (180 samples), the packed short call, the plain synchronous
+    call, tetra_demod_process_async (float and int16, two calls in flight) and tetra_demod_process_resident -- with the fused
+    kernel's DEEP variant (one sample per symbol) and with the generic kernel (100 taps; 0.2 samples per symbol): one stream cut
+    across all of them, every bit against the oracle."""
+    import torch
+    B = pkg.binding
+    Cn = 6
+    sizes = [180, 2000, 40000 if "rrc_tap_count" in prm else 9000, 9001, 5000, 3000]
+    iq, _, _ = synth.gen_batch(Cn, sum(sizes), base_seed=6300, amp=0.5, sps=2.0 if "rrc_tap_count" in prm else 1.02)
+    q = np.clip(np.round(iq.view(np.float32) * 32768.0), -32768, 32767).astype(np.int16)
+    iq_q = (q.astype(np.float32) / np.float32(32768.0)).view(np.complex64)
+    d = pkg.Demodulator(Cn, max(sizes), **prm)
+    cfg = oracle.default_cfg()
+    for k, v in prm.items():
+        setattr(cfg, k, v)
+    orcs = [oracle.Oracle(cfg) for _ in range(Cn)]
+    dev = torch.device("cuda", 0)
+    pos = 0
+
+    def check(bits, nb, data, n, what):
+        for c in range(Cn):
+            r = orcs[c].process(data[c, pos:pos + n])
+            assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (what, c)
+
+    for k, n in enumerate(sizes):
+        if n == 0:
+            continue
+        stride = d.bits_stride(n)
+        if k < 3:                                       # tetra_demod_process: in place / packed / plain, by size
+            bits, nb, _ = d.process(np.ascontiguousarray(iq[:, pos:pos + n]))
+            check(bits, nb, iq, n, "sync %d" % n)
+        elif k < 5:                                     # two asynchronous calls in flight: float, then int16
+            keep = []
+            p2 = pos
+            for fmt, raw in ((B.IQ_CF32, iq), (B.IQ_CS16, q.reshape(Cn, -1, 2))):
+                m = sizes[k] if fmt == B.IQ_CF32 else sizes[k + 1]
+                host_in = _pinned(torch, raw[:, p2:p2 + m])
+                st = d.bits_stride(m)
+                hb = torch.zeros((Cn, st), dtype=torch.uint8).pin_memory()
+                hn = torch.zeros((Cn,), dtype=torch.int32).pin_memory()
+                d.process_async(host_in.data_ptr(), fmt, m, hb.data_ptr(), st, hn.data_ptr())
+                keep.append((host_in, hb, hn, m, iq if fmt == B.IQ_CF32 else iq_q))
+                p2 += m
+            d.wait()
+            for host_in, hb, hn, m, data in keep:
+                check(hb.numpy(), hn.numpy(), data, m, "async %d" % m)
+                pos += m
+            sizes[k + 1] = 0
+            continue
+        else:                                           # device-resident
+            d_iq = torch.from_numpy(np.ascontiguousarray(iq[:, pos:pos + n])).to(dev)
+            d_bits = torch.zeros((Cn, stride), dtype=torch.uint8, device=dev)
+            d_nb = torch.zeros(Cn, dtype=torch.int32, device=dev)
+            d.process_resident(d_iq, n, d_bits, stride, d_nb)
+            check(d_bits.cpu().numpy(), d_nb.cpu().numpy(), iq, n, "resident %d" % n)
+        pos += n
+    assert d.overruns() == 0
+    d.close()
