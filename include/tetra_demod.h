@@ -61,6 +61,8 @@ enum {
                                     1.3x the 4096-channel time instead of 2x.  Results are identical bit for
                                     bit.  Band-edge filters of more than 68 taps (rrc_tap_count 69..72) never run in 32-channel
                                     workgroups. */
+    TETRA_FLAG_GENERIC_KERNEL = 128,   /* filters of 73 .. 129 taps in the one-lane-per-channel kernel instead of the fused kernel's long
+                                        * rows (same results; tests and A/B measurements) */
     TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
                                     the dsp::block sets it):
                                       - tetra_demod_reset keeps ph2 (src/dsp/pi4dqpsk_costas.h:32 is never reset by
@@ -91,7 +93,9 @@ typedef struct tetra_demod_config {
     double symbolrate;       /* 18000 */
     double samplerate;       /* 36000 */
     int32_t rrc_tap_count;   /* 65 (the reference builds with RRC_TAP_COUNT 65, src/main.cpp:36); 2..129.  Up to 72 taps run in the fused
-                              * kernel; 73..129 in the generic one (one lane per channel: correct to the bit, not fast) */
+                              * kernel's regular rows; 73..129 in its LONG variant (4 channels per workgroup, FLL rows of 16 x 9 taps:
+                              * a quarter of the regular throughput beyond 1024 channels), or with TETRA_FLAG_GENERIC_KERNEL in the
+                              * generic kernel (one lane per channel) -- bit-identical results either way */
     int32_t flags;           /* TETRA_FLAG_* */
     double rrc_beta;         /* 0.35 */
     double agc_rate;         /* 0.02 */
@@ -128,7 +132,7 @@ typedef struct tetra_demod_channel_state {
                                       * (pi4dqpsk.cpp:125) and a growing FIR::setTaps clear/zero-fill the RRC's only.  The fused
                                       * kernel keeps 80 samples and saturates the count at 80. */
     float hist_far[2 * 48];          /* the 48 FLL outputs BEFORE hist[] (oldest first): only filters of more than 81 taps look that
-                                      * far back.  Kept by the generic kernel; a launch of the fused kernel (<= 72 taps) does not
+                                      * far back.  Kept by the fused kernel's long rows and by the generic kernel; a launch of the fused kernel's regular rows (<= 72 taps) does not
                                       * carry them, after it they read as zeros -- to tetra_demod_get_state and to a filter that a
                                       * setter grows beyond 81 taps. */
 } tetra_demod_channel_state_t;

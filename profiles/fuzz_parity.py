@@ -80,8 +80,10 @@ def one_case(rng, stats):
     if rng.integers(0, 6) == 0:          # round 4: at and below one sample per symbol step (several symbols from one offset, floor(mu) = 0)
         sps = float(rng.choice([1.02, 1.0, 0.9, 0.6, 0.35, 0.2, 0.12]))          # (below 0.27 + 0.0176: the generic kernel)
         p["samplerate"] = 18000.0 * sps
-    if rng.integers(0, 10) == 0:         # filters beyond the fused kernel's 72 taps: the generic kernel
+    generic = 0
+    if rng.integers(0, 10) == 0:         # filters beyond the 72 taps of the fused kernel's regular rows: its long rows, or the generic kernel
         p["rrc_tap_count"] = int(rng.integers(73, 130))
+        generic = B.FLAG_GENERIC_KERNEL if rng.integers(0, 3) == 0 else 0
     Cn = int(rng.integers(1, 71))
     tm = bool(rng.integers(0, 2))
     shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS, B.FLAG_SMALL_WORKGROUPS]))
@@ -94,7 +96,7 @@ def one_case(rng, stats):
     for c in range(Cn):
         if rng.integers(0, 8) == 0:
             iq[c] = special_channel(rng, int(rng.integers(0, 4)), N)
-    desc = dict(params=p, C=Cn, time_major=tm, shape=shape, quality=quality, quirks=quirks, chunks=chunks, seed=seed)
+    desc = dict(params=p, C=Cn, time_major=tm, shape=shape | generic, quality=quality, quirks=quirks, chunks=chunks, seed=seed)
     try:
         orcs = [oracle.Oracle(oracle_cfg(p)) for _ in range(Cn)]
     except ValueError:
@@ -112,7 +114,7 @@ def one_case(rng, stats):
         return None
     try:
         d = pkg.Demodulator(Cn, 3000, layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR,
-                            flags=shape | (B.FLAG_QUALITY if quality else 0) | (B.FLAG_REFERENCE_QUIRKS if quirks else 0), **p)
+                            flags=shape | generic | (B.FLAG_QUALITY if quality else 0) | (B.FLAG_REFERENCE_QUIRKS if quirks else 0), **p)
     except B.TetraDemodError as e:
         stats["refused"] += 1
         # what the library refuses, the oracle's design must not be asked to run either: only the documented limits

@@ -401,6 +401,10 @@ constexpr int kF4Pad = kF4Lanes * kF4Taps;   // 68
 constexpr int kF16Lanes = 16;                // a whole DPP row per channel: the 4-channel workgroup (at most 4 channels per CU)
 constexpr int kF16Taps = 5;
 constexpr int kF16Pad = kF16Lanes * kF16Taps;   // 80
+constexpr int kF16LTaps = 9;                 // the LONG 4-channel workgroup: 16 positions x 9 taps = 144 padded taps, for filters of 73 .. 129
+constexpr int kF16LPad = kF16Lanes * kF16LTaps; // taps (PI4DQPSK::setRRCTapCount takes any count, pi4dqpsk.cpp:56-70; fll16l_asm.inc)
+constexpr int kHistLong = 128;               // delay-line samples that variant keeps: the newest 80 (hist) + the 48 before them (hist_far)
+constexpr int kBePadLong = kF16LPad;         // its band-edge tap tables: zero-padded (old end) to 144 entries
 constexpr int kBePad = kPadTaps;             // band-edge tap tables are handed to the kernel zero-padded (old end) to 80 entries
 constexpr int ct_gcd(int a, int b) { return b == 0 ? a : ct_gcd(b, a % b); }
 
@@ -420,7 +424,8 @@ template <class V, int LANES, int TAPS> struct FllRowT {
     // the replay walks whole groups: the newest kReplay >= LANES * TAPS stored samples (older ones only reach
     // sums that complete, unused, before the first real step)
     static constexpr int kReplay = ((LANES * TAPS + kGroup - 1) / kGroup) * kGroup;
-    static_assert(16 % LANES == 0 && kReplay <= kHist, "row geometry");
+    // (the long row replays 144 ring slots: its 128 stored samples and, under zero taps, 16 zeros in front of them)
+    static_assert(16 % LANES == 0 && (kReplay <= kHist || LANES * TAPS == kF16LPad), "row geometry");
     V ta[TAPS], tb[TAPS];
     P r14[kRes], r32[kRes];
     P xs;        // lane (pos, channel-in-row) holds x_{i-pos} of its channel
@@ -461,6 +466,7 @@ template <class V, int LANES, int TAPS> struct FllRowT {
 template <class V> using FllRow8 = FllRowT<V, kF8Lanes, kF8Taps>;
 template <class V> using FllRow4 = FllRowT<V, kF4Lanes, kF4Taps>;
 template <class V> using FllRow16 = FllRowT<V, kF16Lanes, kF16Taps>;
+template <class V> using FllRow16L = FllRowT<V, kF16Lanes, kF16LTaps>;
 
 // Drivers of an FLL row.  IO (device: LDS accesses of one lane; host emulation: arrays):
 //   P    load_hist(int g)               lane (pos, ch) <- stored delay-line sample g*LANES + pos of the last Row::kReplay
@@ -512,6 +518,8 @@ template <class Row, class IO, bool ALPHA0> TD_FN void fll_tile(Row& R, const K1
 constexpr int kRrcMaxTaps = 80;
 constexpr int kRrcOut = 8;
 constexpr int kRrcExt = 104;   // >= 7 + 7 (alignment pad) + kRrcMaxTaps - 1 + 16, a multiple of 4
+constexpr int kRrcMaxTapsLong = 129;      // the long 4-channel workgroup (filters of 73 .. 129 taps)
+constexpr int kRrcExtLong = 160;          // >= 7 + 7 + 128 + 16
 struct Tap4 { float v[4]; };
 // One chunk of the walk.  ENDS: 0 = every product; 1 = the FIRST chunk of a window whose taps start exactly at ext[7]
 // (no alignment pad): sample j meets tap kk = j - m of output m, which exists only for j >= m; 2 = the LAST chunk of

@@ -162,8 +162,8 @@ inline void design_bandedge(const DesignParams& p, Design& d, int count) {
 // symbol at least.  While min_step >= 1 every symbol advances by at least one sample (the kernel's forward-progress clamp is
 // then neutral).  Below that the reference emits several symbols from one offset (floor(mu) = 0, complex_fd.cpp:141-143): the
 // kernels' "deep" variant (kernel_fused.hpp: DEEP) does the same, with a symbol ring sized for min_step >= kMinStepDeep; below
-// that (more than 3.7 symbols per sample) and for filters of more than 72 taps the launch takes the generic kernel
-// (kernel_generic.hpp: one lane per channel, HBM scratch instead of LDS rings).  Refused: min_step <= 0 -- the reference's own loop
+// that (more than 3.7 symbols per sample) the launch takes the generic kernel (kernel_generic.hpp: one lane per channel, HBM
+// scratch instead of LDS rings); filters of 73 .. 129 taps take the fused kernel's long rows (needs_long below).  Refused: min_step <= 0 -- the reference's own loop
 // may then never leave process() or walk backwards out of its buffer -- and more than kMaxTaps taps (the delay line this
 // library and its checker keep).  Output rows are sized from min_step (tetra_demod_bits_stride_for), so any accepted parameter
 // set fits its rows.
@@ -184,8 +184,11 @@ inline bool params_ok(const DesignParams& p) {
 inline double min_step(const Design& d) { return (double)d.k2.tr_min_freq - std::fabs((double)d.k2.tr_alpha); }
 // several symbols may share an offset: the launch takes the kernels' DEEP variant
 inline bool needs_deep(const Design& d) { return min_step(d) < 1.0; }
-// beyond the fused kernel's rings and FLL rows: the generic kernel (kernel_generic.hpp)
-inline bool needs_generic(const Design& d) { return d.ntaps > kF8Pad || d.ntaps_be > kF8Pad || min_step(d) < kMinStepDeep; }
+// beyond the fused kernel's symbol ring: the generic kernel (kernel_generic.hpp)
+inline bool needs_generic(const Design& d) { return min_step(d) < kMinStepDeep; }
+// filters beyond the 72 taps of the fused kernel's regular rows: its LONG variant (4 channels per workgroup, FLL rows of 16 x 9
+// taps, 128 delay-line samples) -- or, on request (TETRA_FLAG_GENERIC_KERNEL), the generic kernel
+inline bool needs_long(const Design& d) { return !needs_generic(d) && (d.ntaps > kF8Pad || d.ntaps_be > kF8Pad); }
 inline long long bits_stride_for(const Design& d, long long n) {
     // K symbols are emitted only while (K - 1) min_step - 1 < n (the offsets of a call start at >= 0 and the fractional
     // parts of mu telescope to less than one sample):  K <= (n + 1) / min_step + 1; two symbols of margin for the float

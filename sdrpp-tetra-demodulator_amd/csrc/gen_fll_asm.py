@@ -43,8 +43,9 @@ class Shape:
     interleaved, so a hop between neighbouring positions is a shift by 16/lanes lanes.  The schedule's period is taps - 1
     steps (the residents of a position), which must divide the tile."""
 
-    def __init__(self, lanes, taps, out, prefix, what, fold_c12=True, whole_tile_loads=True):
+    def __init__(self, lanes, taps, out, prefix, what, fold_c12=True, whole_tile_loads=True, be_pad=80):
         self.lanes, self.taps, self.out, self.prefix, self.what = lanes, taps, os.path.join(HERE, out), prefix, what
+        self.be_pad = be_pad          # entries per band-edge tap table in LDS (FusedLds::be80): the imaginary taps sit that far behind the real ones
         # the first two Cody-Waite steps as ONE fma with C1 + C2 (the operand %[negc1] then carries -(C1 + C2)): C1 + C2 is a
         # binary32 number, k is -1, 0 or 1 and x - k*C1 is exact (Sterbenz) for every |x| <= pi, so fma(-k, C1 + C2, x) is
         # fma(-k, C2, fma(-k, C1, x)) bit for bit -- checked over all 2 157 060 024 floats of [-pi, pi] in tests/test_oracle.py.
@@ -71,6 +72,8 @@ SHAPES = {
     "fll4": Shape(4, 17, "fll4_asm.inc", "FLL4_WAVE", "FLL wave, 4 lanes per channel", whole_tile_loads=False),
     # 4-channel workgroups (at most 4 channels per CU): one FLL wave of 4 channels, a whole DPP row per channel (80 = 16 x 5)
     "fll16": Shape(16, 5, "fll16_asm.inc", "FLL16_WAVE", "FLL wave, 16 lanes per channel"),
+    # the LONG 4-channel workgroup: filters of 73 .. 129 taps (144 = 16 x 9 padded taps; tables of 144 entries)
+    "fll16l": Shape(16, 9, "fll16l_asm.inc", "FLL16L_WAVE", "FLL wave, 16 lanes per channel, 9 taps per lane", be_pad=144),
 }
 G = SHAPES["fll"]
 OUT = G.out
@@ -225,7 +228,6 @@ def pk_consts():
     return [u(a) | (u(b) << 32) for (a, b) in pairs]
 
 
-BE_IM_OFFSET = 80 * 4            # byte offset of the imaginary taps behind the real ones in FusedLds::be80
 
 
 def tap_operand(base, j):
@@ -403,7 +405,7 @@ def gen():
     E.ins("v_mov_b32 v%d, %s" % (R_2PI, f32(FL_PI - (-FL_PI))), "valu", [R_2PI])
     for j in range(TAPS):
         E.ins("ds_read_b32 v%d, v%d offset:%d" % (R_TA + j, R_TAPADDR, 4 * j), "lds", [R_TA + j])
-        E.ins("ds_read_b32 v%d, v%d offset:%d" % (R_TB + j, R_TAPADDR, BE_IM_OFFSET + 4 * j), "lds", [R_TB + j])
+        E.ins("ds_read_b32 v%d, v%d offset:%d" % (R_TB + j, R_TAPADDR, 4 * G.be_pad + 4 * j), "lds", [R_TB + j])
     for i in range(NRES):
         E.ins("v_mov_b64 %s, 0" % pair(R_R14 + 2 * i), "valu", [R_R14 + 2 * i, R_R14 + 2 * i + 1])
         E.ins("v_mov_b64 %s, 0" % pair(R_R32 + 2 * i), "valu", [R_R32 + 2 * i, R_R32 + 2 * i + 1])
@@ -493,7 +495,7 @@ def generate(shape=None):
 
 def main():
     rc = 0
-    for name in ("fll", "fll4", "fll16"):
+    for name in ("fll", "fll4", "fll16", "fll16l"):
         text, E, per_tile = generate(SHAPES[name])
         out = SHAPES[name].out
         if "--check" in sys.argv:

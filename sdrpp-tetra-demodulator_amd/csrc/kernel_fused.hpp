@@ -21,9 +21,11 @@
 // their SIMD and the throughput roles fill the slots they leave.  (Cutting the FLL in two -- loop waves plus a helper wave
 // for the far taps -- was built and measured in round 2: it shortens the longest wave but adds work and a seventh role that
 // does not pack into four SIMDs, profiles/r02/r02_c_fll_split_experiment.md; round 3 bounded ANY re-homing of the FIR work --
-// helper wave, matrix pipe -- by ablation: nothing to gain, profiles/r03/r03_b_matrix_pipe_and_coresidency.md.)
+// helper wave, matrix pipe -- by ablation: nothing to gain, profiles/r03/r03_b_matrix_pipe_and_coresidency.md; round 4 measured why the
+// matrix pipe cannot help an exact-f32 chain: v_mfma_f32_*_f32 occupies the vector ALUs for its passes, profiles/r04/r04_l_*.)
 // Two more shapes of the same template: 32 channels in eight waves (FLL rows of 4 lanes per channel: more than 16 channels per
-// CU) and 4 channels (FLL rows of 16 lanes: at most 4 channels per CU); see Roles<CH> below and DESIGN.md section 5.
+// CU) and 4 channels (FLL rows of 16 lanes: at most 4 channels per CU; its LONG variant -- rows of 16 x 9 taps, 128 delay-line
+// samples -- takes filters of 73 .. 129 taps at any channel count); see Roles<CH> below and DESIGN.md section 4.2.
 //
 // Stages are connected by LDS rings (AGC out -> FLL out x -> RRC out y -> symbols) and run as a software pipeline over
 // 32-sample tiles with one workgroup barrier per tile: in epoch e, A works on tile e, F on e-1, C on e-2, D consumes y
@@ -34,6 +36,7 @@
 #include "fll_asm.inc"
 #include "fll4_asm.inc"
 #include "fll16_asm.inc"
+#include "fll16l_asm.inc"
 
 namespace {
 
@@ -77,6 +80,7 @@ constexpr int kFSDeep = 256;             // ... and for timing loops that may em
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
 static_assert(kF16Pad == 80 && kF16Taps == 5, "fll16_asm.inc is generated for 16 positions x 5 taps");
+static_assert(kF16LPad == 144 && kF16LTaps == 9 && kBePadLong == 144, "fll16l_asm.inc is generated for 16 positions x 9 taps, tables of 144");
 
 // Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
 // the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
@@ -111,7 +115,8 @@ namespace role_ids { constexpr int w[7] = { TETRA_ROLE_IDS_WIDE }; }
 #define TETRA_ROLE_IDS_SMALL 1, 2, 0, -1, 7, 3        // E, D, F0, (no F1), A, C
 #endif
 namespace role_ids { constexpr int m[6] = { TETRA_ROLE_IDS_SMALL }; }
-template <int CH> struct Roles {
+// LONG (4-channel shape only): FLL rows of 16 positions x 9 taps and deeper tables, for filters of 73 .. 129 taps.
+template <int CH, bool LONG = false> struct Roles {
     static constexpr int E = CH == 16 ? role_ids::v[0] : CH == 4 ? role_ids::m[0] : role_ids::w[0],
                          D = CH == 16 ? role_ids::v[1] : CH == 4 ? role_ids::m[1] : role_ids::w[1],
                          F0 = CH == 16 ? role_ids::v[2] : CH == 4 ? role_ids::m[2] : role_ids::w[2],
@@ -119,8 +124,9 @@ template <int CH> struct Roles {
                          C = CH == 16 ? role_ids::v[5] : CH == 4 ? role_ids::m[5] : role_ids::w[5],
                          C2 = CH == 32 ? role_ids::w[6] : -1, NF = CH == 4 ? 1 : 2;
     // FLL row geometry: lanes per channel, taps per lane, channels per FLL wave
-    static constexpr int FL = CH == 16 ? kF8Lanes : CH == 4 ? kF16Lanes : kF4Lanes, FT = CH == 16 ? kF8Taps : CH == 4 ? kF16Taps : kF4Taps,
-                         FCH = 64 / FL;
+    static constexpr int FL = CH == 16 ? kF8Lanes : CH == 4 ? kF16Lanes : kF4Lanes,
+                         FT = CH == 16 ? kF8Taps : CH == 4 ? (LONG ? kF16LTaps : kF16Taps) : kF4Taps, FCH = 64 / FL;
+    static_assert(!LONG || CH == 4, "the long rows exist for the 4-channel shape");
     static_assert(NF * FCH == CH, "the FLL waves cover the workgroup's channels");
 };
 
@@ -167,13 +173,21 @@ struct FusedParams {
 // others carry the pointer in `prof` (unused by every non-instrumented kernel).
 template <int CH> struct FusedParamsT : FusedParams {};
 template <> struct FusedParamsT<kFChSmall> : FusedParams { int* cut_flag4; };
+// the long variant also carries the 48 delay-line samples in front of hist's 80 (tetra_demod_channel_state_t::hist_far)
+struct FusedParamsLong : FusedParamsT<kFChSmall> {
+    float2* hist_far;    // [C][kHistLong - kHist]
+    int far_valid;       // 0: not current (a kernel that does not carry them ran since they were written): zeros to every filter
+};
+template <int CH, bool LONG> struct FusedArgs { typedef FusedParamsT<CH> type; };
+template <> struct FusedArgs<kFChSmall, true> { typedef FusedParamsLong type; };
 template <int CH, bool PROF> __device__ __forceinline__ int* fused_cut_flag(const FusedParamsT<CH>& p) {
     if constexpr (CH == kFChSmall) return p.cut_flag4;
     else return PROF ? nullptr : reinterpret_cast<int*>(p.prof);
 }
 
-template <int CH, bool DEEP = false> struct FusedLdsT {
+template <int CH, bool DEEP = false, bool LONG = false> struct FusedLdsT {
     static constexpr int kS = DEEP ? kFSDeep : kFS;
+    static constexpr int kRE = LONG ? kRrcExtLong : kRrcExt, kBP = LONG ? kBePadLong : kBePad;
     float2 a_buf[2][CH][kFAS];
     float2 x_ring[CH][kFXS];
     float2 y_ring[CH][kFYS];
@@ -185,12 +199,13 @@ template <int CH, bool DEEP = false> struct FusedLdsT {
     // interpolator bank with row 0 repeated in front and row 127 behind: rows max(p-1,0), p, min(p+1,127) of
     // complex_fd.cpp:102-121 are then the 24 contiguous floats at bank[p * 8]
     __attribute__((aligned(16))) float bank[(kInterpPhases + 2) * kInterpTaps];
-    __attribute__((aligned(16))) float rrc[kRrcExt];       // zero-extended taps, see rrc_direct8
-    float be80[2][kBePad];   // band-edge taps (re, im), zero-padded at the old end: the FLL waves' assembly loads its taps from here
+    __attribute__((aligned(16))) float rrc[kRE];           // zero-extended taps, see rrc_direct8
+    float be80[2][kBP];      // band-edge taps (re, im), zero-padded at the old end: the FLL waves' assembly loads its taps from here
 };
 typedef FusedLdsT<kFCh> FusedLds;
 static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256 &&
-              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024 && sizeof(FusedLdsT<kFCh, true>) <= 104 * 1024, "LDS budget of a CU");
+              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024 && sizeof(FusedLdsT<kFCh, true>) <= 104 * 1024 &&
+              sizeof(FusedLdsT<kFChSmall, true, true>) <= 40 * 1024, "LDS budget of a CU");
 
 // Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
 // register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
@@ -262,14 +277,17 @@ template <class LDS, class Row> struct FllDeviceIOT {
 #endif
 // DEEP: the timing loop may emit several symbols from one offset (min_step < 1, see kFSDeep): deeper symbol ring, no forward-
 // progress clamp in the timing step, the output-row check on every symbol.  Everything else is the same code.
-template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(FusedParamsT<CH> p) {
-    typedef FusedLdsT<CH, DEEP> Lds;
+// LONG (4-channel shape): filters of 73 .. 129 taps -- FLL rows of 16 x 9 taps (fll16l_asm.inc), tap tables of 144 / 160 entries,
+// 128 delay-line samples carried (hist + hist_far).  Everything else is the same code.
+template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false, bool LONG = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(typename FusedArgs<CH, LONG>::type p) {
+    typedef FusedLdsT<CH, DEEP, LONG> Lds;
+    constexpr int kH = LONG ? kHistLong : kHist;      // delay-line samples in front of the call
     constexpr int kSR = Lds::kS;          // symbol ring depth
     constexpr int kMinAdv = DEEP ? 0 : 1;
     static_assert(!DEEP || CH != kFChWide, "the deep symbol ring is instantiated for the 16- and 4-channel shapes");
-    typedef FllRowT<float, Roles<CH>::FL, Roles<CH>::FT> FllRow;
+    typedef FllRowT<float, Roles<CH, LONG>::FL, Roles<CH, LONG>::FT> FllRow;
     typedef FllDeviceIOT<Lds, FllRow> FllDeviceIO;
-    typedef Roles<CH> R_;
+    typedef Roles<CH, LONG> R_;
     constexpr int kRoleE = R_::E, kRoleD = R_::D, kRoleF0 = R_::F0, kRoleA = R_::A, kRoleC = R_::C;
     constexpr int kThreadsCH = fused_threads(CH);
     __shared__ Lds L;
@@ -291,8 +309,8 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
         row = row < 0 ? 0 : (row > kInterpPhases - 1 ? kInterpPhases - 1 : row);
         L.bank[i] = p.bank[row * kInterpTaps + i % kInterpTaps];
     }
-    if (tid < kRrcExt) L.rrc[tid] = p.rrc_ext[tid];
-    if (tid < kBePad) { L.be80[0][tid] = p.be_re80[tid]; L.be80[1][tid] = p.be_im80[tid]; }
+    if (tid < Lds::kRE) L.rrc[tid] = p.rrc_ext[tid];
+    if (tid < Lds::kBP) { L.be80[0][tid] = p.be_re80[tid]; L.be80[1][tid] = p.be_im80[tid]; }
     // rings start at zero: FIR windows touch slots that were never written (weighted by zero taps, so they must be finite)
     for (int i = tid; i < CH * kFXS; i += kThreadsCH) (&L.x_ring[0][0])[i] = make_float2(0.f, 0.f);
     for (int i = tid; i < CH * kFYS; i += kThreadsCH) (&L.y_ring[0][0])[i] = make_float2(0.f, 0.f);
@@ -301,6 +319,14 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
     for (int i = tid; i < CH * kHist; i += kThreadsCH) {
         const int c = i / kHist, m = i % kHist;
         x_ring_put(L, c, m - kHist, p.hist[(long long)chan(c) * kHist + m]);
+    }
+    if constexpr (LONG) {
+        constexpr int kFar = kHistLong - kHist;
+        if (p.far_valid)
+            for (int i = tid; i < CH * kFar; i += kThreadsCH) {
+                const int c = i / kFar, m = i % kFar;
+                x_ring_put(L, c, m - kHistLong, p.hist_far[(long long)chan(c) * kFar + m]);
+            }
     }
     for (int i = tid; i < CH * (kInterpTaps - 1); i += kThreadsCH) {
         const int c = i / (kInterpTaps - 1), m = i % (kInterpTaps - 1);
@@ -372,7 +398,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
         // instrument the block.
         const int nfull = ALPHA0 ? n / kFT : 0;
         // padded tap kp of the row sits at be80[kp + 80 - LANES * TAPS] (both are padded at the old end)
-        constexpr int kTapOff = kBePad - FllRow::kLanes * FllRow::kTaps;
+        constexpr int kTapOff = Lds::kBP - FllRow::kLanes * FllRow::kTaps;
         if (nfull > 0) {
             int base_ = 0, tiles_ = nfull, st_;
             const unsigned a_addr = lds_addr(&L.a_buf[0][f_c][0]);
@@ -380,7 +406,17 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
             const unsigned tap_addr = lds_addr(&L.be80[0][kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos)]);
             const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - FllRow::kReplay]);
             const unsigned long long p4 = (unsigned long long)__builtin_bit_cast(unsigned, 0.4f);
-            if constexpr (CH == 4) {
+            if constexpr (LONG) {
+                asm volatile(FLL16L_WAVE_ASM
+                             : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
+                             : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
+                               [maxf] "v"(k1.fll_max_freq),
+                               [negc1] "s"(FLL16L_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [p4] "s"(p4),
+                               [k1] "s"(FLL16L_WAVE_K1), [k2] "s"(FLL16L_WAVE_K2), [k3] "s"(FLL16L_WAVE_K3), [k4] "s"(FLL16L_WAVE_K4),
+                               [a_sum] "v"(2u * a_addr + (unsigned)(sizeof(float2) * CH * kFAS))
+                             : "vcc", "scc", "memory", FLL16L_WAVE_CLOBBERS);
+            } else if constexpr (CH == 4) {
                 // (negc1: -C1 of the phasor's Cody-Waite reduction, or -(C1 + C2) for a block generated with the first two steps
                 // folded into one fma -- exact for every phase in [-pi, pi], checked exhaustively in tests/test_oracle.py; the
                 // generator says which in <block>_NEGC1)
@@ -472,7 +508,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
         // valid0 are zeros to the RRC (and only to it).  Rare, and only the tiles whose windows reach into the delay
         // line are affected: they take the masked copy of the loop, wave-uniformly.
         const int valid0 = p.rrc_valid[chan(c)];
-        const bool blanked = __builtin_amdgcn_readfirstlane(__any(valid0 < kHist) ? 1 : 0) != 0;
+        const bool blanked = __builtin_amdgcn_readfirstlane(__any(valid0 < kH) ? 1 : 0) != 0;
         __syncthreads();
         FUSED_EPOCHS(
             const int t = e - 2;
@@ -516,7 +552,7 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
               }
             }
         )
-        if (wave == kRoleC && lane < CH && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kHist ? kHist : valid0 + n;
+        if (wave == kRoleC && lane < CH && live(c)) p.rrc_valid[ch0 + c] = valid0 + n >= kH ? kH : valid0 + n;
     } else if (wave == kRoleD) {
         // ---- timing recovery; consumes y of tiles <= e-3 ------------------------------------------------------
         // 16- and 4-channel workgroups: FOUR lanes per channel (lane = 4 c + kq), each holding one of the symbol's three
@@ -759,6 +795,13 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false> __gl
     for (int i = tid; i < CH * kHist; i += kThreadsCH) {
         const int c = i / kHist, m = i % kHist;
         if (live(c)) p.hist[(long long)(ch0 + c) * kHist + m] = x_ring_get(L, c, n - kHist + m);
+    }
+    if constexpr (LONG) {
+        constexpr int kFar = kHistLong - kHist;
+        for (int i = tid; i < CH * kFar; i += kThreadsCH) {
+            const int c = i / kFar, m = i % kFar;
+            if (live(c)) p.hist_far[(long long)(ch0 + c) * kFar + m] = x_ring_get(L, c, n - kHistLong + m);
+        }
     }
     for (int i = tid; i < CH * (kInterpTaps - 1); i += kThreadsCH) {
         const int c = i / (kInterpTaps - 1), m = i % (kInterpTaps - 1);

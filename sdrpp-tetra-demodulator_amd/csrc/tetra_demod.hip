@@ -4,9 +4,10 @@
 // recovery -> pi/4 Costas -> slicer -> differential decoder -> bit unpacker, as specialised waves connected by LDS rings.  Three
 // workgroup shapes of the one template: 16 channels in six waves (one workgroup per CU up to 4096 channels), 32 channels in
 // eight waves (more than 16 channels per CU) and 4 channels (at most 4 channels per CU); tetra_demod_create plans which
-// channels take which shape, the results are identical bit for bit.  Parameter sets beyond that kernel's rings and FLL rows (73 ..
-// 129 taps, timing loops below 0.27 samples per symbol) run in k_generic (kernel_generic.hpp): one lane per channel, same arithmetic.  (The two-kernel pipeline of round 1 -- k1_agc_fll_rrc / k2_sync_slice with an
-// HBM scratch in between -- was retired in ABI 2; `git log` has it.)
+// channels take which shape, the results are identical bit for bit.  Filters of 73 .. 129 taps take the 4-channel shape's LONG
+// variant (FLL rows of 16 x 9 taps, 128 delay-line samples); timing loops below 0.27 samples per symbol -- and, on request, the
+// long filters -- run in k_generic (kernel_generic.hpp): one lane per channel, same arithmetic.  (The two-kernel pipeline of
+// round 1 -- k1_agc_fll_rrc / k2_sync_slice with an HBM scratch in between -- was retired in ABI 2; `git log` has it.)
 // Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
 // src/dsp/bit_unpacker.cpp:4-10 (see include/tetra_demod.h).
 //
@@ -196,7 +197,7 @@ struct tetra_demod {
     // device memory
     float *agc_g = nullptr, *fll_ph = nullptr, *fll_fr = nullptr;
     float2* hist = nullptr;
-    float2* hist_far = nullptr;     // [C][48]: the delay-line samples before hist's 80 (generic kernel only, kernel_generic.hpp)
+    float2* hist_far = nullptr;     // [C][48]: the delay-line samples before hist's 80 (the fused kernel's long rows and the generic kernel)
     bool far_valid = true;          // false once the fused kernel has run since hist_far was written: it then reads as zeros
     float2 *g_xs = nullptr, *g_ys = nullptr;      // generic kernel's scratch: [C][128 + max_samples] FLL outputs, [C][7 + max_samples] RRC outputs
     float *d_g_be_a = nullptr, *d_g_be_b = nullptr, *d_g_rrc = nullptr;   // un-padded tap tables for it, [kGenMaxTaps] each
@@ -205,6 +206,7 @@ struct tetra_demod {
     int n_wide = 0;             // channels [0, n_wide) run in 32-channel workgroups, [n_wide, C) in 16-channel ones ...
     bool small = false;         // ... or, when they are at most 4 per CU (or the flag forces it), in 4-channel ones
     bool force_small = false;   // TETRA_FLAG_SMALL_WORKGROUPS
+    bool force_generic = false; // TETRA_FLAG_GENERIC_KERNEL
     int cus = 256;
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // TETRA_FLAG_KEEP_RRC_OUT: time-major RRC output scratch [(7 + max_samples)][C]
@@ -303,6 +305,19 @@ int upload_tables(tetra_demod* h) {
         HIP_TRY(h, hipMemcpy(h->d_be_re80, re72.data(), sizeof(float) * kBePad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_be_im80, im72.data(), sizeof(float) * kBePad, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rrx.data(), sizeof(float) * kRrcExt, hipMemcpyHostToDevice));
+    } else {
+        // filters of 73 .. 129 taps: the same tables in the long rows' sizes (kernel_fused.hpp: LONG)
+        std::vector<float> re(kBePadLong, 0.f), im(kBePadLong, 0.f), rrx(kRrcExtLong, 0.f);
+        const int o = kBePadLong - h->design.ntaps_be;
+        const int rpad = (8 - ((h->design.ntaps - 1) & 7)) & 7;
+        for (int k = 0; k < h->design.ntaps_be; k++) {
+            re[o + k] = h->design.be_re[k];
+            im[o + k] = h->design.be_im[k];
+        }
+        for (int k = 0; k < h->design.ntaps; k++) rrx[7 + rpad + k] = h->design.rrc[k];
+        HIP_TRY(h, hipMemcpy(h->d_be_re80, re.data(), sizeof(float) * kBePadLong, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_be_im80, im.data(), sizeof(float) * kBePadLong, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_rrc_ext, rrx.data(), sizeof(float) * kRrcExtLong, hipMemcpyHostToDevice));
     }
     return TETRA_OK;
 }
@@ -581,6 +596,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) { h->n_wide = h->C; h->small = false; }
         if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) { h->n_wide = 0; h->small = false; }
         if (cfg->flags & TETRA_FLAG_SMALL_WORKGROUPS) { h->n_wide = 0; h->small = h->force_small = true; }
+        h->force_generic = (cfg->flags & TETRA_FLAG_GENERIC_KERNEL) != 0;
     }
     if (h->keep_y) A(dalloc(h, &h->y, C * ((size_t)h->max_samples + kYHist)));
     A(dalloc(h, &h->ybuf, C * kYHist));
@@ -591,8 +607,8 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         A(dalloc(h, &h->q_sym, C * (size_t)h->q_sym_stride));
     }
     A(dalloc(h, &h->d_overruns, (size_t)1));
-    A(dalloc(h, &h->d_be_re80, (size_t)kBePad)); A(dalloc(h, &h->d_be_im80, (size_t)kBePad));
-    A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExt));
+    A(dalloc(h, &h->d_be_re80, (size_t)kBePadLong)); A(dalloc(h, &h->d_be_im80, (size_t)kBePadLong));   // (sized for the long rows' tables)
+    A(dalloc(h, &h->d_rrc_ext, (size_t)kRrcExtLong));
     A(dalloc(h, &h->d_bank, (size_t)kInterpPhases * kInterpTaps));
     if (rc == TETRA_OK && hipMemset(h->d_overruns, 0, sizeof(int)) != hipSuccess) rc = TETRA_ERR_HIP;
     for (auto& slot : h->ev)
@@ -635,9 +651,10 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         return TETRA_OK;
     }
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
-    if (host::needs_generic(h->design)) {
-        // filters of more than 72 taps / timing loops slower than 0.27 samples per symbol: one lane per channel, delay lines in an
-        // HBM scratch that is allocated on the first such call (kernel_generic.hpp)
+    const bool long_rows = host::needs_long(h->design) && !h->force_generic;
+    if (host::needs_generic(h->design) || (host::needs_long(h->design) && h->force_generic)) {
+        // timing loops slower than 0.27 samples per symbol (and, with TETRA_FLAG_GENERIC_KERNEL, filters of more than 72 taps): one
+        // lane per channel, delay lines in an HBM scratch that is allocated on the first such call (kernel_generic.hpp)
         const size_t xs_stride = (size_t)kGenHist + (size_t)h->max_samples, ys_stride = (size_t)kYHist + (size_t)h->max_samples;
         if (!h->g_xs) HIP_TRY(h, hipMalloc((void**)&h->g_xs, sizeof(float2) * xs_stride * (size_t)h->C));
         if (!h->g_ys) HIP_TRY(h, hipMalloc((void**)&h->g_ys, sizeof(float2) * ys_stride * (size_t)h->C));
@@ -675,7 +692,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         h->far_valid = true;
         return TETRA_OK;
     }
-    h->far_valid = false;          // the fused kernel carries the newest 80 delay-line samples only
+    const bool far_was_valid = h->far_valid;
+    h->far_valid = long_rows;      // the fused kernel carries the newest 80 delay-line samples only -- its long rows all 128
     {
         FusedParams pf;
         pf.iq = reinterpret_cast<const float2*>(d_iq);
@@ -701,8 +719,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         // (the same for a timing loop that may emit several symbols from one offset: the deep symbol ring exists for the 16-
         // and 4-channel shapes)
         const bool deep = host::needs_deep(h->design);
-        const int n_wide = h->design.ntaps_be <= kF4Pad && !deep ? h->n_wide : 0;
-        const bool rest_small = h->force_small || (h->small && h->C - n_wide <= kFChSmall * h->cus);
+        const int n_wide = h->design.ntaps_be <= kF4Pad && !deep && !long_rows ? h->n_wide : 0;
+        const bool rest_small = long_rows || h->force_small || (h->small && h->C - n_wide <= kFChSmall * h->cus);
         const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh),
             gs((h->C - n_wide + kFChSmall - 1) / kFChSmall);
         // the FLL's loop filter runs with alpha = 0 (fll.cpp:25; design.hpp never produces anything else): only those kernels exist
@@ -738,7 +756,15 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                 FusedParamsT<kFChSmall> ps;
                 static_cast<FusedParams&>(ps) = pf;
                 ps.cut_flag4 = h->cut_flag;
-                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true>), gs, ts, 0, s, ps);
+                if (long_rows) {
+                    // filters of 73 .. 129 taps: FLL rows of 16 x 9 taps, 4 channels per workgroup whatever the channel count
+                    FusedParamsLong pl;
+                    static_cast<FusedParamsT<kFChSmall>&>(pl) = ps;
+                    pl.hist_far = h->hist_far;
+                    pl.far_valid = far_was_valid ? 1 : 0;
+                    if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true, true>), gs, ts, 0, s, pl);
+                    else hipLaunchKernelGGL((k_fused<true, false, kFChSmall, false, true>), gs, ts, 0, s, pl);
+                } else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true>), gs, ts, 0, s, ps);
                 else hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, ps);
             } else if (n_wide < h->C) {
                 pf.ch_base = n_wide;

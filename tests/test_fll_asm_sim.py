@@ -27,6 +27,8 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     if mutate:
         lines = mutate(lines)
     hop, nch = 16 // lanes, 64 // lanes
+    # the long rows (16 x 9 = 144 padded taps, filters of 73 .. 129 taps): tap tables of 144 entries, 128 delay-line samples
+    BEP, KH = (144, 128) if lanes * taps > 80 else (80, KHIST)
     nres = taps - 1
     group = max(nres, lanes)
     replay = -(-(lanes * taps) // group) * group
@@ -40,33 +42,30 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     ocfg = oracle.default_cfg()
     ocfg.agc_rate = 0.0
     ocfg.rrc_tap_count = ntaps
-    ecfg = emul.default_cfg()
-    ecfg.agc_rate = 0.0
-    ecfg.rrc_tap_count = ntaps
-    tab = emul.design(ecfg)
+    otab = oracle.Oracle(ocfg).tab          # (the tables: the oracle's design; the emulation's are capped at 80 taps)
     want_x, want_state, hist, start = [], [], [], []
     for c in range(nch):
         o = oracle.Oracle(ocfg)
         if warm:
             r0 = o.process(iq_all[c, :warm], stages=True)
-            hist.append(r0["x"][-KHIST:])
+            hist.append(r0["x"][-KH:])
             start.append((o.st.fll_phase, o.st.fll_freq))
         r = o.process(iq[c], stages=True)
         want_x.append(r["x"])
         want_state.append((o.st.fll_phase, o.st.fll_freq))
     # LDS image: [a_buf[2][nch][32] float2] [tap table re[80] | im[80]] [x_ring[nch][8 + 256 + 1] float2]; a_buf first, like in
     # FusedLds: the block flips between its halves with an XOR of the address
-    nt = int(tab.ntaps)
-    be = np.zeros((2, 80), np.float32)
-    be[0, 80 - nt:] = np.array(tab.be_re[:nt], np.float32)
-    be[1, 80 - nt:] = np.array(tab.be_im[:nt], np.float32)
+    nt = int(otab.ntaps_be)
+    be = np.zeros((2, BEP), np.float32)
+    be[0, BEP - nt:] = np.array(otab.be_a[:nt], np.float32)
+    be[1, BEP - nt:] = np.array(otab.be_b[:nt], np.float32)
     AROW = (TILE + 2) * 8           # kernel_fused.hpp kFAS: rows of the AGC output buffer are padded by two samples
     a_bytes = 2 * nch * AROW
     off_a, off_be = 0, a_bytes
-    off_x = off_be + 2 * 80 * 4
+    off_x = off_be + 2 * BEP * 4
     row = (KFXP + KFX + 1) * 8
     lds = np.zeros(off_x + nch * row + 64, np.uint8)
-    lds[off_be:off_be + 2 * 80 * 4] = be.view(np.uint8).reshape(-1)
+    lds[off_be:off_be + 2 * BEP * 4] = be.view(np.uint8).reshape(-1)
 
     def put_tile(t):
         if t >= ntiles:
@@ -78,14 +77,14 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
 
     put_tile(0)
     if warm:
-        assert warm >= KHIST
-        for c in range(nch):          # the last 80 outputs of the first call sit at the end of the ring (kernel_fused.hpp prologue)
-            a = off_x + c * row + (KFXP + KFX - KHIST) * 8
-            lds[a:a + KHIST * 8] = np.ascontiguousarray(hist[c]).view(np.uint8)
+        assert warm >= KH
+        for c in range(nch):          # the last 80 (128) outputs of the first call sit at the end of the ring (kernel_fused.hpp prologue)
+            a = off_x + c * row + (KFXP + KFX - KH) * 8
+            lds[a:a + KH * 8] = np.ascontiguousarray(hist[c]).view(np.uint8)
     lane = np.arange(64)
     pos = (lane & 15) // hop
     ch = (lane >> 4) * hop + lane % hop
-    tap_off = 80 - lanes * taps
+    tap_off = BEP - lanes * taps
     vec = {
         "ph": np.array([np.float32(start[c][0]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
         "fr": np.array([np.float32(start[c][1]).view(np.uint32) for c in ch], np.uint32) if warm else np.zeros(64, np.uint32),
@@ -94,12 +93,12 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
         "x_rowlane": (off_x + ch * row + KFXP * 8 - 8 * pos).astype(np.uint32),
         "tap_addr": (off_be + 4 * (tap_off + taps * (lanes - 1 - pos))).astype(np.uint32),
         "hist_addr": (off_x + ch * row + (KFXP + KFX - replay) * 8).astype(np.uint32),
-        "maxf": np.full(64, np.float32(tab.k1.fll_max_freq).view(np.uint32), np.uint32),
+        "maxf": np.full(64, np.float32(otab.fll_max_freq).view(np.uint32), np.uint32),
     }
     f32 = lambda x: int(np.float32(x).view(np.uint32))
     sca = {
         # (a block generated with the first two Cody-Waite steps folded into one fma takes -(C1 + C2) here: <macro>_NEGC1)
-        "negc1": f32(-(np.float32(3.140625) + np.float32(9.67502593994140625e-4))) if folded else f32(-3.140625), "beta": f32(tab.k1.fll_beta), "minf": f32(tab.k1.fll_min_freq),
+        "negc1": f32(-(np.float32(3.140625) + np.float32(9.67502593994140625e-4))) if folded else f32(-3.140625), "beta": f32(otab.fll_beta), "minf": f32(otab.fll_min_freq),
         "p4": (f32(0.4), 0), "base": 0, "tiles": ntiles, "st": 0,
         "k1": consts["K1"], "k2": consts["K2"], "k3": consts["K3"], "k4": consts["K4"],
     }
@@ -120,7 +119,8 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
     return bad
 
 
-GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4, 17), ("fll16_asm.inc", "FLL16_WAVE", 16, 5)]
+GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4, 17), ("fll16_asm.inc", "FLL16_WAVE", 16, 5),
+              ("fll16l_asm.inc", "FLL16L_WAVE", 16, 9)]
 
 
 @pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
@@ -135,7 +135,8 @@ def test_generated_fll_assembly_second_call_replays_the_delay_line(oracle, emul,
 
 @pytest.mark.parametrize("fname,macro,lanes,taps,ntaps", [GEOMETRIES[0] + (2,), GEOMETRIES[0] + (33,), GEOMETRIES[0] + (72,),
                                                           GEOMETRIES[1] + (2,), GEOMETRIES[1] + (33,), GEOMETRIES[1] + (68,),
-                                                          GEOMETRIES[2] + (2,), GEOMETRIES[2] + (33,), GEOMETRIES[2] + (72,)])
+                                                          GEOMETRIES[2] + (2,), GEOMETRIES[2] + (33,), GEOMETRIES[2] + (72,),
+                                                          GEOMETRIES[3] + (73,), GEOMETRIES[3] + (100,), GEOMETRIES[3] + (129,)])
 def test_generated_fll_assembly_other_tap_counts(oracle, emul, synth, fname, macro, lanes, taps, ntaps):
     """Band-edge filters shorter than the row (zero-padded at the old end) and as long as the row holds."""
     assert _run(oracle, emul, synth, fname, macro, lanes, taps, ntaps=ntaps) == []
