@@ -70,7 +70,7 @@ def make_input(torch, synth, device, n_channels, n_samples, seed):
     return out, txb
 
 
-KERNEL_SOURCES = ("kernel_fused.hpp", "demod_core.hpp", "fll_asm.inc", "fll4_asm.inc", "fll16_asm.inc", "fll16l_asm.inc")      # what k_fused is compiled from (+ the flags below)
+KERNEL_SOURCES = ("kernel_fused.hpp", "demod_core.hpp", "fll_asm.inc", "fll4_asm.inc", "fll16_asm.inc", "fll16l_asm.inc", "fll8l_asm.inc")      # what k_fused is compiled from (+ the flags below)
 
 
 def kernel_source_hash():

@@ -93,9 +93,9 @@ typedef struct tetra_demod_config {
     double symbolrate;       /* 18000 */
     double samplerate;       /* 36000 */
     int32_t rrc_tap_count;   /* 65 (the reference builds with RRC_TAP_COUNT 65, src/main.cpp:36); 2..129.  Up to 72 taps run in the fused
-                              * kernel's regular rows; 73..129 in its LONG variant (4 channels per workgroup, FLL rows of 16 x 9 taps:
-                              * a quarter of the regular throughput beyond 1024 channels), or with TETRA_FLAG_GENERIC_KERNEL in the
-                              * generic kernel (one lane per channel) -- bit-identical results either way */
+                              * kernel's regular rows; 73..129 in its LONG variant (FLL rows of 16 x 9 taps in 4-channel workgroups up to
+                              * 1024 channels, 8 x 17 in 16-channel ones beyond: about three quarters of the 65-tap rate), or with
+                              * TETRA_FLAG_GENERIC_KERNEL in the generic kernel (one lane per channel) -- bit-identical results */
     int32_t flags;           /* TETRA_FLAG_* */
     double rrc_beta;         /* 0.35 */
     double agc_rate;         /* 0.02 */

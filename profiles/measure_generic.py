@@ -7,7 +7,8 @@ import numpy as np, torch, tetra_amd
 pkg = tetra_amd.pkg
 B = pkg.binding
 dev = torch.device('cuda', 0)
-CASES = ((256, dict(rrc_tap_count=100), 0), (1024, dict(rrc_tap_count=100), 0), (4096, dict(rrc_tap_count=100), 0),
+CASES = ((256, dict(rrc_tap_count=100), 0), (1024, dict(rrc_tap_count=100), 0), (1028, dict(rrc_tap_count=100), 0), (4096, dict(rrc_tap_count=100), 0),
+         (4096, dict(rrc_tap_count=100), B.FLAG_SMALL_WORKGROUPS), (8192, dict(rrc_tap_count=100), 0),
          (4096, dict(rrc_tap_count=129), 0), (4096, dict(rrc_tap_count=65), 0),
          (4096, dict(rrc_tap_count=100), B.FLAG_GENERIC_KERNEL), (256, dict(rrc_tap_count=129), B.FLAG_GENERIC_KERNEL),
          (4096, dict(samplerate=18000.0 * 0.2), 0))
@@ -25,6 +26,6 @@ for C, prm, flags in CASES:
     for _ in range(3):
         d.process_device(iq, N, bits, stride, nb, None, s); torch.cuda.synchronize()
         ms.append(float(d.kernel_ms_history(1)[0]))
-    print(json.dumps(dict(channels=C, samples=N, params=prm, kernel="generic" if flags or "samplerate" in prm else ("fused, long rows" if prm.get("rrc_tap_count", 65) > 72 else "fused"),
+    print(json.dumps(dict(channels=C, samples=N, params=prm, flags=flags, kernel="generic" if flags & B.FLAG_GENERIC_KERNEL or "samplerate" in prm else ("fused, long rows" if prm.get("rrc_tap_count", 65) > 72 else "fused"),
                           kernel_ms=round(min(ms), 3), msamples_s=round(C * N / min(ms) / 1e3, 1))))
     d.close()

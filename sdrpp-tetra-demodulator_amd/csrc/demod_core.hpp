@@ -403,6 +403,8 @@ constexpr int kF16Taps = 5;
 constexpr int kF16Pad = kF16Lanes * kF16Taps;   // 80
 constexpr int kF16LTaps = 9;                 // the LONG 4-channel workgroup: 16 positions x 9 taps = 144 padded taps, for filters of 73 .. 129
 constexpr int kF16LPad = kF16Lanes * kF16LTaps; // taps (PI4DQPSK::setRRCTapCount takes any count, pi4dqpsk.cpp:56-70; fll16l_asm.inc)
+constexpr int kF8LTaps = 17;                 // ... and the LONG 16-channel workgroup: 8 positions x 17 taps = 136 padded taps (fll8l_asm.inc)
+constexpr int kF8LPad = kF8Lanes * kF8LTaps;
 constexpr int kHistLong = 128;               // delay-line samples that variant keeps: the newest 80 (hist) + the 48 before them (hist_far)
 constexpr int kBePadLong = kF16LPad;         // its band-edge tap tables: zero-padded (old end) to 144 entries
 constexpr int kBePad = kPadTaps;             // band-edge tap tables are handed to the kernel zero-padded (old end) to 80 entries
@@ -425,7 +427,7 @@ template <class V, int LANES, int TAPS> struct FllRowT {
     // sums that complete, unused, before the first real step)
     static constexpr int kReplay = ((LANES * TAPS + kGroup - 1) / kGroup) * kGroup;
     // (the long row replays 144 ring slots: its 128 stored samples and, under zero taps, 16 zeros in front of them)
-    static_assert(16 % LANES == 0 && (kReplay <= kHist || LANES * TAPS == kF16LPad), "row geometry");
+    static_assert(16 % LANES == 0 && (kReplay <= kHist || LANES * TAPS == kF16LPad || LANES * TAPS == kF8LPad), "row geometry");
     V ta[TAPS], tb[TAPS];
     P r14[kRes], r32[kRes];
     P xs;        // lane (pos, channel-in-row) holds x_{i-pos} of its channel
@@ -467,6 +469,7 @@ template <class V> using FllRow8 = FllRowT<V, kF8Lanes, kF8Taps>;
 template <class V> using FllRow4 = FllRowT<V, kF4Lanes, kF4Taps>;
 template <class V> using FllRow16 = FllRowT<V, kF16Lanes, kF16Taps>;
 template <class V> using FllRow16L = FllRowT<V, kF16Lanes, kF16LTaps>;
+template <class V> using FllRow8L = FllRowT<V, kF8Lanes, kF8LTaps>;
 
 // Drivers of an FLL row.  IO (device: LDS accesses of one lane; host emulation: arrays):
 //   P    load_hist(int g)               lane (pos, ch) <- stored delay-line sample g*LANES + pos of the last Row::kReplay

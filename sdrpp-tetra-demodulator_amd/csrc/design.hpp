@@ -186,8 +186,8 @@ inline double min_step(const Design& d) { return (double)d.k2.tr_min_freq - std:
 inline bool needs_deep(const Design& d) { return min_step(d) < 1.0; }
 // beyond the fused kernel's symbol ring: the generic kernel (kernel_generic.hpp)
 inline bool needs_generic(const Design& d) { return min_step(d) < kMinStepDeep; }
-// filters beyond the 72 taps of the fused kernel's regular rows: its LONG variant (4 channels per workgroup, FLL rows of 16 x 9
-// taps, 128 delay-line samples) -- or, on request (TETRA_FLAG_GENERIC_KERNEL), the generic kernel
+// filters beyond the 72 taps of the fused kernel's regular rows: its LONG variant (FLL rows of 16 x 9 taps in 4-channel workgroups,
+// 8 x 17 in 16-channel ones; 128 delay-line samples) -- or, on request (TETRA_FLAG_GENERIC_KERNEL), the generic kernel
 inline bool needs_long(const Design& d) { return !needs_generic(d) && (d.ntaps > kF8Pad || d.ntaps_be > kF8Pad); }
 inline long long bits_stride_for(const Design& d, long long n) {
     // K symbols are emitted only while (K - 1) min_step - 1 < n (the offsets of a call start at >= 0 and the fractional

@@ -74,6 +74,8 @@ SHAPES = {
     "fll16": Shape(16, 5, "fll16_asm.inc", "FLL16_WAVE", "FLL wave, 16 lanes per channel"),
     # the LONG 4-channel workgroup: filters of 73 .. 129 taps (144 = 16 x 9 padded taps; tables of 144 entries)
     "fll16l": Shape(16, 9, "fll16l_asm.inc", "FLL16L_WAVE", "FLL wave, 16 lanes per channel, 9 taps per lane", be_pad=144),
+    # the LONG 16-channel workgroup: the same filters on rows of 8 lanes per channel (136 = 8 x 17 padded taps), for more than 1024 channels
+    "fll8l": Shape(8, 17, "fll8l_asm.inc", "FLL8L_WAVE", "FLL wave, 8 lanes per channel, 17 taps per lane", be_pad=144),
 }
 G = SHAPES["fll"]
 OUT = G.out
@@ -495,7 +497,7 @@ def generate(shape=None):
 
 def main():
     rc = 0
-    for name in ("fll", "fll4", "fll16", "fll16l"):
+    for name in ("fll", "fll4", "fll16", "fll16l", "fll8l"):
         text, E, per_tile = generate(SHAPES[name])
         out = SHAPES[name].out
         if "--check" in sys.argv:

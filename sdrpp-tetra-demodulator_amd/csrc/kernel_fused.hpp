@@ -37,6 +37,7 @@
 #include "fll4_asm.inc"
 #include "fll16_asm.inc"
 #include "fll16l_asm.inc"
+#include "fll8l_asm.inc"
 
 namespace {
 
@@ -81,6 +82,7 @@ static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 posi
 static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
 static_assert(kF16Pad == 80 && kF16Taps == 5, "fll16_asm.inc is generated for 16 positions x 5 taps");
 static_assert(kF16LPad == 144 && kF16LTaps == 9 && kBePadLong == 144, "fll16l_asm.inc is generated for 16 positions x 9 taps, tables of 144");
+static_assert(kF8LPad == 136 && kF8LTaps == 17, "fll8l_asm.inc is generated for 8 positions x 17 taps, tables of 144");
 
 // Wave index of each role, in the order E, D, F0, F1, A, C.  A workgroup's waves go to the CU's four SIMDs cyclically and
 // the OLDER wave of a SIMD is served first, so this table decides who shares a SIMD with whom and who has priority there:
@@ -115,7 +117,7 @@ namespace role_ids { constexpr int w[7] = { TETRA_ROLE_IDS_WIDE }; }
 #define TETRA_ROLE_IDS_SMALL 1, 2, 0, -1, 7, 3        // E, D, F0, (no F1), A, C
 #endif
 namespace role_ids { constexpr int m[6] = { TETRA_ROLE_IDS_SMALL }; }
-// LONG (4-channel shape only): FLL rows of 16 positions x 9 taps and deeper tables, for filters of 73 .. 129 taps.
+// LONG (4- and 16-channel shapes): FLL rows of 16 positions x 9 taps / 8 x 17 and deeper tables, for filters of 73 .. 129 taps.
 template <int CH, bool LONG = false> struct Roles {
     static constexpr int E = CH == 16 ? role_ids::v[0] : CH == 4 ? role_ids::m[0] : role_ids::w[0],
                          D = CH == 16 ? role_ids::v[1] : CH == 4 ? role_ids::m[1] : role_ids::w[1],
@@ -125,8 +127,8 @@ template <int CH, bool LONG = false> struct Roles {
                          C2 = CH == 32 ? role_ids::w[6] : -1, NF = CH == 4 ? 1 : 2;
     // FLL row geometry: lanes per channel, taps per lane, channels per FLL wave
     static constexpr int FL = CH == 16 ? kF8Lanes : CH == 4 ? kF16Lanes : kF4Lanes,
-                         FT = CH == 16 ? kF8Taps : CH == 4 ? (LONG ? kF16LTaps : kF16Taps) : kF4Taps, FCH = 64 / FL;
-    static_assert(!LONG || CH == 4, "the long rows exist for the 4-channel shape");
+                         FT = CH == 16 ? (LONG ? kF8LTaps : kF8Taps) : CH == 4 ? (LONG ? kF16LTaps : kF16Taps) : kF4Taps, FCH = 64 / FL;
+    static_assert(!LONG || CH == 4 || CH == 16, "the long rows exist for the 4- and 16-channel shapes");
     static_assert(NF * FCH == CH, "the FLL waves cover the workgroup's channels");
 };
 
@@ -174,12 +176,12 @@ struct FusedParams {
 template <int CH> struct FusedParamsT : FusedParams {};
 template <> struct FusedParamsT<kFChSmall> : FusedParams { int* cut_flag4; };
 // the long variant also carries the 48 delay-line samples in front of hist's 80 (tetra_demod_channel_state_t::hist_far)
-struct FusedParamsLong : FusedParamsT<kFChSmall> {
+template <int CH> struct FusedParamsLongT : FusedParamsT<CH> {
     float2* hist_far;    // [C][kHistLong - kHist]
     int far_valid;       // 0: not current (a kernel that does not carry them ran since they were written): zeros to every filter
 };
 template <int CH, bool LONG> struct FusedArgs { typedef FusedParamsT<CH> type; };
-template <> struct FusedArgs<kFChSmall, true> { typedef FusedParamsLong type; };
+template <int CH> struct FusedArgs<CH, true> { typedef FusedParamsLongT<CH> type; };
 template <int CH, bool PROF> __device__ __forceinline__ int* fused_cut_flag(const FusedParamsT<CH>& p) {
     if constexpr (CH == kFChSmall) return p.cut_flag4;
     else return PROF ? nullptr : reinterpret_cast<int*>(p.prof);
@@ -205,7 +207,7 @@ template <int CH, bool DEEP = false, bool LONG = false> struct FusedLdsT {
 typedef FusedLdsT<kFCh> FusedLds;
 static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256 &&
               sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024 && sizeof(FusedLdsT<kFCh, true>) <= 104 * 1024 &&
-              sizeof(FusedLdsT<kFChSmall, true, true>) <= 40 * 1024, "LDS budget of a CU");
+              sizeof(FusedLdsT<kFChSmall, true, true>) <= 40 * 1024 && sizeof(FusedLdsT<kFCh, true, true>) <= 108 * 1024, "LDS budget of a CU");
 
 // Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
 // register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
@@ -277,8 +279,8 @@ template <class LDS, class Row> struct FllDeviceIOT {
 #endif
 // DEEP: the timing loop may emit several symbols from one offset (min_step < 1, see kFSDeep): deeper symbol ring, no forward-
 // progress clamp in the timing step, the output-row check on every symbol.  Everything else is the same code.
-// LONG (4-channel shape): filters of 73 .. 129 taps -- FLL rows of 16 x 9 taps (fll16l_asm.inc), tap tables of 144 / 160 entries,
-// 128 delay-line samples carried (hist + hist_far).  Everything else is the same code.
+// LONG (4- and 16-channel shapes): filters of 73 .. 129 taps -- FLL rows of 16 x 9 taps (fll16l_asm.inc) / 8 x 17 (fll8l_asm.inc), tap
+// tables of 144 / 160 entries, 128 delay-line samples carried (hist + hist_far).  Everything else is the same code.
 template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false, bool LONG = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(typename FusedArgs<CH, LONG>::type p) {
     typedef FusedLdsT<CH, DEEP, LONG> Lds;
     constexpr int kH = LONG ? kHistLong : kHist;      // delay-line samples in front of the call
@@ -406,7 +408,17 @@ template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false, bool
             const unsigned tap_addr = lds_addr(&L.be80[0][kTapOff + FllRow::kTaps * (FllRow::kLanes - 1 - f_pos)]);
             const unsigned hist_addr = lds_addr(&L.x_ring[f_c][kFXP + kFX - FllRow::kReplay]);
             const unsigned long long p4 = (unsigned long long)__builtin_bit_cast(unsigned, 0.4f);
-            if constexpr (LONG) {
+            if constexpr (LONG && CH == 16) {
+                asm volatile(FLL8L_WAVE_ASM
+                             : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
+                             : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),
+                               [maxf] "v"(k1.fll_max_freq),
+                               [negc1] "s"(FLL8L_WAVE_NEGC1), [beta] "s"(k1.fll_beta), [minf] "s"(k1.fll_min_freq),
+                               [p4] "s"(p4),
+                               [k1] "s"(FLL8L_WAVE_K1), [k2] "s"(FLL8L_WAVE_K2), [k3] "s"(FLL8L_WAVE_K3), [k4] "s"(FLL8L_WAVE_K4),
+                               [a_sum] "v"(2u * a_addr + (unsigned)(sizeof(float2) * CH * kFAS))
+                             : "vcc", "scc", "memory", FLL8L_WAVE_CLOBBERS);
+            } else if constexpr (LONG) {
                 asm volatile(FLL16L_WAVE_ASM
                              : [ph] "+v"(ph), [fr] "+v"(fr), [base] "+s"(base_), [tiles] "+s"(tiles_), [st] "=&s"(st_)
                              : [a_addr] "v"(a_addr), [x_rowlane] "v"(x_rowlane), [tap_addr] "v"(tap_addr), [hist_addr] "v"(hist_addr),

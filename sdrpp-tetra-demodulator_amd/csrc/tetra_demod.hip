@@ -4,8 +4,8 @@
 // recovery -> pi/4 Costas -> slicer -> differential decoder -> bit unpacker, as specialised waves connected by LDS rings.  Three
 // workgroup shapes of the one template: 16 channels in six waves (one workgroup per CU up to 4096 channels), 32 channels in
 // eight waves (more than 16 channels per CU) and 4 channels (at most 4 channels per CU); tetra_demod_create plans which
-// channels take which shape, the results are identical bit for bit.  Filters of 73 .. 129 taps take the 4-channel shape's LONG
-// variant (FLL rows of 16 x 9 taps, 128 delay-line samples); timing loops below 0.27 samples per symbol -- and, on request, the
+// channels take which shape, the results are identical bit for bit.  Filters of 73 .. 129 taps take the LONG variant of the 4- or
+// the 16-channel shape (FLL rows of 16 x 9 / 8 x 17 taps, 128 delay-line samples); timing loops below 0.27 samples per symbol -- and, on request, the
 // long filters -- run in k_generic (kernel_generic.hpp): one lane per channel, same arithmetic.  (The two-kernel pipeline of
 // round 1 -- k1_agc_fll_rrc / k2_sync_slice with an HBM scratch in between -- was retired in ABI 2; `git log` has it.)
 // Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
@@ -207,6 +207,7 @@ struct tetra_demod {
     bool small = false;         // ... or, when they are at most 4 per CU (or the flag forces it), in 4-channel ones
     bool force_small = false;   // TETRA_FLAG_SMALL_WORKGROUPS
     bool force_generic = false; // TETRA_FLAG_GENERIC_KERNEL
+    bool force_shape = false;   // TETRA_FLAG_WIDE_WORKGROUPS / _NARROW_: the caller chose
     int cus = 256;
     int* rrc_valid = nullptr;   // [C] delay-line samples the RRC may see (tetra_demod.h: tetra_demod_channel_state.rrc_valid)
     float2* y = nullptr;        // TETRA_FLAG_KEEP_RRC_OUT: time-major RRC output scratch [(7 + max_samples)][C]
@@ -593,8 +594,8 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
         const bool rest_wide = rest > 0 && t32 < t16 && t32 < t4;
         h->n_wide = (int)(rest_wide ? h->C : full);
         h->small = rest > 0 && !rest_wide && t4 < t16;
-        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) { h->n_wide = h->C; h->small = false; }
-        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) { h->n_wide = 0; h->small = false; }
+        if (cfg->flags & TETRA_FLAG_WIDE_WORKGROUPS) { h->n_wide = h->C; h->small = false; h->force_shape = true; }
+        if (cfg->flags & TETRA_FLAG_NARROW_WORKGROUPS) { h->n_wide = 0; h->small = false; h->force_shape = true; }
         if (cfg->flags & TETRA_FLAG_SMALL_WORKGROUPS) { h->n_wide = 0; h->small = h->force_small = true; }
         h->force_generic = (cfg->flags & TETRA_FLAG_GENERIC_KERNEL) != 0;
     }
@@ -720,7 +721,9 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         // and 4-channel shapes)
         const bool deep = host::needs_deep(h->design);
         const int n_wide = h->design.ntaps_be <= kF4Pad && !deep && !long_rows ? h->n_wide : 0;
-        const bool rest_small = long_rows || h->force_small || (h->small && h->C - n_wide <= kFChSmall * h->cus);
+        // (long rows: 4-channel workgroups while every one of them has a CU to itself, 16-channel ones beyond -- or as the flags say)
+        const bool rest_small = h->force_small || (long_rows ? !h->force_shape && h->C <= kFChSmall * h->cus
+                                                             : h->small && h->C - n_wide <= kFChSmall * h->cus);
         const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh),
             gs((h->C - n_wide + kFChSmall - 1) / kFChSmall);
         // the FLL's loop filter runs with alpha = 0 (fll.cpp:25; design.hpp never produces anything else): only those kernels exist
@@ -758,7 +761,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                 ps.cut_flag4 = h->cut_flag;
                 if (long_rows) {
                     // filters of 73 .. 129 taps: FLL rows of 16 x 9 taps, 4 channels per workgroup whatever the channel count
-                    FusedParamsLong pl;
+                    FusedParamsLongT<kFChSmall> pl;
                     static_cast<FusedParamsT<kFChSmall>&>(pl) = ps;
                     pl.hist_far = h->hist_far;
                     pl.far_valid = far_was_valid ? 1 : 0;
@@ -770,7 +773,15 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                 pf.ch_base = n_wide;
                 FusedParamsT<kFCh> pn;
                 static_cast<FusedParams&>(pn) = pf;
-                if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true>), gf, dim3(kFThreads), 0, s, pn);
+                if (long_rows) {
+                    // filters of 73 .. 129 taps on more than 1024 channels: FLL rows of 8 x 17 taps
+                    FusedParamsLongT<kFCh> pl;
+                    static_cast<FusedParamsT<kFCh>&>(pl) = pn;
+                    pl.hist_far = h->hist_far;
+                    pl.far_valid = far_was_valid ? 1 : 0;
+                    if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true, true>), gf, dim3(kFThreads), 0, s, pl);
+                    else hipLaunchKernelGGL((k_fused<true, false, kFCh, false, true>), gf, dim3(kFThreads), 0, s, pl);
+                } else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true>), gf, dim3(kFThreads), 0, s, pn);
                 else hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pn);
             }
         }

@@ -120,7 +120,7 @@ def _run(oracle, emul, synth, fname, macro, lanes, taps, mutate=None, ntaps=65, 
 
 
 GEOMETRIES = [("fll_asm.inc", "FLL_WAVE", 8, 9), ("fll4_asm.inc", "FLL4_WAVE", 4, 17), ("fll16_asm.inc", "FLL16_WAVE", 16, 5),
-              ("fll16l_asm.inc", "FLL16L_WAVE", 16, 9)]
+              ("fll16l_asm.inc", "FLL16L_WAVE", 16, 9), ("fll8l_asm.inc", "FLL8L_WAVE", 8, 17)]
 
 
 @pytest.mark.parametrize("fname,macro,lanes,taps", GEOMETRIES)
@@ -136,7 +136,8 @@ def test_generated_fll_assembly_second_call_replays_the_delay_line(oracle, emul,
 @pytest.mark.parametrize("fname,macro,lanes,taps,ntaps", [GEOMETRIES[0] + (2,), GEOMETRIES[0] + (33,), GEOMETRIES[0] + (72,),
                                                           GEOMETRIES[1] + (2,), GEOMETRIES[1] + (33,), GEOMETRIES[1] + (68,),
                                                           GEOMETRIES[2] + (2,), GEOMETRIES[2] + (33,), GEOMETRIES[2] + (72,),
-                                                          GEOMETRIES[3] + (73,), GEOMETRIES[3] + (100,), GEOMETRIES[3] + (129,)])
+                                                          GEOMETRIES[3] + (73,), GEOMETRIES[3] + (100,), GEOMETRIES[3] + (129,),
+                                                          GEOMETRIES[4] + (73,), GEOMETRIES[4] + (100,), GEOMETRIES[4] + (129,)])
 def test_generated_fll_assembly_other_tap_counts(oracle, emul, synth, fname, macro, lanes, taps, ntaps):
     """Band-edge filters shorter than the row (zero-padded at the old end) and as long as the row holds."""
     assert _run(oracle, emul, synth, fname, macro, lanes, taps, ntaps=ntaps) == []

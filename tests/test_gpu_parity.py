@@ -1030,20 +1030,20 @@ GENERIC_CASES = [dict(rrc_tap_count=73), dict(rrc_tap_count=100), dict(rrc_tap_c
 
 @pytest.mark.parametrize("case", range(len(GENERIC_CASES)))
 @pytest.mark.parametrize("time_major", [False, True])
-@pytest.mark.parametrize("kernel", ["long_rows", "generic"])
+@pytest.mark.parametrize("kernel", ["long_rows", "long_rows16", "generic"])
 def test_generic_kernel_long_filters_and_slow_timing_loops(pkg, oracle, synth, case, time_major, kernel):
     """VERDICT r3 missing 1 / weak 9: parameter sets the reference accepts and the fused kernel's regular rows cannot hold --
     filters of 73 .. 129 taps (/root/reference src/dsp/pi4dqpsk.cpp:11-30,56-70 take any count) and timing loops below 0.27
     samples per symbol (complex_fd.cpp:98-145: up to ten symbols from ONE offset at min_step 0.1).  The long filters run in the
-    fused kernel's LONG variant (FLL rows of 16 x 9 taps, 128 delay-line samples) or, with TETRA_FLAG_GENERIC_KERNEL, in the generic
-    kernel; the slow loops always in the generic kernel.  Bit for bit the contract either way: bits, counts, symbol bit patterns,
+    fused kernel's LONG variant (4-channel workgroups with FLL rows of 16 x 9 taps, or 16-channel ones with rows of 8 x 17; 128
+    delay-line samples) or, with TETRA_FLAG_GENERIC_KERNEL, in the generic kernel; the slow loops always in the generic kernel.  Bit for bit the contract either way: bits, counts, symbol bit patterns,
     the RRC output and the whole loop state incl. the 128-sample delay line against the oracle, ragged calls with carried state,
     both layouts, with the quality statistic riding along."""
     B = pkg.binding
     prm = GENERIC_CASES[case]
-    force = B.FLAG_GENERIC_KERNEL if kernel == "generic" else 0
-    if kernel == "generic" and ("rrc_tap_count" not in prm or prm.get("samplerate", 36000.0) < 18000.0 * 0.3):
-        pytest.skip("slow timing loops take the generic kernel with or without the flag")
+    force = B.FLAG_GENERIC_KERNEL if kernel == "generic" else B.FLAG_NARROW_WORKGROUPS if kernel == "long_rows16" else 0
+    if kernel != "long_rows" and ("rrc_tap_count" not in prm or prm.get("samplerate", 36000.0) < 18000.0 * 0.3):
+        pytest.skip("slow timing loops take the generic kernel with or without the flags")
     Cn = 9
     cuts = [0, 1, 2, 90, 91, 700, 1500]
     iq, _, _ = synth.gen_batch(Cn, cuts[-1], base_seed=6100 + case, sps=1.02 if "samplerate" in prm else 2.0)
@@ -1078,7 +1078,7 @@ def test_generic_kernel_long_filters_and_slow_timing_loops(pkg, oracle, synth, c
 
 
 @pytest.mark.parametrize("quirks", [False, True])
-@pytest.mark.parametrize("kernel", ["long_rows", "generic"])
+@pytest.mark.parametrize("kernel", ["long_rows", "long_rows16", "generic"])
 def test_setters_move_a_handle_between_the_fused_and_the_generic_kernel(pkg, oracle, synth, quirks, kernel):
     """65 taps (fused kernel) -> setRRCTapCount(101) (the fused kernel's long rows, or the generic kernel with
     TETRA_FLAG_GENERIC_KERNEL) -> 2 samples per symbol kept, rate 0.15 samples per symbol
@@ -1088,7 +1088,8 @@ def test_setters_move_a_handle_between_the_fused_and_the_generic_kernel(pkg, ora
     B = pkg.binding
     Cn, n = 5, 1200
     iq, _, _ = synth.gen_batch(Cn, 4 * n, base_seed=6200)
-    d = pkg.Demodulator(Cn, n, flags=(B.FLAG_REFERENCE_QUIRKS if quirks else 0) | (B.FLAG_GENERIC_KERNEL if kernel == "generic" else 0))
+    d = pkg.Demodulator(Cn, n, flags=(B.FLAG_REFERENCE_QUIRKS if quirks else 0) | (B.FLAG_GENERIC_KERNEL if kernel == "generic" else
+                                                                                   B.FLAG_NARROW_WORKGROUPS if kernel == "long_rows16" else 0))
     orcs = [oracle.Oracle() for _ in range(Cn)]
 
     def step(k, fused):
