@@ -63,7 +63,7 @@ def modulate(bits, n_samples, sps=2.0, beta=0.35, tau=0.0, ppm=0.0):
         frac = t - k0
         for j in range(-SPAN, SPAN + 1):
             pj = np.empty(n_samples)
-            for ph in range(isps):
+            for ph in range(min(isps, n_samples)):          # (a stream shorter than one symbol has fewer phases than isps)
                 pj[ph::isps] = rrc_pulse(frac[ph] - j, beta)
             idx = np.clip(k0 + j + base, 0, pad.shape[0] - 1)
             valid = (k0 + j >= 0) & (k0 + j < K)
