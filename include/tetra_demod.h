@@ -130,7 +130,8 @@ typedef struct tetra_demod_channel_state {
     int32_t rrc_valid;               /* how many of the newest delay-line samples the RRC FIR may see, 0..128 (>= taps - 1 = all; older
                                       * ones are zeros to it).  The reference keeps a delay line per FIR object; rrc.reset()
                                       * (pi4dqpsk.cpp:125) and a growing FIR::setTaps clear/zero-fill the RRC's only.  The fused
-                                      * kernel keeps 80 samples and saturates the count at 80. */
+                                      * kernel's regular rows keep 80 samples and saturate the count at 80 (its long rows and the
+                                      * generic kernel: 128). */
     float hist_far[2 * 48];          /* the 48 FLL outputs BEFORE hist[] (oldest first): only filters of more than 81 taps look that
                                       * far back.  Kept by the fused kernel's long rows and by the generic kernel; a launch of the fused kernel's regular rows (<= 72 taps) does not
                                       * carry them, after it they read as zeros -- to tetra_demod_get_state and to a filter that a
