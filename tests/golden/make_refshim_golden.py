@@ -144,6 +144,30 @@ def main():
         out[tag + "_bits"] = np.concatenate([p_[1] for p_ in parts])
         out[tag + "_state"] = state_vec(r)
         r.close()
+    # 9. filters beyond 72 taps (PI4DQPSK::init takes any count, pi4dqpsk.cpp:11-30): 101 and 129 taps, three ragged calls each; the
+    #    129-tap one at 1.0 samples per symbol (long filter AND several symbols from one offset).  Seeds on which the contract-mode
+    #    oracle makes the reference code's decisions throughout (see 7.)
+    for tag, taps, rate, sps in (("long101", 101, 36000.0, 2.0), ("long129", 129, 36000.0, 2.0), ("long129s", 129, 18000.0, 1.02)):
+        cfg = ob.default_cfg()
+        cfg.rrc_tap_count = taps
+        cfg.samplerate = rate
+        seed = 700
+        while True:
+            iq9, _, _ = synth.gen_channel(5000, seed, sps=sps, cfo=0.01)
+            r = T.RefChain(L, cfg)
+            parts = [r.process(iq9[a_:b_]) for a_, b_ in ((0, 7), (7, 1900), (1900, 5000))]
+            st9 = state_vec(r)
+            r.close()
+            bits9 = np.concatenate([p_[1] for p_ in parts])
+            o = ob.Oracle(cfg).process(iq9)
+            if len(o["bits"]) == len(bits9) and np.array_equal(o["bits"], bits9):
+                break
+            seed += 1
+        out[tag + "_iq"] = iq9
+        out[tag + "_cfg"] = np.array([taps, rate], np.float64)
+        out[tag + "_sym"] = np.concatenate([p_[0] for p_ in parts])
+        out[tag + "_bits"] = bits9
+        out[tag + "_state"] = st9
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim_vectors.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")

@@ -314,3 +314,50 @@ def test_gpu_equals_reference_code_outputs_for_random_parameter_sets(vec, pkg, s
         _close(sym[0][:nb[0] // 2], vec["rand%d_sym" % k], bits[0][:nb[0]], vec["rand%d_bits" % k], "random set %d (%s)" % (k, shape))
         _gpu_state_close(d, 0, vec["rand%d_state" % k], "random set %d (%s)" % (k, shape))
         d.close()
+
+
+LONG_TAGS = ("long101", "long129", "long129s")
+LONG_CUTS = ((0, 7), (7, 1900), (1900, 5000))
+
+
+def _long_cfg(vec, oracle, tag):
+    cfg = oracle.default_cfg()
+    cfg.rrc_tap_count = int(vec[tag + "_cfg"][0])
+    cfg.samplerate = float(vec[tag + "_cfg"][1])
+    return cfg
+
+
+def test_oracle_equals_reference_code_outputs_for_long_filters(vec, oracle):
+    """Filters of 101 and 129 taps (PI4DQPSK::init takes any count, /root/reference src/dsp/pi4dqpsk.cpp:11-30), the 129-tap one also
+    at one sample per symbol; three ragged calls each.  Reference-float mode: symbols, bits and final state bit for bit; contract
+    mode: all bits, symbols within the tolerance, state within STATE_TOL."""
+    for tag in LONG_TAGS:
+        iq = vec[tag + "_iq"]
+        o = oracle.Oracle(_long_cfg(vec, oracle, tag), reference_floats=True)
+        parts = [o.process(iq[a:b]) for a, b in LONG_CUTS]
+        _exact(o, dict(sym=_cat(parts, "sym"), bits=_cat(parts, "bits")), vec[tag + "_sym"], vec[tag + "_bits"], vec[tag + "_state"], tag)
+        o = oracle.Oracle(_long_cfg(vec, oracle, tag))
+        parts = [o.process(iq[a:b]) for a, b in LONG_CUTS]
+        _close(_cat(parts, "sym"), vec[tag + "_sym"], _cat(parts, "bits"), vec[tag + "_bits"], tag)
+        _state_close(lambda k: getattr(o.st, k), vec[tag + "_state"], tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["long_rows", "long_rows16", "generic"])
+def test_gpu_equals_reference_code_outputs_for_long_filters(vec, pkg, kernel):
+    """The same three scenarios through the C ABI: the fused kernel's long rows (4- and 16-channel workgroups) and the generic
+    kernel against the reference code's outputs and final state directly, no oracle in between."""
+    B = pkg.binding
+    force = {"long_rows": 0, "long_rows16": B.FLAG_NARROW_WORKGROUPS, "generic": B.FLAG_GENERIC_KERNEL}[kernel]
+    for tag in LONG_TAGS:
+        iq = vec[tag + "_iq"]
+        d = pkg.Demodulator(1, 5000, flags=B.FLAG_REFERENCE_QUIRKS | force, rrc_tap_count=int(vec[tag + "_cfg"][0]),
+                            samplerate=float(vec[tag + "_cfg"][1]))
+        syms, bitss = [], []
+        for a, b in LONG_CUTS:
+            bits, nb, sym = d.process(np.ascontiguousarray(iq[None, a:b]), want_sym=True)
+            syms.append(sym[0][:nb[0] // 2].copy())
+            bitss.append(bits[0][:nb[0]].copy())
+        _close(np.concatenate(syms), vec[tag + "_sym"], np.concatenate(bitss), vec[tag + "_bits"], "%s (%s)" % (tag, kernel))
+        _gpu_state_close(d, 0, vec[tag + "_state"], "%s (%s)" % (tag, kernel))
+        d.close()
