@@ -193,7 +193,9 @@ def plan_case(rng, stats):
     scale = (rng.uniform(0.2, 1.5, Cn) * np.exp(1j * rng.uniform(-np.pi, np.pi, Cn))).astype(np.complex64)
     iq = np.ascontiguousarray(pool[idx, :n1 + n2] * scale[:, None])
     p = dict(symbolrate=18000.0, samplerate=18000.0 * sps)
-    desc = dict(mode="plan", C=Cn, sps=sps, time_major=tm, n=[n1, n2])
+    if rng.integers(0, 8) == 0:          # the long rows' plan: 4-channel workgroups up to 4 channels per CU, 16-channel ones beyond
+        p["rrc_tap_count"] = int(rng.integers(73, 130))
+    desc = dict(mode="plan", C=Cn, sps=sps, time_major=tm, n=[n1, n2], params=p)
     d = pkg.Demodulator(Cn, 400, layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR, **p)
     states = None
     pos = 0
@@ -260,7 +262,9 @@ def async_case(rng, stats):
         raw, val = f, iq
     raw = raw.reshape(Cn, -1, 2)
     p = dict(symbolrate=18000.0, samplerate=18000.0 * sps)
-    desc = dict(mode="async", C=Cn, sps=sps, time_major=tm, fmt=fmt, sizes=sizes)
+    if rng.integers(0, 8) == 0:
+        p["rrc_tap_count"] = int(rng.integers(73, 130))
+    desc = dict(mode="async", C=Cn, sps=sps, time_major=tm, fmt=fmt, sizes=sizes, params=p)
     d = pkg.Demodulator(Cn, max(sizes), layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR, **p)
     pin = Pinned()
     keep, pos = [], 0
