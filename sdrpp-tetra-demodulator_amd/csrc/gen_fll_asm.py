@@ -398,6 +398,8 @@ def replay_step(E, g, n_reg, o_reg):
 
 def gen():
     E = Emitter()
+    if os.environ.get("TETRA_EXP_SETPRIO"):          # experiment builds: the FLL wave at a raised issue / fetch priority
+        E.ins("s_setprio %d" % int(os.environ["TETRA_EXP_SETPRIO"]), "salu")
     E.comment("state, constants and addresses into the block's fixed registers; taps from LDS; sums and pipeline start at zero")
     for (reg, opnd) in ((R_PH, "ph"), (R_FR, "fr"), (R_AADDR, "a_addr"), (R_XROWL, "x_rowlane"), (R_TAPADDR, "tap_addr"),
                         (R_HADDR, "hist_addr"), (R_MAXF, "maxf"), (R_ASUM, "a_sum")):
