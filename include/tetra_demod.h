@@ -61,8 +61,9 @@ enum {
                                     1.3x the 4096-channel time instead of 2x.  Results are identical bit for
                                     bit.  Band-edge filters of more than 68 taps (rrc_tap_count 69..72) never run in 32-channel
                                     workgroups. */
-    TETRA_FLAG_GENERIC_KERNEL = 128,   /* filters of 73 .. 129 taps in the one-lane-per-channel kernel instead of the fused kernel's long
-                                        * rows (same results; tests and A/B measurements) */
+    TETRA_FLAG_GENERIC_KERNEL = 128,   /* filters of 73 .. 129 taps and timing loops below 0.27 samples per symbol in the one-lane-per-channel
+                                        * kernel instead of the fused kernel's long rows / deepest symbol ring (same results; tests and A/B
+                                        * measurements) */
     TETRA_FLAG_REFERENCE_QUIRKS = 8 /* follow the reference to the letter where this library otherwise tidies up (the C++ mirror of
                                     the dsp::block sets it):
                                       - tetra_demod_reset keeps ph2 (src/dsp/pi4dqpsk_costas.h:32 is never reset by
@@ -106,7 +107,8 @@ typedef struct tetra_demod_config {
     double omega_rel_limit;  /* 0.02.  Accepted: 0 <= limit < 1 with min_step = samplerate / symbolrate x (1 - limit) - |mu_gain| > 0
                               * samples per symbol.  Below min_step = 1 the reference emits several symbols from one offset
                               * (floor(mu) = 0, complex_fd.cpp:141-143) and so do the kernels (ABI 4): down to 0.27 in the fused
-                              * kernel (16- and 4-channel workgroups with a deeper symbol ring), below that in the generic one.
+                              * kernel (16- and 4-channel workgroups with a deeper symbol ring), down to 0.07 in its 4-channel
+                              * workgroups with a 1024-deep one, below that in the generic kernel.
                               * Refused (TETRA_ERR_UNSUPPORTED, also from the setters): min_step <= 0, where the reference's own
                               * loop may never leave process() */
     /* Optional caller-supplied tables (NULL = design them like the reference does).  In an SDR++

@@ -78,7 +78,7 @@ DRY = False      # --dry: the oracle side only (checks the script's own mechanic
 def one_case(rng, stats):
     sps, p = draw_params(rng)
     if rng.integers(0, 6) == 0:          # round 4: at and below one sample per symbol step (several symbols from one offset, floor(mu) = 0)
-        sps = float(rng.choice([1.02, 1.0, 0.9, 0.6, 0.35, 0.2, 0.12]))          # (below 0.27 + 0.0176: the generic kernel)
+        sps = float(rng.choice([1.02, 1.0, 0.9, 0.6, 0.35, 0.2, 0.12]))          # (below 0.27 + 0.0176: 4-channel workgroups with the 1024-deep symbol ring)
         p["samplerate"] = 18000.0 * sps
     generic = 0
     if rng.integers(0, 10) == 0:         # filters beyond the 72 taps of the fused kernel's regular rows: its long rows, or the generic kernel

@@ -11,7 +11,8 @@ CASES = ((256, dict(rrc_tap_count=100), 0), (1024, dict(rrc_tap_count=100), 0), 
          (4096, dict(rrc_tap_count=100), B.FLAG_SMALL_WORKGROUPS), (8192, dict(rrc_tap_count=100), 0),
          (4096, dict(rrc_tap_count=129), 0), (4096, dict(rrc_tap_count=65), 0),
          (4096, dict(rrc_tap_count=100), B.FLAG_GENERIC_KERNEL), (256, dict(rrc_tap_count=129), B.FLAG_GENERIC_KERNEL),
-         (4096, dict(samplerate=18000.0 * 0.2), 0))
+         (1024, dict(samplerate=18000.0 * 0.2), 0), (4096, dict(samplerate=18000.0 * 0.2), 0), (4096, dict(samplerate=18000.0 * 0.12), 0),
+         (4096, dict(samplerate=18000.0 * 0.2), B.FLAG_GENERIC_KERNEL), (4096, dict(samplerate=18000.0 * 0.06), 0))
 N = 36000
 for C, prm, flags in CASES:
     d = pkg.Demodulator(C, N, flags=flags, **prm)
@@ -26,6 +27,6 @@ for C, prm, flags in CASES:
     for _ in range(3):
         d.process_device(iq, N, bits, stride, nb, None, s); torch.cuda.synchronize()
         ms.append(float(d.kernel_ms_history(1)[0]))
-    print(json.dumps(dict(channels=C, samples=N, params=prm, flags=flags, kernel="generic" if flags & B.FLAG_GENERIC_KERNEL or "samplerate" in prm else ("fused, long rows" if prm.get("rrc_tap_count", 65) > 72 else "fused"),
+    print(json.dumps(dict(channels=C, samples=N, params=prm, flags=flags, kernel="generic" if flags & B.FLAG_GENERIC_KERNEL or prm.get("samplerate", 36000.0) < 18000.0 * 0.07 else "fused, 1024-deep symbol ring" if "samplerate" in prm else ("fused, long rows" if prm.get("rrc_tap_count", 65) > 72 else "fused"),
                           kernel_ms=round(min(ms), 3), msamples_s=round(C * N / min(ms) / 1e3, 1))))
     d.close()

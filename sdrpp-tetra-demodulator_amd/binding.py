@@ -20,7 +20,7 @@ FLAG_RETIRED_TWO_KERNEL = 1      # refused by tetra_demod_create since ABI 2
 FLAG_KEEP_RRC_OUT = 2
 FLAG_QUALITY = 4
 FLAG_REFERENCE_QUIRKS = 8
-FLAG_GENERIC_KERNEL = 128        # filters of 73 .. 129 taps in the one-lane-per-channel kernel instead of the fused kernel's long rows
+FLAG_GENERIC_KERNEL = 128        # filters of 73 .. 129 taps / loops below 0.27 samples per symbol in the one-lane-per-channel kernel
 
 PARAMS = dict(symbolrate=0, samplerate=1, rrc_tap_count=2, rrc_beta=3, agc_rate=4, costas_bandwidth=5,
               fll_bandwidth=6, omega_gain=7, mu_gain=8, omega_rel_limit=9)

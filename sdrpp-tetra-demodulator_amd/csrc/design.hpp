@@ -162,12 +162,14 @@ inline void design_bandedge(const DesignParams& p, Design& d, int count) {
 // symbol at least.  While min_step >= 1 every symbol advances by at least one sample (the kernel's forward-progress clamp is
 // then neutral).  Below that the reference emits several symbols from one offset (floor(mu) = 0, complex_fd.cpp:141-143): the
 // kernels' "deep" variant (kernel_fused.hpp: DEEP) does the same, with a symbol ring sized for min_step >= kMinStepDeep; below
-// that (more than 3.7 symbols per sample) the launch takes the generic kernel (kernel_generic.hpp: one lane per channel, HBM
-// scratch instead of LDS rings); filters of 73 .. 129 taps take the fused kernel's long rows (needs_long below).  Refused: min_step <= 0 -- the reference's own loop
+// that (more than 3.7 symbols per sample) its second level (4-channel workgroups, ring sized for min_step >= kMinStepDeeper), and
+// below THAT the generic kernel (kernel_generic.hpp: one lane per channel, HBM scratch instead of LDS rings); filters of 73 .. 129
+// taps take the fused kernel's long rows (needs_long below).  Refused: min_step <= 0 -- the reference's own loop
 // may then never leave process() or walk backwards out of its buffer -- and more than kMaxTaps taps (the delay line this
 // library and its checker keep).  Output rows are sized from min_step (tetra_demod_bits_stride_for), so any accepted parameter
 // set fits its rows.
 constexpr double kMinStepDeep = 0.27;
+constexpr double kMinStepDeeper = 0.07;        // the 4-channel shape's second ring level (kernel_fused.hpp: kFSDeeper)
 constexpr int kMaxTaps = 129;          // = kernel_generic.hpp kGenMaxTaps = TETRA_DEMOD_MAX_TAPS = the oracle's TETRA_ORACLE_MAX_TAPS
 inline bool params_ok(const DesignParams& p) {
     if (p.rrc_tap_count < 2 || p.rrc_tap_count > kMaxTaps) return false;
@@ -185,7 +187,10 @@ inline double min_step(const Design& d) { return (double)d.k2.tr_min_freq - std:
 // several symbols may share an offset: the launch takes the kernels' DEEP variant
 inline bool needs_deep(const Design& d) { return min_step(d) < 1.0; }
 // beyond the fused kernel's symbol ring: the generic kernel (kernel_generic.hpp)
-inline bool needs_generic(const Design& d) { return min_step(d) < kMinStepDeep; }
+inline bool needs_generic(const Design& d) { return min_step(d) < kMinStepDeeper; }
+// 0: every symbol advances at least one sample; 1: several symbols may share an offset (deep symbol ring, 16- and 4-channel shapes);
+// 2: more than 3.7 of them per sample (the 4-channel shape's 1024-deep ring)
+inline int deep_level(const Design& d) { return min_step(d) < kMinStepDeep ? 2 : min_step(d) < 1.0 ? 1 : 0; }
 // filters beyond the 72 taps of the fused kernel's regular rows: its LONG variant (FLL rows of 16 x 9 taps in 4-channel workgroups,
 // 8 x 17 in 16-channel ones; 128 delay-line samples) -- or, on request (TETRA_FLAG_GENERIC_KERNEL), the generic kernel
 inline bool needs_long(const Design& d) { return !needs_generic(d) && (d.ntaps > kF8Pad || d.ntaps_be > kF8Pad); }

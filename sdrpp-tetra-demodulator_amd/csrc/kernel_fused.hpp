@@ -78,6 +78,8 @@ constexpr int kFSDeep = 256;             // ... and for timing loops that may em
                                          // complex_fd.cpp:141-143): an epoch's 32 samples then carry up to 33 / min_step + 1 symbols, the
                                          // Costas wave runs one epoch behind, so the ring holds 2 (33 / min_step + 1) <= 256 for
                                          // min_step >= kMinStepDeep (design.hpp: 0.27 samples per symbol).  16- and 4-channel shapes only.
+constexpr int kFSDeeper = 1024;          // ... and the 4-channel shape's second level: 2 (33 / min_step + 1) <= 1024 for min_step >= kMinStepDeeper
+                                         // (0.07: up to fifteen symbols from one offset)
 static_assert(kF8Pad == 72 && kF8Taps == 9, "fll_asm.inc is generated for 8 positions x 9 taps");
 static_assert(kF4Pad == 68 && kF4Taps == 17, "fll4_asm.inc is generated for 4 positions x 17 taps");
 static_assert(kF16Pad == 80 && kF16Taps == 5, "fll16_asm.inc is generated for 16 positions x 5 taps");
@@ -187,8 +189,8 @@ template <int CH, bool PROF> __device__ __forceinline__ int* fused_cut_flag(cons
     else return PROF ? nullptr : reinterpret_cast<int*>(p.prof);
 }
 
-template <int CH, bool DEEP = false, bool LONG = false> struct FusedLdsT {
-    static constexpr int kS = DEEP ? kFSDeep : kFS;
+template <int CH, int DEEP = 0, bool LONG = false> struct FusedLdsT {
+    static constexpr int kS = DEEP == 2 ? kFSDeeper : DEEP ? kFSDeep : kFS;
     static constexpr int kRE = LONG ? kRrcExtLong : kRrcExt, kBP = LONG ? kBePadLong : kBePad;
     float2 a_buf[2][CH][kFAS];
     float2 x_ring[CH][kFXS];
@@ -206,8 +208,9 @@ template <int CH, bool DEEP = false, bool LONG = false> struct FusedLdsT {
 };
 typedef FusedLdsT<kFCh> FusedLds;
 static_assert(sizeof(FusedLdsT<kFCh>) <= 80 * 1024 && sizeof(FusedLdsT<kFChWide>) <= 160 * 1024 - 256 &&
-              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024 && sizeof(FusedLdsT<kFCh, true>) <= 104 * 1024 &&
-              sizeof(FusedLdsT<kFChSmall, true, true>) <= 40 * 1024 && sizeof(FusedLdsT<kFCh, true, true>) <= 108 * 1024, "LDS budget of a CU");
+              sizeof(FusedLdsT<kFChSmall>) <= 32 * 1024 && sizeof(FusedLdsT<kFCh, 1>) <= 104 * 1024 &&
+              sizeof(FusedLdsT<kFChSmall, 1, true>) <= 40 * 1024 && sizeof(FusedLdsT<kFCh, 1, true>) <= 108 * 1024 &&
+              sizeof(FusedLdsT<kFChSmall, 2, true>) <= 64 * 1024, "LDS budget of a CU");
 
 // Typed LDS pointers built from a 32-bit LDS byte address.  Keeping the (loop-invariant) row base in one pinned vector
 // register makes the compiler address a sliding window as `base register + immediate offsets` (ds_read2_b64 /
@@ -281,12 +284,13 @@ template <class LDS, class Row> struct FllDeviceIOT {
 // progress clamp in the timing step, the output-row check on every symbol.  Everything else is the same code.
 // LONG (4- and 16-channel shapes): filters of 73 .. 129 taps -- FLL rows of 16 x 9 taps (fll16l_asm.inc) / 8 x 17 (fll8l_asm.inc), tap
 // tables of 144 / 160 entries, 128 delay-line samples carried (hist + hist_far).  Everything else is the same code.
-template <bool ALPHA0, bool PROF = false, int CH = kFCh, bool DEEP = false, bool LONG = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(typename FusedArgs<CH, LONG>::type p) {
+template <bool ALPHA0, bool PROF = false, int CH = kFCh, int DEEP = 0, bool LONG = false> __global__ __launch_bounds__(fused_threads(CH), TETRA_EXP_WAVES_PER_EU) void k_fused(typename FusedArgs<CH, LONG>::type p) {
     typedef FusedLdsT<CH, DEEP, LONG> Lds;
     constexpr int kH = LONG ? kHistLong : kHist;      // delay-line samples in front of the call
     constexpr int kSR = Lds::kS;          // symbol ring depth
     constexpr int kMinAdv = DEEP ? 0 : 1;
     static_assert(!DEEP || CH != kFChWide, "the deep symbol ring is instantiated for the 16- and 4-channel shapes");
+    static_assert(DEEP < 2 || CH == kFChSmall, "... and its second level for the 4-channel shape");
     typedef FllRowT<float, Roles<CH, LONG>::FL, Roles<CH, LONG>::FT> FllRow;
     typedef FllDeviceIOT<Lds, FllRow> FllDeviceIO;
     typedef Roles<CH, LONG> R_;

@@ -1,7 +1,7 @@
 // kernel_generic.hpp -- the chain for the parameter sets the fused kernel's rings cannot hold (included by tetra_demod.hip; device
-// code only): timing loops whose smallest step is below 0.27 samples per symbol (COMPLEX_FD::process, src/dsp/complex_fd.cpp:98-145,
+// code only): timing loops whose smallest step is below 0.07 samples per symbol (COMPLEX_FD::process, src/dsp/complex_fd.cpp:98-145,
 // emits several symbols from one offset for as long as floor(mu) is 0) -- and, on request (TETRA_FLAG_GENERIC_KERNEL: tests, A/B
-// runs), RRC / band-edge filters of 73 .. 129 taps (the reference's PI4DQPSK::init and setRRCTapCount take any count,
+// runs), loops below 0.27 and RRC / band-edge filters of 73 .. 129 taps (the reference's PI4DQPSK::init and setRRCTapCount take any count,
 // src/dsp/pi4dqpsk.cpp:11-30,56-70), which otherwise run in the fused kernel's LONG rows.  The plugin itself runs 65 taps at 2 samples per symbol (src/main.cpp:40,84) and never gets here: this kernel exists so
 // that such parameters are IMPLEMENTED -- bit for bit the arithmetic contract, like the fused kernel -- instead of refused.  It is
 // not fast and is not meant to be: ONE LANE PER CHANNEL walks the whole call stage by stage, direct-form FIRs over a delay line

@@ -5,7 +5,7 @@
 // workgroup shapes of the one template: 16 channels in six waves (one workgroup per CU up to 4096 channels), 32 channels in
 // eight waves (more than 16 channels per CU) and 4 channels (at most 4 channels per CU); tetra_demod_create plans which
 // channels take which shape, the results are identical bit for bit.  Filters of 73 .. 129 taps take the LONG variant of the 4- or
-// the 16-channel shape (FLL rows of 16 x 9 / 8 x 17 taps, 128 delay-line samples); timing loops below 0.27 samples per symbol -- and, on request, the
+// the 16-channel shape (FLL rows of 16 x 9 / 8 x 17 taps, 128 delay-line samples); timing loops below 0.07 samples per symbol -- and, on request, the
 // long filters -- run in k_generic (kernel_generic.hpp): one lane per channel, same arithmetic.  (The two-kernel pipeline of
 // round 1 -- k1_agc_fll_rrc / k2_sync_slice with an HBM scratch in between -- was retired in ABI 2; `git log` has it.)
 // Reference path replaced: src/dsp/pi4dqpsk.cpp:132-140, src/dsp/dqpsk_sym_extr.cpp:4-55,
@@ -653,8 +653,8 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
     }
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
     const bool long_rows = host::needs_long(h->design) && !h->force_generic;
-    if (host::needs_generic(h->design) || (host::needs_long(h->design) && h->force_generic)) {
-        // timing loops slower than 0.27 samples per symbol (and, with TETRA_FLAG_GENERIC_KERNEL, filters of more than 72 taps): one
+    if (host::needs_generic(h->design) || ((host::needs_long(h->design) || host::deep_level(h->design) == 2) && h->force_generic)) {
+        // timing loops slower than 0.07 samples per symbol (and, with TETRA_FLAG_GENERIC_KERNEL, those below 0.27 and filters of more than 72 taps): one
         // lane per channel, delay lines in an HBM scratch that is allocated on the first such call (kernel_generic.hpp)
         const size_t xs_stride = (size_t)kGenHist + (size_t)h->max_samples, ys_stride = (size_t)kYHist + (size_t)h->max_samples;
         if (!h->g_xs) HIP_TRY(h, hipMalloc((void**)&h->g_xs, sizeof(float2) * xs_stride * (size_t)h->C));
@@ -720,9 +720,10 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         // (the same for a timing loop that may emit several symbols from one offset: the deep symbol ring exists for the 16-
         // and 4-channel shapes)
         const bool deep = host::needs_deep(h->design);
+        const bool deeper = host::deep_level(h->design) == 2;      // more than 3.7 symbols per sample: the 4-channel shape's 1024-deep ring
         const int n_wide = h->design.ntaps_be <= kF4Pad && !deep && !long_rows ? h->n_wide : 0;
         // (long rows: 4-channel workgroups while every one of them has a CU to itself, 16-channel ones beyond -- or as the flags say)
-        const bool rest_small = h->force_small || (long_rows ? !h->force_shape && h->C <= kFChSmall * h->cus
+        const bool rest_small = deeper || h->force_small || (long_rows ? !h->force_shape && h->C <= kFChSmall * h->cus
                                                              : h->small && h->C - n_wide <= kFChSmall * h->cus);
         const dim3 gw((n_wide + kFChWide - 1) / kFChWide), gf((h->C - n_wide + kFCh - 1) / kFCh),
             gs((h->C - n_wide + kFChSmall - 1) / kFChSmall);
@@ -765,9 +766,11 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                     static_cast<FusedParamsT<kFChSmall>&>(pl) = ps;
                     pl.hist_far = h->hist_far;
                     pl.far_valid = far_was_valid ? 1 : 0;
-                    if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true, true>), gs, ts, 0, s, pl);
-                    else hipLaunchKernelGGL((k_fused<true, false, kFChSmall, false, true>), gs, ts, 0, s, pl);
-                } else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, true>), gs, ts, 0, s, ps);
+                    if (deeper) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, 2, true>), gs, ts, 0, s, pl);
+                    else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, 1, true>), gs, ts, 0, s, pl);
+                    else hipLaunchKernelGGL((k_fused<true, false, kFChSmall, 0, true>), gs, ts, 0, s, pl);
+                } else if (deeper) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, 2>), gs, ts, 0, s, ps);
+                else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFChSmall, 1>), gs, ts, 0, s, ps);
                 else hipLaunchKernelGGL((k_fused<true, false, kFChSmall>), gs, ts, 0, s, ps);
             } else if (n_wide < h->C) {
                 pf.ch_base = n_wide;
@@ -779,9 +782,9 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
                     static_cast<FusedParamsT<kFCh>&>(pl) = pn;
                     pl.hist_far = h->hist_far;
                     pl.far_valid = far_was_valid ? 1 : 0;
-                    if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true, true>), gf, dim3(kFThreads), 0, s, pl);
-                    else hipLaunchKernelGGL((k_fused<true, false, kFCh, false, true>), gf, dim3(kFThreads), 0, s, pl);
-                } else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, true>), gf, dim3(kFThreads), 0, s, pn);
+                    if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, 1, true>), gf, dim3(kFThreads), 0, s, pl);
+                    else hipLaunchKernelGGL((k_fused<true, false, kFCh, 0, true>), gf, dim3(kFThreads), 0, s, pl);
+                } else if (deep) hipLaunchKernelGGL((k_fused<true, false, kFCh, 1>), gf, dim3(kFThreads), 0, s, pn);
                 else hipLaunchKernelGGL((k_fused<true>), gf, dim3(kFThreads), 0, s, pn);
             }
         }

@@ -1025,7 +1025,8 @@ def test_below_one_sample_per_symbol_a_poisoned_channel_is_cut_off_and_reported(
 
 GENERIC_CASES = [dict(rrc_tap_count=73), dict(rrc_tap_count=100), dict(rrc_tap_count=129, rrc_beta=0.3),
                  dict(samplerate=18000.0 * 0.12), dict(samplerate=18000.0 * 0.2, rrc_tap_count=90),
-                 dict(samplerate=18000.0, rrc_tap_count=90), dict(samplerate=18000.0 * 0.5, rrc_tap_count=129)]      # long rows + deep symbol ring
+                 dict(samplerate=18000.0, rrc_tap_count=90), dict(samplerate=18000.0 * 0.5, rrc_tap_count=129),      # long rows + deep symbol ring
+                 dict(samplerate=18000.0 * 0.06)]                                                                    # below 0.07: the generic kernel only
 
 
 @pytest.mark.parametrize("case", range(len(GENERIC_CASES)))
@@ -1036,14 +1037,19 @@ def test_generic_kernel_long_filters_and_slow_timing_loops(pkg, oracle, synth, c
     filters of 73 .. 129 taps (/root/reference src/dsp/pi4dqpsk.cpp:11-30,56-70 take any count) and timing loops below 0.27
     samples per symbol (complex_fd.cpp:98-145: up to ten symbols from ONE offset at min_step 0.1).  The long filters run in the
     fused kernel's LONG variant (4-channel workgroups with FLL rows of 16 x 9 taps, or 16-channel ones with rows of 8 x 17; 128
-    delay-line samples) or, with TETRA_FLAG_GENERIC_KERNEL, in the generic kernel; the slow loops always in the generic kernel.  Bit for bit the contract either way: bits, counts, symbol bit patterns,
+    delay-line samples), the slow loops down to 0.07 samples per symbol in the 4-channel shape's 1024-deep symbol ring -- or, with
+    TETRA_FLAG_GENERIC_KERNEL (and always below 0.07), in the generic kernel.  Bit for bit the contract either way: bits, counts, symbol bit patterns,
     the RRC output and the whole loop state incl. the 128-sample delay line against the oracle, ragged calls with carried state,
     both layouts, with the quality statistic riding along."""
     B = pkg.binding
     prm = GENERIC_CASES[case]
     force = B.FLAG_GENERIC_KERNEL if kernel == "generic" else B.FLAG_NARROW_WORKGROUPS if kernel == "long_rows16" else 0
-    if kernel != "long_rows" and ("rrc_tap_count" not in prm or prm.get("samplerate", 36000.0) < 18000.0 * 0.3):
-        pytest.skip("slow timing loops take the generic kernel with or without the flags")
+    slow = prm.get("samplerate", 36000.0) < 18000.0 * 0.3          # more than 3.7 symbols per sample: 4-channel workgroups, 1024-deep ring
+    if kernel == "long_rows16" and ("rrc_tap_count" not in prm or slow):
+        pytest.skip("16-channel long rows: filters beyond 72 taps on timing loops of at least 0.27 samples per symbol")
+    if kernel == "generic" and prm.get("samplerate", 36000.0) < 18000.0 * 0.07:
+        pytest.skip("below 0.07 samples per symbol the generic kernel runs with or without the flag")
+    regular_rows = kernel != "generic" and "rrc_tap_count" not in prm and prm.get("samplerate", 36000.0) >= 18000.0 * 0.07
     Cn = 9
     cuts = [0, 1, 2, 90, 91, 700, 1500]
     iq, _, _ = synth.gen_batch(Cn, cuts[-1], base_seed=6100 + case, sps=1.02 if "samplerate" in prm else 2.0)
@@ -1068,10 +1074,15 @@ def test_generic_kernel_long_filters_and_slow_timing_loops(pkg, oracle, synth, c
     err, sync = d.quality()
     for c, o in enumerate(orcs):
         st = d.get_state(c)
-        for f in ("agc_gain", "fll_phase", "fll_freq", "mu", "omega", "offset", "costas_phase", "costas_freq", "ph2", "prev", "rrc_valid"):
+        for f in ("agc_gain", "fll_phase", "fll_freq", "mu", "omega", "offset", "costas_phase", "costas_freq", "ph2", "prev"):
             assert getattr(st, f) == getattr(o.st, f), (c, f)
         line = np.concatenate([np.array(st.hist_far[:], np.float32), np.array(st.hist[:], np.float32)])
-        assert np.array_equal(_u32(line), _u32(np.array(o.st.hist[:], np.float32))), c
+        if regular_rows:          # the fused kernel's regular rows keep the newest 80 delay-line samples (tetra_demod.h: hist_far, rrc_valid)
+            assert st.rrc_valid == min(o.st.rrc_valid, 80) and not np.any(line[:96]), c
+            assert np.array_equal(_u32(line[96:]), _u32(np.array(o.st.hist[:], np.float32)[-160:])), c
+        else:
+            assert st.rrc_valid == o.st.rrc_valid, c
+            assert np.array_equal(_u32(line), _u32(np.array(o.st.hist[:], np.float32))), c
         assert abs(float(err[c]) - float(o.st.standarderr)) < 2e-6
     assert d.overruns() == 0
     d.close()
