@@ -29,7 +29,7 @@ extern "C" {
 
 struct emul_tables {
     int ntaps;
-    float rrc[kPadTaps], be_re[kPadTaps], be_im[kPadTaps];  // unpadded, [ntaps] used
+    float rrc[kBePadLong], be_re[kBePadLong], be_im[kBePadLong];  // unpadded, [ntaps] used (up to 129: the long rows)
     float bank[kInterpPhases * kInterpTaps];
     K1Consts k1;
     K2Consts k2;
@@ -80,7 +80,7 @@ void emul_reset_state(const emul_tables* t, tetra_demod_channel_state_t* st) {
     std::memset(st, 0, sizeof(*st));
     st->agc_gain = 1.0f;
     st->omega = t->tr_omega;
-    st->rrc_valid = kHist;
+    st->rrc_valid = t->ntaps > kF8Pad ? kHistLong : kHist;      // "all of it": the long rows keep 128 delay-line samples
 }
 
 // Fused pipeline: the building blocks of csrc/kernel_fused.hpp (agc_step, FllRowT + fll_replay/fll_tile,
@@ -92,7 +92,8 @@ namespace {
 // One DPP row of an FLL wave: Row::kHop channels interleaved on the 16 lanes, lane = kHop * pos + channel-in-row.
 template <class Row> struct FllEmulIO {
     static constexpr int H = Row::kHop;
-    const float* hist[H];   // per channel of the row: stored delay line [80][2]
+    const float* hist[H];   // per channel of the row: stored delay line [hist_len][2]
+    int hist_len = kHist;   // 80; the long rows: 144 = 16 zeros (under zero taps) + the 128 samples they keep
     const float* a[H];      // AGC output of the whole chunk [n][2]
     float* x[H];            // FLL output [n][2]
     int tile_base = 0;
@@ -102,7 +103,7 @@ template <class Row> struct FllEmulIO {
         Row16 re, im;
         for (int l = 0; l < 16; l++) {
             const int pos = l / H, par = l % H;
-            const int m = (kHist - Row::kReplay) + g * Row::kLanes + pos;
+            const int m = (hist_len - Row::kReplay) + g * Row::kLanes + pos;
             re.l[l] = hist[par][2 * m];
             im.l[l] = hist[par][2 * m + 1];
         }
@@ -131,12 +132,22 @@ template <class Row> struct FllEmulIO {
 };
 
 // F stage of emul_fused for one row geometry: FLL rows of Row::kHop interleaved channels.
-template <class Row> void emul_fll(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* re72,
+// (LONG: the rows of filters beyond 72 taps -- tables padded to 144, delay line = [16 zeros | hist_far 48 | hist 80])
+template <class Row, bool LONG = false> void emul_fll(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* re72,
                                    const float* im72, std::vector<float>& a, std::vector<float>& x) {
     constexpr int H = Row::kHop, tile = 32;
-    static_assert(Row::kReplay <= kHist, "the delay line holds the replayed samples");
-    constexpr int tap_off = kBePad - Row::kLanes * Row::kTaps;       // padded tap kp of the row = entry kp + tap_off of the 80-padded table
-    std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kHist, 0.f), dump((size_t)std::max(n, 1) * 2);
+    constexpr int kLine = LONG ? kF16LPad : kHist;
+    static_assert(Row::kReplay <= kLine, "the delay line holds the replayed samples");
+    constexpr int tap_off = (LONG ? kBePadLong : kBePad) - Row::kLanes * Row::kTaps;       // padded tap kp of the row = entry kp + tap_off of the padded table
+    std::vector<float> zeros((size_t)std::max(n, 1) * 2, 0.f), zhist(2 * kLine, 0.f), dump((size_t)std::max(n, 1) * 2);
+    std::vector<std::vector<float>> lines;
+    if (LONG)
+        for (int c = 0; c < C; c++) {
+            std::vector<float> ln(2 * kLine, 0.f);
+            std::memcpy(ln.data() + 2 * (kLine - kHistLong), st[c].hist_far, sizeof(float) * 2 * (kHistLong - kHist));
+            std::memcpy(ln.data() + 2 * (kLine - kHist), st[c].hist, sizeof(float) * 2 * kHist);
+            lines.push_back(ln);
+        }
     for (int c0 = 0; c0 < C; c0 += H) {
         Row R;
         for (int j = 0; j < Row::kTaps; j++) {
@@ -151,10 +162,11 @@ template <class Row> void emul_fll(const emul_tables* t, tetra_demod_channel_sta
             R.tb[j] = tb;
         }
         FllEmulIO<Row> io;
+        io.hist_len = kLine;
         for (int par = 0; par < H; par++) {
             const bool have = c0 + par < C;
             const int c = have ? c0 + par : c0;
-            io.hist[par] = have ? st[c].hist : zhist.data();
+            io.hist[par] = !have ? zhist.data() : LONG ? lines[c].data() : st[c].hist;
             io.a[par] = have ? &a[(size_t)c * n * 2] : zeros.data();
             io.x[par] = have ? &x[(size_t)c * n * 2] : dump.data();
         }
@@ -183,10 +195,13 @@ extern "C" {
 // C <= 64 channels (processed in rows of two).  iq [C][n] channel-major.  Outputs like emul_k2, plus y_out [C][n].
 int emul_fused_shape(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int n, const float* iq, float* y_out,
                      uint8_t* bits, int bits_stride, int32_t* n_bits, float* sym, int fll_lanes) {
-    if (C < 1 || C > 64 || t->ntaps > kF8Pad) return -1;
-    float re72[kBePad] = { 0 }, im72[kBePad] = { 0 };
-    float rrc_ext[kRrcExt] = { 0 };
-    const int o72 = kBePad - t->ntaps;
+    if (C < 1 || C > 64 || t->ntaps > kRrcMaxTapsLong) return -1;
+    const bool long_rows = t->ntaps > kF8Pad;          // filters beyond 72 taps: the LONG variant of the 4- / 16-channel shape
+    if (long_rows && fll_lanes != 16 && fll_lanes != 8) return -1;
+    const int kH = long_rows ? kHistLong : kHist;      // delay-line samples carried
+    float re72[kBePadLong] = { 0 }, im72[kBePadLong] = { 0 };
+    float rrc_ext[kRrcExtLong] = { 0 };
+    const int o72 = (long_rows ? kBePadLong : kBePad) - t->ntaps;
     const int rpad = (8 - ((t->ntaps - 1) & 7)) & 7;      // RRC windows start on a multiple of 8 (see kernel_fused.hpp)
     for (int k = 0; k < t->ntaps; k++) { re72[o72 + k] = t->be_re[k]; im72[o72 + k] = t->be_im[k]; rrc_ext[7 + rpad + k] = t->rrc[k]; }
     const int rrc_chunks = (t->ntaps - 1 + rpad) / 8 + 1;
@@ -202,24 +217,27 @@ int emul_fused_shape(const emul_tables* t, tetra_demod_channel_state_t* st, int 
         st[c].agc_gain = g;
     }
     // F: FLL rows (8 lanes per channel: the 16-channel workgroup; 4 lanes: the 32-channel one; taps beyond 68 need the former)
-    if (fll_lanes == 4 && t->ntaps <= kF4Pad) emul_fll<FllRow4<Row16>>(t, st, C, n, re72, im72, a, x);
+    if (long_rows && fll_lanes == 16) emul_fll<FllRow16L<Row16>, true>(t, st, C, n, re72, im72, a, x);
+    else if (long_rows) emul_fll<FllRow8L<Row16>, true>(t, st, C, n, re72, im72, a, x);
+    else if (fll_lanes == 4 && t->ntaps <= kF4Pad) emul_fll<FllRow4<Row16>>(t, st, C, n, re72, im72, a, x);
     else if (fll_lanes == 8) emul_fll<FllRow8<Row16>>(t, st, C, n, re72, im72, a, x);
     else if (fll_lanes == 16) emul_fll<FllRow16<Row16>>(t, st, C, n, re72, im72, a, x);
     else return -1;
     // C: RRC, eight outputs at a time, over [history | x]
     std::vector<float> y((size_t)C * n * 2);
     for (int c = 0; c < C; c++) {
-        std::vector<float> xf0((size_t)(8 + kHist + n + 16) * 2, 0.f);      // 8 zero samples in front: the aligned window may reach x_{-87}
+        std::vector<float> xf0((size_t)(8 + kH + n + 16) * 2, 0.f);      // 8 zero samples in front: the aligned window may reach x_{-87} (x_{-135})
         float* const xfp = xf0.data() + 16;
-        std::memcpy(xfp, st[c].hist, sizeof(float) * 2 * kHist);
-        if (n) std::memcpy(xfp + 2 * kHist, &x[(size_t)c * n * 2], sizeof(float) * 2 * n);
+        if (long_rows) std::memcpy(xfp, st[c].hist_far, sizeof(float) * 2 * (kHistLong - kHist));
+        std::memcpy(xfp + 2 * (kH - kHist), st[c].hist, sizeof(float) * 2 * kHist);
+        if (n) std::memcpy(xfp + 2 * kH, &x[(size_t)c * n * 2], sizeof(float) * 2 * n);
         struct { float* p; float* data() { return p; } } xf{ xfp };
         for (int i0 = 0; i0 < n; i0 += 8) {
             Pair<float> out[kRrcOut];
             const int start = i0 - (t->ntaps - 1) - rpad;
-            const float* w = xf.data() + 2 * (kHist + start);
+            const float* w = xf.data() + 2 * (kH + start);
             const int valid0 = st[c].rrc_valid;           // delay-line samples the RRC may see (tetra_demod.h)
-            const bool tri = rpad == 0 && rrc_chunks >= 2 && st[c].rrc_valid >= kHist;
+            const bool tri = rpad == 0 && rrc_chunks >= 2 && st[c].rrc_valid >= kH;
             auto run = [&](auto T) { rrc_direct8<decltype(T)::value>(rrc_chunks, [&](int q) { const bool seen = start + q >= -valid0;
                                                  return Pair<float>(seen ? w[2 * q] : 0.0f, seen ? w[2 * q + 1] : 0.0f); },
                         [&](int q) { Tap4 r; for (int z = 0; z < 4; z++) r.v[z] = rrc_ext[4 * q + z]; return r; }, out); };
@@ -231,10 +249,13 @@ int emul_fused_shape(const emul_tables* t, tetra_demod_channel_state_t* st, int 
             }
         }
         // new delay line
-        std::vector<float> nh(2 * kHist);
-        std::memcpy(nh.data(), xf.data() + 2 * n, sizeof(float) * 2 * kHist);
-        std::memcpy(st[c].hist, nh.data(), sizeof(float) * 2 * kHist);
-        st[c].rrc_valid = st[c].rrc_valid + n >= kHist ? kHist : st[c].rrc_valid + n;
+        // (the regular rows carry the newest 80 samples: what lies before them reads as zeros afterwards, tetra_demod.h hist_far)
+        std::vector<float> nh(2 * kH);
+        std::memcpy(nh.data(), xf.data() + 2 * n, sizeof(float) * 2 * kH);
+        std::memset(st[c].hist_far, 0, sizeof(st[c].hist_far));
+        if (long_rows) std::memcpy(st[c].hist_far, nh.data(), sizeof(float) * 2 * (kHistLong - kHist));
+        std::memcpy(st[c].hist, nh.data() + 2 * (kH - kHist), sizeof(float) * 2 * kHist);
+        st[c].rrc_valid = st[c].rrc_valid + n >= kH ? kH : st[c].rrc_valid + n;
     }
     if (y_out && n) std::memcpy(y_out, y.data(), sizeof(float) * y.size());
     // D + E

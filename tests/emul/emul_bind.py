@@ -32,7 +32,7 @@ class K2Consts(C.Structure):
 
 
 class Tables(C.Structure):
-    _fields_ = [("ntaps", C.c_int), ("rrc", C.c_float * 80), ("be_re", C.c_float * 80), ("be_im", C.c_float * 80),
+    _fields_ = [("ntaps", C.c_int), ("rrc", C.c_float * 144), ("be_re", C.c_float * 144), ("be_im", C.c_float * 144),
                 ("bank", C.c_float * 1024), ("k1", K1Consts), ("k2", K2Consts), ("tr_omega", C.c_float)]
 
 

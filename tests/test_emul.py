@@ -191,8 +191,11 @@ def test_fused_stage_code_equals_oracle(emul, oracle, synth, fll_lanes, lanes=Tr
         pos += n
 
 
-@pytest.mark.parametrize("nt,fll_lanes", [(33, 8), (72, 8), (33, 4), (68, 4), (2, 4), (2, 16), (33, 16), (72, 16)])
+@pytest.mark.parametrize("nt,fll_lanes", [(33, 8), (72, 8), (33, 4), (68, 4), (2, 4), (2, 16), (33, 16), (72, 16),
+                                          (73, 16), (100, 16), (129, 16), (73, 8), (100, 8), (129, 8)])
 def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, fll_lanes, lanes=True):
+    """(Beyond 72 taps: the LONG rows -- 16 lanes x 9 taps of the 4-channel workgroup, 8 x 17 of the 16-channel one -- with tables
+    of 144 entries and the 128-sample delay line, hist_far + hist.)"""
     N = 2500
     iq, _, _ = synth.gen_channel(N, 77)
     ocfg = oracle.default_cfg()
@@ -207,6 +210,34 @@ def test_fused_stage_code_other_tap_counts(emul, oracle, synth, nt, fll_lanes, l
         assert np.array_equal(_u32(q["y"][0]), _u32(r["y"])), (lanes, nt)
         nb = int(q["n_bits"][0])
         assert np.array_equal(q["bits"][0][:nb], r["bits"]), (lanes, nt)
+    if nt > 72:          # the carried delay line of the long rows: all 128 samples, the oracle's
+        st = e.st[0]
+        line = np.concatenate([np.array(st.hist_far[:], np.float32), np.array(st.hist[:], np.float32)])
+        assert np.array_equal(_u32(line), _u32(np.array(o.st.hist[:], np.float32))) and st.rrc_valid == o.st.rrc_valid == 128
+
+
+@pytest.mark.parametrize("fll_lanes", [16, 8])
+def test_long_rows_ragged_calls_equal_oracle(emul, oracle, synth, fll_lanes):
+    """The long rows' C++ form (what the kernels run for the partial tile at the end of every call) over ragged calls with carried
+    state, 101 taps, three channels: RRC output, bits, symbols against the oracle, bit for bit."""
+    Cn, N = 3, 3000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=654)
+    ocfg = oracle.default_cfg()
+    ocfg.rrc_tap_count = 101
+    ecfg = emul.default_cfg()
+    ecfg.rrc_tap_count = 101
+    e = emul.EmulDemod(Cn, ecfg, fused=True, fll_lanes=fll_lanes)
+    orc = [oracle.Oracle(ocfg) for _ in range(Cn)]
+    pos = 0
+    for n in (1, 7, 31, 33, 64, 17, 900, 0, 1000, 947):
+        q = e.process(iq[:, pos:pos + n], want_sym=True)
+        for c in range(Cn):
+            r = orc[c].process(iq[c, pos:pos + n], stages=True)
+            assert np.array_equal(_u32(q["y"][c]), _u32(r["y"])), (n, c)
+            nb = int(q["n_bits"][c])
+            assert nb == r["bits"].size and np.array_equal(q["bits"][c][:nb], r["bits"]), (n, c)
+            assert np.array_equal(_u32(q["sym"][c][:nb // 2]), _u32(r["sym"])), (n, c)
+        pos += n
 
 
 def test_quality_distance_is_the_reference_expression_including_signed_zeros(emul):
