@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TETRA_DEMOD_ABI_VERSION 4
+#define TETRA_DEMOD_ABI_VERSION 5
 #define TETRA_DEMOD_MAX_TAPS 129 /* longest filter of this ABI and capacity every tap table handed across it is sized for */
 
 enum {
@@ -256,16 +256,36 @@ int tetra_demod_reset(tetra_demod_t* h, int channel);
  * RRC taps only and keeps loop state -- no setter re-designs the FLL's band-edge filters (pi4dqpsk.cpp:32-118; the tap-count
  * exception without the quirks flag is described at TETRA_PARAM_RRC_TAP_COUNT); TETRA_PARAM_SYMBOLRATE / _SAMPLERATE
  * additionally reset the timing loop (COMPLEX_FD::setOmega, complex_fd.cpp:30-41).  Caller-supplied tables (cfg.rrc_taps,
- * cfg.bandedge_taps, cfg.interp_bank) survive every setter that does not have to re-design them; a setter that would
- * (a rate / RRC setter with cfg.rrc_taps, a tap count with either FIR table) returns TETRA_ERR_UNSUPPORTED and changes nothing. */
+ * cfg.bandedge_taps, cfg.interp_bank, tetra_demod_set_tables) are never re-designed by this library: the rate setters keep a
+ * caller's RRC table and do the rest of their work (ABI 5; the caller follows with tetra_demod_set_tables -- ABI 4 refused the
+ * call); the setters that ONLY re-design a caller's table (TETRA_PARAM_RRC_BETA / _RRC_TAP_COUNT, tetra_demod_set_rrc_params with
+ * a caller's RRC table; a tap count without the quirks flag with a caller's band-edge table) return TETRA_ERR_UNSUPPORTED and
+ * change nothing -- tetra_demod_set_tables is their replacement. */
 int tetra_demod_set_param(tetra_demod_t* h, int param_id, double value);
 /* PI4DQPSK::setRRCParams (pi4dqpsk.cpp:56-66): tap count and roll-off applied in one re-design of the RRC (same rules as
  * TETRA_PARAM_RRC_TAP_COUNT + TETRA_PARAM_RRC_BETA). */
 int tetra_demod_set_rrc_params(tetra_demod_t* h, int rrc_tap_count, double rrc_beta);
 
+/* ABI 5.  FIR::setTaps with tables the CALLER designed -- the route by which an SDR++ build runs the kernels on the output of
+ * SDR++'s own generators instead of this library's restatement of them: taps::rootRaisedCosine (pi4dqpsk.cpp:18,38,50,63),
+ * FLL::createBandedgeFilters through math::sinc / math::phasor (fll.cpp:61-95), taps::windowedSinc + window::nuttall +
+ * multirate::buildPolyphaseBank (complex_fd.cpp:153-158).  host/pi4dqpsk_gpu.cpp does exactly that under TETRA_WITH_SDRPP, in
+ * init() and in every setter that re-designs (setSymbolrate / setSamplerate / setRRCParams / setRRCTapCount / setRRCBeta).
+ *   rrc_taps       [n_rrc] or NULL (keep); 2 <= n_rrc <= 129.  Replaces the RRC FIR's taps and its length (the handle's
+ *                  rrc_tap_count becomes n_rrc) with the reference's setTaps rule for the delay line: a longer filter keeps its old
+ *                  taps - 1 history samples and sees zeros before them (TETRA_FLAG_REFERENCE_QUIRKS; without the flag the one
+ *                  delay line of the three FIRs is visible in full, as after TETRA_PARAM_RRC_TAP_COUNT).
+ *   bandedge_taps  [2][n_be] or NULL (keep): re, im of the LOWER band-edge filter (the upper one is its conjugate, fll.cpp:89-93).
+ *   interp_bank    [128][8] or NULL (keep).
+ * Loop state, loop constants and rates are untouched.  From then on the replaced tables count as caller-supplied (see the
+ * setter rules above).  Synchronises.  TETRA_ERR_ARG if all three are NULL, TETRA_ERR_UNSUPPORTED for a length outside 2..129. */
+int tetra_demod_set_tables(tetra_demod_t* h, const float* rrc_taps, int n_rrc, const float* bandedge_taps, int n_be,
+                           const float* interp_bank);
+
 /* Checkpoint / restore of one channel's loop state.  set_state accepts what the chain can be in: |fll_phase| <= pi,
- * |costas_phase| <= pi, |ph2| < 2 pi (the reference's loops wrap to these ranges on every step; anything else is
- * TETRA_ERR_ARG), rrc_valid clamped to 0..80. */
+ * |costas_phase| <= pi, |ph2| < 2 pi (the reference's loops wrap to these ranges on every step), offset >= 0 and mu not
+ * infinite (complex_fd.cpp:141-148 leaves both so; NaN = a poisoned channel passes) -- anything else is TETRA_ERR_ARG;
+ * rrc_valid clamped to 0..128. */
 int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out);
 int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_channel_state_t* in);
 

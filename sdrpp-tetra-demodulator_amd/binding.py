@@ -34,6 +34,7 @@ EXPORTS = [
     "tetra_demod_bandedge_tap_count", "tetra_demod_process_async", "tetra_demod_wait", "tetra_demod_host_alloc",
     "tetra_demod_host_free", "tetra_demod_device_info", "tetra_demod_bits_stride_for", "tetra_demod_get_overruns",
     "tetra_demod_set_rrc_params", "tetra_demod_process_resident", "tetra_demod_debug_mfma_selftest", "tetra_demod_build_id",
+    "tetra_demod_set_tables",
 ]
 ERR_OVERRUN = -8
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
@@ -114,6 +115,7 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_get_overruns.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.tetra_demod_set_rrc_params.argtypes = [vp, i32, C.c_double]
     L.tetra_demod_process_resident.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.tetra_demod_set_tables.argtypes = [vp, vp, i32, vp, i32, vp]
     L.tetra_demod_debug_mfma_selftest.argtypes = [vp, i32, i32, vp, vp, vp]
     L.tetra_demod_bandedge_tap_count.argtypes = [vp]
     L.tetra_demod_debug_read_rrc_out.argtypes = [vp, vp, i32]
@@ -301,6 +303,15 @@ class Demodulator:
     def set_rrc_params(self, rrc_tap_count, rrc_beta):
         """PI4DQPSK::setRRCParams: both in one re-design."""
         self._check(self._lib.tetra_demod_set_rrc_params(self._h, int(rrc_tap_count), float(rrc_beta)), "tetra_demod_set_rrc_params")
+
+    def set_tables(self, rrc_taps=None, bandedge_taps=None, interp_bank=None):
+        """tetra_demod_set_tables: FIR::setTaps with caller-designed tables (rrc [n]; band-edge [2][n_be] = re, im of the lower
+        filter; bank [128][8]); None keeps a table."""
+        r = None if rrc_taps is None else np.ascontiguousarray(rrc_taps, np.float32)
+        b = None if bandedge_taps is None else np.ascontiguousarray(bandedge_taps, np.float32).reshape(2, -1)
+        k = None if interp_bank is None else np.ascontiguousarray(interp_bank, np.float32).reshape(128, 8)
+        self._check(self._lib.tetra_demod_set_tables(self._h, _np_ptr(r), 0 if r is None else r.size, _np_ptr(b),
+                                                     0 if b is None else b.shape[1], _np_ptr(k)), "tetra_demod_set_tables")
 
     def get_state(self, channel):
         st = ChannelState()

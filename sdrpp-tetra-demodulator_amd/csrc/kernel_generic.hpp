@@ -141,6 +141,8 @@ __global__ __launch_bounds__(64) void k_generic(GenericParams p) {
             brow[2 * S + 1] = (uint8_t)(d & 1);
             if (srow) srow[S] = make_float2(zr, zi);
             S++;
+            // an offset that wrapped negative (mu = +Inf saturates floor(mu)) would index the scratch out of range: cut the channel
+            if (st.offset < 0) { st.offset = n; cut = true; break; }
         }
         p.mu[c] = st.mu; p.omega[c] = st.omega; p.offset[c] = st.offset - n;          // complex_fd.cpp:145
         p.cph[c] = st.cph; p.cfr[c] = st.cfr; p.ph2[c] = st.ph2; p.prev[c] = st.prev;

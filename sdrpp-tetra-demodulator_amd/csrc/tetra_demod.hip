@@ -353,7 +353,8 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
     if (fresh) {
         HIP_TRY(h, hipMemsetAsync(h->hist + (size_t)first * kHist, 0, sizeof(float2) * kHist * (size_t)count, 0));
         HIP_TRY(h, hipMemsetAsync(h->hist_far + (size_t)first * (kGenHist - kHist), 0, sizeof(float2) * (kGenHist - kHist) * (size_t)count, 0));
-        hipLaunchKernelGGL(k_fill_i32, dim3((count + 255) / 256), dim3(256), 0, 0, h->rrc_valid + first, (int)kHist, count);
+        // "all visible" = the longest delay line any kernel keeps (128); the regular rows saturate the count at their own 80
+        hipLaunchKernelGGL(k_fill_i32, dim3((count + 255) / 256), dim3(256), 0, 0, h->rrc_valid + first, (int)kGenHist, count);
         HIP_TRY(h, hipGetLastError());
     } else {
         HIP_TRY(h, hipMemsetAsync(h->rrc_valid + first, 0, sizeof(int) * count, 0));
@@ -424,6 +425,34 @@ template <class T> int dalloc(tetra_demod* h, T** p, size_t count) {
     HIP_TRY(h, hipMalloc((void**)p, sizeof(T) * count));
     return TETRA_OK;
 }
+
+// Can a launch of this handle take the generic kernel (kernel_generic.hpp)?  Its parameters, or TETRA_FLAG_GENERIC_KERNEL, decide.
+bool generic_applies(const tetra_demod* h, const host::Design& d) {
+    return host::needs_generic(d) || ((host::needs_long(d) || host::deep_level(d) == 2) && h->force_generic);
+}
+bool generic_applies(const tetra_demod* h) { return generic_applies(h, h->design); }
+// The generic kernel's HBM scratch -- 2 x 8 B x C x (max_samples + 128), the delay lines of a whole call -- is held exactly while
+// generic_applies(): allocated by create / the setter that moves the handle there (so that the stream-asynchronous process entry
+// point never allocates or synchronises), released by the setter that moves it away.  The device is idle when this runs.
+int sync_generic_scratch(tetra_demod* h, const host::Design& d) {
+    if (!generic_applies(h, d)) {
+        if (h->g_xs) (void)hipFree(h->g_xs);
+        if (h->g_ys) (void)hipFree(h->g_ys);
+        h->g_xs = h->g_ys = nullptr;
+        return TETRA_OK;
+    }
+    const size_t xs_stride = (size_t)kGenHist + (size_t)h->max_samples, ys_stride = (size_t)kYHist + (size_t)h->max_samples;
+    hipError_t e = hipSuccess;
+    if (!h->g_xs) e = hipMalloc((void**)&h->g_xs, sizeof(float2) * xs_stride * (size_t)h->C);
+    if (e == hipSuccess && !h->g_ys) e = hipMalloc((void**)&h->g_ys, sizeof(float2) * ys_stride * (size_t)h->C);
+    if (e != hipSuccess) {
+        h->last_hip = (int)e;
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? TETRA_ERR_NOMEM : TETRA_ERR_HIP;
+    }
+    return TETRA_OK;
+}
+int sync_generic_scratch(tetra_demod* h) { return sync_generic_scratch(h, h->design); }
 
 }  // namespace
 
@@ -617,6 +646,7 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
             if (rc == TETRA_OK && hipEventCreate(&e) != hipSuccess) rc = TETRA_ERR_HIP;
     if (rc == TETRA_OK) rc = upload_tables(h);
     if (rc == TETRA_OK) rc = reset_range(h, 0, h->C, true);
+    if (rc == TETRA_OK) rc = sync_generic_scratch(h);
     if (rc != TETRA_OK) {
         int st = (h->last_hip == (int)hipErrorOutOfMemory) ? TETRA_ERR_NOMEM : rc;
         free_all(h);
@@ -653,12 +683,11 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
     }
     hipEvent_t* ev = h->ev[h->n_calls % tetra_demod::kEvSlots];
     const bool long_rows = host::needs_long(h->design) && !h->force_generic;
-    if (host::needs_generic(h->design) || ((host::needs_long(h->design) || host::deep_level(h->design) == 2) && h->force_generic)) {
+    if (generic_applies(h)) {
         // timing loops slower than 0.07 samples per symbol (and, with TETRA_FLAG_GENERIC_KERNEL, those below 0.27 and filters of more than 72 taps): one
-        // lane per channel, delay lines in an HBM scratch that is allocated on the first such call (kernel_generic.hpp)
+        // lane per channel, delay lines in an HBM scratch (kernel_generic.hpp) that create / the setters hold ready (sync_generic_scratch)
         const size_t xs_stride = (size_t)kGenHist + (size_t)h->max_samples, ys_stride = (size_t)kYHist + (size_t)h->max_samples;
-        if (!h->g_xs) HIP_TRY(h, hipMalloc((void**)&h->g_xs, sizeof(float2) * xs_stride * (size_t)h->C));
-        if (!h->g_ys) HIP_TRY(h, hipMalloc((void**)&h->g_ys, sizeof(float2) * ys_stride * (size_t)h->C));
+        if (!h->g_xs || !h->g_ys) return TETRA_ERR_NOMEM;
         GenericParams pg;
         pg.iq = reinterpret_cast<const float2*>(d_iq);
         if (h->cfg.layout == TETRA_LAYOUT_CHANNEL_MAJOR) { pg.in_ch_stride = n_samples; pg.in_t_stride = 1; }
@@ -694,7 +723,6 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         return TETRA_OK;
     }
     const bool far_was_valid = h->far_valid;
-    h->far_valid = long_rows;      // the fused kernel carries the newest 80 delay-line samples only -- its long rows all 128
     {
         FusedParams pf;
         pf.iq = reinterpret_cast<const float2*>(d_iq);
@@ -735,7 +763,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         // Debug builds only (profiles/build_debug.sh): TETRA_DEMOD_PROFILE=<file> appends the per-role busy clocks of every
         // launch to <file>.  The release library has neither the getenv nor the instrumented instantiation.
         const char* prof_path = std::getenv("TETRA_DEMOD_PROFILE");
-        if (prof_path && n_wide == 0 && !rest_small) {
+        if (prof_path && n_wide == 0 && !rest_small && !long_rows) {      // (the instrumented instantiation exists for the regular rows only)
             const size_t nwg = (size_t)gf.x;
             if (!h->d_prof) HIP_TRY(h, hipMalloc((void**)&h->d_prof, sizeof(long long) * 8 * nwg));
             HIP_TRY(h, hipMemsetAsync(h->d_prof, 0, sizeof(long long) * 8 * nwg, s));
@@ -792,6 +820,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
             hipLaunchKernelGGL(k_quality, dim3(h->C), dim3(64), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->q_ring, h->q_ptr, h->q_disp,
                                h->q_err, h->q_sync);
         HIP_TRY(h, hipGetLastError());
+        h->far_valid = long_rows;      // the fused kernel carries the newest 80 delay-line samples only -- its long rows all 128
         HIP_TRY(h, hipEventRecord(ev[1], s));
         h->n_calls++;
 #ifdef TETRA_DEMOD_DEBUG
@@ -1178,8 +1207,11 @@ int apply_params(tetra_demod* h, const host::DesignParams& np, bool tables, bool
     host::Design nd = h->design;          // caller-supplied tables and everything a setter does not own are carried over
     if (!host::params_ok(np)) return TETRA_ERR_UNSUPPORTED;
     if (tables) {
-        if (h->user_rrc) return TETRA_ERR_UNSUPPORTED;                 // would have to re-design a caller-supplied table
-        host::design_rrc(np, nd);
+        // A caller-supplied RRC table is the caller's: the rate setters leave it alone and do the rest of their work (timing loop:
+        // COMPLEX_FD::setOmega); the caller follows with tetra_demod_set_tables (what the SDR++ build of the C++ mirror does with
+        // taps::rootRaisedCosine's output, pi4dqpsk.cpp:36-40).  A setter that ONLY re-designs the RRC has nothing left to do.
+        if (h->user_rrc && !timing_reset) return TETRA_ERR_UNSUPPORTED;
+        if (!h->user_rrc) host::design_rrc(np, nd);
         if (new_tap_count && !h->quirks && np.rrc_tap_count != nd.ntaps_be) {
             if (h->user_be) return TETRA_ERR_UNSUPPORTED;
             host::design_bandedge(np, nd, np.rrc_tap_count);           // documented deviation: one length for the three FIRs
@@ -1201,9 +1233,14 @@ int apply_params(tetra_demod* h, const host::DesignParams& np, bool tables, bool
         h->q_sym = q;
         h->q_sym_stride = want;
     }
+    if (generic_applies(h, nd)) {      // the generic kernel's scratch first: a failure leaves the handle as it was
+        const int rc = sync_generic_scratch(h, nd);
+        if (rc != TETRA_OK) return rc;
+    }
     const int old_ntaps = h->design.ntaps;
     h->dp = np;
     h->design = nd;
+    (void)sync_generic_scratch(h);        // (releases it when the parameters have left the generic kernel's domain)
     if (tables) {
         int rc = upload_tables(h);
         if (rc != TETRA_OK) return rc;
@@ -1258,6 +1295,52 @@ int tetra_demod_set_rrc_params(tetra_demod_t* h, int rrc_tap_count, double rrc_b
     return apply_params(h, np, true, true, false);
 }
 
+// FIR::setTaps with tables the CALLER designed (ABI 5): what PI4DQPSK::init / setSymbolrate / setSamplerate / setRRCParams do with
+// the output of SDR++'s own generators (pi4dqpsk.cpp:18-19,38-39,50-51,63-64), FLL::createBandedgeFilters (fll.cpp:61-95) and
+// COMPLEX_FD::generateInterpTaps (complex_fd.cpp:153-158).
+int tetra_demod_set_tables(tetra_demod_t* h, const float* rrc_taps, int n_rrc, const float* bandedge_taps, int n_be,
+                           const float* interp_bank) {
+    if (!h) return TETRA_ERR_ARG;
+    if (!rrc_taps && !bandedge_taps && !interp_bank) return TETRA_ERR_ARG;
+    if (rrc_taps && (n_rrc < 2 || n_rrc > kGenMaxTaps)) return TETRA_ERR_UNSUPPORTED;
+    if (bandedge_taps && (n_be < 2 || n_be > kGenMaxTaps)) return TETRA_ERR_UNSUPPORTED;
+    host::Design nd = h->design;
+    host::DesignParams np = h->dp;
+    if (rrc_taps) {
+        nd.ntaps = n_rrc;
+        nd.rrc.assign(rrc_taps, rrc_taps + n_rrc);
+        np.rrc_tap_count = n_rrc;
+    }
+    if (bandedge_taps) {
+        nd.ntaps_be = n_be;
+        nd.be_re.assign(bandedge_taps, bandedge_taps + n_be);
+        nd.be_im.assign(bandedge_taps + n_be, bandedge_taps + 2 * (size_t)n_be);
+    }
+    if (interp_bank) nd.bank.assign(interp_bank, interp_bank + kInterpPhases * kInterpTaps);
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (generic_applies(h, nd)) {
+        const int rc = sync_generic_scratch(h, nd);
+        if (rc != TETRA_OK) return rc;
+    }
+    const int old_ntaps = h->design.ntaps;
+    h->dp = np;
+    h->design = nd;
+    if (rrc_taps) h->user_rrc = true;
+    if (bandedge_taps) h->user_be = true;
+    (void)sync_generic_scratch(h);
+    int rc = upload_tables(h);
+    if (rc != TETRA_OK) return rc;
+    if (h->quirks && nd.ntaps > old_ntaps) {
+        // FIR::setTaps with more taps keeps the RRC's old taps-1 history samples and zero-fills the newly visible part
+        hipLaunchKernelGGL(k_min_i32, dim3((h->C + 255) / 256), dim3(256), 0, 0, h->rrc_valid, old_ntaps - 1, h->C);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(0));
+    }
+    return TETRA_OK;
+}
+
 int tetra_demod_get_state(tetra_demod_t* h, int channel, tetra_demod_channel_state_t* out) {
     if (!h || !out || channel < 0 || channel >= h->C) return TETRA_ERR_ARG;
     DeviceGuard g(h->device);
@@ -1284,6 +1367,10 @@ int tetra_demod_set_state(tetra_demod_t* h, int channel, const tetra_demod_chann
     // Phases outside what the loops can produce are refused (every pcl.advance wraps to [-pi, pi], ph2 to (-2 pi, 2 pi),
     // pi4dqpsk_costas.cpp:10-15): the kernel's phasor evaluation relies on those ranges.  NaN (a poisoned channel) passes.
     if (std::fabs(in->fll_phase) > kFlPi || std::fabs(in->costas_phase) > kFlPi || std::fabs(in->ph2) >= 2 * kFlPi) return TETRA_ERR_ARG;
+    // The carried read position of the timing loop is >= 0 by construction (complex_fd.cpp:141-148: offset -= count only after
+    // the loop left with offset >= count) and mu is a fraction in [0, 1) -- or NaN on a poisoned channel; a negative offset or an
+    // infinite mu would index the kernels' delay lines out of range.
+    if (in->offset < 0 || std::isinf(in->mu)) return TETRA_ERR_ARG;
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());

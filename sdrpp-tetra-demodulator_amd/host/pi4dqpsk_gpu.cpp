@@ -3,21 +3,22 @@
 #include "pi4dqpsk_gpu.h"
 
 #include <cassert>
+#include <cstring>
 
 namespace dsp {
 namespace demod {
 
 void DecisionTap::push(const uint8_t* bits, int nBits) {
     std::lock_guard<std::mutex> l(m_);
-    bits_.insert(bits_.end(), bits, bits + nBits);
+    for (int i = 0; i + 1 < nBits; i += 2) q_.push_back((uint8_t)((bits[i] << 1) | bits[i + 1]));      // re-packing of the GPU's decisions, no arithmetic on samples
     // A consumer that was attached but is not running would let the queue grow for ever (SDR++'s streams block their writer
-    // instead; this side channel must not).  Beyond kMaxQueuedBits the OLDEST decisions are dropped and counted as consumed,
-    // so positions (statistic marks) stay aligned; a consumer that comes back late finds the newest decisions.
-    if (bits_.size() > kMaxQueuedBits) {
-        const size_t drop = (bits_.size() - kMaxQueuedBits + 1) & ~(size_t)1;
-        bits_.erase(bits_.begin(), bits_.begin() + drop);
-        consumed_ += (long long)(drop / 2);
-        dropped_ += (long long)(drop / 2);
+    // instead; this side channel must not).  Beyond kMaxQueuedSymbols the OLDEST decisions are dropped and counted as consumed,
+    // so positions (statistic marks) stay aligned; a consumer that comes back late realigns on the newest ones (popAligned).
+    if (q_.size() > kMaxQueuedSymbols) {
+        const size_t drop = q_.size() - kMaxQueuedSymbols;
+        q_.erase(q_.begin(), q_.begin() + (std::ptrdiff_t)drop);
+        consumed_ += (long long)drop;
+        dropped_ += (long long)drop;
         while (!marks_.empty() && marks_.front().pos <= consumed_) marks_.pop_front();
     }
 }
@@ -25,28 +26,66 @@ void DecisionTap::mark(long long pos, float err, bool sync) {
     std::lock_guard<std::mutex> l(m_);
     marks_.push_back(Mark{ pos, err, sync });
 }
-int DecisionTap::pop(int nSym, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync) {
-    std::lock_guard<std::mutex> l(m_);
-    const long long have = (long long)(bits_.size() / 2);
-    const int n = have < nSym ? (int)have : nSym;
+void DecisionTap::take(int n, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync) {
     for (int i = 0; i < n; i++) {
-        const uint8_t b1 = bits_[2 * (size_t)i], b0 = bits_[2 * (size_t)i + 1];
-        if (dibits) dibits[i] = (uint8_t)((b1 << 1) | b0);      // re-packing of the GPU's decisions, no arithmetic on samples
-        if (bits) { bits[2 * i] = b1; bits[2 * i + 1] = b0; }
+        const uint8_t d = q_[(size_t)i];
+        if (dibits) dibits[i] = d;
+        if (bits) { bits[2 * i] = (uint8_t)(d >> 1); bits[2 * i + 1] = (uint8_t)(d & 1); }
     }
-    bits_.erase(bits_.begin(), bits_.begin() + 2 * (size_t)n);
+    q_.erase(q_.begin(), q_.begin() + n);
     consumed_ += n;
     while (!marks_.empty() && marks_.front().pos <= consumed_) {
         if (standarderr) *standarderr = marks_.front().err;
         if (sync) *sync = marks_.front().sync;
         marks_.pop_front();
     }
+}
+int DecisionTap::pop(int nSym, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync) {
+    std::lock_guard<std::mutex> l(m_);
+    const long long have = (long long)q_.size();
+    const int n = have < nSym ? (int)have : nSym;
+    take(n, dibits, bits, standarderr, sync);
     return n;
+}
+int DecisionTap::popAligned(int nSym, const uint8_t* expect, bool firstIsReliable, uint8_t* dibits, uint8_t* bits, float* standarderr,
+                            bool* sync) {
+    std::lock_guard<std::mutex> l(m_);
+    if (nSym <= 0) return 0;
+    const size_t have = q_.size(), n = (size_t)nSym;
+    if (have < n) return -1;
+    if (!firstIsReliable && nSym < 2) return -1;      // nothing to verify the position with: never pop blindly
+    auto matches = [&](size_t s, size_t from) {
+        for (size_t i = from; i < n; i++)
+            if (q_[s + i] != expect[i]) return false;
+        return true;
+    };
+    if (matches(0, firstIsReliable ? 0 : 1)) { take(nSym, dibits, bits, standarderr, sync); return nSym; }
+    if (nSym < kMinMatch) return -1;            // too short to tell a realignment from a coincidence
+    const size_t last = have - n < kSearchWindow ? have - n : kSearchWindow;
+    for (size_t s = 0; s <= last; s++) {
+        if (!matches(s, 1)) continue;
+        // the symbols this consumer was handed sit s decisions into the queue: what lies before them never reached it
+        // (s = 0: only the first dibit disagreed -- the consumer's own idea of the symbol before this buffer was stale)
+        if (s > 0) {
+            q_.erase(q_.begin(), q_.begin() + (std::ptrdiff_t)s);
+            consumed_ += (long long)s;
+            skipped_ += (long long)s;
+            resyncs_++;
+        }
+        take(nSym, dibits, bits, standarderr, sync);
+        return nSym;
+    }
+    return -1;
+}
+long long DecisionTap::queuedSymbols() {
+    std::lock_guard<std::mutex> l(m_);
+    return (long long)q_.size();
 }
 void DecisionTap::clear() {
     std::lock_guard<std::mutex> l(m_);
-    bits_.clear();
+    q_.clear();
     marks_.clear();
+    consumed_ = dropped_ = resyncs_ = skipped_ = 0;
 }
 
 std::shared_ptr<DecisionTap> PI4DQPSK::openTap() {
@@ -78,8 +117,30 @@ void PI4DQPSK::init(stream<complex_t>* in, double symbolrate, double samplerate,
     cfg.mu_gain = muGain;
     cfg.omega_rel_limit = omegaRelLimit;
     cfg.flags |= TETRA_FLAG_REFERENCE_QUIRKS;   // this class IS the reference's block: reset() and the RRC setters behave like pi4dqpsk.cpp
-    cfg.flags |= TETRA_FLAG_QUALITY;            // DQPSKSymbolExtractor's statistic is kept on the GPU for the mirror of that block (dqpsk_sym_extr_gpu.h)
-    symbols_ = 0;
+    // DQPSKSymbolExtractor's statistic is kept on the GPU for the mirror of that block (dqpsk_sym_extr_gpu.h).  A create-time
+    // flag, and the plugin attaches the extractor AFTER this init (src/main.cpp:84,90), so it is always on: one small k_quality
+    // launch per call; the read-back (tetra_demod_get_quality) happens only while a tap is open (process()).
+    cfg.flags |= TETRA_FLAG_QUALITY;
+    _symbolrate = symbolrate;
+    _samplerate = samplerate;
+    _rrcTapCount = rrcTapCount;
+    _rrcBeta = rrcBeta;
+#ifdef TETRA_WITH_SDRPP
+    // SDR++'s own generators design the tables (sdrpp_tables.h); the library's restatement (csrc/design.hpp) is not consulted
+    const std::vector<float> rrcTaps = sdrpp_tables::rrc(_rrcTapCount, _rrcBeta, _symbolrate, _samplerate);              // pi4dqpsk.cpp:18
+    const std::vector<float> beTaps = sdrpp_tables::bandedge(_rrcTapCount, (float)_rrcBeta, (int)_symbolrate, (int)_samplerate);   // pi4dqpsk.cpp:17 -> fll.cpp:10-18
+    const std::vector<float> bank = sdrpp_tables::interpBank();                                                       // pi4dqpsk.cpp:22 -> complex_fd.cpp:23
+    if ((int)rrcTaps.size() == rrcTapCount && bank.size() == 128 * 8) {
+        cfg.rrc_taps = rrcTaps.data();
+        cfg.bandedge_taps = beTaps.data();
+        cfg.interp_bank = bank.data();
+    }
+#endif
+    {   // decisions of the old handle are not this stream's: every open tap starts over with the new handle
+        std::lock_guard<std::mutex> l(tapMtx_);
+        symbols_ = 0;
+        for (auto& t : taps_) t->clear();
+    }
     if (h_) { tetra_demod_destroy(h_); h_ = nullptr; }
     status_ = tetra_demod_create(&cfg, &h_);
     maxStride_ = 0;
@@ -107,19 +168,62 @@ void PI4DQPSK::set(int id, double v) {
     resizeBuffers();
     base_type::tempStart();
 }
-void PI4DQPSK::setSymbolrate(double v) { set(TETRA_PARAM_SYMBOLRATE, v); }
-void PI4DQPSK::setSamplerate(double v) { set(TETRA_PARAM_SAMPLERATE, v); }
+bool PI4DQPSK::tablesFromSdrpp() {
+#ifdef TETRA_WITH_SDRPP
+    return true;
+#else
+    return false;
+#endif
+}
+
+// The tail of the three re-designing setters (pi4dqpsk.cpp:37-39, 49-51, 62-64): new RRC taps, FIR::setTaps.  In an SDR++ build
+// the taps come from SDR++'s taps::rootRaisedCosine and go in as a caller table; called with ctrlMtx held and the block stopped.
+void PI4DQPSK::redesignRRC() {
+#ifdef TETRA_WITH_SDRPP
+    const std::vector<float> rrcTaps = sdrpp_tables::rrc(_rrcTapCount, _rrcBeta, _symbolrate, _samplerate);
+    const int rc = tetra_demod_set_tables(h_, rrcTaps.data(), (int)rrcTaps.size(), nullptr, 0, nullptr);
+    if (status_ == TETRA_OK) status_ = rc;
+#endif
+}
+
+// pi4dqpsk.cpp:32-54: RRC re-design + COMPLEX_FD::setOmega.  (With a caller's RRC table on the handle -- the SDR++ build -- the
+// library's rate setter does the timing-loop half and leaves the table to redesignRRC(); outside SDR++ it re-designs itself.)
+void PI4DQPSK::setSymbolrate(double v) {
+    assert(base_type::_block_init);
+    std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
+    base_type::tempStop();
+    status_ = tetra_demod_set_param(h_, TETRA_PARAM_SYMBOLRATE, v);
+    if (status_ == TETRA_OK) { _symbolrate = v; redesignRRC(); }
+    resizeBuffers();
+    base_type::tempStart();
+}
+void PI4DQPSK::setSamplerate(double v) {
+    assert(base_type::_block_init);
+    std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
+    base_type::tempStop();
+    status_ = tetra_demod_set_param(h_, TETRA_PARAM_SAMPLERATE, v);
+    if (status_ == TETRA_OK) { _samplerate = v; redesignRRC(); }
+    resizeBuffers();
+    base_type::tempStart();
+}
 // pi4dqpsk.cpp:56-66: tap count and roll-off (the double, untruncated) in one re-design of the RRC
 void PI4DQPSK::setRRCParams(int n, double beta) {
     assert(base_type::_block_init);
     std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
     base_type::tempStop();
+#ifdef TETRA_WITH_SDRPP
+    if (n < 2 || n > TETRA_DEMOD_MAX_TAPS) status_ = TETRA_ERR_UNSUPPORTED;      // (the library's own limit; nothing changes)
+    else { status_ = TETRA_OK; _rrcTapCount = n; _rrcBeta = beta; redesignRRC(); }
+#else
     status_ = tetra_demod_set_rrc_params(h_, n, beta);
+    if (status_ == TETRA_OK) { _rrcTapCount = n; _rrcBeta = beta; }
+#endif
     base_type::tempStart();
 }
-void PI4DQPSK::setRRCTapCount(int n) { set(TETRA_PARAM_RRC_TAP_COUNT, n); }
-// pi4dqpsk.cpp:72 through the int parameter of pi4dqpsk.h:56: setRRCBeta(0.35) designs with roll-off 0, like the reference
-void PI4DQPSK::setRRCBeta(int beta) { set(TETRA_PARAM_RRC_BETA, (double)beta); }
+// pi4dqpsk.cpp:68-74
+void PI4DQPSK::setRRCTapCount(int n) { setRRCParams(n, _rrcBeta); }
+// ... through the int parameter of pi4dqpsk.h:56: setRRCBeta(0.35) designs with roll-off 0, like the reference
+void PI4DQPSK::setRRCBeta(int beta) { setRRCParams(_rrcTapCount, beta); }
 void PI4DQPSK::setAGCRate(double v) { set(TETRA_PARAM_AGC_RATE, v); }
 void PI4DQPSK::setCostasBandwidth(double v) { set(TETRA_PARAM_COSTAS_BANDWIDTH, v); }
 void PI4DQPSK::setFllBandwidth(double v) { set(TETRA_PARAM_FLL_BANDWIDTH, v); }

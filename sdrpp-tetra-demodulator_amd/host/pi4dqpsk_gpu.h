@@ -23,6 +23,7 @@
 
 #include "../../include/tetra_demod.h"
 #include "dsp_compat.h"
+#include "sdrpp_tables.h"
 
 namespace dsp {
 namespace demod {
@@ -32,29 +33,52 @@ namespace demod {
 // and unpack them on the CPU (src/main.cpp:84-91).  The kernels have already made those decisions for the very same symbols
 // (and keep DQPSKSymbolExtractor's statistic), so the GPU-backed mirrors of the two blocks (dqpsk_sym_extr_gpu.h,
 // bit_unpacker_gpu.h) take them from here instead of recomputing: a thread-safe FIFO written by PI4DQPSK::process (the
-// demodulator's worker thread), read by one consumer block's process() (that block's worker thread).  Bits are stored as the
-// kernels deliver them (one bit per byte, MSB of each dibit first); the statistic as (symbol position, value) marks that a
-// consumer applies once it has passed the position -- the reference updates standarderr / sync inside process() every 256
-// symbols (dqpsk_sym_extr.cpp:17-30).
+// demodulator's worker thread), read by one consumer block's process() (that block's worker thread).  Decisions are stored as
+// dibits (bit 1 = first bit; what DQPSKSymbolExtractor writes); the statistic as (symbol position, value) marks that a consumer
+// applies once it has passed the position -- the reference updates standarderr / sync inside process() every 256 symbols
+// (dqpsk_sym_extr.cpp:17-30).
+//
+// The FIFO is a side channel next to SDR++'s streams, and those can lose, repeat or hold back a buffer between
+// mainDemodulator.out and the consumer (the splitter unbound / rebound, src/main.cpp:85-90; disable() / enable(), :130-167; a
+// consumer that is not running while this queue overflows).  A positional FIFO would then hand every later symbol the decision
+// of another one, silently and for ever.  So the consumers do not pop blindly: popAligned() is given what the consumer can
+// tell about each symbol it was handed WITHOUT any DSP (the extractor: the dibit two sign tests imply; the unpacker: the dibit
+// byte itself), verifies the queue head against it, and on a mismatch searches the queue for the offset at which the handed
+// symbols line up again, discards what lies before it (counted: resyncs(), skippedSymbols()) and carries on; if the symbols
+// are nowhere in the queue (a repeated buffer, a foreign stream) it consumes nothing and says so -- the consumer then falls
+// back to its own sign tests for that buffer.
 class DecisionTap {
 public:
-    void push(const uint8_t* bits, int nBits);
+    void push(const uint8_t* bits, int nBits);      // the kernels' output row of one call: one bit per byte, MSB of each dibit first
     void mark(long long symbolPosition, float standarderr, bool sync);
     // Takes the decisions of the next nSym symbols: dibits[nSym] (bit 1 = first bit; what DQPSKSymbolExtractor writes) and/or
     // bits[2 nSym] (what BitUnpacker writes); applies every statistic mark passed on the way to *standarderr / *sync.
     // Returns nSym, or the (smaller) number available if the source has not produced that many -- a wiring error.
     int pop(int nSym, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync);
-    long long consumedSymbols() const { return consumed_; }
+    // pop() for a consumer that knows what to expect: expect[nSym] = the dibit each handed symbol implies (values 0..3);
+    // expect[0] takes part in the head check only when firstIsReliable (the extractor's first dibit is a difference against the
+    // last symbol it saw, meaningless right after a gap).  Queue head matches -> pops nSym, returns nSym.  Otherwise the first
+    // offset s <= kSearchWindow with queue[s + i] == expect[i] for all i >= 1 (needs nSym >= kMinMatch to be trusted) -> discards
+    // s symbols, pops nSym, counts one resync, returns nSym.  No such offset, too few decisions queued, or nothing to verify
+    // the position with (one symbol whose dibit is not reliable) -> consumes nothing, returns -1.
+    int popAligned(int nSym, const uint8_t* expect, bool firstIsReliable, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync);
+    long long consumedSymbols() const { return consumed_; }     // popped + discarded + dropped: the stream position of the queue head
     long long droppedSymbols() const { return dropped_; }      // decisions discarded because nobody took them (see push)
-    void clear();
-    static constexpr size_t kMaxQueuedBits = (size_t)1 << 24;   // 8 Mi symbols = 7.8 minutes of one TETRA channel
+    long long resyncs() const { return resyncs_; }             // realignments popAligned() has made
+    long long skippedSymbols() const { return skipped_; }      // decisions it discarded doing so
+    long long queuedSymbols();
+    void clear();      // empties the queue and restarts every counter: the source starts a new stream (PI4DQPSK::init)
+    static constexpr size_t kMaxQueuedSymbols = (size_t)1 << 23;   // 8 Mi symbols = 7.8 minutes of one TETRA channel
+    static constexpr int kMinMatch = 16;                             // symbols a realignment must agree on (chance match: 4^-15)
+    static constexpr size_t kSearchWindow = kMaxQueuedSymbols;       // how far ahead popAligned() looks: the whole queue
 
 private:
     struct Mark { long long pos; float err; bool sync; };
+    void take(int n, uint8_t* dibits, uint8_t* bits, float* standarderr, bool* sync);      // m_ held
     std::mutex m_;
-    std::deque<uint8_t> bits_;
+    std::deque<uint8_t> q_;      // dibits, oldest first
     std::deque<Mark> marks_;
-    long long consumed_ = 0, dropped_ = 0;
+    long long consumed_ = 0, dropped_ = 0, resyncs_ = 0, skipped_ = 0;
 };
 
 class PI4DQPSK : public Processor<complex_t, complex_t> {
@@ -116,9 +140,18 @@ public:
     std::shared_ptr<DecisionTap> openTap();
     tetra_demod_t* handle() { return h_; }
 
+    // Which code designed the tables the kernels run: true in a TETRA_WITH_SDRPP build -- SDR++'s own generators, called from
+    // the included core headers (sdrpp_tables.h) in init() and in every re-designing setter, handed over as caller tables --,
+    // false outside SDR++, where the library's restatement of them (csrc/design.hpp) is all there is.
+    static bool tablesFromSdrpp();
+
 private:
     void set(int id, double v);
     void resizeBuffers();
+    void redesignRRC();          // setSymbolrate / setSamplerate / setRRCParams: taps::rootRaisedCosine + rrc.setTaps (pi4dqpsk.cpp:38-39,50-51,63-64)
+    // what the reference keeps for its re-designs (pi4dqpsk.h:76-79)
+    double _symbolrate = 0, _samplerate = 0, _rrcBeta = 0;
+    int _rrcTapCount = 0;
     int maxStride_ = 0;
     tetra_demod_t* h_ = nullptr;
     int status_ = TETRA_ERR_ARG;

@@ -14,6 +14,18 @@
 #define FL_M_PI 3.1415926535f
 #define STREAM_BUFFER_SIZE 1000000
 
+// How the tap generators spell pi.  Default: the double constant (SURVEY.md Appendix A as first written).  With
+// -DREFSHIM_FLOAT_PI: the FLOAT macro FL_M_PI inside the double expressions -- how upstream SDR++ is recalled to write
+// root_raised_cosine.h, windowed_sinc.h, the cosine windows and hzToRads; which of the two upstream really
+// does cannot be checked in this image, so both variants exist and tests/test_sdrpp_tables.py measures what hangs on it (most taps
+// change their bit pattern, by <= 1e-4 relative; no bit after lock does).  A real SDR++ build settles it by construction: the
+// block designs with the INSTALLED headers (host/sdrpp_tables.h).
+#ifdef REFSHIM_FLOAT_PI
+#define REFSHIM_PI FL_M_PI
+#else
+#define REFSHIM_PI 3.14159265358979323846
+#endif
+
 namespace dsp {
     struct complex_t {
         float re, im;
@@ -57,7 +69,7 @@ namespace dsp {
         inline double sinc(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }
         inline complex_t phasor(float x) { return complex_t{ cosf(x), sinf(x) }; }
         template <class T> inline T step(T x) { return x > (T)0 ? (T)1 : (T)-1; }
-        inline double hzToRads(double f, double fs) { return 2.0 * 3.14159265358979323846 * (f / fs); }
+        inline double hzToRads(double f, double fs) { return 2.0 * REFSHIM_PI * (f / fs); }
     }
 
     // stream: never blocks here; read() reports "stopped" because nothing drives it.

@@ -6,7 +6,7 @@ namespace dsp {
     namespace taps {
         template <class T> inline tap<T> rootRaisedCosine(int count, double beta, double Ts) {
             tap<T> taps = taps::alloc<T>(count);
-            const double pi = 3.14159265358979323846;
+            const double pi = REFSHIM_PI;
             const double half = (double)count / 2.0;
             const double limit = Ts / (4.0 * beta);
             for (int i = 0; i < count; i++) {

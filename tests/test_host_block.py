@@ -28,7 +28,7 @@ def _build(pkg):
 def test_block_mirror_builds_and_links(pkg):
     exe = _build(pkg)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "abi 4" in out and "default taps 65" in out and "decision tap ok" in out
+    assert "abi 5" in out and "default taps 65" in out and "decision tap ok" in out and "decision tap alignment ok" in out
 
 
 @pytest.mark.gpu
@@ -80,6 +80,49 @@ def test_three_mirrored_blocks_stream_like_the_plugin(pkg, oracle, synth, tmp_pa
     raw = np.fromfile(f_dib, np.uint8)
     ns = w2["dibits"].size
     assert raw.size == 3 * ns and np.array_equal(raw[:ns], w2["dibits"]) and np.array_equal(raw[ns:], w2["bits"])
+
+
+@pytest.mark.gpu
+def test_decision_tap_realigns_when_a_symbol_buffer_is_lost_or_repeated(pkg, oracle, synth, tmp_path):
+    """VERDICT r4 weak 7 / next 6.  The three mirrored blocks on their worker threads as above, but the relay that stands where
+    SDR++'s splitter is (src/main.cpp:85-90) LOSES symbol buffer 20 and hands buffer 60 on twice -- what re-binding the splitter
+    or disable() / enable() (src/main.cpp:130-167) can do to the blocks behind it.  A positional side channel would hand every
+    later symbol another symbol's decision for ever; the self-checking one finds the gap (one resync, exactly the lost buffer's
+    symbols skipped), slices the repeated buffer from its own signs (one fallback) and is back on the kernels' decisions with the
+    next buffer: the sink's bits for every buffer the extractor was handed equal the oracle's for that buffer (the repeated copy's
+    first dibit excepted: a difference against that buffer's own last symbol, in the reference's block too), and the statistic
+    marks still arrive at their stream positions (standarderr == the oracle's at the end)."""
+    exe = _build(pkg)
+    N, chunk = 36000, 180
+    iq, _, _ = synth.gen_channel(N, 79)
+    f_in = tmp_path / "iq.f32"
+    iq.view(np.float32).tofile(f_in)
+    f_bits, f_dib, f_sym, f_cnt = tmp_path / "bits.u8", tmp_path / "dib.u8", tmp_path / "sym.f32", tmp_path / "cnt.i32"
+    r = subprocess.run([exe, "chain3", str(f_in), str(chunk), str(f_bits), str(f_dib), str(f_sym), "20", "60", str(f_cnt)], timeout=300,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    o = oracle.Oracle()
+    per_chunk = [o.process(iq[p:p + chunk])["bits"] for p in range(0, N, chunk)]
+    fwd = np.fromfile(f_cnt, np.int32).reshape(-1, 2)
+    assert [int(k) for k in fwd[:, 0]] == [k for k in range(N // chunk) if k != 20 for _ in range(2 if k == 60 else 1)]
+    bits = np.fromfile(f_bits, np.uint8)
+    pos, seen = 0, set()
+    for k, ns in fwd:
+        want = per_chunk[int(k)]
+        assert 2 * int(ns) == want.size
+        got = bits[pos:pos + want.size]
+        first = 2 if int(k) in seen else 0          # the repeated copy: its first dibit is sliced against its own last symbol
+        assert np.array_equal(got[first:], want[first:]), int(k)
+        seen.add(int(k))
+        pos += want.size
+    assert pos == bits.size
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("extractor resyncs")][0].split()
+    resyncs, skipped, fallbacks, u_resyncs, u_fallbacks = int(line[2]), int(line[4]), int(line[6]), int(line[9]), int(line[11])
+    assert (resyncs, skipped, fallbacks) == (1, per_chunk[20].size // 2, 1), line
+    # the unpacker sits behind the extractor: it sees the extractor's dibits, i.e. the same gap and the same repeated buffer
+    assert u_resyncs == 1 and u_fallbacks == 1, line
+    st = [ln for ln in r.stdout.splitlines() if ln.startswith("standarderr")][0].split()
+    assert abs(float(st[1]) - float(o.st.standarderr)) < 2e-6 and int(st[3]) == int(o.st.sync) == 1
 
 
 @pytest.mark.gpu
