@@ -330,10 +330,89 @@ def test_caller_tables_survive_setters(pkg, oracle, synth):
         d.set_param(name, val)
         t = d.tables()
         assert np.array_equal(t["rrc"], rrc) and np.array_equal(t["be_re"], be[:65]) and np.array_equal(t["be_im"], be[65:]), name
-    for name, val in (("symbolrate", 17000.0), ("rrc_beta", 0.5), ("rrc_tap_count", 33)):
+    for name, val in (("rrc_beta", 0.5), ("rrc_tap_count", 33)):
         with pytest.raises(pkg.TetraDemodError):
             d.set_param(name, val)
         assert np.array_equal(d.tables()["rrc"], rrc)
+    with pytest.raises(pkg.TetraDemodError):
+        d.set_rrc_params(65, 0.5)
+    # ABI 5: a rate setter keeps the caller's RRC table and does the rest of its work (COMPLEX_FD::setOmega: the timing loop is
+    # reset to the new nominal step); the caller follows with set_tables -- here a 49-tap filter and another bank, while the
+    # band-edge filters stay the caller's first ones
+    iq, _, _ = synth.gen_batch(2, 1000, base_seed=91)
+    d.process(iq)
+    d.set_param("symbolrate", 17000.0)
+    t = d.tables()
+    assert np.array_equal(t["rrc"], rrc) and np.array_equal(t["be_re"], be[:65])
+    st = d.get_state(0)
+    assert st.mu == 0.0 and st.offset == 0 and abs(st.omega - 36000.0 / 17000.0) < 1e-6
+    rrc49 = (np.hanning(49) / np.hanning(49).sum()).astype(np.float32)
+    bank = (o.interp_bank() * np.float32(0.75)).astype(np.float32)
+    d.set_tables(rrc_taps=rrc49, interp_bank=bank)
+    t = d.tables()
+    assert np.array_equal(t["rrc"], rrc49) and np.array_equal(t["be_re"], be[:65]) and np.array_equal(t["be_im"], be[65:]) and np.array_equal(t["bank"], bank)
+    with pytest.raises(pkg.TetraDemodError):
+        d.set_tables()                                   # nothing to install
+    with pytest.raises(pkg.TetraDemodError):
+        d.set_tables(rrc_taps=np.zeros(130, np.float32))  # beyond TETRA_DEMOD_MAX_TAPS
+    d.close()
+
+
+def test_set_tables_mid_stream_equals_the_oracle_with_the_same_tables(pkg, oracle, synth):
+    """tetra_demod_set_tables on a live handle (TETRA_FLAG_REFERENCE_QUIRKS, like the C++ mirror): shorter RRC, longer RRC (FIR::setTaps'
+    history rule: the newly visible delay-line samples read as zeros), other band-edge filters, another bank, a 101-tap RRC (the
+    long rows) and back -- after each, symbols / bits / counts equal the oracle whose tables were overwritten with the same arrays."""
+    import ctypes as C
+    Cn, n = 5, 3000
+    iq, _, _ = synth.gen_batch(Cn, 8 * n, base_seed=640)
+    d = pkg.Demodulator(Cn, n, flags=pkg.binding.FLAG_REFERENCE_QUIRKS)
+    orcs = [oracle.Oracle() for _ in range(Cn)]
+    rng = np.random.default_rng(5)
+
+    def lowpass(k, cut):
+        x = np.arange(k) - (k - 1) / 2.0
+        h = np.sinc(cut * x) * np.hanning(k + 2)[1:-1]
+        return (h / h.sum()).astype(np.float32)
+
+    def install(rrc=None, be=None, bank=None):
+        d.set_tables(rrc_taps=rrc, bandedge_taps=be, interp_bank=bank)
+        for o in orcs:
+            if rrc is not None:
+                old = int(o.tab.ntaps)
+                o.tab.ntaps = len(rrc)
+                o.tab.cfg.rrc_tap_count = len(rrc)
+                for i, v in enumerate(rrc):
+                    o.tab.rrc[i] = float(v)
+                if len(rrc) > old:
+                    oracle.lib().tetra_oracle_rrc_taps_grown(C.byref(o.st), old)
+            if be is not None:
+                o.tab.ntaps_be = be.shape[1]
+                for i in range(be.shape[1]):
+                    o.tab.be_a[i] = float(be[0, i])
+                    o.tab.be_b[i] = float(be[1, i])
+            if bank is not None:
+                for p in range(128):
+                    for k in range(8):
+                        o.tab.bank[p][k] = float(bank[p, k])
+
+    a, b = orcs[0].bandedge_taps()
+    steps = [
+        dict(),
+        dict(rrc=lowpass(33, 0.5)),
+        dict(rrc=lowpass(71, 0.5)),
+        dict(be=np.stack([a * np.float32(0.9), b * np.float32(1.1)]).astype(np.float32)),
+        dict(bank=(orcs[0].interp_bank() * (1 + 0.01 * rng.standard_normal((128, 8)))).astype(np.float32)),
+        dict(rrc=lowpass(101, 0.5)),
+        dict(rrc=lowpass(65, 0.5), be=np.stack([a[8:], b[8:]]).astype(np.float32)),
+        dict(rrc=lowpass(72, 0.45)),
+    ]
+    for k, kw in enumerate(steps):
+        if k == 5:
+            for o in orcs:          # the regular rows carried the newest 80 delay-line samples only: a filter grown beyond them sees zeros there
+                o.forget_far_history()
+        if kw:
+            install(**kw)
+        _run_vs_oracles(d, orcs, iq[:, k * n:(k + 1) * n])
     d.close()
 
 
