@@ -40,9 +40,11 @@ typedef struct tetra_chan_config {
 
 /* tetra_chan_config_t.reserved */
 enum {
-    TETRA_CHAN_FLAG_VALU_DFT = 1 /* keep the direct-sum DFT kernel even where the matrix-pipe form exists (M = 800 = 25 x 32 runs its
-                                    two DFT stages as chained v_mfma_f32_16x16x4_f32 by default); same results within the
-                                    documented float32 tolerance.  For A/B measurements and tests. */
+    TETRA_CHAN_FLAG_VALU_DFT = 1,  /* keep the direct-sum DFT kernel even where a faster form exists; same results within the
+                                     documented float32 tolerance.  For A/B measurements and tests. */
+    TETRA_CHAN_FLAG_MATRIX_DFT = 2 /* M = 800: the two DFT stages as chained v_mfma_f32_16x16x4_f32 (25 x 32 matrix products: round 4's
+                                     form, any decimation) even at D = M / 2, where the default is the 32 x 5 x 5 mixed-radix FFT in
+                                     registers / LDS (a tenth of the flops: the kernel is then bound by its HBM traffic).  A/B, tests. */
 };
 
 typedef struct tetra_chan tetra_chan_t;

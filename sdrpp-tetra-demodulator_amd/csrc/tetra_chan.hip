@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/tetra_chan.h"
+#include "chan_fft_core.hpp"
 
 namespace {
 
@@ -247,6 +248,51 @@ template <int P> __global__ __launch_bounds__(kThreads, 3) void k_channelise_mfm
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FFT form for M = 800, D = M / 2 (BASELINE config 5; round 5): the frame's DFT as a 32 x 5 x 5 mixed-radix FFT in registers
+// and LDS instead of a 25 x 32 matrix product -- 39 kflop per frame instead of 365, which moves the kernel from the vector pipe to
+// its HBM traffic (40 MB in, 80 MB out per 12500 frames).  One workgroup = 4 waves = one block of 8 consecutive frames per pass:
+//   fold       200 threads x 4 bins: P + 4 sample loads serve the 8 frames of a bin (consecutive frames at D = M / 2 share all
+//              but every other sample); v_t[r] -> LDS, linear in r
+//   stage 1    lane = n1 (25 of each 32; two frames per wave): 32-point FFT over n2 in registers, transposed in place in LDS
+//   stage 2    lane = k2 (all 32; two frames per wave): twiddle, 5 x 5 DFT over n1 in registers, then for every k1 the 32 lanes store
+//              32 consecutive bins: 256-byte runs of the [frame][channel] rows, two per store instruction
+// The lane-level code is chan_fft_core.hpp (also compiled for the host: tests/emul/chan_emul.cpp).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ChanFftParams {
+    const float2* xbuf;
+    float2* out;
+    const float* h;        // the prototype re-ordered for the fold [800][2][P]
+    const float2* tw;      // [25][32] exp(-j 2 pi n1 k2 / 800)
+    int frames, blocks, n_in;
+    int ph0;
+    long long abs0;
+};
+
+template <int P> __global__ __launch_bounds__(kThreads, 2) void k_channelise_fft(ChanFftParams p) {
+    using namespace chanfft;
+    __shared__ c32 lds[kBlockFrames * kFrameLds];          // 52.8 KB: three workgroups per CU
+    const int tid = threadIdx.x;
+    BlockCtx c;
+    c.xbuf = reinterpret_cast<const c32*>(p.xbuf);
+    c.L = kM * P;
+    c.out = reinterpret_cast<c32*>(p.out);
+    c.h = p.h;
+    c.tw = reinterpret_cast<const c32*>(p.tw);
+    c.frames = p.frames; c.ph0 = p.ph0; c.abs0 = p.abs0;
+    // one block of 8 frames per workgroup (no loop: nothing is carried from block to block, and a loop makes the compiler keep the
+    // transforms' ~100 literal twiddles in VGPRs across it)
+    const int blk = blockIdx.x;
+    phase_fold<P>(c, blk, tid, lds);
+    __syncthreads();
+    {
+        c32 x[32];
+        if (phase_fft32_compute(tid, lds, x)) phase_fft32_store(tid, lds, x);
+    }
+    __syncthreads();
+    phase_dft25_store(c, blk, tid, lds);
+}
+
 }  // namespace
 
 struct tetra_chan {
@@ -260,6 +306,9 @@ struct tetra_chan {
     float2 *d_w1 = nullptr, *d_w2 = nullptr, *d_wm = nullptr;
     float *d_bc = nullptr, *d_ac = nullptr;   // matrix-pipe form: the two constant block-twiddle operands (k_channelise_mfma)
     bool mfma = false;
+    bool fft = false;           // M = 800, D = 400: the mixed-radix FFT kernel (k_channelise_fft)
+    float2* d_tw = nullptr;     // its [25][32] inter-stage twiddles
+    float* d_ht = nullptr;      // and the prototype re-ordered for its fold [800][2][P]
     int cus = 256;
     float2* st_out = nullptr;   // host-path staging
     size_t st_out_frames = 0;
@@ -340,6 +389,18 @@ int upload_twiddles(tetra_chan* h) {
     CH_TRY(h, hipMemcpy(h->d_w2, w2.data(), sizeof(float2) * w2.size(), hipMemcpyHostToDevice));
     CH_TRY(h, hipMemcpy(h->d_wm, wm.data(), sizeof(float2) * wm.size(), hipMemcpyHostToDevice));
     CH_TRY(h, hipMemcpy(h->d_h, h->proto.data(), sizeof(float) * h->proto.size(), hipMemcpyHostToDevice));
+    if (h->fft) {
+        std::vector<float2> t((size_t)chanfft::kN1 * chanfft::kN2);
+        for (int n1 = 0; n1 < chanfft::kN1; n1++)
+            for (int k2 = 0; k2 < chanfft::kN2; k2++) {
+                const double a = -2.0 * pi * (double)((n1 * k2) % chanfft::kM) / chanfft::kM;
+                t[(size_t)n1 * chanfft::kN2 + k2] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        CH_TRY(h, hipMemcpy(h->d_tw, t.data(), sizeof(float2) * t.size(), hipMemcpyHostToDevice));
+        std::vector<float> ht((size_t)2 * chanfft::kM * h->P);
+        chanfft::fold_transpose_prototype(h->proto.data(), h->P, ht.data());
+        CH_TRY(h, hipMemcpy(h->d_ht, ht.data(), sizeof(float) * ht.size(), hipMemcpyHostToDevice));
+    }
     if (h->mfma) {
         // stage 1: Bc[k][col], k = n1 | N1 + n1, col = k1 | 32 + k1:  re = Vr Wr - Vi Wi, im = Vr Wi + Vi Wr, W = W_N1^(n1 k1)
         std::vector<float> bc((size_t)4 * kMK1 * 64, 0.f), ac((size_t)64 * 64, 0.f);
@@ -365,7 +426,7 @@ int upload_twiddles(tetra_chan* h) {
 }
 
 void free_all(tetra_chan* h) {
-    void* ptrs[] = { h->xbuf, h->xalt, h->d_h, h->d_w1, h->d_w2, h->d_wm, h->d_bc, h->d_ac, h->st_out };
+    void* ptrs[] = { h->xbuf, h->xalt, h->d_h, h->d_w1, h->d_w2, h->d_wm, h->d_bc, h->d_ac, h->d_tw, h->d_ht, h->st_out };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
 }
@@ -406,18 +467,23 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
     h->device = dev;
     h->M = cfg->n_channels; h->P = cfg->taps_per_channel; h->D = cfg->decimation; h->L = h->M * h->P;
     h->N1 = n1; h->N2 = n2; h->max_in = cfg->max_in;
-    h->mfma = n1 == kMN1 && n2 == kMN2 && (cfg->taps_per_channel == 8 || cfg->taps_per_channel == 6 || cfg->taps_per_channel == 4) &&
-              !(cfg->reserved & TETRA_CHAN_FLAG_VALU_DFT);
+    const bool p_ok = cfg->taps_per_channel == 8 || cfg->taps_per_channel == 6 || cfg->taps_per_channel == 4;
+    h->fft = cfg->n_channels == chanfft::kM && cfg->decimation == chanfft::kM / 2 && p_ok &&
+             !(cfg->reserved & (TETRA_CHAN_FLAG_VALU_DFT | TETRA_CHAN_FLAG_MATRIX_DFT));
+    h->mfma = !h->fft && n1 == kMN1 && n2 == kMN2 && p_ok && !(cfg->reserved & TETRA_CHAN_FLAG_VALU_DFT);
     if (cfg->prototype) h->proto.assign(cfg->prototype, cfg->prototype + h->L);
     else design_prototype(h->M, h->P, cfg->cutoff_rel, h->proto);
     Guard g(dev);
     if (!g.ok) { delete h; return TETRA_ERR_NO_DEVICE; }
-    bool ok = hipMalloc((void**)&h->xbuf, sizeof(float2) * ((size_t)h->L - 1 + h->max_in)) == hipSuccess &&
-              hipMalloc((void**)&h->xalt, sizeof(float2) * ((size_t)h->L - 1 + h->max_in)) == hipSuccess &&
+    // (+ kSlack: the FFT kernel's last block may read past the call's last sample, chan_fft_core.hpp)
+    bool ok = hipMalloc((void**)&h->xbuf, sizeof(float2) * ((size_t)h->L - 1 + h->max_in + chanfft::kSlack)) == hipSuccess &&
+              hipMalloc((void**)&h->xalt, sizeof(float2) * ((size_t)h->L - 1 + h->max_in + chanfft::kSlack)) == hipSuccess &&
               hipMalloc((void**)&h->d_h, sizeof(float) * h->L) == hipSuccess &&
               hipMalloc((void**)&h->d_w1, sizeof(float2) * h->N1) == hipSuccess &&
               hipMalloc((void**)&h->d_w2, sizeof(float2) * h->N2) == hipSuccess &&
               hipMalloc((void**)&h->d_wm, sizeof(float2) * h->M) == hipSuccess &&
+              (!h->fft || (hipMalloc((void**)&h->d_tw, sizeof(float2) * chanfft::kN1 * chanfft::kN2) == hipSuccess &&
+                           hipMalloc((void**)&h->d_ht, sizeof(float) * 2 * chanfft::kM * h->P) == hipSuccess)) &&
               (!h->mfma || (hipMalloc((void**)&h->d_bc, sizeof(float) * 4 * kMK1 * 64) == hipSuccess &&
                             hipMalloc((void**)&h->d_ac, sizeof(float) * 64 * 64) == hipSuccess)) &&
               hipEventCreate(&h->ev[0]) == hipSuccess && hipEventCreate(&h->ev[1]) == hipSuccess;
@@ -454,7 +520,18 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     const size_t hist = (size_t)h->L - 1;
     if (n_in > 0) CH_TRY(h, hipMemcpyAsync(h->xbuf + hist, d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
     CH_TRY(h, hipEventRecord(h->ev[0], s));
-    if (frames > 0 && h->mfma) {
+    if (frames > 0 && h->fft) {
+        ChanFftParams p;
+        p.xbuf = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_ht; p.tw = h->d_tw;
+        p.frames = frames; p.blocks = (frames + chanfft::kBlockFrames - 1) / chanfft::kBlockFrames; p.n_in = n_in;
+        p.ph0 = h->phase; p.abs0 = h->consumed;
+        // one block of 8 frames per workgroup: the hardware hands the next block to whichever CU is through first
+        const dim3 grid(p.blocks);
+        if (h->P == 8) hipLaunchKernelGGL(k_channelise_fft<8>, grid, dim3(kThreads), 0, s, p);
+        else if (h->P == 6) hipLaunchKernelGGL(k_channelise_fft<6>, grid, dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL(k_channelise_fft<4>, grid, dim3(kThreads), 0, s, p);
+        CH_TRY(h, hipGetLastError());
+    } else if (frames > 0 && h->mfma) {
         ChanMfmaParams p;
         p.xbuf = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_h; p.bc = h->d_bc; p.ac = h->d_ac; p.wm = h->d_wm;
         p.P = h->P; p.D = h->D; p.frames = frames; p.ph0 = h->phase; p.abs0 = h->consumed;

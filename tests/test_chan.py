@@ -69,14 +69,42 @@ def test_oracle_memoised_phasors_are_the_definition(oracle):
             assert abs(y[m, k] - acc) < 1e-6 * (1 + abs(acc))
 
 
+def test_fft_kernel_lane_code_on_the_host_matches_the_definition(oracle):
+    """Round 5: M = 800 at D = 400 runs as a 32 x 5 x 5 mixed-radix FFT (csrc/chan_fft_core.hpp).  The kernel's lane-level source --
+    fold with its slot / class maps, 32-point FFT, transposed LDS block, twiddle, 5 x 5 DFT, store map -- compiled for the host and run
+    thread by thread, phase by phase (tests/emul/chan_emul.cpp), against the double-precision definition: the two register-level
+    transforms against numpy's FFT, whole frames for 4 / 6 / 8 taps per channel with ragged chunks, carried history and sub-frame
+    phase (the samples past a call's end that the last block reads are NaN here: they must never reach a stored frame)."""
+    from tests.emul import chan_emul_bind as ce
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(32) + 1j * rng.standard_normal(32)).astype(np.complex64)
+    assert np.abs(ce.fft32(x) - np.fft.fft(x.astype(np.complex128))).max() < 3e-6
+    x = (rng.standard_normal(25) + 1j * rng.standard_normal(25)).astype(np.complex64)
+    assert np.abs(ce.dft25(x) - np.fft.fft(x.astype(np.complex128))).max() < 3e-6
+    for P in (8, 6, 4):
+        co = oracle.ChanOracle(800, P, 400)
+        em = ce.ChanFftEmul(P, co.h)
+        nin = 400 * 37 + 123
+        x = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(np.complex64)
+        cuts = [0, 7, 7 + 399, nin // 3, nin // 3 + 1, nin]
+        for a, b in zip(cuts, cuts[1:]):
+            yo, ye = co.process(x[a:b]), em.process(x[a:b])
+            assert yo.shape == ye.shape
+            if len(yo):
+                assert np.isfinite(ye).all() and np.abs(yo - ye).max() / np.abs(yo).max() < 2e-6, (P, a, b)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,P,D,nin,flags", [(32, 8, 16, 3000, 0), (800, 8, 400, 800 * 5, 0), (800, 8, 400, 800 * 5, 1), (60, 4, 20, 1234, 0),
+@pytest.mark.parametrize("M,P,D,nin,flags", [(32, 8, 16, 3000, 0), (800, 8, 400, 800 * 5, 0), (800, 8, 400, 800 * 5, 1), (800, 8, 400, 800 * 5, 2), (60, 4, 20, 1234, 0),
                                              (32, 4, 32, 1000, 0), (800, 8, 400, 400 * 1000 + 123, 0), (800, 8, 400, 400 * 120 + 7, 1),
+                                             (800, 8, 400, 400 * 1000 + 123, 2), (800, 6, 400, 400 * 130 + 399, 0), (800, 4, 400, 400 * 41 + 1, 0),
                                              (800, 6, 800, 800 * 40, 0)])
 def test_gpu_matches_definition(pkg, oracle, M, P, D, nin, flags):
-    """flags 1 = TETRA_CHAN_FLAG_VALU_DFT: M = 800 = 25 x 32 runs its DFT stages on the matrix pipe by default and as direct sums
-    with the flag; both against the double-precision definition, also at size (1000 frames of BASELINE config 5's geometry:
-    VERDICT r3 item 7) and with a critically sampled bank (D = M)."""
+    """M = 800 at D = 400 (BASELINE config 5's geometry) runs its DFT as a 32 x 5 x 5 mixed-radix FFT in registers / LDS by default
+    (round 5), with flags 2 = TETRA_CHAN_FLAG_MATRIX_DFT as 25 x 32 matrix products on the matrix pipe (round 4's form; also what
+    other decimations of M = 800 take) and with flags 1 = TETRA_CHAN_FLAG_VALU_DFT as direct sums; all against the double-precision
+    definition, also at size (1000 frames of config 5's geometry: VERDICT r3 item 7), for 4 / 6 / 8 taps per channel and with a
+    critically sampled bank (D = M)."""
     rng = np.random.default_rng(M)
     x = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(np.complex64)
     ch = pkg.Channeliser(M, P, D, max_in=nin, flags=flags)
