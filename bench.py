@@ -447,9 +447,10 @@ def main():
     nh = min(args.steps, 64)
     k1_ms = float(dem.kernel_ms_history(nh).mean())
 
-    # size-independent property at full size: after lock every channel returns its transmitted bits
+    # size-independent property at full size: after lock every channel returns its transmitted bits -- on EVERY rank (each has its
+    # own channel range and input); the counters are summed over the ranks after the timed region, one failing rank fails the job
     check = None
-    if not args.no_check and rank == 0:
+    if not args.no_check:
         dem.reset()
         step()
         torch.cuda.synchronize(device)
@@ -460,9 +461,15 @@ def main():
             lag, e, n = pkg.synth.align_and_count_errors(hb[j][: hn[j]], txb[c % BASE_CHANNELS], skip=3 * hn[j] // 4)
             errs += e
             ncmp += n
-        check = dict(channels_checked=len(hn), bits_compared_last_quarter=int(ncmp), bit_errors=int(errs))
-        if errs > 1e-3 * ncmp:
-            raise SystemExit("known-answer check failed: %d bit errors in %d bits after lock" % (errs, ncmp))
+        bad = int(errs > 1e-3 * ncmp or ncmp == 0)
+        nchk, ranks_ok = len(hn), 1 - bad
+        if dist is not None:
+            nchk, ncmp, errs, ranks_ok, bad = pkg.shard.sum_over_ranks(dist, [nchk, ncmp, errs, ranks_ok, bad],
+                                                                       device=device if args.backend == "nccl" else None)
+        check = dict(channels_checked=int(nchk), bits_compared_last_quarter=int(ncmp), bit_errors=int(errs), ranks_checked=world,
+                     ranks_green=int(ranks_ok))
+        if bad:
+            raise SystemExit("known-answer check failed on %d of %d rank(s): %d bit errors in %d bits after lock" % (bad, world, errs, ncmp))
 
     # The same workload handed over time-major, iq[n][c] (what a channeliser emits; the AGC wave's loads then coalesce across
     # the channel axis as north_star words it): a second handle on the transposed samples, informational A/B.

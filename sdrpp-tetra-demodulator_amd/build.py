@@ -13,6 +13,10 @@ DEPS = ["tetra_burst_sync.hip", "bsync_core.hpp", os.path.join("..", "..", "incl
 # -ffp-contract=off + correctly rounded sqrt: the arithmetic contract shared with the oracle.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"]
+# Per-source additions.  tetra_chan.hip: no SLP packing -- the mixed-radix FFT's complex arithmetic otherwise becomes v_pk_*_f32 plus
+# ~400 v_mov swizzles per block, and packed f32 is no faster than two scalar ops on gfx950 (MI355X_MICROARCH.md); measured 38.5 vs
+# 41 us per 12500 frames (profiles/r05/README.md).  The demodulator's sources keep exactly the flags their kernels were tuned with.
+EXTRA_FLAGS = {"tetra_chan.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc_path():
@@ -41,6 +45,8 @@ def source_hash():
         with open(path, "rb") as f:
             hsh.update(os.path.basename(path).encode() + b"\0" + f.read() + b"\0")
     hsh.update(" ".join(HIPCC_FLAGS).encode())
+    for src in sorted(EXTRA_FLAGS):
+        hsh.update((src + " " + " ".join(EXTRA_FLAGS[src])).encode())
     return hsh.hexdigest()
 
 
@@ -82,15 +88,30 @@ def build(force=False, verbose=False):
                 # fll_asm.inc is generated (and committed): refuse to build from one that is not what the generator emits
                 subprocess.run([sys.executable, os.path.join(CSRC, "gen_fll_asm.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
                 tmp = LIB + ".tmp.%d" % os.getpid()
-                cmd = [hipcc_path()] + HIPCC_FLAGS + ["-DTETRA_BUILD_ID=\"%s\"" % source_hash(), "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-                if verbose:
-                    print(" ".join(cmd))
+                objs = []
                 try:
-                    subprocess.run(cmd, check=True)
+                    # one object per source (its own flags), compiled side by side, then one link
+                    base = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-DTETRA_BUILD_ID=\"%s\"" % source_hash(), "-c"]
+                    procs = []
+                    for src in SOURCES:
+                        obj = "%s.%s.o" % (tmp, src)
+                        objs.append(obj)
+                        cmd = [hipcc_path()] + base + EXTRA_FLAGS.get(src, []) + ["-o", obj, os.path.join(CSRC, src)]
+                        if verbose:
+                            print(" ".join(cmd))
+                        procs.append((cmd, subprocess.Popen(cmd)))
+                    for cmd, pr in procs:
+                        if pr.wait() != 0:
+                            raise subprocess.CalledProcessError(pr.returncode, cmd)
+                    link = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
+                    if verbose:
+                        print(" ".join(link))
+                    subprocess.run(link, check=True)
                     os.replace(tmp, LIB)
                 finally:
-                    if os.path.exists(tmp):
-                        os.remove(tmp)
+                    for f in objs + [tmp]:
+                        if os.path.exists(f):
+                            os.remove(f)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB

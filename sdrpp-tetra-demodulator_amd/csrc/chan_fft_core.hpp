@@ -257,20 +257,35 @@ CHAN_HD void phase_fft32_store(int tid, c32* lds, const c32 x[32]) {
 }
 
 // phase 3 (every lane: k2 = tid & 31, frame t = tid >> 5): twiddle, 25-point DFT over n1, coalesced stores of X[k2 + 32 k1]
-CHAN_HD void phase_dft25_store(const BlockCtx& c, int blk, int tid, const c32* lds) {
+// The inter-stage twiddles W800^(n1 k2), n1 = 1 .. 24, of lane k2: 24 loads from a 6.4 KB table.  Requested BEFORE stage 1 (they do not
+// depend on it) so that their latency passes behind the 32-point FFTs instead of in front of the 5 x 5 DFTs (measured: 4 us of 37).
+CHAN_HD void load_twiddles(const BlockCtx& c, int tid, c32 tw[kN1 - 1]) {
+    const int k2 = tid & 31;
+#pragma unroll
+    for (int n1 = 1; n1 < kN1; n1++) tw[n1 - 1] = c.tw[n1 * kN2 + k2];
+}
+template <int EXP = 0> CHAN_HD void phase_dft25_store(const BlockCtx& c, long long j0, int tid, const c32* lds, const c32 tw[kN1 - 1]) {
     CHAN_FP_FAST
     const int k2 = tid & 31, t = tid >> 5;
-    const long long j = (long long)kBlockFrames * blk + t;
+    const long long j = j0 + t;               // j0 = the first frame of the block (of the pair)
     const c32* f = lds + t * kFrameLds;
     c32 x[25];
 #pragma unroll
     for (int n1 = 0; n1 < kN1; n1++) {
         const c32 v = f[kRowStride * n1 + k2];
-        x[n1] = n1 == 0 ? v : cmul(v, c.tw[n1 * kN2 + k2]);
+        x[n1] = (n1 == 0 || (EXP & 2)) ? v : cmul(v, tw[n1 - 1]);
     }
     dft25(x);
     if (j >= c.frames) return;
     c32* dst = c.out + j * kM + k2;
+    if (EXP & 1) {                            // (experiment: the whole transform, one store)
+        c32 acc = x[0];
+#pragma unroll
+        for (int k1 = 1; k1 < kN1; k1++) acc = cadd(acc, x[k1]);
+        dst[0] = acc;
+        return;
+    }
+    // (16-byte stores through a lane-pair exchange were measured: no gain, 38.2 vs 37.7 us -- profiles/r05/README.md)
 #pragma unroll
     for (int k1 = 0; k1 < kN1; k1++) dst[kN2 * k1] = x[k1];
 }

@@ -266,10 +266,12 @@ struct ChanFftParams {
     const float2* tw;      // [25][32] exp(-j 2 pi n1 k2 / 800)
     int frames, blocks, n_in;
     int ph0;
+    int xcd_span;          // blocks per XCD (ceil(blocks / 8)); 0 = no remap
+    int exp;               // ablation switches (profiles/measure_chan_fft.py; compile-time variants of the P = 8 kernel): 1 = one store per lane, 2 = no inter-stage twiddles
     long long abs0;
 };
 
-template <int P> __global__ __launch_bounds__(kThreads, 2) void k_channelise_fft(ChanFftParams p) {
+template <int P, int EXP = 0> __global__ __launch_bounds__(kThreads, 2) void k_channelise_fft(ChanFftParams p) {
     using namespace chanfft;
     __shared__ c32 lds[kBlockFrames * kFrameLds];          // 52.8 KB: three workgroups per CU
     const int tid = threadIdx.x;
@@ -280,17 +282,27 @@ template <int P> __global__ __launch_bounds__(kThreads, 2) void k_channelise_fft
     c.h = p.h;
     c.tw = reinterpret_cast<const c32*>(p.tw);
     c.frames = p.frames; c.ph0 = p.ph0; c.abs0 = p.abs0;
-    // one block of 8 frames per workgroup (no loop: nothing is carried from block to block, and a loop makes the compiler keep the
-    // transforms' ~100 literal twiddles in VGPRs across it)
-    const int blk = blockIdx.x;
+    // One block of 8 frames per workgroup, no loop over blocks: nothing is carried from block to block, and a loop makes the compiler
+    // keep the transforms' ~100 literal twiddles in VGPRs across it (256 VGPRs + spills instead of 147: three workgroups per CU).
+    // Consecutive blocks share two thirds of their samples (a block reads 9600, 3200 of them new).  Workgroups are dealt to the 8 XCDs
+    // round-robin, each with its own L2: with blk = blockIdx.x the three blocks that read a sample sit on three XCDs and every L2
+    // fetches it again (measured: 2.9x the algorithmic read traffic).  So the XCD a workgroup lands on (blockIdx.x mod 8) takes a
+    // CONTIGUOUS range of blocks, in order: neighbours in time meet in one L2.
+    int blk = blockIdx.x;
+    if (p.xcd_span > 0) {
+        blk = (int)(blockIdx.x & 7) * p.xcd_span + (int)(blockIdx.x >> 3);
+        if (blk >= p.blocks || (int)(blockIdx.x >> 3) >= p.xcd_span) return;
+    }
     phase_fold<P>(c, blk, tid, lds);
     __syncthreads();
+    c32 tw[kN1 - 1];
+    load_twiddles(c, tid, tw);
     {
         c32 x[32];
         if (phase_fft32_compute(tid, lds, x)) phase_fft32_store(tid, lds, x);
     }
     __syncthreads();
-    phase_dft25_store(c, blk, tid, lds);
+    phase_dft25_store<EXP>(c, (long long)kBlockFrames * blk, tid, lds, tw);
 }
 
 }  // namespace
@@ -526,8 +538,13 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
         p.frames = frames; p.blocks = (frames + chanfft::kBlockFrames - 1) / chanfft::kBlockFrames; p.n_in = n_in;
         p.ph0 = h->phase; p.abs0 = h->consumed;
         // one block of 8 frames per workgroup: the hardware hands the next block to whichever CU is through first
-        const dim3 grid(p.blocks);
-        if (h->P == 8) hipLaunchKernelGGL(k_channelise_fft<8>, grid, dim3(kThreads), 0, s, p);
+        p.xcd_span = (h->cfg.reserved & 0x100) ? 0 : (p.blocks + 7) / 8;      // (0x100: experiment switch, no remap)
+        p.exp = (h->cfg.reserved >> 9) & 3;                                      // (0x200: one store per lane instead of 25, 0x400: no inter-stage twiddles)
+        const dim3 grid(p.xcd_span > 0 ? 8 * p.xcd_span : p.blocks);
+        if (h->P == 8 && p.exp == 1) hipLaunchKernelGGL((k_channelise_fft<8, 1>), grid, dim3(kThreads), 0, s, p);
+        else if (h->P == 8 && p.exp == 2) hipLaunchKernelGGL((k_channelise_fft<8, 2>), grid, dim3(kThreads), 0, s, p);
+        else if (h->P == 8 && p.exp == 3) hipLaunchKernelGGL((k_channelise_fft<8, 3>), grid, dim3(kThreads), 0, s, p);
+        else if (h->P == 8) hipLaunchKernelGGL(k_channelise_fft<8>, grid, dim3(kThreads), 0, s, p);
         else if (h->P == 6) hipLaunchKernelGGL(k_channelise_fft<6>, grid, dim3(kThreads), 0, s, p);
         else hipLaunchKernelGGL(k_channelise_fft<4>, grid, dim3(kThreads), 0, s, p);
         CH_TRY(h, hipGetLastError());

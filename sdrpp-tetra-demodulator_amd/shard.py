@@ -23,6 +23,14 @@ def max_over_ranks(dist, value, device=None):
     return float(t.item())
 
 
+def sum_over_ranks(dist, values, device=None):
+    """SUM all-reduce of a short list of python ints (per-rank check counters): every rank gets the job's totals."""
+    import torch
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
+
+
 def gather_channel_rows(dist, local_rows, n_channels, world_size, device=None):
     """Concatenate per-rank row blocks (e.g. n_bits per channel) back into channel order on every rank."""
     import torch

@@ -41,7 +41,7 @@ int chan_fft_emul(const float* xbuf, int n_in, int P, int ph0, long long abs0, c
             for (int tid = 0; tid < 256; tid++) phase_fold<PP>(c, blk, tid, lds.data());
             for (int tid = 0; tid < 256; tid++) live[tid] = phase_fft32_compute(tid, lds.data(), regs[tid].x);      // every lane reads ...
             for (int tid = 0; tid < 256; tid++) if (live[tid]) phase_fft32_store(tid, lds.data(), regs[tid].x);       // ... before any lane writes
-            for (int tid = 0; tid < 256; tid++) phase_dft25_store(c, blk, tid, lds.data());
+            for (int tid = 0; tid < 256; tid++) { c32 tw[kN1 - 1]; load_twiddles(c, tid, tw); phase_dft25_store(c, (long long)kBlockFrames * blk, tid, lds.data(), tw); }
         }
     };
     if (P == 8) run(std::integral_constant<int, 8>());

@@ -53,6 +53,31 @@ def test_bench_gpus_2_runs_two_ranks(backend):
     assert abs(value - 2 * 4096 * 36000 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * value
 
 
+def test_bench_gpus_8_folded_onto_the_box(tmp_path):
+    """the driver's SCALE run is `bench.py --gpus 8` on an 8-GPU node that no round has had.  Here the same
+    command starts EIGHT ranks (512 channels each so that eight handles, inputs and bit rows fit beside each other on one GPU),
+    folded onto the GPUs the box has: rendezvous, eight communicators' worth of barriers and the MAX / SUM reductions, eight
+    known-answer checks -- every rank's own channel range against its own transmitted bits -- and a line nobody can mistake for
+    an 8-GPU measurement."""
+    import torch
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--channels", "512",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    d = _line(r)
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(d, open(os.path.join(OUT, "bench_gpus8_folded.json"), "w"))
+    ngpu = torch.cuda.device_count()
+    assert d["n_ranks"] == 8 and d["gpus_physical"] == ngpu and d["n_gpus"] == min(8, ngpu) and d["scaling"] == "weak"
+    assert d["functional_only"] == (ngpu < 8)
+    if ngpu < 8:
+        assert d["value"] is None and d["value_functional"] > 0 and "NOT an 8-GPU measurement" in d["functional_note"]
+        assert d["dist_backend"] == "gloo" and "RCCL needs one GPU per rank" in d["dist_backend_note"]
+    ck = d["check"]
+    assert ck["ranks_checked"] == 8 and ck["ranks_green"] == 8 and ck["channels_checked"] == 8 * 32
+    assert ck["bit_errors"] <= 1e-3 * ck["bits_compared_last_quarter"] and ck["bits_compared_last_quarter"] > 8 * 32 * 8000
+    assert d["config"]["channels_per_gpu"] == 512
+
+
 def test_bench_rccl_half_of_the_rank_path_on_one_gpu():
     """RCCL refuses several ranks on one device, so on a one-GPU box its half of bench.py's N > 1 path -- communicator set-up
     with device_id, barrier, MAX all-reduce of the elapsed time on a device tensor, tear-down -- runs as a ONE-rank group
