@@ -651,8 +651,10 @@ def main():
             dem = None
             import subprocess
             chain = {}
-            for key, script in (("stages", "measure_pipeline.py"), ("overlapped", "measure_pipeline_overlap.py")):
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", script)], capture_output=True, text=True)
+            # (frames handed on PACKED, 16 words per frame: the on-device chain's form since round 5; "stages_byte_frames" = round 4's)
+            for key, script, extra in (("stages", "measure_pipeline.py", ["packed"]), ("stages_byte_frames", "measure_pipeline.py", []),
+                                       ("overlapped", "measure_pipeline_overlap.py", ["packed"])):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", script)] + extra, capture_output=True, text=True)
                 lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 chain[key] = json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
             out["chain"] = chain

@@ -45,6 +45,7 @@ enum { TETRA_RX_S_UNLOCKED = 0, TETRA_RX_S_KNOW_FSTART = 1, TETRA_RX_S_LOCKED = 
 
 #define TETRA_BITS_PER_TS 510      /* tetra_common.h:237-238 */
 #define TETRA_FRAME_STRIDE 512     /* bytes per emitted frame row (510 bits + 2 zero bytes) */
+#define TETRA_FRAME_WORDS 16       /* 32-bit words per PACKED frame row (first bit = most significant; word 15 carries bits 480 .. 509) */
 #define TETRA_FRAME_NONE (-2)      /* frame_type of an unused output slot */
 
 /* struct tetra_rx_state (tetra_burst_sync.h:12-20) without bitbuf / burst_cb_priv */
@@ -76,6 +77,17 @@ int tetra_bsync_max_frames(tetra_bsync_t* h);
 int tetra_bsync_process_device(tetra_bsync_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits,
                                uint8_t* d_frames, int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames,
                                void* hip_stream);
+/*
+ * The same call with the frames PACKED, for consumers on the device (round 5): d_frames_packed [C][max_frames][TETRA_FRAME_WORDS]
+ * uint32, 32 bits per word, first bit of the frame = most significant bit of word 0, the two spare bits of word 15 zero.  The
+ * synchroniser has the stream packed in LDS anyway; handing the frames on like that writes 64 bytes per frame instead of 512 and
+ * lets the demultiplexer behind (tetra_burst_demux_packed_device) read an eighth of the bytes.  Everything else -- state, frame
+ * types, bit numbers, counts -- is identical to tetra_bsync_process_device (tests compare the two bit for bit); the byte-per-bit
+ * form stays what the host decoder's tetra_burst_rx_cb() takes.
+ */
+int tetra_bsync_process_packed_device(tetra_bsync_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits,
+                                      uint32_t* d_frames_packed, int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames,
+                                      void* hip_stream);
 /* Host-pointer variant (copies in/out, synchronises). */
 int tetra_bsync_process(tetra_bsync_t* h, const uint8_t* bits, int bits_stride, const int32_t* n_bits, uint8_t* frames,
                         int32_t* frame_type, uint32_t* frame_bitnum, int32_t* n_frames);
@@ -104,6 +116,13 @@ int tetra_burst_demux_device(const uint8_t* d_frames, const int32_t* d_frame_typ
  */
 int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
                                      uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream);
+
+/* The two demultiplexers reading PACKED frames (d_frames_packed [n][TETRA_FRAME_WORDS] as tetra_bsync_process_packed_device writes
+ * them); rows, validity, row order and counts are those of the byte-per-bit forms above. */
+int tetra_burst_demux_packed_device(const uint32_t* d_frames_packed, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                    uint8_t* d_rows, int row_stride, int32_t* d_valid, void* hip_stream);
+int tetra_burst_demux_compact_packed_device(const uint32_t* d_frames_packed, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                            uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream);
 
 #ifdef __cplusplus
 }

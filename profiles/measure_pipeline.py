@@ -3,7 +3,9 @@ stream every stage is enqueued on): IQ [4096 channels x 36000 samples = 1 s of s
   -> tetra_demod_process_device -> tetra_bsync_process_device -> tetra_burst_demux_device x4 -> tetra_lmac_decode_batch_device x4
 (SB1, SB2, SCH/F and BBK).  64 distinct synthetic downlinks (training sequences in place, random payload) tiled to 4096
 channels; the chain is run over three consecutive seconds of signal with state carried and the third -- demodulator
-converged, synchroniser LOCKED on every channel -- is the one timed."""
+converged, synchroniser LOCKED on every channel -- is the one timed.
+`python profiles/measure_pipeline.py packed` (round 5) hands the frames on PACKED (16 words per frame instead of 512 bytes:
+tetra_bsync_process_packed_device -> tetra_burst_demux_packed_device); without the argument the byte-per-bit frames of round 4."""
 import json
 import os
 import sys
@@ -18,6 +20,7 @@ pkg = tetra_amd.pkg
 lb, bb = pkg.lmac_binding, pkg.bsync_binding
 dev = torch.device("cuda", 0)
 C, N, SEC, DISTINCT = 4096, 36000, 3, 64
+PACKED = "packed" in sys.argv[1:]
 stride = pkg.binding.bits_stride(N)
 n_slots = SEC * N // 510 + 2
 iq_all = np.stack([pkg.synth.gen_channel(SEC * N, 4000 + c, bits=pkg.synth.gen_slot_bits(n_slots, c))[0] for c in range(DISTINCT)])
@@ -27,7 +30,7 @@ bs = bb.BurstSync(C, stride)
 F = bs.max_frames
 d_bits = torch.zeros((C, stride), dtype=torch.uint8, device=dev)
 d_nbits = torch.zeros(C, dtype=torch.int32, device=dev)
-d_frames = torch.zeros((C, F, 512), dtype=torch.uint8, device=dev)
+d_frames = torch.zeros((C, F, 16), dtype=torch.int32, device=dev) if PACKED else torch.zeros((C, F, 512), dtype=torch.uint8, device=dev)
 d_ft = torch.zeros((C, F), dtype=torch.int32, device=dev)
 d_fb = torch.zeros((C, F), dtype=torch.int32, device=dev)
 d_nf = torch.zeros(C, dtype=torch.int32, device=dev)
@@ -49,11 +52,11 @@ for sec in range(SEC):
     marks[0].record(s)
     d.process_device(d_iq, N, d_bits, stride, d_nbits, stream=s)
     marks.append(ev()); marks[-1].record(s)
-    bs.process_device(d_bits, stride, d_nbits, d_frames, d_ft, d_fb, d_nf, s)
+    (bs.process_packed_device if PACKED else bs.process_device)(d_bits, stride, d_nbits, d_frames, d_ft, d_fb, d_nf, s)
     marks.append(ev()); marks[-1].record(s)
     for name, tpsap, blk, rs, os_ in kinds:
         rows, valid, t2, ok = bufs[name]
-        bb.demux_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, valid, s)
+        bb.demux_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, valid, s, packed=PACKED)
     marks.append(ev()); marks[-1].record(s)
     for name, tpsap, blk, rs, os_ in kinds:
         rows, valid, t2, ok = bufs[name]
@@ -72,8 +75,10 @@ for sec in range(SEC):
     # row slot read + type-1 bits, CRC flag and scrambling code per slot.
     n_bits_total = int(d_nbits.sum().item())
     frames_total = int(nf.sum())
-    by = {"demod": 9.0 * C * N, "burst_sync": n_bits_total + 512.0 * frames_total + 8.0 * C * F}
-    by["demux_x4"] = sum(4.0 * C * F + float(rs) * int((bufs[name][1] != 0).sum().item()) + float(rs) * C * F for name, _, _, rs, _ in kinds)
+    fbytes = 64.0 if PACKED else 512.0
+    by = {"demod": 9.0 * C * N, "burst_sync": n_bits_total + fbytes * frames_total + 8.0 * C * F}
+    by["demux_x4"] = sum(4.0 * C * F + (float(rs) / 8.0 if PACKED else float(rs)) * int((bufs[name][1] != 0).sum().item()) + float(rs) * C * F
+                         for name, _, _, rs, _ in kinds)
     by["lmac_x4"] = sum((float(rs) + os_ + 8.0) * C * F for _, _, _, rs, os_ in kinds)
     steps = {"SB1": 80 + 4, "SB2": 144 + 4, "SCH/F": 288 + 4}          # trellis steps per block incl. the flush (BBK: no Viterbi)
     wave_instr = sum(68.0 * steps[k[0]] * (C * F / 64.0) for k in kinds if k[0] in steps)
@@ -83,7 +88,7 @@ for sec in range(SEC):
     roof["lmac_x4"]["valu_wave_instr_per_s"] = round(wave_instr / (t[3] * 1e-3) / 1e9, 1)
     roof["lmac_x4"]["frac_valu_issue_614G"] = round(wave_instr / (t[3] * 1e-3) / 614.4e9, 4)
     roof["lmac_x4"]["bound"] = "valu-issue (integer add-compare-select)"
-    print(json.dumps({"second": sec, "channels": C, "samples_per_channel": N, "ms_demod": round(t[0], 3), "ms_burst_sync": round(t[1], 3),
+    print(json.dumps({"second": sec, "frames_packed": PACKED, "channels": C, "samples_per_channel": N, "ms_demod": round(t[0], 3), "ms_burst_sync": round(t[1], 3),
                       "ms_demux_x4": round(t[2], 3), "ms_lmac_x4": round(t[3], 3), "ms_total": round(sum(t), 3),
                       "x_real_time": round(1000.0 / sum(t), 1), "channels_locked": locked, "frames": int(nf.sum()),
                       "bursts_with_callback": int((ft >= 0).sum()), "frame_slots_decoded_per_kind": C * F, "roofline": roof}))

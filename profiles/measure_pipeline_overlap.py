@@ -27,7 +27,7 @@ bs = bb.BurstSync(C, stride)
 F = bs.max_frames
 d_bits = [torch.zeros((C, stride), dtype=torch.uint8, device=dev) for _ in range(2)]
 d_nbits = [torch.zeros(C, dtype=torch.int32, device=dev) for _ in range(2)]
-d_frames = torch.zeros((C, F, 512), dtype=torch.uint8, device=dev)
+d_frames = torch.zeros((C, F, 16), dtype=torch.int32, device=dev) if "packed" in sys.argv[1:] else torch.zeros((C, F, 512), dtype=torch.uint8, device=dev)
 d_ft = torch.zeros((C, F), dtype=torch.int32, device=dev)
 d_fb = torch.zeros((C, F), dtype=torch.int32, device=dev)
 d_nf = torch.zeros(C, dtype=torch.int32, device=dev)
@@ -39,19 +39,20 @@ bufs = {k[0]: (torch.zeros((C * F, k[3]), dtype=torch.uint8, device=dev), torch.
 
 
 cbufs = {k[0]: (torch.zeros((C * F,), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)) for k in kinds}
+PACKED = "packed" in sys.argv[1:]      # round 5: frames handed on as 16 words instead of 512 bytes
 COMPACT = True      # set per run: rows only for the frames that carry the kind (tetra_burst_demux_compact_device + counted decoder)
 
 
 def chain(b, stream):
-    bs.process_device(d_bits[b], stride, d_nbits[b], d_frames, d_ft, d_fb, d_nf, stream)
+    (bs.process_packed_device if PACKED else bs.process_device)(d_bits[b], stride, d_nbits[b], d_frames, d_ft, d_fb, d_nf, stream)
     for name, tpsap, blk, rs, os_ in kinds:
         rows, valid, t2, ok = bufs[name]
         if COMPACT:
             idx, cnt = cbufs[name]
-            bb.demux_compact_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, idx, cnt, stream)
+            bb.demux_compact_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, idx, cnt, stream, packed=PACKED)
             lb.decode_counted_device(tpsap, rows, C * F, cnt, rs, d_scr, idx, t2, os_, ok, stream)
         else:
-            bb.demux_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, valid, stream)
+            bb.demux_device(d_frames, d_ft, C * F, tpsap, blk, rows, rs, valid, stream, packed=PACKED)
             lb.decode_batch_device(tpsap, rows, C * F, rs, d_scr, t2, os_, ok, stream)
 
 

@@ -7,7 +7,9 @@ from .binding import TetraDemodError, load_library
 
 BSYNC_EXPORTS = ["tetra_bsync_create", "tetra_bsync_destroy", "tetra_bsync_reset", "tetra_bsync_max_frames",
                  "tetra_bsync_process_device", "tetra_bsync_process", "tetra_bsync_get_state", "tetra_burst_demux_device",
-                 "tetra_burst_demux_compact_device"]
+                 "tetra_burst_demux_compact_device", "tetra_bsync_process_packed_device", "tetra_burst_demux_packed_device",
+                 "tetra_burst_demux_compact_packed_device"]
+FRAME_WORDS = 16
 RX_S_UNLOCKED, RX_S_KNOW_FSTART, RX_S_LOCKED = 0, 1, 2
 FRAME_STRIDE, FRAME_NONE, BITS_PER_TS = 512, -2, 510
 
@@ -34,6 +36,9 @@ def _lib():
         L.tetra_bsync_get_state.argtypes = [vp, i32, i32, vp]
         L.tetra_burst_demux_device.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
         L.tetra_burst_demux_compact_device.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
+        L.tetra_bsync_process_packed_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.tetra_burst_demux_packed_device.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+        L.tetra_burst_demux_compact_packed_device.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
         for n in BSYNC_EXPORTS:
             getattr(L, n).restype = i32
         _ready = True
@@ -99,6 +104,15 @@ class BurstSync:
         if rc:
             raise TetraDemodError(rc, "tetra_bsync_process_device")
 
+    def process_packed_device(self, d_bits, bits_stride, d_n_bits, d_frames_packed, d_frame_type, d_frame_bitnum, d_n_frames, stream=None):
+        """Frames as [C][max_frames][16] int32 / uint32 words (first bit = most significant) instead of [C][max_frames][512] bytes."""
+        vp = C.c_void_p
+        rc = _lib().tetra_bsync_process_packed_device(self._h, vp(d_bits.data_ptr()), int(bits_stride), vp(d_n_bits.data_ptr()),
+                                                      vp(d_frames_packed.data_ptr()), vp(d_frame_type.data_ptr()),
+                                                      vp(d_frame_bitnum.data_ptr()), vp(d_n_frames.data_ptr()), _stream(stream))
+        if rc:
+            raise TetraDemodError(rc, "tetra_bsync_process_packed_device")
+
     def states(self, first=0, count=None):
         count = self.n_channels - first if count is None else count
         arr = (BsyncState * count)()
@@ -108,18 +122,20 @@ class BurstSync:
         return [(s.state, s.bits_in_buf, s.bitbuf_start_bitnum, s.next_frame_start_bitnum) for s in arr]
 
 
-def demux_compact_device(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_row_frame, d_n_rows, stream=None):
+def demux_compact_device(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_row_frame, d_n_rows, stream=None, packed=False):
     vp = C.c_void_p
-    rc = _lib().tetra_burst_demux_compact_device(vp(d_frames.data_ptr()), vp(d_frame_type.data_ptr()), int(n), int(tpsap), int(blk_num),
+    fn = _lib().tetra_burst_demux_compact_packed_device if packed else _lib().tetra_burst_demux_compact_device
+    rc = fn(vp(d_frames.data_ptr()), vp(d_frame_type.data_ptr()), int(n), int(tpsap), int(blk_num),
                                                  vp(d_rows.data_ptr()), int(row_stride), vp(d_row_frame.data_ptr()),
                                                  vp(d_n_rows.data_ptr()), _stream(stream))
     if rc:
         raise TetraDemodError(rc, "tetra_burst_demux_compact_device")
 
 
-def demux_device(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_valid, stream=None):
+def demux_device(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_valid, stream=None, packed=False):
     vp = C.c_void_p
-    rc = _lib().tetra_burst_demux_device(vp(d_frames.data_ptr()), vp(d_frame_type.data_ptr()), int(n), int(tpsap), int(blk_num),
+    fn = _lib().tetra_burst_demux_packed_device if packed else _lib().tetra_burst_demux_device
+    rc = fn(vp(d_frames.data_ptr()), vp(d_frame_type.data_ptr()), int(n), int(tpsap), int(blk_num),
                                          vp(d_rows.data_ptr()), int(row_stride), vp(d_valid.data_ptr()), _stream(stream))
     if rc:
         raise TetraDemodError(rc, "tetra_burst_demux_device")

@@ -1,6 +1,6 @@
 // tetra_burst_sync.hip -- batched burst synchroniser + burst demultiplexer (include/tetra_burst_sync.h).
 //
-// k_burst_sync: one 64-lane workgroup per channel.
+// k_burst_sync: one workgroup of four wavefronts per channel (the byte work of steps 1, 2 and 4 on all 256 lanes; step 3 on one wave).
 //   1. the channel's stream of this call -- carried buffer (<= 4096 bits, one byte per bit in HBM) followed by the new
 //      bits -- is packed 32 bits per word into LDS; the new bits start word-aligned, 32 bytes -> one word per lane-step
 //      with 16-byte loads and one multiply per 8 bytes (the scan kernel's trick);
@@ -22,11 +22,14 @@ namespace {
 using namespace bsync_core;
 
 constexpr int kLanes = 64;
+constexpr int kThreadsBS = 256;       // k_burst_sync: four wavefronts per channel for the byte work, one of them walks the state machine
 constexpr int kMaxBitsLimit = 262144;
 
 struct FrameRec { int bx; int type; uint32_t bitnum; };
 
-__global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict__ bits, int bits_stride, const int* __restrict__ n_bits,
+// PACKED: the consumed frames leave as 16 words of 32 bits (first bit = most significant; word 15 holds bits 480 .. 509 in its top 30
+// bits) instead of 512 bytes: an eighth of the bytes for the demultiplexer behind (tetra_bsync_process_packed_device).
+template <bool PACKED> __global__ __launch_bounds__(kThreadsBS) void k_burst_sync(const uint8_t* __restrict__ bits, int bits_stride, const int* __restrict__ n_bits,
                                                        int max_bits, int max_frames, State* __restrict__ states,
                                                        uint8_t* __restrict__ carry, uint8_t* __restrict__ frames,
                                                        int* __restrict__ frame_type, uint32_t* __restrict__ frame_bitnum,
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
     __shared__ int sh_nframes, sh_carry_x;
     __shared__ State sh_state;
 
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & (kLanes - 1);
     const uint8_t* in = bits + (size_t)ch * bits_stride;
     uint8_t* cbuf = carry + (size_t)ch * kBuf;
     State st = states[ch];
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
     const int x0 = kOff - (int)st.bits_in_buf, xe = kOff + n_new;
 
     // 1. pack the stream
-    for (int w = lane; w < words; w += kLanes) {
+    for (int w = tid; w < words; w += kThreadsBS) {
         uint32_t v = 0;
         const int xb = 32 * w;
         if (xb + 32 > x0 && xb < kOff) {                         // carried bits: byte by byte (at most 128 words)
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
     __syncthreads();
 
     // 2. match bitmaps
-    for (int w = lane; w < words; w += kLanes) {
+    for (int w = tid; w < words; w += kThreadsBS) {
         uint32_t a = 0, b = 0, c = 0;
         if (w + 2 < words && 32 * w + 32 > x0 && 32 * w < xe) match_word(s, w, x0, xe, a, b, c);
         m_sync[w] = a;
@@ -107,36 +110,47 @@ __global__ __launch_bounds__(kLanes) void k_burst_sync(const uint8_t* __restrict
         }
         return -1;
     };
-    int carry_x = 0;
-    const int nrun = run(st, s, m_sync, m_n1, m_n2, m_any, n_new, carry_x, first_wave, [&](int f, int bx, int type, uint32_t bitnum) {
-        if (lane == 0 && f < max_frames) rec[f] = FrameRec{ bx, type, bitnum };
-    });
-    if (lane == 0) {
-        sh_nframes = nrun < max_frames ? nrun : max_frames;
-        sh_carry_x = carry_x;
-        sh_state = st;
+    if (tid < kLanes) {      // (one wavefront walks the events; the other three join again for the byte work behind the barrier)
+        int carry_x = 0;
+        const int nrun = run(st, s, m_sync, m_n1, m_n2, m_any, n_new, carry_x, first_wave, [&](int f, int bx, int type, uint32_t bitnum) {
+            if (lane == 0 && f < max_frames) rec[f] = FrameRec{ bx, type, bitnum };
+        });
+        if (lane == 0) {
+            sh_nframes = nrun < max_frames ? nrun : max_frames;
+            sh_carry_x = carry_x;
+            sh_state = st;
+        }
     }
     __syncthreads();
 
     // 4. frames, carry, state
     const int nf = sh_nframes;
+    if (PACKED) {
+        uint32_t* pout = reinterpret_cast<uint32_t*>(frames) + (size_t)ch * max_frames * TETRA_FRAME_WORDS;
+        for (int i = tid; i < nf * TETRA_FRAME_WORDS; i += kThreadsBS) {
+            const int f = i / TETRA_FRAME_WORDS, w = i % TETRA_FRAME_WORDS;
+            uint32_t v = window(s, rec[f].bx + 32 * w, 32);
+            if (w == TETRA_FRAME_WORDS - 1) v &= 0xfffffffcu;              // bits 510, 511 of the row are not the frame's
+            pout[i] = v;
+        }
+    }
     uint8_t* fout = frames + (size_t)ch * max_frames * TETRA_FRAME_STRIDE;
-    for (int f = 0; f < nf; ++f) {
+    for (int f = 0; !PACKED && f < nf; ++f) {
         const int bx = rec[f].bx;
         uint32_t* dst = reinterpret_cast<uint32_t*>(fout + (size_t)f * TETRA_FRAME_STRIDE);
-        for (int d = lane; d < TETRA_FRAME_STRIDE / 4; d += kLanes) {
+        for (int d = tid; d < TETRA_FRAME_STRIDE / 4; d += kThreadsBS) {
             uint32_t nib = window(s, bx + 4 * d, 4);                       // first bit = MSB
             if (4 * d + 4 > kTs) nib &= (4 * d >= kTs) ? 0u : (0xfu << (4 * d + 4 - kTs)) & 0xfu;
             dst[d] = ((nib >> 3) & 1u) | (((nib >> 2) & 1u) << 8) | (((nib >> 1) & 1u) << 16) | ((nib & 1u) << 24);
         }
     }
-    for (int f = lane; f < max_frames; f += kLanes) {
+    for (int f = tid; f < max_frames; f += kThreadsBS) {
         frame_type[(size_t)ch * max_frames + f] = f < nf ? rec[f].type : TETRA_FRAME_NONE;
         frame_bitnum[(size_t)ch * max_frames + f] = f < nf ? rec[f].bitnum : 0u;
     }
     const int cx = sh_carry_x, nc = xe - cx;
-    for (int i = lane; i < nc; i += kLanes) cbuf[i] = (uint8_t)get_bit(s, cx + i);
-    if (lane == 0) {
+    for (int i = tid; i < nc; i += kThreadsBS) cbuf[i] = (uint8_t)get_bit(s, cx + i);
+    if (tid == 0) {
         states[ch] = sh_state;
         n_frames[ch] = nf;
     }
@@ -159,25 +173,53 @@ __host__ __device__ inline Pieces pieces_for(int train, int tpsap, int blk_num) 
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_burst_demux(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type, int n,
+// four consecutive bits of a block (positions 4 d .. 4 d + 3 of its up to two pieces) as four bytes, first bit in the low byte.
+// PACKED: the frame is 16 words, first bit most significant (k_burst_sync<true>); else 512 bytes, one bit per byte.
+template <bool PACKED> __device__ __forceinline__ uint32_t demux_dword(const uint8_t* frames, int r, const Pieces& p, int d) {
+    uint32_t v = 0;
+    if (PACKED) {
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(frames) + (size_t)r * TETRA_FRAME_WORDS;
+        const int i = 4 * d;
+        int x = -1;                                       // all four bits inside one piece: one 4-bit window of the packed row
+        if (i + 4 <= p.len0) x = p.off0 + i;
+        else if (i >= p.len0 && i + 4 <= p.len0 + p.len1) x = p.off1 + i - p.len0;
+        if (x >= 0) {
+            const int w = x >> 5;
+            const uint64_t two = ((uint64_t)f[w] << 32) | (w + 1 < TETRA_FRAME_WORDS ? f[w + 1] : 0u);
+            const uint32_t nib = (uint32_t)(two >> (60 - (x & 31))) & 0xfu;      // first bit = most significant
+            return ((nib >> 3) & 1u) | (((nib >> 2) & 1u) << 8) | (((nib >> 1) & 1u) << 16) | ((nib & 1u) << 24);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                      // a piece boundary or the block's end inside these four bits
+            const int ii = i + k;
+            const int xx = ii < p.len0 ? p.off0 + ii : (ii < p.len0 + p.len1 ? p.off1 + ii - p.len0 : -1);
+            if (xx >= 0) v |= ((f[xx >> 5] >> (31 - (xx & 31))) & 1u) << (8 * k);
+        }
+    } else {
+        const uint8_t* f = frames + (size_t)r * TETRA_FRAME_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * d + k;
+            uint32_t byte = 0;
+            if (i < p.len0) byte = f[p.off0 + i];
+            else if (i < p.len0 + p.len1) byte = f[p.off1 + i - p.len0];
+            v |= byte << (8 * k);
+        }
+    }
+    return v;
+}
+
+// one thread per output dword -- or, WIDE (rows a multiple of 8 bytes, 8-byte aligned), per pair of dwords: half the threads, 8-byte stores
+template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_burst_demux(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type, int n,
                                                      int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride,
                                                      int* __restrict__ valid) {
-    const int row_dw = row_stride >> 2;
+    const int row_u = row_stride >> (WIDE ? 3 : 2);
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)n * row_dw) return;
-    const int r = (int)(gid / row_dw), d = (int)(gid % row_dw);
+    if (gid >= (long long)n * row_u) return;
+    const int r = (int)(gid / row_u), d = (int)(gid % row_u);
     const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
-    const uint8_t* f = frames + (size_t)r * TETRA_FRAME_STRIDE;
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = 4 * d + k;
-        uint32_t byte = 0;
-        if (i < p.len0) byte = f[p.off0 + i];
-        else if (i < p.len0 + p.len1) byte = f[p.off1 + i - p.len0];
-        v |= byte << (8 * k);
-    }
-    reinterpret_cast<uint32_t*>(rows + (size_t)r * row_stride)[d] = v;
+    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)r * row_stride)[d] = make_uint2(demux_dword<PACKED>(frames, r, p, 2 * d), demux_dword<PACKED>(frames, r, p, 2 * d + 1));
+    else reinterpret_cast<uint32_t*>(rows + (size_t)r * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
     if (d == 0) valid[r] = p.len0 > 0;
 }
 
@@ -224,27 +266,18 @@ __global__ __launch_bounds__(256) void k_demux_index(const int* __restrict__ fra
     if (has) row_frame[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
 }
 // 4. the gather itself, one thread per output dword of the worst case; rows past *n_rows do not exist
-__global__ __launch_bounds__(256) void k_demux_gather(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type,
+template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_demux_gather(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type,
                                                       const int* __restrict__ row_frame, const int* __restrict__ n_rows, int n,
                                                       int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride) {
-    const int row_dw = row_stride >> 2;
+    const int row_u = row_stride >> (WIDE ? 3 : 2);
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)n * row_dw) return;
-    const int j = (int)(gid / row_dw), d = (int)(gid % row_dw);
+    if (gid >= (long long)n * row_u) return;
+    const int j = (int)(gid / row_u), d = (int)(gid % row_u);
     if (j >= *n_rows) return;
     const int r = row_frame[j];
     const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
-    const uint8_t* f = frames + (size_t)r * TETRA_FRAME_STRIDE;
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = 4 * d + k;
-        uint32_t byte = 0;
-        if (i < p.len0) byte = f[p.off0 + i];
-        else if (i < p.len0 + p.len1) byte = f[p.off1 + i - p.len0];
-        v |= byte << (8 * k);
-    }
-    reinterpret_cast<uint32_t*>(rows + (size_t)j * row_stride)[d] = v;
+    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)j * row_stride)[d] = make_uint2(demux_dword<PACKED>(frames, r, p, 2 * d), demux_dword<PACKED>(frames, r, p, 2 * d + 1));
+    else reinterpret_cast<uint32_t*>(rows + (size_t)j * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
 }
 
 size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 5 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
@@ -276,7 +309,9 @@ int tetra_bsync_create(int n_channels, int max_bits, int device, tetra_bsync_t**
     }
     // the attribute belongs to the kernel, not to the handle: always raise it to the ceiling so that handles of different
     // sizes can coexist
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_burst_sync), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_burst_sync<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 64) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_burst_sync<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 64) != hipSuccess) {
         tetra_bsync_destroy(h);
         return TETRA_ERR_HIP;
@@ -304,16 +339,33 @@ int tetra_bsync_reset(tetra_bsync_t* h) {
 
 int tetra_bsync_max_frames(tetra_bsync_t* h) { return h ? h->max_frames : TETRA_ERR_ARG; }
 
-int tetra_bsync_process_device(tetra_bsync_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits, uint8_t* d_frames,
-                               int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames, void* hip_stream) {
+}  // extern "C"
+
+namespace {
+template <bool PACKED> int bsync_launch(tetra_bsync_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits, void* d_frames,
+                                        int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames, void* hip_stream) {
     if (!h || !d_bits || !d_n_bits || !d_frames || !d_frame_type || !d_frame_bitnum || !d_n_frames) return TETRA_ERR_ARG;
     if (bits_stride < 4) return TETRA_ERR_ARG;
     if (bits_stride < h->max_bits) return TETRA_ERR_SIZE;      // rows must be able to hold the max_bits the handle was sized for
     if ((bits_stride & 3) || ((uintptr_t)d_bits & 3) || ((uintptr_t)d_frames & 3)) return TETRA_ERR_ALIGN;
-    hipLaunchKernelGGL(k_burst_sync, dim3(h->n_channels), dim3(kLanes), lds_bytes(h->max_bits, h->max_frames),
+    hipLaunchKernelGGL(k_burst_sync<PACKED>, dim3(h->n_channels), dim3(kThreadsBS), lds_bytes(h->max_bits, h->max_frames),
                        static_cast<hipStream_t>(hip_stream), d_bits, bits_stride, d_n_bits, h->max_bits, h->max_frames, h->d_state,
-                       h->d_carry, d_frames, d_frame_type, d_frame_bitnum, d_n_frames);
+                       h->d_carry, static_cast<uint8_t*>(d_frames), d_frame_type, d_frame_bitnum, d_n_frames);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+}  // namespace
+
+extern "C" {
+
+int tetra_bsync_process_device(tetra_bsync_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits, uint8_t* d_frames,
+                               int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames, void* hip_stream) {
+    return bsync_launch<false>(h, d_bits, bits_stride, d_n_bits, d_frames, d_frame_type, d_frame_bitnum, d_n_frames, hip_stream);
+}
+
+int tetra_bsync_process_packed_device(tetra_bsync_t* h, const uint8_t* d_bits, int bits_stride, const int32_t* d_n_bits,
+                                      uint32_t* d_frames_packed, int32_t* d_frame_type, uint32_t* d_frame_bitnum, int32_t* d_n_frames,
+                                      void* hip_stream) {
+    return bsync_launch<true>(h, d_bits, bits_stride, d_n_bits, d_frames_packed, d_frame_type, d_frame_bitnum, d_n_frames, hip_stream);
 }
 
 int tetra_bsync_process(tetra_bsync_t* h, const uint8_t* bits, int bits_stride, const int32_t* n_bits, uint8_t* frames,
@@ -361,8 +413,12 @@ int tetra_bsync_get_state(tetra_bsync_t* h, int first, int count, tetra_bsync_st
     return TETRA_OK;
 }
 
-int tetra_burst_demux_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num, uint8_t* d_rows,
-                             int row_stride, int32_t* d_valid, void* hip_stream) {
+}  // extern "C"
+
+namespace {
+template <bool PACKED> int demux_launch(const void* d_frames_v, const int32_t* d_frame_type, int n, int tpsap, int blk_num, uint8_t* d_rows,
+                                        int row_stride, int32_t* d_valid, void* hip_stream) {
+    const uint8_t* d_frames = static_cast<const uint8_t*>(d_frames_v);
     if (!d_frames || !d_frame_type || !d_rows || !d_valid || n < 0 || tpsap < 0 || tpsap > 5) return TETRA_ERR_ARG;
     if (n == 0) return TETRA_OK;
     // the longest block this kind can have must fit the row
@@ -373,14 +429,20 @@ int tetra_burst_demux_device(const uint8_t* d_frames, const int32_t* d_frame_typ
     if (longest.len0 == 0) return TETRA_ERR_ARG;                      // no burst type carries (tpsap, blk_num)
     if (row_stride < longest.len0 + longest.len1) return TETRA_ERR_SIZE;
     if ((row_stride & 3) || ((uintptr_t)d_rows & 3)) return TETRA_ERR_ALIGN;
-    const long long total = (long long)n * (row_stride >> 2);
-    hipLaunchKernelGGL(k_burst_demux, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames,
-                       d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_valid);
+    if (PACKED && ((uintptr_t)d_frames & 3)) return TETRA_ERR_ALIGN;
+    const bool wide = !(row_stride & 7) && !((uintptr_t)d_rows & 7);
+    const long long total = (long long)n * (row_stride >> (wide ? 3 : 2));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (wide) hipLaunchKernelGGL((k_burst_demux<PACKED, true>), grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames, d_frame_type, n,
+                                 tpsap, blk_num, d_rows, row_stride, d_valid);
+    else hipLaunchKernelGGL((k_burst_demux<PACKED, false>), grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames, d_frame_type, n,
+                            tpsap, blk_num, d_rows, row_stride, d_valid);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 
-int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
-                                     uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream) {
+template <bool PACKED> int demux_compact_launch(const void* d_frames_v, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                                uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream) {
+    const uint8_t* d_frames = static_cast<const uint8_t*>(d_frames_v);
     if (!d_frames || !d_frame_type || !d_rows || !d_row_frame || !d_n_rows || n < 0) return TETRA_ERR_ARG;
     if (tpsap < 0 || tpsap > 5) return TETRA_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -399,12 +461,36 @@ int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_f
     hipLaunchKernelGGL(k_demux_count, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off);
     hipLaunchKernelGGL(k_demux_scan, dim3(1), dim3(1024), 0, s, off, nblocks, d_n_rows);
     hipLaunchKernelGGL(k_demux_index, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off, d_row_frame);
-    const long long total = (long long)n * (row_stride >> 2);
-    hipLaunchKernelGGL(k_demux_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_frames, d_frame_type, d_row_frame,
-                       d_n_rows, n, tpsap, blk_num, d_rows, row_stride);
+    const bool wide = !(row_stride & 7) && !((uintptr_t)d_rows & 7);
+    const long long total = (long long)n * (row_stride >> (wide ? 3 : 2));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (wide) hipLaunchKernelGGL((k_demux_gather<PACKED, true>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
+                                 blk_num, d_rows, row_stride);
+    else hipLaunchKernelGGL((k_demux_gather<PACKED, false>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
+                            blk_num, d_rows, row_stride);
     const hipError_t launch = hipGetLastError();
     if (hipFreeAsync(off, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
     return TETRA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int tetra_burst_demux_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num, uint8_t* d_rows,
+                             int row_stride, int32_t* d_valid, void* hip_stream) {
+    return demux_launch<false>(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_valid, hip_stream);
+}
+int tetra_burst_demux_packed_device(const uint32_t* d_frames_packed, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                    uint8_t* d_rows, int row_stride, int32_t* d_valid, void* hip_stream) {
+    return demux_launch<true>(d_frames_packed, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_valid, hip_stream);
+}
+int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                     uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream) {
+    return demux_compact_launch<false>(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_row_frame, d_n_rows, hip_stream);
+}
+int tetra_burst_demux_compact_packed_device(const uint32_t* d_frames_packed, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
+                                            uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream) {
+    return demux_compact_launch<true>(d_frames_packed, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_row_frame, d_n_rows, hip_stream);
 }
 
 }  // extern "C"

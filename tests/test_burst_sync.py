@@ -288,6 +288,77 @@ def test_gpu_burst_sync_and_demux_equal_the_reference_run(pkg, ref):
 
 
 @pytest.mark.gpu
+def test_gpu_packed_frames_path_equals_the_byte_path(pkg, ref):
+    """Round 5: the on-device chain hands frames on PACKED (16 words per frame instead of 512 bytes):
+    tetra_bsync_process_packed_device -> tetra_burst_demux_packed_device / _compact_packed_device.  Two receivers fed the same
+    ragged calls, one through each path: states, frame types, bit numbers and counts are identical after every call, the packed
+    frames are the byte frames' bits (first bit = most significant, spare bits zero), and every demultiplexed row, validity flag,
+    compacted row, row order and count equals the byte path's -- which the tests above pin on the reference's own run."""
+    import torch
+    bb = pkg.bsync_binding
+    rng = np.random.default_rng(79)
+    Cn, max_bits = 24, 9000
+    streams = [make_stream(ref, 5000 + c) for c in range(Cn)]
+    a, b = bb.BurstSync(Cn, max_bits), bb.BurstSync(Cn, max_bits)
+    F = a.max_frames
+    dev = torch.device("cuda", 0)
+    stride = (max_bits + 15) & ~15
+    pos = np.zeros(Cn, np.int64)
+    d_fr = torch.zeros((Cn, F, 512), dtype=torch.uint8, device=dev)
+    d_fp = torch.full((Cn, F, 16), -1, dtype=torch.int32, device=dev)
+    outs = [[torch.zeros((Cn, F), dtype=torch.int32, device=dev), torch.zeros((Cn, F), dtype=torch.int32, device=dev),
+             torch.zeros(Cn, dtype=torch.int32, device=dev)] for _ in range(2)]
+    frames_seen = 0
+    for call in range(7):
+        rows = rng.integers(0, 2, (Cn, stride), dtype=np.uint8)
+        nb = np.zeros(Cn, np.int32)
+        for c in range(Cn):
+            n = int(min(rng.choice([1, 300, 4000, 9000]), streams[c].size - pos[c]))
+            rows[c, :n] = streams[c][pos[c]:pos[c] + n]
+            nb[c] = n
+            pos[c] += n
+        d_rows_in, d_nb = torch.from_numpy(rows).to(dev), torch.from_numpy(nb).to(dev)
+        a.process_device(d_rows_in, stride, d_nb, d_fr, *outs[0])
+        b.process_packed_device(d_rows_in, stride, d_nb, d_fp, *outs[1])
+        torch.cuda.synchronize()
+        assert a.states() == b.states(), call
+        ft, fb, nf = (t.cpu().numpy() for t in outs[0])
+        ft2, fb2, nf2 = (t.cpu().numpy() for t in outs[1])
+        assert np.array_equal(ft, ft2) and np.array_equal(fb, fb2) and np.array_equal(nf, nf2), call
+        fr, fp = d_fr.cpu().numpy(), d_fp.cpu().numpy().view(np.uint32)
+        for c in range(Cn):
+            for k in range(nf[c]):
+                want = np.packbits(np.concatenate([fr[c, k, :510], np.zeros(2, np.uint8)])).view(">u4").astype(np.uint32)
+                assert np.array_equal(fp[c, k], want), (call, c, k)
+            frames_seen += int(nf[c])
+        n_all = Cn * F
+        for tp, blk, rs in ((0, 1, 120), (1, 2, 216), (2, 1, 216), (2, 2, 216), (3, 0, 32), (5, 0, 432)):
+            r1 = torch.full((n_all, rs), 7, dtype=torch.uint8, device=dev)
+            r2 = torch.full((n_all, rs), 8, dtype=torch.uint8, device=dev)
+            v1 = torch.zeros(n_all, dtype=torch.int32, device=dev)
+            v2 = torch.ones(n_all, dtype=torch.int32, device=dev)
+            bb.demux_device(d_fr.reshape(n_all, 512), outs[0][0].reshape(n_all), n_all, tp, blk, r1, rs, v1)
+            bb.demux_device(d_fp.reshape(n_all, 16), outs[1][0].reshape(n_all), n_all, tp, blk, r2, rs, v2, packed=True)
+            c1 = torch.full((n_all, rs), 7, dtype=torch.uint8, device=dev)
+            c2 = torch.full((n_all, rs), 7, dtype=torch.uint8, device=dev)
+            i1 = torch.full((n_all,), -1, dtype=torch.int32, device=dev)
+            i2 = torch.full((n_all,), -1, dtype=torch.int32, device=dev)
+            k1 = torch.full((1,), -1, dtype=torch.int32, device=dev)
+            k2 = torch.full((1,), -1, dtype=torch.int32, device=dev)
+            bb.demux_compact_device(d_fr.reshape(n_all, 512), outs[0][0].reshape(n_all), n_all, tp, blk, c1, rs, i1, k1)
+            bb.demux_compact_device(d_fp.reshape(n_all, 16), outs[1][0].reshape(n_all), n_all, tp, blk, c2, rs, i2, k2, packed=True)
+            torch.cuda.synchronize()
+            live = (outs[0][0].reshape(n_all) != bb.FRAME_NONE).cpu().numpy()       # unused slots hold stale frames in the byte buffer
+            assert np.array_equal(v1.cpu().numpy()[live], v2.cpu().numpy()[live]) and not v2.cpu().numpy()[~live].any()
+            assert np.array_equal(r1.cpu().numpy()[live], r2.cpu().numpy()[live]), (call, tp, blk)
+            assert np.array_equal(k1.cpu().numpy(), k2.cpu().numpy()) and np.array_equal(i1.cpu().numpy(), i2.cpu().numpy())
+            assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy()), (call, tp, blk)
+    a.close()
+    b.close()
+    assert frames_seen > 400
+
+
+@pytest.mark.gpu
 def test_gpu_demux_equals_restated_rx_cb(pkg, ref, oracle):
     import torch
     rng = np.random.default_rng(5)
