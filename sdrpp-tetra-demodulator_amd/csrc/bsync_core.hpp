@@ -172,12 +172,36 @@ BS_FN int locked_find(const uint32_t* s, const uint32_t* m_sync, const uint32_t*
     return type;
 }
 
+// One LOCKED call on a buffer of exactly one frame, [bx, bx + 510): what tetra_burst_sync_in reports for it (the rx_cb type, or -1)
+// and whether the receiver falls back to UNLOCKED behind it (tetra_burst_sync.c:105-150).  A pure function of the bitmaps: frames in
+// LOCKED steady state can be evaluated side by side, one per lane (run()'s `batch`).
+struct FrameEval { int reported; bool unlocks; };
+BS_FN FrameEval locked_frame_eval(const uint32_t* s, const uint32_t* m_sync, const uint32_t* m_n1, const uint32_t* m_n2, const uint32_t* m_any,
+                                  int bx) {
+    int offs = 0;
+    const int rc = locked_find(s, m_sync, m_n1, m_n2, m_any, bx, kTs, offs, [](const uint32_t* m, int a, int b) { return first_set(m, a, b); });
+    FrameEval e = { -1, false };
+    if (rc == kSync) {
+        if (offs == 214) e.reported = rc;
+        else e.unlocks = true;
+    } else if (rc == kNorm1 || rc == kNorm2) {
+        if (offs == 244) e.reported = rc;
+    } else {
+        e.unlocks = true;
+    }
+    return e;
+}
+
 // Runs the state machine over the new bits.  emit(f, bx, type, bitnum) is called for the f-th consumed frame (buffer
 // coordinate of its first bit, the reference's rx_cb type or -1, absolute bit number of its first bit).  On return
 // st holds the new state and carry_x the coordinate of the first bit that stays buffered ([carry_x, xe) = the new bitbuf).
-template <class First, class Emit>
+// batch(bx, K, f0, abs_bx, unlocked): LOCKED steady state (the fed position a equals the buffer start bx, so every call consumes
+// exactly the next 510 bits): evaluate up to K whole frames [bx + 510 k, bx + 510 (k + 1)) and emit them as frames f0, f0 + 1, ... up to
+// and including the first one that unlocks the receiver; returns how many it consumed (0 = not taken: the serial path runs).  The
+// kernel does this one frame per lane -- ~70 dependent event steps per second of signal become two -- the host emulation in a loop.
+template <class First, class Emit, class Batch>
 BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32_t* m_n1, const uint32_t* m_n2, const uint32_t* m_any,
-              int n_new, int& carry_x, First first, Emit emit) {
+              int n_new, int& carry_x, First first, Emit emit, Batch batch) {
     const int x0 = kOff - (int)st.bits_in_buf, xe = kOff + n_new;
     const uint32_t abs0 = st.bitbuf_start_bitnum;               // absolute bit number of coordinate x0
     auto abs_of = [&](int x) { return abs0 + (uint32_t)(x - x0); };
@@ -231,6 +255,18 @@ BS_FN int run(State& st, const uint32_t* s, const uint32_t* m_sync, const uint32
             state = kLocked;
             locked_call();
         } else {
+            if (a == bx && xe - bx >= 2 * kTs) {
+                bool unlocked = false;
+                const int done = batch(bx, (xe - bx) / kTs, frames, abs_of(bx), unlocked);
+                if (done > 0) {                                 // `done` LOCKED calls of exactly one frame each, a = bx + 510 after every one
+                    frames += done;
+                    bx += kTs * done;
+                    nfs += (uint32_t)(kTs * done);
+                    a = bx;
+                    if (unlocked) state = kUnlocked;
+                    continue;
+                }
+            }
             const int an = (a + 1 > bx + kTs) ? a + 1 : bx + kTs;
             if (an > xe) { a = xe; break; }
             a = an;

@@ -112,9 +112,24 @@ template <bool PACKED> __global__ __launch_bounds__(kThreadsBS) void k_burst_syn
     };
     if (tid < kLanes) {      // (one wavefront walks the events; the other three join again for the byte work behind the barrier)
         int carry_x = 0;
+        // LOCKED steady state: one frame per lane, 64 per round, up to and including the first frame that unlocks the receiver
+        auto batch = [&](int bx, int K, int f0, uint32_t abs_bx, bool& unlocked) -> int {
+            int done = 0;
+            while (done < K) {
+                const int k = done + lane, here = K - done < kLanes ? K - done : kLanes;
+                FrameEval e = { -1, false };
+                if (lane < here) e = locked_frame_eval(s, m_sync, m_n1, m_n2, m_any, bx + kTs * k);
+                const unsigned long long um = __ballot(e.unlocks);
+                const int take = um ? __builtin_ctzll(um) + 1 : here;
+                if (lane < take && f0 + k < max_frames) rec[f0 + k] = FrameRec{ bx + kTs * k, e.reported, abs_bx + (uint32_t)(kTs * k) };
+                done += take;
+                if (um) { unlocked = true; break; }
+            }
+            return done;
+        };
         const int nrun = run(st, s, m_sync, m_n1, m_n2, m_any, n_new, carry_x, first_wave, [&](int f, int bx, int type, uint32_t bitnum) {
             if (lane == 0 && f < max_frames) rec[f] = FrameRec{ bx, type, bitnum };
-        });
+        }, batch);
         if (lane == 0) {
             sh_nframes = nrun < max_frames ? nrun : max_frames;
             sh_carry_x = carry_x;

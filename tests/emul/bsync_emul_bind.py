@@ -23,7 +23,9 @@ def build(force=False):
 class Emul:
     """One channel: same interface as oracle.binding.BurstSyncOracle."""
 
-    def __init__(self):
+    def __init__(self, batch=True):
+        """batch: LOCKED steady state evaluated frame-parallel like the kernel does (run()'s batch hook) or event by event."""
+        self.batch = 1 if batch else 0
         global _lib
         if _lib is None:
             build()
@@ -44,6 +46,6 @@ class Emul:
         bn = np.zeros(cap, np.uint32)
         vp = C.c_void_p
         n = _lib.bsync_emul_process(self.st.ctypes.data_as(vp), self.carry.ctypes.data_as(vp), b.ctypes.data_as(vp), b.size,
-                                    fr.ctypes.data_as(vp), ty.ctypes.data_as(vp), bn.ctypes.data_as(vp), cap)
+                                    fr.ctypes.data_as(vp), ty.ctypes.data_as(vp), bn.ctypes.data_as(vp), cap, self.batch)
         assert n >= 0
         return fr[:n, :510].copy(), ty[:n].copy(), bn[:n].copy()

@@ -178,18 +178,19 @@ def test_kernel_logic_equals_literal_state_machine(ref, oracle):
     hist = {}
     for seed in range(80):
         tx = make_stream(ref, seed)
-        o, e = oracle.BurstSyncOracle(), bsync_emul_bind.Emul()
+        # the kernel logic both ways: LOCKED steady state frame-parallel (what the kernel runs since round 5) and event by event
+        o, e, e2 = oracle.BurstSyncOracle(), bsync_emul_bind.Emul(batch=True), bsync_emul_bind.Emul(batch=False)
         pos = 0
         while pos < tx.size:
             n = int(rng.choice([1, 7, 37, 510, 1000, 5000, 36000]))
             chunk = tx[pos:pos + n]
             pos += n
-            fo, fe = o.feed(chunk, 1), e.feed(chunk)
+            fo, fe, fe2 = o.feed(chunk, 1), e.feed(chunk), e2.feed(chunk)
             for t in fo[1]:
                 hist[int(t)] = hist.get(int(t), 0) + 1
-            assert len(fo[0]) == len(fe[0]), (seed, pos)
-            assert all(np.array_equal(a, b) for a, b in zip(fo, fe)), (seed, pos)
-            assert o.state == e.state, (seed, pos)
+            assert len(fo[0]) == len(fe[0]) == len(fe2[0]), (seed, pos)
+            assert all(np.array_equal(a, b) for a, b in zip(fo, fe)) and all(np.array_equal(a, b) for a, b in zip(fo, fe2)), (seed, pos)
+            assert o.state == e.state == e2.state, (seed, pos)
     assert min(hist.get(k, 0) for k in (-1, 0, 1, 3)) > 50        # every outcome was exercised
 
 
