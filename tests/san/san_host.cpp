@@ -1,6 +1,6 @@
 // Sanitizer run of the host-side glue (sdrpp-tetra-demodulator_amd/host/: dsp_compat.h's stream / block / Processor and
 // the PI4DQPSK / PI4DQPSKBank classes), built by tests/test_sanitizers.py under -fsanitize=address,undefined.
-//   san_host            no GPU needed: the stream/worker-thread machinery with a pass-through block (start, temp-stop while
+//   san_host            no GPU needed: the DecisionTap alignment scenarios (tests/host/tap_selftest.h), the stream/worker-thread machinery with a pass-through block (start, temp-stop while
 //                       data flows, stop with a blocked writer and a blocked reader), and the GPU classes' error paths
 //                       (un-initialised use, bad parameters)
 //   san_host gpu        additionally streams chunks through a real PI4DQPSK and a PI4DQPSKBank (run by the -m gpu test)
@@ -14,6 +14,7 @@
 #include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
 #include "../../sdrpp-tetra-demodulator_amd/host/dqpsk_sym_extr_gpu.h"
 #include "../../sdrpp-tetra-demodulator_amd/host/bit_unpacker_gpu.h"
+#include "../host/tap_selftest.h"
 
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "san_host: check failed line %d: %s\n", __LINE__, #c); return 1; } } while (0)
 
@@ -264,6 +265,7 @@ int main(int argc, char** argv) {
     if (stream_machinery()) return 1;
     if (error_paths(gpu || tetra_demod_device_count() > 0)) return 2;     // the "set-up fails" checks only where there is no GPU
     if (gpu && gpu_paths()) return 3;
+    if (tap_alignment_selftest()) return 4;      // the self-checking DecisionTap: lost / repeated buffers, stopped consumer, queue overflow
     std::puts("san_host: ok");
     return 0;
 }

@@ -16,7 +16,7 @@ def _build(pkg):
     srcs = [os.path.join(ROOT, "tests", "host", "test_block.cpp")] + [os.path.join(PK, "host", f) for f in
                                                                        ("pi4dqpsk_gpu.cpp", "dqpsk_sym_extr_gpu.cpp", "bit_unpacker_gpu.cpp")]
     deps = srcs + [os.path.join(PK, "host", f) for f in ("pi4dqpsk_gpu.h", "dqpsk_sym_extr_gpu.h", "bit_unpacker_gpu.h", "dsp_compat.h")] + \
-        [os.path.join(ROOT, "include", "tetra_demod.h")]
+        [os.path.join(ROOT, "include", "tetra_demod.h"), os.path.join(ROOT, "tests", "host", "tap_selftest.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         # libamdhip64 only for the test driver's own device buffers ("multibank-device"); the mirror itself needs just the C ABI
         subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + srcs +
