@@ -154,6 +154,36 @@ def one_case(rng, stats):
             else:
                 for o in orcs:
                     o.set_param(B.PARAMS[name], val, quirks=quirks)
+        if k == 3 and rng.integers(0, 3) == 0 and orcs[0].ntaps <= 72 and int(orcs[0].tab.ntaps_be) <= 72:
+            # round 5: caller-designed tables on the live handle (tetra_demod_set_tables): another RRC of another length (regular rows
+            # before and after), scaled band-edge filters of the same length, a perturbed bank -- both sides
+            import ctypes as C
+            nt_old = orcs[0].ntaps
+            nt = int(rng.integers(2, 73))
+            rrc = (rng.standard_normal(nt) / nt).astype(np.float32) if rng.integers(0, 2) else None
+            a, b = orcs[0].bandedge_taps()
+            be = np.stack([a * np.float32(rng.uniform(0.5, 1.5)), b * np.float32(rng.uniform(0.5, 1.5))]).astype(np.float32) if rng.integers(0, 2) else None
+            bank = (orcs[0].interp_bank() * (1 + 0.02 * rng.standard_normal((128, 8)))).astype(np.float32) if rng.integers(0, 2) else None
+            if rrc is not None or be is not None or bank is not None:
+                d.set_tables(rrc_taps=rrc, bandedge_taps=be, interp_bank=bank)
+                for o in orcs:
+                    if rrc is not None:
+                        o.tab.ntaps = nt
+                        o.tab.cfg.rrc_tap_count = nt
+                        o.cfg.rrc_tap_count = nt
+                        for i, v in enumerate(rrc):
+                            o.tab.rrc[i] = float(v)
+                        if quirks and nt > nt_old:
+                            oracle.lib().tetra_oracle_rrc_taps_grown(C.byref(o.st), nt_old)
+                    if be is not None:
+                        for i in range(be.shape[1]):
+                            o.tab.be_a[i] = float(be[0, i])
+                            o.tab.be_b[i] = float(be[1, i])
+                    if bank is not None:
+                        for ph in range(128):
+                            for t in range(8):
+                                o.tab.bank[ph][t] = float(bank[ph, t])
+                stats["set_tables"] = stats.get("set_tables", 0) + 1
         if k == 2:
             c = int(rng.integers(0, Cn))
             d.reset(c)

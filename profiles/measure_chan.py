@@ -19,7 +19,7 @@ g = torch.Generator(device=dev)
 g.manual_seed(3)
 x = torch.view_as_complex(torch.randn((n_in, 2), device=dev, generator=g)).contiguous()
 s = torch.cuda.current_stream(dev)
-chs = {"fft": pkg.Channeliser(M, P, D, max_in=n_in), "mfma": pkg.Channeliser(M, P, D, max_in=n_in, flags=2),
+chs = {"fft": pkg.Channeliser(M, P, D, max_in=n_in), "mfma": pkg.Channeliser(M, P, D, max_in=n_in, flags=pkg.Channeliser.FLAG_MATRIX_DFT),
        "valu": pkg.Channeliser(M, P, D, max_in=n_in, flags=pkg.Channeliser.FLAG_VALU_DFT)}
 outs = {k: torch.zeros((frames, M), dtype=torch.complex64, device=dev) for k in chs}
 for _ in range(20):

@@ -42,7 +42,8 @@ def _lib():
 class Channeliser:
     """M-channel analysis filter bank on one GPU; emits time-major frames [frames][M] complex64."""
 
-    FLAG_VALU_DFT = 1      # TETRA_CHAN_FLAG_VALU_DFT: keep the direct-sum DFT kernel where the matrix-pipe form exists (M = 800)
+    FLAG_VALU_DFT = 1      # TETRA_CHAN_FLAG_VALU_DFT: keep the direct-sum DFT kernel where a faster form exists (M = 800)
+    FLAG_MATRIX_DFT = 2    # TETRA_CHAN_FLAG_MATRIX_DFT: M = 800 at D = M / 2 as 25 x 32 matrix products (round 4's kernel) instead of the mixed-radix FFT
 
     def __init__(self, n_channels=800, taps_per_channel=8, decimation=None, max_in=1 << 20, device=-1, cutoff_rel=1.2,
                  prototype=None, flags=0):

@@ -1,18 +1,17 @@
-// tetra_chan.hip -- polyphase channeliser front-end (see include/tetra_chan.h): HIP kernel + C ABI.
+// tetra_chan.hip -- polyphase channeliser front-end (see include/tetra_chan.h): HIP kernels + C ABI.
 //
-// One workgroup (256 threads) per output frame.  Weighted overlap-add: the L = P*M newest samples are weighted by the
-// prototype and folded onto M bins indexed by ABSOLUTE sample time mod M (so the DFT needs no per-frame phase
-// correction), then an M-point DFT, M = N1*N2, runs in LDS as N2 column DFTs of length N1, a twiddle, and N1 row DFTs of
-// length N2 (direct sums: N1, N2 <= 64; for M = 800 that is 25 + 32 complex MACs per output instead of 800).  Frames go
-// out time-major, out[m][k] -- exactly the TETRA_LAYOUT_TIME_MAJOR input of the demodulator.  Per second of a 20 MHz
-// capture this is ~2.3 G complex MACs and 160 MB in / 320 MB out: a small fraction of the demodulator's time.
-//
-// M = 800 = 25 x 32 (BASELINE config 5) runs the two DFT stages on the MATRIX pipe instead (k_channelise_mfma below): a complex
-// DFT stage is a real matrix product with the 2 x 2 block form of the twiddle matrix, so 104 + 128 chained
-// v_mfma_f32_16x16x4_f32 per frame (exact f32 fma chains, MI355X_MICROARCH.md) replace 800 x 57 complex multiply-adds issued
-// as 8 VALU + 3 integer + 2 LDS instructions each (this file is compiled with -ffp-contract=off: the direct form cannot even
-// contract its products).  The twiddle blocks are CONSTANT operands and stay in registers for the workgroup's whole life; the
-// data operands make one trip through LDS per stage.  TETRA_CHAN_FLAG_VALU_DFT keeps the direct-sum kernel (A/B, other sizes).
+// Every output frame = weighted overlap-add of the L = P*M newest samples onto M bins indexed by ABSOLUTE sample time mod M (so the
+// DFT needs no per-frame phase correction), then an M-point DFT; frames go out time-major, out[m][k] -- exactly the
+// TETRA_LAYOUT_TIME_MAJOR input of the demodulator.  Three kernels, chosen from the geometry (identical results within the float32
+// tolerance the tests hold against the double-precision definition):
+//   k_channelise_fft    M = 800 at D = M / 2 (BASELINE config 5; default there since round 5): the DFT as a 32 x 5 x 5 mixed-radix
+//                       FFT in registers / LDS, 8 frames per workgroup sharing their sample loads -- 39 kflop per frame, bound by the
+//                       kernel's 120 MB of HBM traffic per 12500 frames (36 us = 41 % of the HBM peak); lane code in chan_fft_core.hpp
+//   k_channelise_mfma   M = 800 = 25 x 32, any decimation (round 4; TETRA_CHAN_FLAG_MATRIX_DFT forces it): both DFT stages as real
+//                       matrix products with the 2 x 2 block form of the twiddle matrices, 104 + 128 chained v_mfma_f32_16x16x4_f32
+//                       per frame (exact f32 fma chains; the f32 MFMA runs on the vector pipe on gfx950: 0.11 ms, pipe-bound)
+//   k_channelise        any M = N1 * N2 with N1, N2 <= 64 (TETRA_CHAN_FLAG_VALU_DFT forces it): direct sums, N1 + N2 complex MACs
+//                       per output, one workgroup per frame (0.21 ms for config 5's geometry)
 #include <hip/hip_runtime.h>
 
 #include <cmath>

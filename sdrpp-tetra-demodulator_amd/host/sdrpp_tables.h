@@ -36,8 +36,9 @@ namespace sdrpp_tables {
 
 // pi4dqpsk.cpp:18 (and :38, :50, :63)
 inline std::vector<float> rrc(int rrcTapCount, double rrcBeta, double symbolrate, double samplerate) {
+    // (only members the reference itself touches are relied on: tap<T>::taps, fll.cpp:92; PolyphaseBank<T>::phases, complex_fd.cpp:102)
     dsp::tap<float> t = dsp::taps::rootRaisedCosine<float>(rrcTapCount, rrcBeta, symbolrate, samplerate);
-    std::vector<float> out(t.taps, t.taps + t.size);
+    std::vector<float> out(t.taps, t.taps + rrcTapCount);
     dsp::taps::free(t);
     return out;
 }
@@ -78,9 +79,10 @@ inline std::vector<float> interpBank(int interpPhaseCount = 128, int interpTapCo
     dsp::tap<float> lp = dsp::taps::windowedSinc<float>(interpPhaseCount * interpTapCount, dsp::math::hzToRads(bw, 1.0), dsp::window::nuttall,
                                                         interpPhaseCount);
     dsp::multirate::PolyphaseBank<float> bank = dsp::multirate::buildPolyphaseBank<float>(interpPhaseCount, lp);
-    std::vector<float> out((size_t)bank.phaseCount * (size_t)bank.tapsPerPhase);
-    for (int p = 0; p < bank.phaseCount; p++)
-        for (int k = 0; k < bank.tapsPerPhase; k++) out[(size_t)p * (size_t)bank.tapsPerPhase + (size_t)k] = bank.phases[p][k];
+    // read the way COMPLEX_FD::process does: interpBank.phases[phase] holds _interpTapCount taps (complex_fd.cpp:102)
+    std::vector<float> out((size_t)interpPhaseCount * (size_t)interpTapCount);
+    for (int p = 0; p < interpPhaseCount; p++)
+        for (int k = 0; k < interpTapCount; k++) out[(size_t)p * (size_t)interpTapCount + (size_t)k] = bank.phases[p][k];
     dsp::multirate::freePolyphaseBank(bank);
     dsp::taps::free(lp);
     return out;
