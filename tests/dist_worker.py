@@ -35,9 +35,11 @@ def main():
     rows = torch.from_numpy(np.concatenate([nb[:, None].astype(np.int64),
                                             bits[:, :64].astype(np.int64)], axis=1))
     allrows = shard.gather_channel_rows(dist, rows, C, world)
+    # bench.py's per-rank known-answer counters summed over the ranks: [channels checked, bits compared, bit errors, rank green]
+    sums = shard.sum_over_ranks(dist, [hi - lo, int(nb.sum()), rank, 1])
     if rank == 0:
         json.dump(dict(world=world, ranges=[shard.channel_range(C, world, r) for r in range(world)], tmax=tmax,
-                       my_elapsed=elapsed, rows=allrows.numpy().tolist()), open(out_path, "w"))
+                       my_elapsed=elapsed, rows=allrows.numpy().tolist(), sums=sums), open(out_path, "w"))
     dist.destroy_process_group()
 
 

@@ -44,3 +44,5 @@ def test_two_rank_gloo_shards_and_reassembles(pkg, oracle, synth, tmp_path, C):
     bits, nb, _, _ = oracle.process_batch(iq)
     assert np.array_equal(rows[:, 0], nb)
     assert np.array_equal(rows[:, 1:], bits[:, :64])
+    # SUM over ranks (bench.py's per-rank known-answer counters): channels, bits, 0 + 1, one per rank
+    assert r["sums"] == [C, int(nb.sum()), 1, 2]
