@@ -55,7 +55,9 @@ int tetra_chan_destroy(tetra_chan_t* h);
 /* Frames the next process call with n_in samples will emit (depends on the carried sub-frame phase). */
 int tetra_chan_frames_for(tetra_chan_t* h, int n_in);
 /* x: n_in wideband complex64 samples (device pointer); out: [frames][M] complex64 (device pointer, capacity >=
- * tetra_chan_frames_for(n_in) frames); *n_frames receives the frame count.  Enqueued on hip_stream, no sync.
+ * tetra_chan_frames_for(n_in) frames); *n_frames receives the frame count.  Enqueued on hip_stream, no sync: d_x is read by the
+ * work enqueued here (at M = 800, D = M / 2 the kernel reads it IN PLACE -- no staging copy, every sample crosses HBM once -- and
+ * the last L - 1 samples are copied into the handle's delay line behind it), so it must stay untouched until that work has run.
  * The filter history and the sub-frame phase are carried across calls (results independent of the chunking). */
 int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream);
 /* Host-pointer variant: copies in, runs, copies out, synchronises. */

@@ -168,19 +168,41 @@ template <int P> CHAN_HD void fold_load_coef(const float* ht, int u, FoldCoef<P>
         k.c[1][q] = ht[(2 * u + 1) * P + q];
     }
 }
-// No bounds checks: x0 - u - 800 (P - 1) never lies before the buffer (the block's first frame has its newest sample at or after the
-// first new one and the buffer starts L - 1 samples earlier), and the samples PAST the call's last one that the frames beyond
-// `frames` ask for are read from the kSlack elements every sample buffer carries behind its end -- whatever they hold only reaches
-// results that are never stored (frames are independent).
-constexpr int kSlack = 4 * kM;
-template <int P, int CLS> CHAN_HD void fold_slot(const c32* x0, int u, const FoldCoef<P>& k, c32 out[kBlockFrames]) {
+// ---- one block of kBlockFrames frames on a workgroup of 256 threads: three phases, a barrier after each ------------------
+struct BlockCtx {
+    const c32* x;         // the call's n_in NEW samples, where the caller left them (read in place: no staging copy)
+    const c32* hist;      // the L - 1 samples before them, oldest first (the handle's carried delay line)
+    int n_in;
+    c32* out;             // [frames][800]
+    const float* h;       // prototype, re-ordered for the fold: [800][2][P] (fold_transpose_prototype)
+    const c32* tw;        // [25][32]: W800^(n1 k2)
+    int frames;           // frames of this call
+    int ph0;              // samples already consumed towards the call's first frame
+    long long abs0;       // absolute time of the first new sample
+    int L;                // 800 P
+};
+
+// Sample s of the stream, s counted from the call's first new sample.  Blocks in the middle of a call read only new samples and
+// index the caller's buffer directly (CAREFUL = false).  The first two blocks reach back into the delay line (s < 0), and the last
+// block of a call whose frame count is not a multiple of 8 asks for samples past the call's end for the frames it does not store:
+// those read the last sample instead (any value would do: it only reaches results that are never stored).
+template <bool CAREFUL> CHAN_HD c32 sample_at(const BlockCtx& c, long long s) {
+    if (!CAREFUL) return c.x[s];
+    if (s < 0) return c.hist[(c.L - 1) + s];
+    return c.x[s < c.n_in ? s : c.n_in - 1];
+}
+// does a block with its first frame's newest sample at index newest0 need the careful accessor?  (it reads
+// [newest0 - (L - 1), newest0 + 7 * 400])
+CHAN_HD bool block_is_careful(const BlockCtx& c, long long newest0) {
+    return newest0 < c.L - 1 || newest0 + (kBlockFrames - 1) * (kM / 2) > c.n_in - 1;
+}
+
+template <int P, int CLS, bool CAREFUL> CHAN_HD void fold_slot(const BlockCtx& c, long long s0, const FoldCoef<P>& k, c32 out[kBlockFrames]) {
     CHAN_FP_FAST
     constexpr int kS = P + 3 + CLS;                   // class 0 frames reach sample m = 3, class 1 frames m = 4
-    c32 S[kS];                                        // S[j] = sample m = j - (P - 1)
+    c32 S[kS];                                        // S[j] = sample m = j - (P - 1) = stream sample s0 + 800 m  (s0 = newest0 - u)
 #pragma unroll
-    for (int j = 0; j < kS; j++) {
-        S[j] = x0[-u + kM * (j - (P - 1))];
-    }
+    for (int j = 0; j < kS; j++) S[j] = sample_at<CAREFUL>(c, s0 + kM * (j - (P - 1)));
 #pragma unroll
     for (int t = 0; t < kBlockFrames; t++) {
         const int s = (t + CLS) >> 1;
@@ -196,33 +218,20 @@ template <int P, int CLS> CHAN_HD void fold_slot(const c32* x0, int u, const Fol
     }
 }
 
-// ---- one block of kBlockFrames frames on a workgroup of 256 threads: three phases, a barrier after each ------------------
-struct BlockCtx {
-    const c32* xbuf;      // [L - 1 history | n_in new samples | kSlack readable elements]
-    c32* out;             // [frames][800]
-    const float* h;       // prototype, re-ordered for the fold: [800][2][P] (fold_transpose_prototype)
-    const c32* tw;        // [25][32]: W800^(n1 k2)
-    int frames;           // frames of this call
-    int ph0;              // samples already consumed towards the call's first frame
-    long long abs0;       // absolute time of the first new sample
-    int L;                // 800 P
-};
-
 // phase 1 (threads < kFoldThreads): fold the block's 8 frames, v_t[r] -> lds[t][r].  Slot after slot: a slot's 2 P coefficients and
 // P + 4 samples live only while its 8 frames are summed.
-template <int P> CHAN_HD void phase_fold(const BlockCtx& c, int blk, int tid, c32* lds) {
+template <int P, bool CAREFUL> CHAN_HD void phase_fold_t(const BlockCtx& c, int blk, int tid, c32* lds) {
     if (tid >= kFoldThreads) return;
     const long long newest0 = (long long)(kBlockFrames * blk + 1) * (kM / 2) - 1 - c.ph0;     // index of the block's first frame's newest sample among the new samples
     const int a = (int)((c.abs0 + newest0) % kM);
-    const c32* x0 = c.xbuf + (c.L - 1) + newest0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int u = kFoldThreads * i + tid;
         FoldCoef<P> k;
         fold_load_coef<P>(c.h, u, k);
         c32 v[kBlockFrames];
-        if (i < 2) fold_slot<P, 0>(x0, u, k, v);
-        else fold_slot<P, 1>(x0, u, k, v);
+        if (i < 2) fold_slot<P, 0, CAREFUL>(c, newest0 - u, k, v);
+        else fold_slot<P, 1, CAREFUL>(c, newest0 - u, k, v);
         int r = a - u;
         r += r < 0 ? kM : 0;
 #pragma unroll
@@ -233,6 +242,11 @@ template <int P> CHAN_HD void phase_fold(const BlockCtx& c, int blk, int tid, c3
         if (i == 1) asm volatile("" ::: "memory");
 #endif
     }
+}
+template <int P> CHAN_HD void phase_fold(const BlockCtx& c, int blk, int tid, c32* lds) {
+    const long long newest0 = (long long)(kBlockFrames * blk + 1) * (kM / 2) - 1 - c.ph0;
+    if (block_is_careful(c, newest0)) phase_fold_t<P, true>(c, blk, tid, lds);      // (uniform over the workgroup)
+    else phase_fold_t<P, false>(c, blk, tid, lds);
 }
 
 // phase 2 (lanes n1 < 25 of each half-wave; wave w, half f -> frame 2 w + f): 32-point FFT over n2, result transposed IN PLACE:

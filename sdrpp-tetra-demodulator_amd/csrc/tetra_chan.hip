@@ -259,7 +259,8 @@ template <int P> __global__ __launch_bounds__(kThreads, 3) void k_channelise_mfm
 // The lane-level code is chan_fft_core.hpp (also compiled for the host: tests/emul/chan_emul.cpp).
 // ---------------------------------------------------------------------------------------------------------------------
 struct ChanFftParams {
-    const float2* xbuf;
+    const float2* x;       // the call's new samples (the caller's buffer)
+    const float2* hist;    // the L - 1 samples before them
     float2* out;
     const float* h;        // the prototype re-ordered for the fold [800][2][P]
     const float2* tw;      // [25][32] exp(-j 2 pi n1 k2 / 800)
@@ -275,7 +276,9 @@ template <int P, int EXP = 0> __global__ __launch_bounds__(kThreads, 2) void k_c
     __shared__ c32 lds[kBlockFrames * kFrameLds];          // 52.8 KB: three workgroups per CU
     const int tid = threadIdx.x;
     BlockCtx c;
-    c.xbuf = reinterpret_cast<const c32*>(p.xbuf);
+    c.x = reinterpret_cast<const c32*>(p.x);
+    c.hist = reinterpret_cast<const c32*>(p.hist);
+    c.n_in = p.n_in;
     c.L = kM * P;
     c.out = reinterpret_cast<c32*>(p.out);
     c.h = p.h;
@@ -486,9 +489,10 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
     else design_prototype(h->M, h->P, cfg->cutoff_rel, h->proto);
     Guard g(dev);
     if (!g.ok) { delete h; return TETRA_ERR_NO_DEVICE; }
-    // (+ kSlack: the FFT kernel's last block may read past the call's last sample, chan_fft_core.hpp)
-    bool ok = hipMalloc((void**)&h->xbuf, sizeof(float2) * ((size_t)h->L - 1 + h->max_in + chanfft::kSlack)) == hipSuccess &&
-              hipMalloc((void**)&h->xalt, sizeof(float2) * ((size_t)h->L - 1 + h->max_in + chanfft::kSlack)) == hipSuccess &&
+    // (the FFT kernel reads the caller's samples in place: its handles keep only the L - 1 samples of delay line, twice)
+    const size_t xelems = (size_t)h->L - 1 + (h->fft ? 0 : (size_t)h->max_in);
+    bool ok = hipMalloc((void**)&h->xbuf, sizeof(float2) * xelems) == hipSuccess &&
+              hipMalloc((void**)&h->xalt, sizeof(float2) * xelems) == hipSuccess &&
               hipMalloc((void**)&h->d_h, sizeof(float) * h->L) == hipSuccess &&
               hipMalloc((void**)&h->d_w1, sizeof(float2) * h->N1) == hipSuccess &&
               hipMalloc((void**)&h->d_w2, sizeof(float2) * h->N2) == hipSuccess &&
@@ -529,11 +533,13 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     const int frames = (h->phase + n_in) / h->D;
     *n_frames = frames;
     const size_t hist = (size_t)h->L - 1;
-    if (n_in > 0) CH_TRY(h, hipMemcpyAsync(h->xbuf + hist, d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
+    // The FFT kernel reads the new samples where the caller left them (and the L - 1 before them from the handle's delay line): no
+    // staging copy -- every sample crosses HBM once.  The other two kernels index one contiguous [history | new] buffer.
+    if (n_in > 0 && !h->fft) CH_TRY(h, hipMemcpyAsync(h->xbuf + hist, d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
     CH_TRY(h, hipEventRecord(h->ev[0], s));
     if (frames > 0 && h->fft) {
         ChanFftParams p;
-        p.xbuf = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_ht; p.tw = h->d_tw;
+        p.x = reinterpret_cast<const float2*>(d_x); p.hist = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_ht; p.tw = h->d_tw;
         p.frames = frames; p.blocks = (frames + chanfft::kBlockFrames - 1) / chanfft::kBlockFrames; p.n_in = n_in;
         p.ph0 = h->phase; p.abs0 = h->consumed;
         // one block of 8 frames per workgroup: the hardware hands the next block to whichever CU is through first
@@ -572,7 +578,14 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     // carry: the last L-1 samples of [history | new] become the next call's history -- ONE copy into the other buffer
     // (whatever n_in is; an in-place move would overlap for n_in < L-1), then the buffers swap roles.  Stream order keeps the
     // kernel above ahead of the copy and the copy ahead of the next call's writes.
-    if (n_in > 0) {
+    if (n_in > 0 && h->fft) {
+        // the same from the two places the samples live in: what is left of the old delay line, then the tail of the caller's buffer
+        const size_t from_x = (size_t)n_in < hist ? (size_t)n_in : hist, keep = hist - from_x;
+        if (keep) CH_TRY(h, hipMemcpyAsync(h->xalt, h->xbuf + n_in, sizeof(float2) * keep, hipMemcpyDeviceToDevice, s));
+        CH_TRY(h, hipMemcpyAsync(h->xalt + keep, reinterpret_cast<const float2*>(d_x) + ((size_t)n_in - from_x), sizeof(float2) * from_x,
+                                 hipMemcpyDeviceToDevice, s));
+        float2* t = h->xbuf; h->xbuf = h->xalt; h->xalt = t;
+    } else if (n_in > 0) {
         CH_TRY(h, hipMemcpyAsync(h->xalt, h->xbuf + n_in, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
         float2* t = h->xbuf; h->xbuf = h->xalt; h->xalt = t;
     }

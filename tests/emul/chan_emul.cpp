@@ -12,8 +12,8 @@ using namespace chanfft;
 
 extern "C" {
 
-// xbuf: [L - 1 history | n_in new | chanfft::kSlack readable elements] complex (interleaved floats); out: [frames][800] complex.  P in {4, 6, 8}.  Returns frames.
-int chan_fft_emul(const float* xbuf, int n_in, int P, int ph0, long long abs0, const float* h, float* out) {
+// hist: the L - 1 samples before the call (oldest first); x: the call's n_in new samples -- two separate buffers, like the kernel sees them; out: [frames][800] complex.  P in {4, 6, 8}.  Returns frames.
+int chan_fft_emul(const float* hist, const float* x, int n_in, int P, int ph0, long long abs0, const float* h, float* out) {
     const int L = kM * P, D = kM / 2;
     const int frames = (ph0 + n_in) / D;
     std::vector<c32> tw((size_t)kN1 * kN2);
@@ -24,7 +24,9 @@ int chan_fft_emul(const float* xbuf, int n_in, int P, int ph0, long long abs0, c
             tw[(size_t)n1 * kN2 + k2] = mk((float)std::cos(a), (float)std::sin(a));
         }
     BlockCtx c;
-    c.xbuf = reinterpret_cast<const c32*>(xbuf);
+    c.x = reinterpret_cast<const c32*>(x);
+    c.hist = reinterpret_cast<const c32*>(hist);
+    c.n_in = n_in;
     c.out = reinterpret_cast<c32*>(out);
     c.h = h; c.tw = tw.data(); c.frames = frames; c.ph0 = ph0; c.abs0 = abs0; c.L = L;
     std::vector<c32> lds((size_t)kBlockFrames * kFrameLds);

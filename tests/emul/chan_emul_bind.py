@@ -22,7 +22,7 @@ def lib():
     global _lib
     if _lib is None:
         L = C.CDLL(build())
-        L.chan_fft_emul.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.chan_fft_emul.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
         L.chan_fft_emul.restype = C.c_int
         L.chan_fft32.argtypes = [C.c_void_p, C.c_void_p]
         L.chan_dft25.argtypes = [C.c_void_p, C.c_void_p]
@@ -41,12 +41,14 @@ class ChanFftEmul:
 
     def process(self, x):
         x = np.ascontiguousarray(x, np.complex64)
-        buf = np.concatenate([self.hist, x, np.full(3200, np.nan + 0j, np.complex64)])      # the slack past the end is never used by a stored frame
         frames = (self.phase + len(x)) // 400
         out = np.zeros((max(frames, 1), 800), np.complex64)
-        got = lib().chan_fft_emul(buf.ctypes.data, len(x), self.P, self.phase, self.consumed, self.h.ctypes.data, out.ctypes.data)
+        # exact-size buffers in their own allocations (no slack behind the new samples: the kernel must not read past them)
+        xs = x.copy() if len(x) else np.zeros(1, np.complex64)
+        got = lib().chan_fft_emul(self.hist.ctypes.data, xs.ctypes.data, len(x), self.P, self.phase, self.consumed, self.h.ctypes.data,
+                                  out.ctypes.data)
         assert got == frames
-        self.hist = buf[len(buf) - 3200 - (self.L - 1):len(buf) - 3200].copy()
+        self.hist = np.concatenate([self.hist, x])[len(x):].copy()
         self.phase = (self.phase + len(x)) % 400
         self.consumed += len(x)
         return out[:frames]
