@@ -3,11 +3,15 @@
 The kernels reproduce the oracle's CONTRACT float recipe bit for bit; the reference's compiled objects reproduce its
 REFERENCE_FLOATS recipe bit for bit (tests/test_reference_shim.py).  The two recipes are the same algorithm with another
 rounding sequence.  tests/recipe_disagreement.py runs both on the plugin's parameters (src/main.cpp:35-44,78-84) over Es/N0; the
-full sweep (128 channels x 2 s per point) is committed as profiles/r05/recipe_disagreement.{json,md}.  Asserted here, on a smaller
-fresh sweep and on the committed one:
-  * at and above the reference's stated operating point ("~20 dB", /root/reference README.md:51) no bit differs after lock;
+full sweeps are committed as profiles/r05/recipe_disagreement.{json,md} (128 channels x 2 s per point, 30 ... 8 dB) and
+profiles/r05/recipe_disagreement_onset.{json,md} (1024 channels x 2 s at 22 / 20 / 18 / 16 dB).  Asserted here, on a smaller fresh
+sweep and on the committed ones:
+  * above the reference's stated operating point ("~20 dB", /root/reference README.md:51) no bit differs after lock (22 dB and up:
+    0 bits in 1024 channel-seconds); AT 20 dB and below, post-lock differences appear at the rate of true bit errors and never
+    exceed them (a decision only flips between the recipes where noise has put a symbol on a decision boundary);
   * wherever bits differ, the two recipes make equally many TRUE bit errors: |BER_contract - BER_ref_float| stays inside the
-    binomial error of the comparison (3 sigma of the independent-errors bound; measured <= 0.4) -- different bits, same BER;
+    error of the comparison (4 sigma of the independent-errors bound -- errors come in small bursts, so the bound is tight-ish;
+    measured <= 2.5) -- different bits, same BER;
   * differences before lock exist at every Es/N0 (a boundary decision during acquisition) and are bounded.
 """
 import json
@@ -21,18 +25,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _check(res):
     for e, r in res.items():
         e = float(e)
-        if e >= 20.0:
-            assert r["bits_differing_after_lock"] == 0 and r["channels_with_other_symbol_count"] == 0, (e, r)
-        assert rd.ber_gap_in_sigmas(r) < 3.0, (e, r)
-        assert r["bits_differing_before_lock"] <= 40 * r["channels"], (e, r)      # (measured worst: 14 per channel at 8 dB)
-        if e >= 12.0:
-            assert r["bits_differing_after_lock"] <= 2 * r["channels"], (e, r)
+        true_errors = r["locked_true_errors_contract"] + r["locked_true_errors_ref_float"]
+        if e >= 22.0:
+            assert r["locked_bits_differing_after_lock"] == 0, (e, r)
+        assert r["locked_bits_differing_after_lock"] <= true_errors + 2, (e, r)          # never more than the true bit errors
+        assert rd.ber_gap_in_sigmas(r) < 4.0, (e, r)
+        assert r["bits_differing_before_lock"] <= 40 * r["channels"], (e, r)            # (measured worst: 14 per channel at 8 dB)
+        assert r["channels_locked"] >= 0.99 * r["channels"], (e, r)                     # (measured: 1 of 1024 not yet locked at 20 dB)
 
 
 def test_contract_vs_reference_float_recipe_fresh_sweep():
     res = rd.sweep(esn0_list=(25.0, 20.0, 15.0, 10.0), channels=24, base_seed=91000)
     _check(res)
-    assert res[10.0]["true_errors_contract"] > 1000          # the low end really is in the error-making regime
+    assert res[10.0]["locked_true_errors_contract"] > 1000          # the low end really is in the error-making regime
     print("\n" + rd.markdown(res))
 
 
@@ -41,3 +46,10 @@ def test_committed_sweep_supports_the_documented_claim():
         res = json.load(f)
     assert sorted(float(k) for k in res) == sorted(rd.ESN0_DB) and all(r["channels"] >= 64 and r["seconds"] >= 2.0 for r in res.values())
     _check(res)
+    for e in ("30.0", "25.0", "20.0"):
+        assert res[e]["locked_bits_differing_after_lock"] == 0          # 128 channel-seconds each
+    with open(os.path.join(ROOT, "profiles", "r05", "recipe_disagreement_onset.json")) as f:
+        onset = json.load(f)
+    assert all(r["channels"] >= 1024 for r in onset.values())
+    _check(onset)
+    assert onset["22.0"]["locked_bits_differing_after_lock"] == 0 and onset["20.0"]["locked_bits_differing_after_lock"] <= 4
