@@ -71,6 +71,19 @@ void ref_reset(void* h) { ((Chain*)h)->demod.reset(); }
 
 int ref_sync(void* h) { return ((Chain*)h)->extractor.sync ? 1 : 0; }
 
+// The tables the reference's objects designed FOR THEMSELVES with the core headers they were compiled against (read-out; the members
+// are protected): rrc[count], lower band-edge filter re / im [be_count], interpolator bank [128][8].  Returns the RRC tap count;
+// *be_count receives the band-edge filters' length (the FLL keeps its construction-time filters across PI4DQPSK's setters).
+int ref_get_tables(void* h, float* rrc, float* be_re, float* be_im, float* bank, int* be_count) {
+    Chain* c = (Chain*)h;
+    const int n = c->demod._rrcTapCount, nb = c->demod.fll._filt_size;
+    for (int i = 0; i < n; i++) { rrc[i] = c->demod.rrcTaps.taps[i]; }
+    for (int i = 0; i < nb; i++) { be_re[i] = c->demod.fll.lbandedgerrcTaps.taps[i].re; be_im[i] = c->demod.fll.lbandedgerrcTaps.taps[i].im; }
+    for (int p = 0; p < 128; p++) { for (int k = 0; k < 8; k++) { bank[p * 8 + k] = c->demod.recov.interpBank.phases[p][k]; } }
+    *be_count = nb;
+    return n;
+}
+
 // The loop state of the reference's objects, for the bit-exact comparison with the oracle's reference-float mode.  The members
 // are protected / private in the reference's headers; this file (and only this file) is compiled with g++ -fno-access-control
 // so that they can be READ without touching or wrapping the reference's sources.

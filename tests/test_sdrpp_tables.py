@@ -122,6 +122,77 @@ def test_float_pi_variant_changes_most_taps_and_no_bit_after_lock(pkg, oracle, s
           "channels settle on another one); %d bits differ before lock" % (n_rrc, n_bank, worst_rms, worst_max, other_quadrant, differing_before_lock))
 
 
+REF = os.environ.get("TETRA_REFERENCE_DIR", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "src", "dsp", "pi4dqpsk.cpp")), reason="reference sources not present (container-only)")
+@pytest.mark.parametrize("float_pi", [False, True])
+def test_sdrpp_route_hands_over_what_the_reference_objects_design_for_themselves(pkg, tmp_path, float_pi):
+    """The closure itself (container only): the REFERENCE's own objects, compiled where they lie against a header variant, design
+    their tables inside PI4DQPSK::init / FLL::init / COMPLEX_FD::init and the setters; host/sdrpp_tables.h, compiled against the SAME
+    headers, must produce those very tables -- RRC, both band-edge halves (the one piece of the reference's own arithmetic restated on
+    the route, fll.cpp:61-95), interpolator bank -- bit for bit: after init for several parameter sets, and after setSymbolrate /
+    setSamplerate / setRRCParams / setRRCTapCount / setRRCBeta(int).  Together with test_handle_runs_the_included_headers_tables
+    (GPU: handle tables == sdrpp_tables output) this says: in an SDR++ build the kernels run the tables the reference would."""
+    import ctypes as C
+    out_dir = os.path.join(SHIM, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libref_shim_fpi.so" if float_pi else "libref_shim_tables.so")
+    srcs = [os.path.join(SHIM, "ref_driver.cpp")] + [os.path.join(REF, "src", "dsp", f) for f in
+                                                     ("pi4dqpsk.cpp", "fll.cpp", "complex_fd.cpp", "pi4dqpsk_costas.cpp", "dqpsk_sym_extr.cpp", "bit_unpacker.cpp")]
+    deps = srcs + [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(SHIM, "dsp")) for f in fs]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-access-control", "-fPIC", "-shared", "-w", "-I", SHIM, "-I",
+                        os.path.join(REF, "src")] + (["-DREFSHIM_FLOAT_PI"] if float_pi else []) + ["-o", so] + srcs, check=True)
+    L = C.CDLL(so)
+    L.ref_create.restype = C.c_void_p
+    L.ref_create.argtypes = [C.c_double, C.c_double, C.c_int] + [C.c_double] * 7
+    L.ref_destroy.argtypes = [C.c_void_p]
+    L.ref_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.ref_set_rrc_params.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.ref_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.POINTER(C.c_int)]
+    L.ref_get_tables.restype = C.c_int
+    exe = _build(pkg, float_pi)
+
+    def ref_tables(h):
+        rrc, re, im, bank = (np.zeros(n, np.float32) for n in (129, 129, 129, 1024))
+        nb = C.c_int(0)
+        n = L.ref_get_tables(h, *(a.ctypes.data_as(C.c_void_p) for a in (rrc, re, im, bank)), C.byref(nb))
+        return dict(rrc=rrc[:n], be_re=re[:nb.value], be_im=im[:nb.value], bank=bank.reshape(128, 8))
+
+    def same(a, b):
+        return a.shape == b.shape and np.array_equal(_u32(a), _u32(b))
+
+    omega_gain, mu_gain = 1.5636e-4, 0.017603
+    for i, (count, beta, sr, fs) in enumerate([(65, 0.35, 18000, 36000), (49, 0.5, 17000, 34000), (71, 1.0, 18000, 36000), (33, 0.2, 18000, 50000)]):
+        h = L.ref_create(sr, fs, count, beta, 0.02, 0.01, 0.006, omega_gain, mu_gain, 0.02)
+        want = ref_tables(h)
+        got = _tables(exe, tmp_path, count, beta, sr, fs, tag="i%d" % i)
+        assert all(same(want[k], got[k]) for k in ("rrc", "be_re", "be_im", "bank")), (count, beta, sr, fs)
+        L.ref_destroy(h)
+    # the setters: what the reference's objects hold afterwards == the route's re-design with the mirror's bookkeeping
+    h = L.ref_create(18000.0, 36000.0, 65, 0.35, 0.02, 0.01, 0.006, omega_gain, mu_gain, 0.02)
+    be0 = ref_tables(h)
+    count, beta, sr, fs = 65, 0.35, 18000.0, 36000.0
+    for step, (what, arg) in enumerate([("sr", 17000.0), ("fs", 34000.0), ("rrc", (49, 0.5)), ("count", 71), ("beta_int", 1), ("rrc", (65, 0.35))]):
+        if what == "sr":
+            L.ref_set_param(h, 0, arg); sr = arg
+        elif what == "fs":
+            L.ref_set_param(h, 1, arg); fs = arg
+        elif what == "rrc":
+            L.ref_set_rrc_params(h, arg[0], arg[1]); count, beta = arg
+        elif what == "count":
+            L.ref_set_param(h, 2, float(arg)); count = arg
+        else:
+            L.ref_set_param(h, 3, float(arg)); beta = float(int(arg))
+        want = ref_tables(h)
+        got = _tables(exe, tmp_path, count, beta, sr, fs, tag="s%d" % step)
+        assert same(want["rrc"], got["rrc"]), (step, what)
+        # ... and the FLL's filters and the bank are still the construction-time ones (no PI4DQPSK setter re-designs them)
+        assert same(want["be_re"], be0["be_re"]) and same(want["be_im"], be0["be_im"]) and same(want["bank"], be0["bank"]), (step, what)
+    L.ref_destroy(h)
+
+
 STEPS = [  # (what the driver's step does to the oracle, (count, quirks-mode tap-count setter needed))
     lambda o: None,
     lambda o: o.set_param(0, 17000, quirks=True),
