@@ -289,6 +289,52 @@ def test_exact_probe_and_baseline_channels(ref, oracle, synth):
         r.close()
 
 
+def test_exact_with_the_float_pi_header_variant(oracle, synth):
+    """The same exactness when the reference is compiled against the header variant that spells pi as the float macro FL_M_PI
+    (-DREFSHIM_FLOAT_PI; tests/refshim/dsp/processor.h): its objects then design OTHER tables (58 of 65 RRC taps, 849 of 1024
+    interpolator taps differ), and the oracle's reference-float mode handed those tables -- read out of the reference's objects --
+    reproduces every symbol float, bit and the loop state bit for bit: the per-sample transcription does not lean on the tables,
+    and the tables are data."""
+    out_dir = os.path.join(SHIM, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libref_shim_fpi.so")
+    srcs = [os.path.join(SHIM, "ref_driver.cpp")] + [os.path.join(REF_DSP, s) for s in SOURCES]
+    deps = srcs + [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(SHIM, "dsp")) for f in fs]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-access-control", "-fPIC", "-shared", "-w", "-DREFSHIM_FLOAT_PI",
+                        "-I", SHIM, "-I", os.path.join(REF, "src"), "-o", so] + srcs, check=True)
+    L = C.CDLL(so)
+    L.ref_create.restype = C.c_void_p
+    L.ref_create.argtypes = [C.c_double, C.c_double, C.c_int] + [C.c_double] * 7
+    L.ref_destroy.argtypes = [C.c_void_p]
+    L.ref_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_process.restype = C.c_int
+    L.ref_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_get_state.restype = None
+    L.ref_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.POINTER(C.c_int)]
+    L.ref_get_tables.restype = C.c_int
+    changed = 0
+    for seed in (1234, 1240, 77):
+        iq, _, _ = synth.gen_channel(24000, seed)
+        r = RefChain(L, oracle.default_cfg())
+        rrc, re, im, bank = (np.zeros(n, np.float32) for n in (129, 129, 129, 1024))
+        nb = C.c_int(0)
+        n = L.ref_get_tables(r.h, *(a.ctypes.data_as(C.c_void_p) for a in (rrc, re, im, bank)), C.byref(nb))
+        o = oracle.Oracle(reference_floats=True)
+        assert n == o.ntaps == 65 and nb.value == 65
+        changed = int((rrc[:65].view(np.uint32) != o.rrc_taps().view(np.uint32)).sum())
+        for i in range(65):
+            o.tab.rrc[i], o.tab.be_a[i], o.tab.be_b[i] = float(rrc[i]), float(re[i]), float(im[i])
+        for p in range(128):
+            for k in range(8):
+                o.tab.bank[p][k] = float(bank[8 * p + k])
+        for a, b in ((0, 9001), (9001, 9008), (9008, 24000)):
+            sym, bits = r.process(iq[a:b])
+            _exact(r, o, sym, bits, o.process(iq[a:b]), "seed %d [%d, %d)" % (seed, a, b))
+        r.close()
+    assert changed >= 50          # (58: really other tables than the double-pi design)
+
+
 def test_exact_chunked_streaming(ref, oracle, synth):
     """Carried state call after call (7 / 180 / 4001 samples): exact after EVERY call, not only at the end."""
     iq, _, _ = synth.gen_channel(12000, 42, cfo=-0.02, tau=1.3, amp=0.5)
