@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TETRA_DEMOD_ABI_VERSION 5
+#define TETRA_DEMOD_ABI_VERSION 6
 #define TETRA_DEMOD_MAX_TAPS 129 /* longest filter of this ABI and capacity every tap table handed across it is sized for */
 
 enum {
@@ -61,6 +61,7 @@ enum {
                                     1.3x the 4096-channel time instead of 2x.  Results are identical bit for
                                     bit.  Band-edge filters of more than 68 taps (rrc_tap_count 69..72) never run in 32-channel
                                     workgroups. */
+    TETRA_FLAG_CONSTELLATION = 256,    /* also keep the constellation diagram's 1024-symbol blocks per channel (tetra_demod_get_constellation) */
     TETRA_FLAG_GENERIC_KERNEL = 128,   /* filters of 73 .. 129 taps and timing loops below 0.27 samples per symbol in the one-lane-per-channel
                                         * kernel instead of the fused kernel's long rows / deepest symbol ring (same results; tests and A/B
                                         * measurements) */
@@ -307,6 +308,25 @@ int tetra_demod_bandedge_tap_count(tetra_demod_t* h);
  * n_channels x max_samples/2 complex64 when the caller does not ask for them); costs ~2.5 % of a call's time when
  * enabled (profiles/r02/r02_p_quality_statistic.md). */
 int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync);
+
+/* The plugin's constellation tap for every channel (ABI 6).  The reference splits PI4DQPSK's symbol stream into a second branch,
+ * regroups it with dsp::buffer::Reshaper<complex_t>(.., keep 1024, skip 0) and copies every 1024-symbol block it delivers into the
+ * GUI's diagram buffer (src/main.cpp:85-89 wiring, :376-383 _constDiagSinkHandler; drawn at :337): what is on screen is the LAST
+ * COMPLETE block of 1024 consecutive symbols, blocks counted from the start of the stream.  With thousands of channels on the
+ * device, streaming every symbol to the host for that costs 4 B per input sample; this keeps the regrouping on the device -- a
+ * small kernel after the chain's launch carries each channel's partial block across calls -- and the host fetches 8 KB per channel
+ * when it wants to draw one.
+ *   symbols   [count][TETRA_CONSTELLATION_SYMBOLS][2] float (re, im), host: the last complete block of channels first ..
+ *             first + count - 1 (all zero before a channel's first block completes); may be NULL
+ *   n_blocks  [count] int32, host: blocks completed so far (a caller redraws when it changed); may be NULL
+ * Symbols are exactly the ones the optional `sym` output of the process calls carries (bit patterns).  The block phase follows
+ * the symbol count since create; tetra_demod_reset leaves the tap alone under TETRA_FLAG_REFERENCE_QUIRKS (the Reshaper is another
+ * block, untouched by PI4DQPSK::reset, pi4dqpsk.cpp:119-130) and restarts it otherwise.  SDR++'s Reshaper is core code outside the
+ * reference repository; keep 1024 / skip 0 regrouping is restated from its call site.  Needs
+ * TETRA_FLAG_CONSTELLATION (TETRA_ERR_UNSUPPORTED otherwise); first / count outside the handle's channels: TETRA_ERR_ARG.
+ * Synchronises the device. */
+#define TETRA_CONSTELLATION_SYMBOLS 1024
+int tetra_demod_get_constellation(tetra_demod_t* h, int first, int count, float* symbols, int32_t* n_blocks);
 
 /* Debug/verification tap: RRC output (timing-recovery input) of the last process call,
  * y[n_channels][n_samples] complex64 channel-major, copied to host memory.  Needs

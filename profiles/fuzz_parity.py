@@ -89,6 +89,7 @@ def one_case(rng, stats):
     shape = int(rng.choice([0, B.FLAG_WIDE_WORKGROUPS, B.FLAG_NARROW_WORKGROUPS, B.FLAG_SMALL_WORKGROUPS]))
     quality = bool(rng.integers(0, 3) == 0)
     quirks = bool(rng.integers(0, 3) == 0)
+    constel = bool(rng.integers(0, 3) == 0)       # the plugin's constellation tap riding along (tetra_demod_get_constellation)
     chunks = [int(rng.choice([0, 1, 5, 31, 32, 33, 63, 64, 65, 180, 255, 700, 1500, 3000])) for _ in range(5)]
     N = max(sum(chunks), 1)
     seed = int(rng.integers(0, 1 << 30))
@@ -96,7 +97,7 @@ def one_case(rng, stats):
     for c in range(Cn):
         if rng.integers(0, 8) == 0:
             iq[c] = special_channel(rng, int(rng.integers(0, 4)), N)
-    desc = dict(params=p, C=Cn, time_major=tm, shape=shape | generic, quality=quality, quirks=quirks, chunks=chunks, seed=seed)
+    desc = dict(params=p, C=Cn, time_major=tm, shape=shape | generic, quality=quality, quirks=quirks, constellation=constel, chunks=chunks, seed=seed)
     try:
         orcs = [oracle.Oracle(oracle_cfg(p)) for _ in range(Cn)]
     except ValueError:
@@ -114,7 +115,8 @@ def one_case(rng, stats):
         return None
     try:
         d = pkg.Demodulator(Cn, 3000, layout=B.LAYOUT_TIME_MAJOR if tm else B.LAYOUT_CHANNEL_MAJOR,
-                            flags=shape | generic | (B.FLAG_QUALITY if quality else 0) | (B.FLAG_REFERENCE_QUIRKS if quirks else 0), **p)
+                            flags=shape | generic | (B.FLAG_QUALITY if quality else 0) | (B.FLAG_REFERENCE_QUIRKS if quirks else 0) |
+                            (B.FLAG_CONSTELLATION if constel else 0), **p)
     except B.TetraDemodError as e:
         stats["refused"] += 1
         # what the library refuses, the oracle's design must not be asked to run either: only the documented limits
@@ -123,6 +125,7 @@ def one_case(rng, stats):
     if orcs is None:
         return dict(desc, what="the library accepted parameters the oracle refuses")
     pos = 0
+    cd_streams = [np.zeros(0, np.complex64) for _ in range(Cn)]
     for k, n in enumerate(chunks):
         blk = iq[:, pos:pos + n]
         want_sym = bool(rng.integers(0, 2))
@@ -137,6 +140,16 @@ def one_case(rng, stats):
                 return dict(desc, call=k, ch=c, what="bits", first=int(np.flatnonzero(bits[c][:nb[c]] != r["bits"])[0]))
             if want_sym and not np.array_equal(_u32(sym[c][:nb[c] // 2]), _u32(r["sym"])):
                 return dict(desc, call=k, ch=c, what="sym")
+            if constel:
+                cd_streams[c] = np.concatenate([cd_streams[c], r["sym"]])
+        if constel:
+            cblk, cnb = d.constellation()
+            stats["constellation_checks"] = stats.get("constellation_checks", 0) + Cn
+            for c in range(Cn):
+                done = cd_streams[c].size // 1024
+                want = cd_streams[c][(done - 1) * 1024:done * 1024] if done else np.zeros(1024, np.complex64)
+                if cnb[c] != done or not np.array_equal(_u32(cblk[c]), _u32(want)):
+                    return dict(desc, call=k, ch=c, what="constellation", gpu_blocks=int(cnb[c]), ref_blocks=int(done))
         if quality:
             err, _ = d.quality()
             for c in range(Cn):
@@ -191,6 +204,7 @@ def one_case(rng, stats):
                 orcs[c].reset_reference()
             else:
                 orcs[c].reset()
+                cd_streams[c] = np.zeros(0, np.complex64)      # without the quirks flag a reset restarts the channel's tap too
         pos += n
     for c in range(0, Cn, max(1, Cn // 6)):
         st, o = d.get_state(c), orcs[c].st

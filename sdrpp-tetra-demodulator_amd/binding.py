@@ -20,6 +20,8 @@ FLAG_RETIRED_TWO_KERNEL = 1      # refused by tetra_demod_create since ABI 2
 FLAG_KEEP_RRC_OUT = 2
 FLAG_QUALITY = 4
 FLAG_REFERENCE_QUIRKS = 8
+FLAG_CONSTELLATION = 256         # keep the constellation diagram's 1024-symbol blocks per channel (Demod.constellation)
+CONSTELLATION_SYMBOLS = 1024
 FLAG_GENERIC_KERNEL = 128        # filters of 73 .. 129 taps / loops below 0.27 samples per symbol in the one-lane-per-channel kernel
 
 PARAMS = dict(symbolrate=0, samplerate=1, rrc_tap_count=2, rrc_beta=3, agc_rate=4, costas_bandwidth=5,
@@ -34,7 +36,7 @@ EXPORTS = [
     "tetra_demod_bandedge_tap_count", "tetra_demod_process_async", "tetra_demod_wait", "tetra_demod_host_alloc",
     "tetra_demod_host_free", "tetra_demod_device_info", "tetra_demod_bits_stride_for", "tetra_demod_get_overruns",
     "tetra_demod_set_rrc_params", "tetra_demod_process_resident", "tetra_demod_debug_mfma_selftest", "tetra_demod_build_id",
-    "tetra_demod_set_tables",
+    "tetra_demod_set_tables", "tetra_demod_get_constellation",
 ]
 ERR_OVERRUN = -8
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
@@ -127,6 +129,7 @@ def load_library(rebuild_if_stale=True):
     L.tetra_demod_debug_selftest.argtypes = [vp, vp, vp]
     L.tetra_demod_kernel_ms_history.argtypes = [vp, i32, vp]
     L.tetra_demod_get_quality.argtypes = [vp, vp, vp]
+    L.tetra_demod_get_constellation.argtypes = [vp, i32, i32, vp, vp]
     L.tetra_demod_process_async.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     L.tetra_demod_wait.argtypes = [vp]
     L.tetra_demod_device_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
@@ -362,6 +365,16 @@ class Demodulator:
         sync = np.zeros(self.n_channels, np.uint8)
         self._check(self._lib.tetra_demod_get_quality(self._h, _np_ptr(err), _np_ptr(sync)), "tetra_demod_get_quality")
         return err, sync.astype(bool)
+
+    def constellation(self, first=0, count=None):
+        """(blocks complex64[count][1024], n_blocks int32[count]) -- the last complete 1024-symbol block of the plugin's constellation
+        tap per channel (src/main.cpp:85-89, :376-383) and the number of blocks completed; needs FLAG_CONSTELLATION."""
+        count = self.n_channels - first if count is None else count
+        blk = np.zeros((max(count, 0), CONSTELLATION_SYMBOLS), np.complex64)
+        nb = np.zeros(max(count, 0), np.int32)
+        self._check(self._lib.tetra_demod_get_constellation(self._h, first, count, _np_ptr(blk), _np_ptr(nb)),
+                    "tetra_demod_get_constellation")
+        return blk, nb
 
     def kernel_ms_history(self, n):
         """GPU ms of the n most recent process calls' launches, oldest first (HIP events on each call's stream)."""

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/tetra_demod.h"
+#include "constellation_core.hpp"
 #include "demod_core.hpp"
 #include "design.hpp"
 
@@ -176,6 +177,25 @@ __global__ __launch_bounds__(64) void k_quality(const float2* __restrict__ sym, 
     }
 }
 
+// TETRA_FLAG_CONSTELLATION: the plugin's constellation tap (src/main.cpp:85-89: Reshaper keep 1024 / skip 0 -> :376-383 copies each
+// 1024-symbol block to the diagram) brought up to date after a launch, one workgroup per channel (constellation_core.hpp).
+constexpr int kCdSyms = tetra_cd::kSyms;
+static_assert(kCdSyms == TETRA_CONSTELLATION_SYMBOLS, "header and kernel agree on the block length");
+__global__ __launch_bounds__(256) void k_constellation(const float2* __restrict__ sym, long long sym_stride, const int* __restrict__ n_bits,
+                                                       float2* __restrict__ blk, float2* __restrict__ part, int* __restrict__ fill,
+                                                       int* __restrict__ blocks) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float2* z = sym + (long long)c * sym_stride;
+    float2* B = blk + (long long)c * kCdSyms;
+    float2* P = part + (long long)c * kCdSyms;
+    const int n = n_bits[c] / 2, f0 = fill[c];
+    const tetra_cd::Plan p = tetra_cd::plan(f0, n);
+    tetra_cd::assemble_block(p, tid, 256, z, P, B);
+    __syncthreads();
+    tetra_cd::carry_partial(p, f0, n, tid, 256, z, P);
+    if (tid == 0) { fill[c] = p.r; blocks[c] += p.nb; }
+}
+
 __global__ void k_min_i32(int* p, int v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && p[i] > v) p[i] = v;
@@ -220,6 +240,9 @@ struct tetra_demod {
     int *q_ptr = nullptr, *q_disp = nullptr, *q_sync = nullptr;
     float* q_err = nullptr;
     float2* q_sym = nullptr;    // [C][q_sym_stride] symbols of the last launch when the caller did not ask for them
+    float2 *cd_blk = nullptr, *cd_part = nullptr;   // TETRA_FLAG_CONSTELLATION: [C][1024] last complete / partial block (k_constellation)
+    int *cd_fill = nullptr, *cd_blocks = nullptr;   // [C] symbols in the partial block, blocks completed
+    bool taps_sym() const { return q_ring || cd_blk; }      // a post-launch kernel reads the launch's symbols
     long long q_sym_stride = 0;
     bool user_rrc = false, user_be = false;   // caller-supplied FIR tables (cfg.rrc_taps / cfg.bandedge_taps)
     bool quirks = false;        // TETRA_FLAG_REFERENCE_QUIRKS
@@ -374,6 +397,11 @@ int reset_range(tetra_demod* h, int first, int count, bool fresh) {
             HIP_TRY(h, hipMemsetAsync(h->q_sync + first, 0, sizeof(int) * count, 0));
             HIP_TRY(h, hipMemsetAsync(h->q_err + first, 0, sizeof(float) * count, 0));
         }
+        if (h->cd_blk) {                // (the Reshaper behind the symbol stream is another block too)
+            HIP_TRY(h, hipMemsetAsync(h->cd_blk + (size_t)first * kCdSyms, 0, sizeof(float2) * kCdSyms * (size_t)count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->cd_fill + first, 0, sizeof(int) * count, 0));
+            HIP_TRY(h, hipMemsetAsync(h->cd_blocks + first, 0, sizeof(int) * count, 0));
+        }
         HIP_TRY(h, hipMemsetAsync(h->ybuf + (size_t)first * kYHist, 0, sizeof(float2) * kYHist * (size_t)count, 0));
     }
     HIP_TRY(h, hipStreamSynchronize(0));
@@ -385,7 +413,7 @@ void free_all(tetra_demod* h) {
     for (void* p : gen)
         if (p) (void)hipFree(p);
     void* ptrs[] = { h->agc_g, h->fll_ph, h->fll_fr, h->hist, h->mu, h->omega, h->cph, h->cfr, h->ph2, h->offset,
-                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->d_overruns, h->d_bank, h->d_be_re80, h->d_be_im80,
+                     h->prev, h->rrc_valid, h->y, h->ybuf, h->q_ring, h->q_sym, h->q_ptr, h->q_disp, h->q_sync, h->q_err, h->cd_blk, h->cd_part, h->cd_fill, h->cd_blocks, h->d_overruns, h->d_bank, h->d_be_re80, h->d_be_im80,
                      h->d_rrc_ext, h->st_iq, h->st_bits, h->st_nbits, h->st_sym, h->d_prof };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -633,6 +661,12 @@ int tetra_demod_create(const tetra_demod_config_t* cfg, tetra_demod_t** out) {
     if (cfg->flags & TETRA_FLAG_QUALITY) {
         A(dalloc(h, &h->q_ring, C * 4096)); A(dalloc(h, &h->q_ptr, C));
         A(dalloc(h, &h->q_disp, C)); A(dalloc(h, &h->q_sync, C)); A(dalloc(h, &h->q_err, C));
+    }
+    if (cfg->flags & TETRA_FLAG_CONSTELLATION) {
+        A(dalloc(h, &h->cd_blk, C * (size_t)kCdSyms)); A(dalloc(h, &h->cd_part, C * (size_t)kCdSyms));
+        A(dalloc(h, &h->cd_fill, C)); A(dalloc(h, &h->cd_blocks, C));
+    }
+    if (cfg->flags & (TETRA_FLAG_QUALITY | TETRA_FLAG_CONSTELLATION)) {
         h->q_sym_stride = stride_for(h->design, h->max_samples) / 2;
         A(dalloc(h, &h->q_sym, C * (size_t)h->q_sym_stride));
     }
@@ -702,7 +736,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pg.xs = h->g_xs; pg.ys = h->g_ys; pg.xs_stride = (long long)xs_stride; pg.ys_stride = (long long)ys_stride;
         pg.bits = d_bits; pg.bits_stride = bits_stride; pg.n_bits = d_n_bits;
         pg.sym = reinterpret_cast<float2*>(d_sym); pg.sym_stride = bits_stride / 2;
-        if (h->q_ring && !pg.sym) { pg.sym = h->q_sym; pg.sym_stride = h->q_sym_stride; }
+        if (h->taps_sym() && !pg.sym) { pg.sym = h->q_sym; pg.sym_stride = h->q_sym_stride; }
         pg.overruns = h->d_overruns; pg.cut_flag = h->cut_flag;
         pg.y_dbg = h->keep_y ? h->y : nullptr;
         pg.k1 = h->design.k1; pg.k2 = h->design.k2;
@@ -716,6 +750,9 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         if (h->q_ring)
             hipLaunchKernelGGL(k_quality, dim3(h->C), dim3(64), 0, s, pg.sym, pg.sym_stride, d_n_bits, h->q_ring, h->q_ptr, h->q_disp,
                                h->q_err, h->q_sync);
+        if (h->cd_blk)
+            hipLaunchKernelGGL(k_constellation, dim3(h->C), dim3(256), 0, s, pg.sym, pg.sym_stride, d_n_bits, h->cd_blk, h->cd_part,
+                               h->cd_fill, h->cd_blocks);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(ev[1], s));
         h->n_calls++;
@@ -739,7 +776,7 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         pf.y_dbg = h->keep_y ? h->y : nullptr;
         pf.overruns = h->d_overruns;
         pf.sym_stride = bits_stride / 2;
-        if (h->q_ring && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
+        if (h->taps_sym() && !pf.sym) { pf.sym = h->q_sym; pf.sym_stride = h->q_sym_stride; }   // the statistic reads the symbols
         pf.k1 = h->design.k1; pf.k2 = h->design.k2;
         pf.prof = reinterpret_cast<long long*>(h->cut_flag);      // the non-instrumented 16- / 32-channel kernels read it as the cut flag (kernel_fused.hpp)
         // channels [0, n_wide) in 32-channel workgroups (see tetra_demod_create; their FLL rows hold 4 x 17 taps), the rest in
@@ -819,6 +856,9 @@ int tetra_demod_process_device(tetra_demod_t* h, const float* d_iq, int n_sample
         if (h->q_ring)
             hipLaunchKernelGGL(k_quality, dim3(h->C), dim3(64), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->q_ring, h->q_ptr, h->q_disp,
                                h->q_err, h->q_sync);
+        if (h->cd_blk)
+            hipLaunchKernelGGL(k_constellation, dim3(h->C), dim3(256), 0, s, pf.sym, pf.sym_stride, d_n_bits, h->cd_blk, h->cd_part,
+                               h->cd_fill, h->cd_blocks);
         HIP_TRY(h, hipGetLastError());
         h->far_valid = long_rows;      // the fused kernel carries the newest 80 delay-line samples only -- its long rows all 128
         HIP_TRY(h, hipEventRecord(ev[1], s));
@@ -1224,7 +1264,7 @@ int apply_params(tetra_demod* h, const host::DesignParams& np, bool tables, bool
     DeviceGuard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     HIP_TRY(h, hipDeviceSynchronize());
-    if (h->q_ring && stride_for(nd, h->max_samples) / 2 > h->q_sym_stride) {
+    if (h->taps_sym() && stride_for(nd, h->max_samples) / 2 > h->q_sym_stride) {
         // a slower timing loop emits more symbols per sample: the statistic's symbol scratch grows with it
         const long long want = stride_for(nd, h->max_samples) / 2;
         float2* q = nullptr;
@@ -1453,6 +1493,20 @@ int tetra_demod_get_quality(tetra_demod_t* h, float* standarderr, uint8_t* sync)
         HIP_TRY(h, hipMemcpy(tmp.data(), h->q_sync, sizeof(int) * (size_t)h->C, hipMemcpyDeviceToHost));
         for (int c = 0; c < h->C; c++) sync[c] = (uint8_t)(tmp[c] != 0);
     }
+    return TETRA_OK;
+}
+
+int tetra_demod_get_constellation(tetra_demod_t* h, int first, int count, float* symbols, int32_t* n_blocks) {
+    if (!h) return TETRA_ERR_ARG;
+    if (!h->cd_blk) return TETRA_ERR_UNSUPPORTED;
+    if (first < 0 || count < 0 || first > h->C || count > h->C - first) return TETRA_ERR_ARG;
+    DeviceGuard g(h->device);
+    if (!g.ok) return TETRA_ERR_NO_DEVICE;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (count == 0) return TETRA_OK;
+    if (symbols)
+        HIP_TRY(h, hipMemcpy(symbols, h->cd_blk + (size_t)first * kCdSyms, sizeof(float2) * kCdSyms * (size_t)count, hipMemcpyDeviceToHost));
+    if (n_blocks) HIP_TRY(h, hipMemcpy(n_blocks, h->cd_blocks + first, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
     return TETRA_OK;
 }
 

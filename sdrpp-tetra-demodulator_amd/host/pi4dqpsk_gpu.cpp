@@ -292,6 +292,10 @@ int PI4DQPSKBank::reset(int channel) { return h_ ? tetra_demod_reset(h_, channel
 int PI4DQPSKBank::setParam(int id, double v) { return h_ ? tetra_demod_set_param(h_, id, v) : TETRA_ERR_ARG; }
 int PI4DQPSKBank::quality(float* standarderr, uint8_t* sync) { return h_ ? tetra_demod_get_quality(h_, standarderr, sync) : TETRA_ERR_ARG; }
 
+int PI4DQPSKBank::constellation(int first, int count, complex_t* blocks, int32_t* nBlocks) {
+    return h_ ? tetra_demod_get_constellation(h_, first, count, reinterpret_cast<float*>(blocks), nBlocks) : TETRA_ERR_ARG;
+}
+
 PI4DQPSKMultiBank::~PI4DQPSKMultiBank() { shutdown(); }
 
 void PI4DQPSKMultiBank::shutdown() {
@@ -413,6 +417,21 @@ int PI4DQPSKMultiBank::quality(float* standarderr, uint8_t* sync) {
     if (shards_.empty()) return TETRA_ERR_ARG;
     for (auto& s : shards_) {
         const int rc = tetra_demod_get_quality(s->h, standarderr ? standarderr + s->first : nullptr, sync ? sync + s->first : nullptr);
+        if (rc != TETRA_OK) return rc;
+    }
+    return TETRA_OK;
+}
+
+// the constellation blocks of channels [first, first + count): each shard's part of the range into the caller's arrays
+int PI4DQPSKMultiBank::constellation(int first, int count, complex_t* blocks, int32_t* nBlocks) {
+    if (shards_.empty() || first < 0 || count < 0 || first > channels_ || count > channels_ - first) return TETRA_ERR_ARG;
+    for (auto& s : shards_) {
+        const int lo = first > s->first ? first : s->first;
+        const int hi = first + count < s->first + s->count ? first + count : s->first + s->count;
+        if (hi <= lo) continue;
+        const int rc = tetra_demod_get_constellation(s->h, lo - s->first, hi - lo,
+                                                     blocks ? reinterpret_cast<float*>(blocks + (size_t)(lo - first) * TETRA_CONSTELLATION_SYMBOLS) : nullptr,
+                                                     nBlocks ? nBlocks + (lo - first) : nullptr);
         if (rc != TETRA_OK) return rc;
     }
     return TETRA_OK;

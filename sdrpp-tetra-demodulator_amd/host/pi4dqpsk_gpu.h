@@ -181,6 +181,10 @@ public:
     // DQPSKSymbolExtractor's public standarderr / sync (src/dsp/dqpsk_sym_extr.h:36-37) for every channel; needs
     // TETRA_FLAG_QUALITY in cfg.flags (TETRA_ERR_UNSUPPORTED otherwise).  Either pointer may be null.
     int quality(float* standarderr, uint8_t* sync);
+    // The plugin's constellation tap (src/main.cpp:85-89 Reshaper keep 1024 / skip 0, :376-383 sink) for channels first .. first +
+    // count - 1: blocks[count][1024] = each channel's last complete block of 1024 consecutive symbols (what the GUI's diagram would
+    // hold), nBlocks[count] = blocks completed so far.  Needs TETRA_FLAG_CONSTELLATION in cfg.flags.  Either pointer may be null.
+    int constellation(int first, int count, complex_t* blocks, int32_t* nBlocks);
     int channels() const { return channels_; }
     tetra_demod_t* handle() { return h_; }
 
@@ -219,6 +223,8 @@ public:
     // DQPSKSymbolExtractor's public standarderr / sync (src/dsp/dqpsk_sym_extr.h:36-37) for every channel; needs
     // TETRA_FLAG_QUALITY in cfg.flags (TETRA_ERR_UNSUPPORTED otherwise).  Either pointer may be null.
     int quality(float* standarderr, uint8_t* sync);
+    // PI4DQPSKBank::constellation over the shards (channels first .. first + count - 1 of the whole bank)
+    int constellation(int first, int count, complex_t* blocks, int32_t* nBlocks);
     int channels() const { return channels_; }
     int shards() const { return (int)shards_.size(); }
     // channel range [first, first + count) and device of a shard

@@ -16,6 +16,7 @@
 #include "../../include/tetra_demod.h"
 #include "../../sdrpp-tetra-demodulator_amd/csrc/demod_core.hpp"
 #include "../../sdrpp-tetra-demodulator_amd/csrc/design.hpp"
+#include "../../sdrpp-tetra-demodulator_amd/csrc/constellation_core.hpp"
 
 using namespace tdm;
 
@@ -300,6 +301,21 @@ int emul_fused(const emul_tables* t, tetra_demod_channel_state_t* st, int C, int
 // z[2i], z[2i+1] -> out[i]
 void emul_quality_distance(int n, const float* z, float* out) {
     for (int i = 0; i < n; i++) out[i] = quality_distance(z[2 * i], z[2 * i + 1]);
+}
+
+// k_constellation for one channel and one call (constellation_core.hpp): phase 1 for every thread index, then phase 2 for every
+// thread index (the kernel's barrier), then the two counters.  z[n] this call's symbols (re, im pairs), blk / part [1024] pairs.
+void emul_constellation(int n, const float* z, float* blk, float* part, int* fill, int* blocks, int nthr) {
+    struct Z { float re, im; };
+    const Z* zz = reinterpret_cast<const Z*>(z);
+    Z* B = reinterpret_cast<Z*>(blk);
+    Z* P = reinterpret_cast<Z*>(part);
+    const int f0 = *fill;
+    const tetra_cd::Plan p = tetra_cd::plan(f0, n);
+    for (int tid = 0; tid < nthr; tid++) tetra_cd::assemble_block(p, tid, nthr, zz, P, B);
+    for (int tid = nthr - 1; tid >= 0; tid--) tetra_cd::carry_partial(p, f0, n, tid, nthr, zz, P);
+    *fill = p.r;
+    *blocks += p.nb;
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@ LIB = os.path.join(HERE, "libtetra_emul.so")
 DEPS = [os.path.join(HERE, "emul.cpp"),
         os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "demod_core.hpp"),
         os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "design.hpp"),
+        os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "constellation_core.hpp"),
         os.path.join(ROOT, "include", "tetra_demod.h")]
 
 sys.path.insert(0, ROOT)
@@ -67,6 +68,8 @@ def lib():
         L.emul_bits_stride_for.restype = C.c_longlong
         L.emul_quality_distance.argtypes = [C.c_int, vp, vp]
         L.emul_quality_distance.restype = None
+        L.emul_constellation.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int]
+        L.emul_constellation.restype = None
         _lib = L
     return _lib
 
@@ -102,6 +105,23 @@ def quality_distance(z):
     out = np.zeros(z.size, np.float32)
     lib().emul_quality_distance(int(z.size), _p(z), _p(out))
     return out
+
+
+class ConstellationTap:
+    """One channel of k_constellation (constellation_core.hpp) on the host: feed(z) = one call's symbols."""
+
+    def __init__(self, nthr=256):
+        import numpy as np
+        self.blk = np.zeros(1024, np.complex64)
+        self.part = np.full(1024, np.nan + 1j * np.nan, np.complex64)      # never read beyond `fill`: NaNs would show
+        self.fill = np.zeros(1, np.int32)
+        self.blocks = np.zeros(1, np.int32)
+        self.nthr = nthr
+
+    def feed(self, z):
+        import numpy as np
+        z = np.ascontiguousarray(z, np.complex64)
+        lib().emul_constellation(int(z.size), _p(z), _p(self.blk), _p(self.part), _p(self.fill), _p(self.blocks), self.nthr)
 
 
 def bits_stride(n):

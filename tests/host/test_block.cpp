@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "../../sdrpp-tetra-demodulator_amd/host/pi4dqpsk_gpu.h"
@@ -39,6 +40,7 @@ static int multibank_main(int argc, char** argv) {
     tetra_demod_default_config(&cfg);
     cfg.n_channels = C;
     cfg.max_samples = per;
+    cfg.flags |= TETRA_FLAG_CONSTELLATION;      // the plugin's constellation tap, kept per channel on each shard's GPU
     dsp::demod::PI4DQPSKMultiBank mb;
     int rc = mb.init(cfg, devs);
     if (rc != TETRA_OK) { std::fprintf(stderr, "init failed: %s\n", tetra_demod_strerror(rc)); return 3; }
@@ -105,6 +107,26 @@ static int multibank_main(int argc, char** argv) {
         int first, count, dev;
         mb.shardInfo(g, first, count, dev);
         std::printf("shard %d: channels [%d, %d) on device %d\n", g, first, first + count, dev);
+    }
+    {   // MultiBank::constellation: every channel's last complete 1024-symbol block -> <out_bits>.cd / .cdn for the caller; a range
+        // that starts and ends inside shards must be the same rows
+        std::vector<dsp::complex_t> blk((size_t)C * TETRA_CONSTELLATION_SYMBOLS), mid(blk.size());
+        std::vector<int32_t> nblk((size_t)C), nmid((size_t)C);
+        if (mb.constellation(0, C, blk.data(), nblk.data()) != TETRA_OK) return 10;
+        if (C > 2) {
+            if (mb.constellation(1, C - 2, mid.data(), nmid.data()) != TETRA_OK) return 10;
+            if (std::memcmp(mid.data(), blk.data() + TETRA_CONSTELLATION_SYMBOLS, sizeof(dsp::complex_t) * (size_t)(C - 2) * TETRA_CONSTELLATION_SYMBOLS) ||
+                std::memcmp(nmid.data(), nblk.data() + 1, sizeof(int32_t) * (size_t)(C - 2))) return 11;
+        }
+        if (mb.constellation(C, 1, blk.data(), nullptr) != TETRA_ERR_ARG || mb.constellation(-1, 1, nullptr, nullptr) != TETRA_ERR_ARG) return 12;
+        const std::string base = argv[6];
+        FILE* fc = std::fopen((base + ".cd").c_str(), "wb");
+        FILE* fcn = std::fopen((base + ".cdn").c_str(), "wb");
+        if (!fc || !fcn) return 13;
+        std::fwrite(blk.data(), sizeof(dsp::complex_t), blk.size(), fc);
+        std::fwrite(nblk.data(), sizeof(int32_t), nblk.size(), fcn);
+        std::fclose(fc);
+        std::fclose(fcn);
     }
     if (cfg.flags & TETRA_FLAG_QUALITY) {      // not set by this driver today; exercises the link of MultiBank::quality
         std::vector<float> e((size_t)C);

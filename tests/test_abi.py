@@ -22,7 +22,7 @@ def test_header_symbols_all_exported(pkg):
     for n in names:
         assert hasattr(L, n), "declared in include/tetra_demod.h but not exported: " + n
     assert set(pkg.binding.EXPORTS) == set(names)
-    assert L.tetra_demod_abi_version() == 5
+    assert L.tetra_demod_abi_version() == 6
     assert L.tetra_demod_build_id().decode() == pkg.build.source_hash() == pkg.build.lib_build_id()
 
 
@@ -193,6 +193,9 @@ int main(void) {
     { const char* id = tetra_demod_build_id(); int i; if (!id) return 20; for (i = 0; i < 64; i++) if (!id[i]) return 21; if (id[64]) return 22; }
     /* ABI 5: caller-designed tables on a live handle */
     { float t[4] = { 0 }; if (tetra_demod_set_tables(NULL, t, 2, NULL, 0, NULL) != TETRA_ERR_ARG) return 23; }
+    /* ABI 6: the constellation tap */
+    { float z[2]; int32_t nb; if (tetra_demod_get_constellation(NULL, 0, 1, z, &nb) != TETRA_ERR_ARG) return 24;
+      if (TETRA_CONSTELLATION_SYMBOLS != 1024 || TETRA_FLAG_CONSTELLATION != 256) return 25; }
     printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
     return 0;
 }
@@ -201,7 +204,7 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), lib, "-Wl,-rpath," + os.path.dirname(lib),
                     "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["65", "800", "5"]
+    assert out == ["65", "800", "6"]
 
 
 def test_generated_fll_assembly_is_current():

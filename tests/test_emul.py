@@ -262,3 +262,23 @@ def test_quality_distance_is_the_reference_expression_including_signed_zeros(emu
     assert np.abs(got - want).max() < 1e-6, (np.abs(got - want).argmax(), z[np.abs(got - want).argmax()])
     # the three sign-of-zero cases are really in the set
     assert (want > 5.0).any() and (np.abs(want - 3.9269908) < 1e-6).any() and (np.abs(want - 2.3561945) < 1e-6).any()
+
+
+def test_constellation_tap_keeps_the_last_complete_block_of_1024(emul):
+    """k_constellation's two phases (constellation_core.hpp) on the host against the definition: the plugin regroups the symbol
+    stream into consecutive blocks of 1024 (Reshaper keep 1024 / skip 0, src/main.cpp:88) and shows the last complete one
+    (:376-383).  Ragged calls incl. empty ones, calls that complete 0 / 1 / several blocks, exact fits."""
+    rng = np.random.default_rng(77)
+    for nthr in (256, 64, 1):
+        tap = emul.ConstellationTap(nthr)
+        stream = np.zeros(0, np.complex64)
+        calls = [0, 5, 1019, 0, 1, 1023, 1024, 2048, 3, 4000, 1021, 9000, 0, 7, 500, 524, 18000] + list(rng.integers(0, 3000, 40))
+        for n in calls:
+            z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+            tap.feed(z)
+            stream = np.concatenate([stream, z])
+            nb = stream.size // 1024
+            assert tap.blocks[0] == nb and tap.fill[0] == stream.size % 1024
+            want = stream[(nb - 1) * 1024:nb * 1024] if nb else np.zeros(1024, np.complex64)
+            assert np.array_equal(tap.blk.view(np.uint32), want.view(np.uint32)), (nthr, n, nb)
+            assert np.array_equal(tap.part[:tap.fill[0]].view(np.uint32), stream[nb * 1024:].view(np.uint32))

@@ -644,6 +644,79 @@ def test_quality_statistic(pkg, oracle, synth, pipeline):
     d.close()
 
 
+@pytest.mark.parametrize("variant", ["fused", "wide", "small", "generic", "long_rows", "quality", "auto"])
+def test_constellation_tap(pkg, oracle, synth, variant):
+    """the plugin's constellation tap (src/main.cpp:85-89 Reshaper keep 1024 / skip 0, :376-383 sink) kept on the
+    device per channel: after every call the block fetched = the last complete block of 1024 consecutive symbols of the ORACLE's
+    symbol stream (bit patterns), the count = blocks completed; calls that complete none / one / several blocks, empty calls,
+    with and without the caller asking for the symbols, every workgroup shape, the generic kernel, beside the quality statistic."""
+    B = pkg.binding
+    flags = {"fused": 32, "wide": 16, "small": 64, "generic": B.FLAG_GENERIC_KERNEL, "long_rows": 0, "quality": B.FLAG_QUALITY, "auto": 0}[variant]
+    prm = dict(rrc_tap_count=101) if variant in ("generic", "long_rows") else {}     # 101 taps: k_generic on request, else the fused kernel's long rows
+    Cn, N = 9, 26000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=4242)
+    d = pkg.Demodulator(Cn, 9000, flags=flags | B.FLAG_CONSTELLATION, **prm)
+    cfg = oracle.default_cfg()
+    for key, v in prm.items():
+        setattr(cfg, key, v)
+    orcs = [oracle.Oracle(cfg) for _ in range(Cn)]
+    streams = [np.zeros(0, np.complex64) for _ in range(Cn)]
+    blk, nb = d.constellation()
+    assert blk.shape == (Cn, 1024) and not blk.any() and not nb.any()
+    pos = 0
+    for k, n in enumerate([700, 0, 1300, 100, 48, 2048, 9000, 1, 4100, 8703]):
+        out = d.process(iq[:, pos:pos + n], want_sym=bool(k & 1))
+        blk, nb = d.constellation()
+        for c in range(Cn):
+            r = orcs[c].process(iq[c, pos:pos + n])
+            assert np.array_equal(out[0][c][:out[1][c]], r["bits"])
+            streams[c] = np.concatenate([streams[c], r["sym"]])
+            done = streams[c].size // 1024
+            assert nb[c] == done, (k, c)
+            want = streams[c][(done - 1) * 1024:done * 1024] if done else np.zeros(1024, np.complex64)
+            assert np.array_equal(_u32(blk[c]), _u32(want)), (k, c, done)
+        pos += n
+    assert pos == N and nb.min() >= 12
+    part, pnb = d.constellation(2, 3)                       # a channel range
+    assert np.array_equal(_u32(part), _u32(blk[2:5])) and np.array_equal(pnb, nb[2:5])
+    assert d.constellation(Cn, 0)[0].shape == (0, 1024)
+    for first, count in ((-1, 1), (0, Cn + 1), (Cn, 1), (3, -1)):
+        with pytest.raises(pkg.TetraDemodError):
+            d.constellation(first, count)
+    d.close()
+    with pytest.raises(pkg.TetraDemodError):
+        pkg.Demodulator(1, 64).constellation()
+
+
+@pytest.mark.parametrize("quirks", [False, True])
+def test_constellation_tap_and_reset(pkg, synth, quirks):
+    """tetra_demod_reset and the tap: the Reshaper behind the symbol stream is another block, PI4DQPSK::reset (pi4dqpsk.cpp:119-130)
+    does not touch it -- under TETRA_FLAG_REFERENCE_QUIRKS the block phase and the carried partial block survive a reset; without
+    the flag the reset channel's tap restarts (zero block, zero count) like everything else of it.  The other channels never notice.
+    Checked against the handle's own symbol output (the definition: blocks are made of exactly those symbols)."""
+    B = pkg.binding
+    Cn, N = 5, 9000
+    iq, _, _ = synth.gen_batch(Cn, N, base_seed=515)
+    d = pkg.Demodulator(Cn, 3000, flags=B.FLAG_CONSTELLATION | (B.FLAG_REFERENCE_QUIRKS if quirks else 0))
+    streams = [np.zeros(0, np.complex64) for _ in range(Cn)]
+    for k in range(3):
+        if k == 1:
+            d.reset(3)
+            if not quirks:
+                blk, nb = d.constellation(3, 1)
+                assert nb[0] == 0 and not blk.any()
+                streams[3] = np.zeros(0, np.complex64)
+        bits, nbits, sym = d.process(iq[:, 3000 * k:3000 * (k + 1)], want_sym=True)[:3]
+        blk, nb = d.constellation()
+        for c in range(Cn):
+            streams[c] = np.concatenate([streams[c], sym[c][:nbits[c] // 2]])
+            done = streams[c].size // 1024
+            assert nb[c] == done, (k, c)
+            want = streams[c][(done - 1) * 1024:done * 1024] if done else np.zeros(1024, np.complex64)
+            assert np.array_equal(_u32(blk[c]), _u32(want)), (k, c)
+    d.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_combinations_of_shape_layout_outputs_and_chunking(pkg, oracle, synth, seed):

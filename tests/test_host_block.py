@@ -28,7 +28,7 @@ def _build(pkg):
 def test_block_mirror_builds_and_links(pkg):
     exe = _build(pkg)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "abi 5" in out and "default taps 65" in out and "decision tap ok" in out and "decision tap alignment ok" in out
+    assert "abi 6" in out and "default taps 65" in out and "decision tap ok" in out and "decision tap alignment ok" in out
 
 
 @pytest.mark.gpu
@@ -154,13 +154,24 @@ def test_multibank_two_shards_two_threads_one_device(pkg, oracle, synth, tmp_pat
     if mode == "multibank-cs16":      # what the GPU computes on: x / 32768 of the rounded int16 (exact in binary32)
         q = np.clip(np.rint(iq.view(np.float32) * np.float32(32768.0)), -32768, 32767).astype(np.int16)
         iq = (q.astype(np.float32) * np.float32(1.0 / 32768.0)).view(np.complex64)
+    cd = np.fromfile(str(f_bits) + ".cd", np.complex64).reshape(Cn, 1024)
+    cdn = np.fromfile(str(f_bits) + ".cdn", np.int32)
     for c in range(Cn):
         o = oracle.Oracle()
+        syms = []
         for k in range(calls):
-            want = o.process(iq[c, k * per:(k + 1) * per])["bits"]
+            res = o.process(iq[c, k * per:(k + 1) * per])
+            want = res["bits"]
+            syms.append(res["sym"])
             assert nb[k, c] == want.size and np.array_equal(bits[k, c, :want.size], want), (c, k)
             if k == calls // 2:
                 o.set_param(4, 0.02)
+        # MultiBank::constellation: the plugin's constellation tap (src/main.cpp:85-89, :376-383) shard by shard = the last complete
+        # 1024-symbol block of the oracle's symbol stream
+        syms = np.concatenate(syms)
+        done = syms.size // 1024
+        assert cdn[c] == done and done >= 9
+        assert np.array_equal(cd[c].view(np.uint32), syms[(done - 1) * 1024:done * 1024].view(np.uint32)), c
 
 
 EXE4 = os.path.join(ROOT, "tests", "host", "test_config4")
