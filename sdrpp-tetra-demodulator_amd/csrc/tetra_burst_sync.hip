@@ -224,16 +224,55 @@ template <bool PACKED> __device__ __forceinline__ uint32_t demux_dword(const uin
     return v;
 }
 
+// eight consecutive bits of a block (positions 8 d .. 8 d + 7) as eight bytes.  PACKED frames, all eight inside one piece (every
+// pair of the coded blocks: their pieces start and end on multiples of 8; all but two pairs of the BBK): ONE 8-bit window of the
+// packed row, spread with three 32-bit operations per half -- the counters showed the slot-layout demultiplexer bound by its vector
+// instructions, not by HBM (175 per 8 output bytes, profiles/r05/r05_k_chain_tail_counters.md).
+template <bool PACKED> __device__ __forceinline__ uint2 demux_pair(const uint8_t* frames, int r, const Pieces& p, int d) {
+    if (PACKED) {
+        const int i = 8 * d;
+        int x = -1;
+        if (i + 8 <= p.len0) x = p.off0 + i;
+        else if (i >= p.len0 && i + 8 <= p.len0 + p.len1) x = p.off1 + i - p.len0;
+        if (x >= 0) {
+            const uint32_t* f = reinterpret_cast<const uint32_t*>(frames) + (size_t)r * TETRA_FRAME_WORDS;
+            const int w = x >> 5;
+            const uint64_t two = ((uint64_t)f[w] << 32) | (w + 1 < TETRA_FRAME_WORDS ? f[w + 1] : 0u);
+            const uint32_t rep = ((uint32_t)(two >> (56 - (x & 31))) & 0xffu) * 0x01010101u;      // the byte in every byte; first bit = bit 7
+            // byte k of the result = bit 7 - k: keep that one bit per byte, then "non-zero byte -> 1" (+ 0x7f carries into bit 7 only)
+            const uint32_t lo = (((rep & 0x10204080u) + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+            const uint32_t hi = (((rep & 0x01020408u) + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+            return make_uint2(lo, hi);
+        }
+    }
+    return make_uint2(demux_dword<PACKED>(frames, r, p, 2 * d), demux_dword<PACKED>(frames, r, p, 2 * d + 1));
+}
+
+// global index -> (row, unit within the row) with a 32-bit division wherever the launch's index space allows it (a 64-bit division
+// by a run-time divisor costs ~100 vector instructions per thread)
+__device__ __forceinline__ bool demux_index_of(long long units_total, int row_u, int& r, int& d) {
+    if (units_total <= 0xffffff00ll) {
+        const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+        if (g >= (uint32_t)units_total) return false;
+        const uint32_t q = g / (uint32_t)row_u;
+        r = (int)q; d = (int)(g - q * (uint32_t)row_u);
+        return true;
+    }
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= units_total) return false;
+    r = (int)(gid / row_u); d = (int)(gid % row_u);
+    return true;
+}
+
 // one thread per output dword -- or, WIDE (rows a multiple of 8 bytes, 8-byte aligned), per pair of dwords: half the threads, 8-byte stores
 template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_burst_demux(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type, int n,
                                                      int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride,
                                                      int* __restrict__ valid) {
     const int row_u = row_stride >> (WIDE ? 3 : 2);
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)n * row_u) return;
-    const int r = (int)(gid / row_u), d = (int)(gid % row_u);
+    int r, d;
+    if (!demux_index_of((long long)n * row_u, row_u, r, d)) return;
     const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
-    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)r * row_stride)[d] = make_uint2(demux_dword<PACKED>(frames, r, p, 2 * d), demux_dword<PACKED>(frames, r, p, 2 * d + 1));
+    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)r * row_stride)[d] = demux_pair<PACKED>(frames, r, p, d);
     else reinterpret_cast<uint32_t*>(rows + (size_t)r * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
     if (d == 0) valid[r] = p.len0 > 0;
 }
@@ -285,13 +324,12 @@ template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_demux
                                                       const int* __restrict__ row_frame, const int* __restrict__ n_rows, int n,
                                                       int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride) {
     const int row_u = row_stride >> (WIDE ? 3 : 2);
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)n * row_u) return;
-    const int j = (int)(gid / row_u), d = (int)(gid % row_u);
+    int j, d;
+    if (!demux_index_of((long long)n * row_u, row_u, j, d)) return;
     if (j >= *n_rows) return;
     const int r = row_frame[j];
     const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
-    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)j * row_stride)[d] = make_uint2(demux_dword<PACKED>(frames, r, p, 2 * d), demux_dword<PACKED>(frames, r, p, 2 * d + 1));
+    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)j * row_stride)[d] = demux_pair<PACKED>(frames, r, p, d);
     else reinterpret_cast<uint32_t*>(rows + (size_t)j * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
 }
 
