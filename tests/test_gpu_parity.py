@@ -853,8 +853,9 @@ def test_async_host_path_equals_the_synchronous_one(pkg, oracle, synth, layout):
     q8 = np.clip(np.round(iq.view(np.float32) * 128.0), -128, 127).astype(np.int8)
     iq_q8 = (q8.astype(np.float32) / np.float32(128.0)).view(np.complex64)
     for fmt, data, raw in ((B.IQ_CF32, iq, iq), (B.IQ_CS16, iq_q, q.reshape(Cn, -1, 2)), (B.IQ_CS8, iq_q8, q8.reshape(Cn, -1, 2))):
-        d = pkg.Demodulator(Cn, max(sizes), layout=lay)
+        d = pkg.Demodulator(Cn, max(sizes), layout=lay, flags=B.FLAG_CONSTELLATION | B.FLAG_QUALITY)      # the two post-launch taps ride along, chunk by chunk
         orcs = [oracle.Oracle() for _ in range(Cn)]
+        streams = [[] for _ in range(Cn)]
         keep, pos = [], 0
         for n in sizes:
             blk = raw[:, pos:pos + n]
@@ -873,7 +874,15 @@ def test_async_host_path_equals_the_synchronous_one(pkg, oracle, synth, layout):
             for c in range(Cn):
                 r = orcs[c].process(data[c, p0:p0 + n])
                 assert nb[c] == r["bits"].size and np.array_equal(bits[c][:nb[c]], r["bits"]), (fmt, c, p0)
+                streams[c].append(r["sym"])
                 # (bytes behind n_bits are not part of the result: a row keeps there whatever it held, tetra_demod.h)
+        cblk, cnb = d.constellation()
+        err, _ = d.quality()
+        for c in range(Cn):
+            z = np.concatenate(streams[c])
+            done = z.size // 1024
+            assert cnb[c] == done and np.array_equal(_u32(cblk[c]), _u32(z[(done - 1) * 1024:done * 1024])), (fmt, c)
+            assert abs(err[c] - orcs[c].st.standarderr) < 2e-6, (fmt, c)
         d.close()
 
 
