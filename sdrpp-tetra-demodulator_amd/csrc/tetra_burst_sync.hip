@@ -229,6 +229,7 @@ template <bool PACKED> __device__ __forceinline__ uint32_t demux_dword(const uin
 // packed row, spread with three 32-bit operations per half -- the counters showed the slot-layout demultiplexer bound by its vector
 // instructions, not by HBM (175 per 8 output bytes, profiles/r05/r05_k_chain_tail_counters.md).
 template <bool PACKED> __device__ __forceinline__ uint2 demux_pair(const uint8_t* frames, int r, const Pieces& p, int d) {
+    if (8 * d >= p.len0 + p.len1) return make_uint2(0u, 0u);      // behind the block -- or the frame does not carry the kind (three slots in four)
     if (PACKED) {
         const int i = 8 * d;
         int x = -1;
@@ -331,6 +332,44 @@ template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_demux
     const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
     if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)j * row_stride)[d] = demux_pair<PACKED>(frames, r, p, d);
     else reinterpret_cast<uint32_t*>(rows + (size_t)j * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
+}
+
+// PACKED frames, 8-byte row units, rows of at most 512 bytes (every block kind: 120 .. 432): a wavefront takes 64 / row_u whole rows
+// at a time -- lane -> (row, unit) by one multiply (no division by a run-time row length), the block's pieces picked from three
+// precomputed candidates (the kind is a launch argument; only the burst type differs per row), one 8-bit window per lane, and the
+// wave's stores cover R consecutive rows = one contiguous run.  GATHER: rows are the compacted ones (row j <- frame row_frame[j]).
+struct PiecesLut { Pieces sync, norm1, norm2; };
+constexpr int kDemuxRowIters = 4;
+template <bool GATHER> __global__ __launch_bounds__(256) void k_demux_rows(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type,
+                                                                         const int* __restrict__ row_frame, const int* __restrict__ n_rows, int n,
+                                                                         PiecesLut lut, int row_u, int rows_per_wave, unsigned inv_row_u,
+                                                                         uint8_t* __restrict__ rows, int* __restrict__ valid) {
+    const int lane = threadIdx.x & 63;
+    const int lr = (int)(((unsigned)lane * inv_row_u) >> 16);            // lane / row_u, exact for lane < 64 (inv = ceil(65536 / row_u))
+    const int d = lane - lr * row_u;
+    if (lr >= rows_per_wave) return;
+    const long long have = GATHER ? (long long)*n_rows : (long long)n;
+#pragma unroll
+    for (int it = 0; it < kDemuxRowIters; ++it) {        // a few row groups per wavefront: a wave per 432 bytes is bound by the wave launch rate
+    const long long wave = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kDemuxRowIters + it;
+    const long long j = wave * rows_per_wave + lr;
+    if (j >= have) continue;
+    const int r = GATHER ? row_frame[j] : (int)j;
+    const int t = frame_type[r];
+    // field by field (selecting whole structs sends them through scratch memory)
+    const bool is_s = t == TETRA_TRAIN_SYNC, is_1 = t == TETRA_TRAIN_NORM_1, is_2 = t == TETRA_TRAIN_NORM_2;
+    Pieces p;
+    p.off0 = is_s ? lut.sync.off0 : is_1 ? lut.norm1.off0 : is_2 ? lut.norm2.off0 : 0;
+    p.len0 = is_s ? lut.sync.len0 : is_1 ? lut.norm1.len0 : is_2 ? lut.norm2.len0 : 0;
+    p.off1 = is_s ? lut.sync.off1 : is_1 ? lut.norm1.off1 : is_2 ? lut.norm2.off1 : 0;
+    p.len1 = is_s ? lut.sync.len1 : is_1 ? lut.norm1.len1 : is_2 ? lut.norm2.len1 : 0;
+    reinterpret_cast<uint2*>(rows + (size_t)j * ((size_t)row_u * 8))[d] = demux_pair<true>(frames, r, p, d);
+    if (!GATHER && d == 0) valid[j] = p.len0 > 0;
+    }
+}
+inline PiecesLut lut_for(int tpsap, int blk_num) {
+    return PiecesLut{ pieces_for(TETRA_TRAIN_SYNC, tpsap, blk_num), pieces_for(TETRA_TRAIN_NORM_1, tpsap, blk_num),
+                      pieces_for(TETRA_TRAIN_NORM_2, tpsap, blk_num) };
 }
 
 size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 5 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
@@ -484,6 +523,13 @@ template <bool PACKED> int demux_launch(const void* d_frames_v, const int32_t* d
     if ((row_stride & 3) || ((uintptr_t)d_rows & 3)) return TETRA_ERR_ALIGN;
     if (PACKED && ((uintptr_t)d_frames & 3)) return TETRA_ERR_ALIGN;
     const bool wide = !(row_stride & 7) && !((uintptr_t)d_rows & 7);
+    if (PACKED && wide && row_stride <= 512) {           // whole rows per wavefront (k_demux_rows)
+        const int row_u = row_stride >> 3, rpw = 64 / row_u;
+        const long long waves = ((long long)n + rpw - 1) / rpw;
+        hipLaunchKernelGGL((k_demux_rows<false>), dim3((unsigned)((waves + 4 * kDemuxRowIters - 1) / (4 * kDemuxRowIters))), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames,
+                           d_frame_type, nullptr, nullptr, n, lut_for(tpsap, blk_num), row_u, rpw, (unsigned)((65536 + row_u - 1) / row_u), d_rows, d_valid);
+        return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+    }
     const long long total = (long long)n * (row_stride >> (wide ? 3 : 2));
     const dim3 grid((unsigned)((total + 255) / 256));
     if (wide) hipLaunchKernelGGL((k_burst_demux<PACKED, true>), grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames, d_frame_type, n,
@@ -517,7 +563,12 @@ template <bool PACKED> int demux_compact_launch(const void* d_frames_v, const in
     const bool wide = !(row_stride & 7) && !((uintptr_t)d_rows & 7);
     const long long total = (long long)n * (row_stride >> (wide ? 3 : 2));
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (wide) hipLaunchKernelGGL((k_demux_gather<PACKED, true>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
+    if (PACKED && wide && row_stride <= 512) {           // whole rows per wavefront (k_demux_rows), sized for the worst case of n rows
+        const int row_u = row_stride >> 3, rpw = 64 / row_u;
+        const long long waves = ((long long)n + rpw - 1) / rpw;
+        hipLaunchKernelGGL((k_demux_rows<true>), dim3((unsigned)((waves + 4 * kDemuxRowIters - 1) / (4 * kDemuxRowIters))), dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n,
+                           lut_for(tpsap, blk_num), row_u, rpw, (unsigned)((65536 + row_u - 1) / row_u), d_rows, nullptr);
+    } else if (wide) hipLaunchKernelGGL((k_demux_gather<PACKED, true>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
                                  blk_num, d_rows, row_stride);
     else hipLaunchKernelGGL((k_demux_gather<PACKED, false>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
                             blk_num, d_rows, row_stride);
