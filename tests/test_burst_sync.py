@@ -333,7 +333,10 @@ def test_gpu_packed_frames_path_equals_the_byte_path(pkg, ref):
                 assert np.array_equal(fp[c, k], want), (call, c, k)
             frames_seen += int(nf[c])
         n_all = Cn * F
-        for tp, blk, rs in ((0, 1, 120), (1, 2, 216), (2, 1, 216), (2, 2, 216), (3, 0, 32), (5, 0, 432)):
+        # row lengths: the blocks' own (whole rows per wavefront, k_demux_rows), padded rows (64 / 128 / 512 bytes: 8, 4 and 1 rows
+        # per wavefront; zeros behind the block), a 4-byte multiple and a row beyond 512 bytes (the thread-per-unit kernels)
+        for tp, blk, rs in ((0, 1, 120), (1, 2, 216), (2, 1, 216), (2, 2, 216), (3, 0, 32), (5, 0, 432),
+                            (0, 1, 128), (3, 0, 64), (5, 0, 512), (1, 2, 220), (5, 0, 520), (2, 1, 256)):
             r1 = torch.full((n_all, rs), 7, dtype=torch.uint8, device=dev)
             r2 = torch.full((n_all, rs), 8, dtype=torch.uint8, device=dev)
             v1 = torch.zeros(n_all, dtype=torch.int32, device=dev)
