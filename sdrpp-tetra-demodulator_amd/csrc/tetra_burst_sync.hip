@@ -351,20 +351,20 @@ template <bool GATHER> __global__ __launch_bounds__(256) void k_demux_rows(const
     const long long have = GATHER ? (long long)*n_rows : (long long)n;
 #pragma unroll
     for (int it = 0; it < kDemuxRowIters; ++it) {        // a few row groups per wavefront: a wave per 432 bytes is bound by the wave launch rate
-    const long long wave = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kDemuxRowIters + it;
-    const long long j = wave * rows_per_wave + lr;
-    if (j >= have) continue;
-    const int r = GATHER ? row_frame[j] : (int)j;
-    const int t = frame_type[r];
-    // field by field (selecting whole structs sends them through scratch memory)
-    const bool is_s = t == TETRA_TRAIN_SYNC, is_1 = t == TETRA_TRAIN_NORM_1, is_2 = t == TETRA_TRAIN_NORM_2;
-    Pieces p;
-    p.off0 = is_s ? lut.sync.off0 : is_1 ? lut.norm1.off0 : is_2 ? lut.norm2.off0 : 0;
-    p.len0 = is_s ? lut.sync.len0 : is_1 ? lut.norm1.len0 : is_2 ? lut.norm2.len0 : 0;
-    p.off1 = is_s ? lut.sync.off1 : is_1 ? lut.norm1.off1 : is_2 ? lut.norm2.off1 : 0;
-    p.len1 = is_s ? lut.sync.len1 : is_1 ? lut.norm1.len1 : is_2 ? lut.norm2.len1 : 0;
-    reinterpret_cast<uint2*>(rows + (size_t)j * ((size_t)row_u * 8))[d] = demux_pair<true>(frames, r, p, d);
-    if (!GATHER && d == 0) valid[j] = p.len0 > 0;
+        const long long wave = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kDemuxRowIters + it;
+        const long long j = wave * rows_per_wave + lr;
+        if (j >= have) continue;
+        const int r = GATHER ? row_frame[j] : (int)j;
+        const int t = frame_type[r];
+        // field by field (selecting whole structs sends them through scratch memory)
+        const bool is_s = t == TETRA_TRAIN_SYNC, is_1 = t == TETRA_TRAIN_NORM_1, is_2 = t == TETRA_TRAIN_NORM_2;
+        Pieces p;
+        p.off0 = is_s ? lut.sync.off0 : is_1 ? lut.norm1.off0 : is_2 ? lut.norm2.off0 : 0;
+        p.len0 = is_s ? lut.sync.len0 : is_1 ? lut.norm1.len0 : is_2 ? lut.norm2.len0 : 0;
+        p.off1 = is_s ? lut.sync.off1 : is_1 ? lut.norm1.off1 : is_2 ? lut.norm2.off1 : 0;
+        p.len1 = is_s ? lut.sync.len1 : is_1 ? lut.norm1.len1 : is_2 ? lut.norm2.len1 : 0;
+        reinterpret_cast<uint2*>(rows + (size_t)j * ((size_t)row_u * 8))[d] = demux_pair<true>(frames, r, p, d);
+        if (!GATHER && d == 0) valid[j] = p.len0 > 0;
     }
 }
 inline PiecesLut lut_for(int tpsap, int blk_num) {
