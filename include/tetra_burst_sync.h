@@ -112,7 +112,8 @@ int tetra_burst_demux_device(const uint8_t* d_frames, const int32_t* d_frame_typ
  * row 0 in frame order, d_row_frame[j] = index (into d_frames) of the frame row j came from, *d_n_rows = number of rows
  * (device memory; at most n).  With a real downlink three quarters of the frame slots do not carry a given kind, so the
  * decoder behind (tetra_lmac_decode_counted_device reads the count on the device) has a quarter of the rows to do.
- * Nothing is read back to the host; enqueued on hip_stream.
+ * Rows at and beyond *d_n_rows are unspecified (the head of d_rows serves as the call's scratch before the rows are written: no
+ * allocation, nothing but kernel launches on hip_stream).  Nothing is read back to the host; enqueued on hip_stream.
  */
 int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
                                      uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream);

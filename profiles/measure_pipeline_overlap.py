@@ -21,7 +21,8 @@ stride = pkg.binding.bits_stride(N)
 n_slots = SEC * N // 510 + 2
 iq_all = np.stack([pkg.synth.gen_channel(SEC * N, 4000 + c, bits=pkg.synth.gen_slot_bits(n_slots, c))[0] for c in range(DISTINCT)])
 d_iq = [torch.from_numpy(np.tile(iq_all[:, k * N:(k + 1) * N], (C // DISTINCT, 1))).to(dev) for k in range(SEC)]
-sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+PRIO = "prio" in sys.argv[1:]       # experiment: the demodulator's stream at high priority, the decoder side's at low
+sA, sB = (torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)) if PRIO else (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
 d = pkg.Demodulator(C, N)
 bs = bb.BurstSync(C, stride)
 F = bs.max_frames

@@ -555,8 +555,11 @@ template <bool PACKED> int demux_compact_launch(const void* d_frames_v, const in
     if (row_stride < longest) return TETRA_ERR_SIZE;
     if ((row_stride & 3) || ((uintptr_t)d_rows & 3)) return TETRA_ERR_ALIGN;
     const int nblocks = (n + 255) / 256;
-    int* off = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&off), sizeof(int) * (size_t)nblocks, s) != hipSuccess) return TETRA_ERR_NOMEM;
+    // the per-block counts / offsets of steps 1-3 live in the head of the row buffer itself (4 bytes per 256 frames of a buffer that
+    // holds at least 30 bytes per frame; 4-byte aligned): the gather, which overwrites it, runs after their last reader in stream
+    // order.  (Until round 5 a stream-ordered allocation per call: every so often the pool gave its memory back in between and one
+    // call took milliseconds.)
+    int* off = reinterpret_cast<int*>(d_rows);
     hipLaunchKernelGGL(k_demux_count, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off);
     hipLaunchKernelGGL(k_demux_scan, dim3(1), dim3(1024), 0, s, off, nblocks, d_n_rows);
     hipLaunchKernelGGL(k_demux_index, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off, d_row_frame);
@@ -572,9 +575,7 @@ template <bool PACKED> int demux_compact_launch(const void* d_frames_v, const in
                                  blk_num, d_rows, row_stride);
     else hipLaunchKernelGGL((k_demux_gather<PACKED, false>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
                             blk_num, d_rows, row_stride);
-    const hipError_t launch = hipGetLastError();
-    if (hipFreeAsync(off, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
-    return TETRA_OK;
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 }  // namespace
 

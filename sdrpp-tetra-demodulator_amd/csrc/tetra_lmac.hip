@@ -18,6 +18,8 @@
 // add/compare/select, VALU-bound.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/tetra_lmac.h"
 #include "lmac_core.hpp"
 
@@ -99,6 +101,31 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)(blk0 + q) * out_stride);
         for (int d = lane; d < out_dw; d += kLanes) dst[d] = spread4(((uint32_t)outw[d >> 2][q] >> (4 * (d & 3))) & 0xfu);
     }
+}
+
+// The decoder's decision scratch (up to 200 MB for a second of 4096 channels' SCH/F slots) comes from a stream-ordered pool of this
+// library's own, one per device, that KEEPS what is freed into it (release threshold = everything).  The device's default pool hands
+// unused memory back to the driver at synchronisation points; the next call then maps 200 MB again and takes milliseconds instead of
+// microseconds -- seen as one call in five at 20 ms in the two-stream chain (profiles/r05/README.md).
+std::mutex g_pool_mu;
+hipMemPool_t g_pool[64] = {};
+hipMemPool_t scratch_pool() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (!g_pool[dev]) {
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t p = nullptr;
+        if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
+        g_pool[dev] = p;
+    }
+    return g_pool[dev];
 }
 
 // TPSAP_T_BBK: the reference only descrambles (tetra_lower_mac.c:231-236); 30 bits per block, one lane per block.
@@ -236,13 +263,16 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
         hipLaunchKernelGGL(k_lmac_bbk, dim3((n_blocks + 255) / 256), dim3(256), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
                            p.type345, d_type2, out_stride, d_crc_ok, d_n_blocks, d_init_index);
     } else {
-        // decision scratch: (type2 + 4) steps x 64 lanes x u16 per workgroup, from the stream-ordered allocator (pooled:
-        // after the first call it is a free-list hit), released in stream order right behind the kernel
+        // decision scratch: (type2 + 4) steps x 64 lanes x u16 per workgroup, from the library's keeping pool (scratch_pool():
+        // after the first call a free-list hit), released in stream order right behind the kernel
         const int groups = (n_blocks + kLanes - 1) / kLanes;
         const int dec_steps = p.type2 + kFlush;
+        const size_t bytes = (size_t)groups * dec_steps * kLanes * sizeof(uint16_t);
         uint16_t* scratch = nullptr;
-        if (hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)groups * dec_steps * kLanes * sizeof(uint16_t), s) != hipSuccess)
-            return TETRA_ERR_NOMEM;
+        hipMemPool_t pool = scratch_pool();
+        const hipError_t got = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), bytes, pool, s)
+                                    : hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s);
+        if (got != hipSuccess) { (void)hipGetLastError(); return TETRA_ERR_NOMEM; }
         hipLaunchKernelGGL(k_lmac_decode, dim3(groups), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
                            type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride, d_crc_ok,
                            scratch, dec_steps, d_n_blocks, d_init_index);
