@@ -68,6 +68,10 @@ uint32_t tetra_lmac_scramb_init(uint16_t mcc, uint16_t mnc, uint8_t colour);
  *               4 and >= type2_bits)
  * d_crc_ok      [n_blocks] int32 out: the reference's tup->crc_ok (1/0)
  * Enqueued on hip_stream of the current device, no synchronisation.  n_blocks == 0 is a no-op.
+ * Memory: the Viterbi decisions of a launch (n_blocks x (type2_bits + 4) x 2 bytes) live in a scratch taken from, and returned in
+ * stream order to, a stream-ordered pool this library creates per device on first use and that keeps what is freed into it for
+ * the life of the process (at most the largest launch's scratch; the device's default pool would hand the memory back to the driver
+ * at every synchronisation point and map it again on the next call -- milliseconds).
  */
 int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_blocks, int in_stride,
                                    const uint32_t* d_scramb_init, uint8_t* d_type2, int out_stride, int32_t* d_crc_ok,
