@@ -1,7 +1,7 @@
 """Cost of the post-launch taps on the headline workload: k_fused alone vs + k_constellation vs + k_quality (HIP events of the handle)."""
 import json, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tetra_amd
 pkg = tetra_amd.pkg; B = pkg.binding
 C, N = 4096, 36000
