@@ -16,6 +16,7 @@
 
 #include "../../include/tetra_burst_sync.h"
 #include "bsync_core.hpp"
+#include "demux_core.hpp"
 
 namespace {
 
@@ -171,111 +172,17 @@ template <bool PACKED> __global__ __launch_bounds__(kThreadsBS) void k_burst_syn
     }
 }
 
-// which bits of a burst form the requested block: up to two pieces (offset, length) -- tetra_burst.c:33-49, :343-393
-struct Pieces { int off0, len0, off1, len1; };
-__host__ __device__ inline Pieces pieces_for(int train, int tpsap, int blk_num) {
-    Pieces p = { 0, 0, 0, 0 };
-    if (train == TETRA_TRAIN_SYNC) {
-        if (tpsap == TETRA_TPSAP_T_SB1 && blk_num == 1) p = { 94, 120, 0, 0 };
-        else if (tpsap == TETRA_TPSAP_T_BBK) p = { 252, 30, 0, 0 };
-        else if (tpsap == TETRA_TPSAP_T_SB2 && blk_num == 2) p = { 282, 216, 0, 0 };
-    } else if (train == TETRA_TRAIN_NORM_1 || train == TETRA_TRAIN_NORM_2) {
-        if (tpsap == TETRA_TPSAP_T_BBK) p = { 230, 14, 266, 16 };
-        else if (train == TETRA_TRAIN_NORM_2 && tpsap == TETRA_TPSAP_T_NDB && blk_num == 1) p = { 14, 216, 0, 0 };
-        else if (train == TETRA_TRAIN_NORM_2 && tpsap == TETRA_TPSAP_T_NDB && blk_num == 2) p = { 282, 216, 0, 0 };
-        else if (train == TETRA_TRAIN_NORM_1 && tpsap == TETRA_TPSAP_T_SCH_F) p = { 14, 216, 282, 216 };
-    }
-    return p;
-}
+using demux_core::Pieces;
+using demux_core::PiecesLut;
+using demux_core::pieces_for;
+using demux_core::lut_for;
 
-// four consecutive bits of a block (positions 4 d .. 4 d + 3 of its up to two pieces) as four bytes, first bit in the low byte.
-// PACKED: the frame is 16 words, first bit most significant (k_burst_sync<true>); else 512 bytes, one bit per byte.
-template <bool PACKED> __device__ __forceinline__ uint32_t demux_dword(const uint8_t* frames, int r, const Pieces& p, int d) {
-    uint32_t v = 0;
-    if (PACKED) {
-        const uint32_t* f = reinterpret_cast<const uint32_t*>(frames) + (size_t)r * TETRA_FRAME_WORDS;
-        const int i = 4 * d;
-        int x = -1;                                       // all four bits inside one piece: one 4-bit window of the packed row
-        if (i + 4 <= p.len0) x = p.off0 + i;
-        else if (i >= p.len0 && i + 4 <= p.len0 + p.len1) x = p.off1 + i - p.len0;
-        if (x >= 0) {
-            const int w = x >> 5;
-            const uint64_t two = ((uint64_t)f[w] << 32) | (w + 1 < TETRA_FRAME_WORDS ? f[w + 1] : 0u);
-            const uint32_t nib = (uint32_t)(two >> (60 - (x & 31))) & 0xfu;      // first bit = most significant
-            return ((nib >> 3) & 1u) | (((nib >> 2) & 1u) << 8) | (((nib >> 1) & 1u) << 16) | ((nib & 1u) << 24);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                      // a piece boundary or the block's end inside these four bits
-            const int ii = i + k;
-            const int xx = ii < p.len0 ? p.off0 + ii : (ii < p.len0 + p.len1 ? p.off1 + ii - p.len0 : -1);
-            if (xx >= 0) v |= ((f[xx >> 5] >> (31 - (xx & 31))) & 1u) << (8 * k);
-        }
-    } else {
-        const uint8_t* f = frames + (size_t)r * TETRA_FRAME_STRIDE;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 4 * d + k;
-            uint32_t byte = 0;
-            if (i < p.len0) byte = f[p.off0 + i];
-            else if (i < p.len0 + p.len1) byte = f[p.off1 + i - p.len0];
-            v |= byte << (8 * k);
-        }
-    }
-    return v;
-}
-
-// eight consecutive bits of a block (positions 8 d .. 8 d + 7) as eight bytes.  PACKED frames, all eight inside one piece (every
-// pair of the coded blocks: their pieces start and end on multiples of 8; all but two pairs of the BBK): ONE 8-bit window of the
-// packed row, spread with three 32-bit operations per half -- the counters showed the slot-layout demultiplexer bound by its vector
-// instructions, not by HBM (175 per 8 output bytes, profiles/r05/r05_k_chain_tail_counters.md).
-template <bool PACKED> __device__ __forceinline__ uint2 demux_pair(const uint8_t* frames, int r, const Pieces& p, int d) {
-    if (8 * d >= p.len0 + p.len1) return make_uint2(0u, 0u);      // behind the block -- or the frame does not carry the kind (three slots in four)
-    if (PACKED) {
-        const int i = 8 * d;
-        int x = -1;
-        if (i + 8 <= p.len0) x = p.off0 + i;
-        else if (i >= p.len0 && i + 8 <= p.len0 + p.len1) x = p.off1 + i - p.len0;
-        if (x >= 0) {
-            const uint32_t* f = reinterpret_cast<const uint32_t*>(frames) + (size_t)r * TETRA_FRAME_WORDS;
-            const int w = x >> 5;
-            const uint64_t two = ((uint64_t)f[w] << 32) | (w + 1 < TETRA_FRAME_WORDS ? f[w + 1] : 0u);
-            const uint32_t rep = ((uint32_t)(two >> (56 - (x & 31))) & 0xffu) * 0x01010101u;      // the byte in every byte; first bit = bit 7
-            // byte k of the result = bit 7 - k: keep that one bit per byte, then "non-zero byte -> 1" (+ 0x7f carries into bit 7 only)
-            const uint32_t lo = (((rep & 0x10204080u) + 0x7f7f7f7fu) >> 7) & 0x01010101u;
-            const uint32_t hi = (((rep & 0x01020408u) + 0x7f7f7f7fu) >> 7) & 0x01010101u;
-            return make_uint2(lo, hi);
-        }
-    }
-    return make_uint2(demux_dword<PACKED>(frames, r, p, 2 * d), demux_dword<PACKED>(frames, r, p, 2 * d + 1));
-}
-
-// global index -> (row, unit within the row) with a 32-bit division wherever the launch's index space allows it (a 64-bit division
-// by a run-time divisor costs ~100 vector instructions per thread)
-__device__ __forceinline__ bool demux_index_of(long long units_total, int row_u, int& r, int& d) {
-    if (units_total <= 0xffffff00ll) {
-        const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-        if (g >= (uint32_t)units_total) return false;
-        const uint32_t q = g / (uint32_t)row_u;
-        r = (int)q; d = (int)(g - q * (uint32_t)row_u);
-        return true;
-    }
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= units_total) return false;
-    r = (int)(gid / row_u); d = (int)(gid % row_u);
-    return true;
-}
-
+// The demultiplexer kernels: thread-level code in demux_core.hpp (shared with the host emulation).
 // one thread per output dword -- or, WIDE (rows a multiple of 8 bytes, 8-byte aligned), per pair of dwords: half the threads, 8-byte stores
 template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_burst_demux(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type, int n,
                                                      int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride,
                                                      int* __restrict__ valid) {
-    const int row_u = row_stride >> (WIDE ? 3 : 2);
-    int r, d;
-    if (!demux_index_of((long long)n * row_u, row_u, r, d)) return;
-    const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
-    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)r * row_stride)[d] = demux_pair<PACKED>(frames, r, p, d);
-    else reinterpret_cast<uint32_t*>(rows + (size_t)r * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
-    if (d == 0) valid[r] = p.len0 > 0;
+    demux_core::demux_thread<PACKED, WIDE>(blockIdx.x, threadIdx.x, frames, frame_type, n, tpsap, blk_num, rows, row_stride, valid);
 }
 
 // ---- compacting form of the demultiplexer: only frames that carry the block kind produce a row, in frame order ----
@@ -324,52 +231,16 @@ __global__ __launch_bounds__(256) void k_demux_index(const int* __restrict__ fra
 template <bool PACKED, bool WIDE> __global__ __launch_bounds__(256) void k_demux_gather(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type,
                                                       const int* __restrict__ row_frame, const int* __restrict__ n_rows, int n,
                                                       int tpsap, int blk_num, uint8_t* __restrict__ rows, int row_stride) {
-    const int row_u = row_stride >> (WIDE ? 3 : 2);
-    int j, d;
-    if (!demux_index_of((long long)n * row_u, row_u, j, d)) return;
-    if (j >= *n_rows) return;
-    const int r = row_frame[j];
-    const Pieces p = pieces_for(frame_type[r], tpsap, blk_num);
-    if (WIDE) reinterpret_cast<uint2*>(rows + (size_t)j * row_stride)[d] = demux_pair<PACKED>(frames, r, p, d);
-    else reinterpret_cast<uint32_t*>(rows + (size_t)j * row_stride)[d] = demux_dword<PACKED>(frames, r, p, d);
+    demux_core::gather_thread<PACKED, WIDE>(blockIdx.x, threadIdx.x, frames, frame_type, row_frame, *n_rows, n, tpsap, blk_num, rows, row_stride);
 }
 
-// PACKED frames, 8-byte row units, rows of at most 512 bytes (every block kind: 120 .. 432): a wavefront takes 64 / row_u whole rows
-// at a time -- lane -> (row, unit) by one multiply (no division by a run-time row length), the block's pieces picked from three
-// precomputed candidates (the kind is a launch argument; only the burst type differs per row), one 8-bit window per lane, and the
-// wave's stores cover R consecutive rows = one contiguous run.  GATHER: rows are the compacted ones (row j <- frame row_frame[j]).
-struct PiecesLut { Pieces sync, norm1, norm2; };
-constexpr int kDemuxRowIters = 4;
+// PACKED frames, 8-byte row units, rows of at most 512 bytes: whole rows per wavefront (demux_core::rows_thread).  GATHER: the compacted rows.
 template <bool GATHER> __global__ __launch_bounds__(256) void k_demux_rows(const uint8_t* __restrict__ frames, const int* __restrict__ frame_type,
                                                                          const int* __restrict__ row_frame, const int* __restrict__ n_rows, int n,
                                                                          PiecesLut lut, int row_u, int rows_per_wave, unsigned inv_row_u,
                                                                          uint8_t* __restrict__ rows, int* __restrict__ valid) {
-    const int lane = threadIdx.x & 63;
-    const int lr = (int)(((unsigned)lane * inv_row_u) >> 16);            // lane / row_u, exact for lane < 64 (inv = ceil(65536 / row_u))
-    const int d = lane - lr * row_u;
-    if (lr >= rows_per_wave) return;
     const long long have = GATHER ? (long long)*n_rows : (long long)n;
-#pragma unroll
-    for (int it = 0; it < kDemuxRowIters; ++it) {        // a few row groups per wavefront: a wave per 432 bytes is bound by the wave launch rate
-        const long long wave = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kDemuxRowIters + it;
-        const long long j = wave * rows_per_wave + lr;
-        if (j >= have) continue;
-        const int r = GATHER ? row_frame[j] : (int)j;
-        const int t = frame_type[r];
-        // field by field (selecting whole structs sends them through scratch memory)
-        const bool is_s = t == TETRA_TRAIN_SYNC, is_1 = t == TETRA_TRAIN_NORM_1, is_2 = t == TETRA_TRAIN_NORM_2;
-        Pieces p;
-        p.off0 = is_s ? lut.sync.off0 : is_1 ? lut.norm1.off0 : is_2 ? lut.norm2.off0 : 0;
-        p.len0 = is_s ? lut.sync.len0 : is_1 ? lut.norm1.len0 : is_2 ? lut.norm2.len0 : 0;
-        p.off1 = is_s ? lut.sync.off1 : is_1 ? lut.norm1.off1 : is_2 ? lut.norm2.off1 : 0;
-        p.len1 = is_s ? lut.sync.len1 : is_1 ? lut.norm1.len1 : is_2 ? lut.norm2.len1 : 0;
-        reinterpret_cast<uint2*>(rows + (size_t)j * ((size_t)row_u * 8))[d] = demux_pair<true>(frames, r, p, d);
-        if (!GATHER && d == 0) valid[j] = p.len0 > 0;
-    }
-}
-inline PiecesLut lut_for(int tpsap, int blk_num) {
-    return PiecesLut{ pieces_for(TETRA_TRAIN_SYNC, tpsap, blk_num), pieces_for(TETRA_TRAIN_NORM_1, tpsap, blk_num),
-                      pieces_for(TETRA_TRAIN_NORM_2, tpsap, blk_num) };
+    demux_core::rows_thread<GATHER>(blockIdx.x, threadIdx.x, frames, frame_type, row_frame, have, lut, row_u, rows_per_wave, inv_row_u, rows, valid);
 }
 
 size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 5 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
@@ -523,15 +394,13 @@ template <bool PACKED> int demux_launch(const void* d_frames_v, const int32_t* d
     if ((row_stride & 3) || ((uintptr_t)d_rows & 3)) return TETRA_ERR_ALIGN;
     if (PACKED && ((uintptr_t)d_frames & 3)) return TETRA_ERR_ALIGN;
     const bool wide = !(row_stride & 7) && !((uintptr_t)d_rows & 7);
-    if (PACKED && wide && row_stride <= 512) {           // whole rows per wavefront (k_demux_rows)
+    if (demux_core::use_rows_kernel(PACKED, wide, row_stride)) {           // whole rows per wavefront (k_demux_rows)
         const int row_u = row_stride >> 3, rpw = 64 / row_u;
-        const long long waves = ((long long)n + rpw - 1) / rpw;
-        hipLaunchKernelGGL((k_demux_rows<false>), dim3((unsigned)((waves + 4 * kDemuxRowIters - 1) / (4 * kDemuxRowIters))), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames,
+        hipLaunchKernelGGL((k_demux_rows<false>), dim3((unsigned)demux_core::rows_grid(n, row_stride)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames,
                            d_frame_type, nullptr, nullptr, n, lut_for(tpsap, blk_num), row_u, rpw, (unsigned)((65536 + row_u - 1) / row_u), d_rows, d_valid);
         return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
     }
-    const long long total = (long long)n * (row_stride >> (wide ? 3 : 2));
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const dim3 grid((unsigned)demux_core::units_grid(n, row_stride, wide));
     if (wide) hipLaunchKernelGGL((k_burst_demux<PACKED, true>), grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames, d_frame_type, n,
                                  tpsap, blk_num, d_rows, row_stride, d_valid);
     else hipLaunchKernelGGL((k_burst_demux<PACKED, false>), grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_frames, d_frame_type, n,
@@ -564,12 +433,10 @@ template <bool PACKED> int demux_compact_launch(const void* d_frames_v, const in
     hipLaunchKernelGGL(k_demux_scan, dim3(1), dim3(1024), 0, s, off, nblocks, d_n_rows);
     hipLaunchKernelGGL(k_demux_index, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, tpsap, blk_num, off, d_row_frame);
     const bool wide = !(row_stride & 7) && !((uintptr_t)d_rows & 7);
-    const long long total = (long long)n * (row_stride >> (wide ? 3 : 2));
-    const dim3 grid((unsigned)((total + 255) / 256));
-    if (PACKED && wide && row_stride <= 512) {           // whole rows per wavefront (k_demux_rows), sized for the worst case of n rows
+    const dim3 grid((unsigned)demux_core::units_grid(n, row_stride, wide));
+    if (demux_core::use_rows_kernel(PACKED, wide, row_stride)) {           // whole rows per wavefront (k_demux_rows), sized for the worst case of n rows
         const int row_u = row_stride >> 3, rpw = 64 / row_u;
-        const long long waves = ((long long)n + rpw - 1) / rpw;
-        hipLaunchKernelGGL((k_demux_rows<true>), dim3((unsigned)((waves + 4 * kDemuxRowIters - 1) / (4 * kDemuxRowIters))), dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n,
+        hipLaunchKernelGGL((k_demux_rows<true>), dim3((unsigned)demux_core::rows_grid(n, row_stride)), dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n,
                            lut_for(tpsap, blk_num), row_u, rpw, (unsigned)((65536 + row_u - 1) / row_u), d_rows, nullptr);
     } else if (wide) hipLaunchKernelGGL((k_demux_gather<PACKED, true>), grid, dim3(256), 0, s, d_frames, d_frame_type, d_row_frame, d_n_rows, n, tpsap,
                                  blk_num, d_rows, row_stride);

@@ -42,3 +42,68 @@ extern "C" int bsync_emul_process(State* st, uint8_t* carry, const uint8_t* bits
     for (int x = carry_x; x < xe; ++x) carry[x - carry_x] = (uint8_t)get_bit(s.data(), x);
     return overflow ? -1 : n;
 }
+
+// ---- the demultiplexer kernels (csrc/demux_core.hpp): every (workgroup, thread) of the launch tetra_burst_sync.hip's launchers would
+// make, in turn (threads descending inside a workgroup, workgroups ascending: no thread may depend on another's writes) -------------
+#include "../../sdrpp-tetra-demodulator_amd/csrc/demux_core.hpp"
+
+namespace {
+template <class F> void for_grid(long long blocks, F f) {
+    for (long long b = 0; b < blocks; ++b)
+        for (int t = demux_core::kThreads - 1; t >= 0; --t) f((uint32_t)b, (uint32_t)t);
+}
+}  // namespace
+
+// frames: [n][512] bytes or, packed != 0, [n][16] words.  Returns 0, or -1 for arguments the launchers refuse.
+extern "C" int bsync_emul_demux(const uint8_t* frames, int packed, const int32_t* frame_type, int n, int tpsap, int blk_num, uint8_t* rows,
+                                int row_stride, int32_t* valid) {
+    using namespace demux_core;
+    const PiecesLut lut = lut_for(tpsap, blk_num);
+    int longest = 0;
+    for (const Pieces* p : { &lut.sync, &lut.norm1, &lut.norm2 }) longest = p->len0 + p->len1 > longest ? p->len0 + p->len1 : longest;
+    if (longest == 0 || row_stride < longest || (row_stride & 3)) return -1;
+    const bool wide = !(row_stride & 7) && !((uintptr_t)rows & 7);
+    if (use_rows_kernel(packed != 0, wide, row_stride)) {
+        const int row_u = row_stride >> 3, rpw = 64 / row_u;
+        for_grid(rows_grid(n, row_stride), [&](uint32_t b, uint32_t t) {
+            rows_thread<false>(b, t, frames, frame_type, nullptr, n, lut, row_u, rpw, (uint32_t)((65536 + row_u - 1) / row_u), rows, valid);
+        });
+        return 0;
+    }
+    for_grid(units_grid(n, row_stride, wide), [&](uint32_t b, uint32_t t) {
+        if (packed && wide) demux_thread<true, true>(b, t, frames, frame_type, n, tpsap, blk_num, rows, row_stride, valid);
+        else if (packed) demux_thread<true, false>(b, t, frames, frame_type, n, tpsap, blk_num, rows, row_stride, valid);
+        else if (wide) demux_thread<false, true>(b, t, frames, frame_type, n, tpsap, blk_num, rows, row_stride, valid);
+        else demux_thread<false, false>(b, t, frames, frame_type, n, tpsap, blk_num, rows, row_stride, valid);
+    });
+    return 0;
+}
+
+// the compacting form: row_frame / n_rows as k_demux_count / _scan / _index leave them (frame order), then the gather
+extern "C" int bsync_emul_demux_compact(const uint8_t* frames, int packed, const int32_t* frame_type, int n, int tpsap, int blk_num,
+                                        uint8_t* rows, int row_stride, int32_t* row_frame, int32_t* n_rows) {
+    using namespace demux_core;
+    const PiecesLut lut = lut_for(tpsap, blk_num);
+    int longest = 0;
+    for (const Pieces* p : { &lut.sync, &lut.norm1, &lut.norm2 }) longest = p->len0 + p->len1 > longest ? p->len0 + p->len1 : longest;
+    if (longest == 0 || row_stride < longest || (row_stride & 3)) return -1;
+    int cnt = 0;
+    for (int r = 0; r < n; ++r)
+        if (pieces_for(frame_type[r], tpsap, blk_num).len0 > 0) row_frame[cnt++] = r;
+    *n_rows = cnt;
+    const bool wide = !(row_stride & 7) && !((uintptr_t)rows & 7);
+    if (use_rows_kernel(packed != 0, wide, row_stride)) {
+        const int row_u = row_stride >> 3, rpw = 64 / row_u;
+        for_grid(rows_grid(n, row_stride), [&](uint32_t b, uint32_t t) {
+            rows_thread<true>(b, t, frames, frame_type, row_frame, cnt, lut, row_u, rpw, (uint32_t)((65536 + row_u - 1) / row_u), rows, nullptr);
+        });
+        return 0;
+    }
+    for_grid(units_grid(n, row_stride, wide), [&](uint32_t b, uint32_t t) {
+        if (packed && wide) gather_thread<true, true>(b, t, frames, frame_type, row_frame, cnt, n, tpsap, blk_num, rows, row_stride);
+        else if (packed) gather_thread<true, false>(b, t, frames, frame_type, row_frame, cnt, n, tpsap, blk_num, rows, row_stride);
+        else if (wide) gather_thread<false, true>(b, t, frames, frame_type, row_frame, cnt, n, tpsap, blk_num, rows, row_stride);
+        else gather_thread<false, false>(b, t, frames, frame_type, row_frame, cnt, n, tpsap, blk_num, rows, row_stride);
+    });
+    return 0;
+}

@@ -8,7 +8,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbsync_emul.so")
-DEPS = [os.path.join(HERE, "bsync_emul.cpp"), os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "bsync_core.hpp")]
+DEPS = [os.path.join(HERE, "bsync_emul.cpp"), os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "bsync_core.hpp"),
+        os.path.join(ROOT, "sdrpp-tetra-demodulator_amd", "csrc", "demux_core.hpp"), os.path.join(ROOT, "include", "tetra_burst_sync.h")]
 
 _lib = None
 
@@ -49,3 +50,49 @@ class Emul:
                                     fr.ctypes.data_as(vp), ty.ctypes.data_as(vp), bn.ctypes.data_as(vp), cap, self.batch)
         assert n >= 0
         return fr[:n, :510].copy(), ty[:n].copy(), bn[:n].copy()
+
+
+def _lib_demux():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.bsync_emul_process.restype = C.c_int
+    return _lib
+
+
+def pack_frames(frames):
+    """[n][512] bytes (510 bits + 2 zero bytes) -> [n][16] uint32, first bit = most significant bit of word 0 (k_burst_sync<true>'s form)."""
+    f = np.ascontiguousarray(frames, np.uint8) & 1
+    return np.ascontiguousarray(np.packbits(f, axis=1).view(">u4").astype(np.uint32))
+
+
+def demux(frames, frame_type, tpsap, blk_num, row_stride, packed=False, fill=9):
+    """The thread-level code of tetra_burst_demux[_packed]_device run for every thread of its launch: (rows [n][row_stride], valid [n])."""
+    ft = np.ascontiguousarray(frame_type, np.int32)
+    n = ft.size
+    src = pack_frames(frames) if packed else np.ascontiguousarray(frames, np.uint8)
+    rows = np.full((n, row_stride), fill, np.uint8)
+    valid = np.full(n, fill, np.int32)
+    vp = C.c_void_p
+    rc = _lib_demux().bsync_emul_demux(src.ctypes.data_as(vp), int(packed), ft.ctypes.data_as(vp), n, tpsap, blk_num, rows.ctypes.data_as(vp),
+                                       row_stride, valid.ctypes.data_as(vp))
+    if rc:
+        raise ValueError("refused")
+    return rows, valid
+
+
+def demux_compact(frames, frame_type, tpsap, blk_num, row_stride, packed=False, fill=9):
+    """tetra_burst_demux_compact[_packed]_device: (rows [n][row_stride], row_frame [n], n_rows)."""
+    ft = np.ascontiguousarray(frame_type, np.int32)
+    n = ft.size
+    src = pack_frames(frames) if packed else np.ascontiguousarray(frames, np.uint8)
+    rows = np.full((n, row_stride), fill, np.uint8)
+    row_frame = np.full(n, -1, np.int32)
+    cnt = np.zeros(1, np.int32)
+    vp = C.c_void_p
+    rc = _lib_demux().bsync_emul_demux_compact(src.ctypes.data_as(vp), int(packed), ft.ctypes.data_as(vp), n, tpsap, blk_num,
+                                               rows.ctypes.data_as(vp), row_stride, row_frame.ctypes.data_as(vp), cnt.ctypes.data_as(vp))
+    if rc:
+        raise ValueError("refused")
+    return rows, row_frame, int(cnt[0])

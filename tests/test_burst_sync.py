@@ -170,6 +170,40 @@ def test_reference_state_machine_run_equals_restatement(ref, oracle):
     assert n_calls > 3000 and all(kinds.get(k, 0) > 100 for k in ((0, 1), (1, 2), (2, 1), (2, 2), (3, 0), (5, 0)))
 
 
+def test_demultiplexer_thread_code_equals_restated_rx_cb(oracle):
+    """csrc/demux_core.hpp built for the host: every (workgroup, thread) of the launches tetra_burst_demux[_packed]_device and
+    tetra_burst_demux_compact[_packed]_device make -- whole rows per wavefront for packed frames and 8-byte rows of at most 512 bytes
+    (k_demux_rows), one thread per 4 / 8 output bytes otherwise -- against the restated tetra_burst_rx_cb block split
+    (src/decoder/src/phy/tetra_burst.c:343-393): every kind and block number, the blocks' own row lengths, padded rows (zeros behind
+    the block), 4-byte multiples, rows beyond 512 bytes; frames of every burst type incl. the ones that carry nothing and unused
+    slots; byte and packed frames; slot layout (rows + validity) and compacted rows (frame order, count, index)."""
+    from tests.emul import bsync_emul_bind as E
+    rng = np.random.default_rng(55)
+    for n in (1, 63, 300, 1111):
+        types = rng.choice(np.array([0, 1, 2, 3, 4, -1, -2], np.int32), n)
+        frames = np.zeros((n, 512), np.uint8)
+        frames[:, :510] = rng.integers(0, 2, (n, 510))
+        for tpsap, blk, strides in ((0, 1, (120, 128, 124)), (1, 2, (216, 256, 220)), (2, 1, (216, 224)), (2, 2, (216, 512)),
+                                    (3, 0, (32, 64, 36)), (5, 0, (432, 512, 436, 520))):
+            want = [oracle.bsync_demux(frames[r], int(types[r]), tpsap, blk) if types[r] >= 0 else np.zeros(0, np.uint8) for r in range(n)]
+            carrying = [r for r in range(n) if want[r].size]
+            for stride in strides:
+                for packed in (False, True):
+                    rows, valid = E.demux(frames, types, tpsap, blk, stride, packed=packed)
+                    for r in range(n):
+                        assert valid[r] == (want[r].size > 0), (n, tpsap, blk, stride, packed, r)
+                        assert np.array_equal(rows[r, :want[r].size], want[r]) and not rows[r, want[r].size:].any(), (n, tpsap, blk, stride, packed, r)
+                    crows, cidx, cnt = E.demux_compact(frames, types, tpsap, blk, stride, packed=packed)
+                    assert cnt == len(carrying) and list(cidx[:cnt]) == carrying
+                    for j, r in enumerate(carrying):
+                        assert np.array_equal(crows[j, :want[r].size], want[r]) and not crows[j, want[r].size:].any(), (n, tpsap, blk, stride, packed, j)
+                    assert (crows[cnt:] == 9).all()          # rows past the count are not written by the gather
+    with pytest.raises(ValueError):
+        E.demux(frames, types, 0, 2, 436)                    # no burst carries SB1 as block 2
+    with pytest.raises(ValueError):
+        E.demux(frames, types, 5, 0, 216)                    # row too short for SCH/F
+
+
 def test_kernel_logic_equals_literal_state_machine(ref, oracle):
     """csrc/bsync_core.hpp built for the host (event-driven, bitmaps, literal fallback) == the literal restatement fed one
     bit per call: frames, types, bit numbers and the carried state after every call, for arbitrary call sizes."""
