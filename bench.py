@@ -198,28 +198,47 @@ def wideband_tetra(torch, synth, device, M, n_in, carriers, seed=5):
 
 
 def wideband_config5(args, torch, pkg, device, local_rank):
-    """BASELINE config 5 (informational, NOT the metric line): 20 MHz wideband capture -> 800 x 25 kHz channels
-    (2x oversampled, 50 ksps each) -> demodulator in time-major layout -> bits.  One step = 0.25 s of capture.  The capture
-    holds 16 TETRA carriers spread over the band (one at a negative frequency index, one at each band edge region) over a
+    """BASELINE config 5 (informational, NOT the metric line): 20 MHz wideband capture -> 800 x 25 kHz channels (2x oversampled
+    bank, 50 ksps each) -> 18 / 25 rational resampler -> 36 ksps -> demodulator created with the DEFAULT configuration = the plugin's
+    own operating point (VFO_SAMPLERATE 36000, 2 samples per symbol: /root/reference/src/main.cpp:35,75,84), time-major layout -> bits.
+    One step = 0.25 s of capture.  `--config5-rate 50000` keeps round 5's route (no resampler, the demodulator run at 50 ksps).
+    The capture holds 16 TETRA carriers spread over the band (one at a negative frequency index, one at each band edge region) over a
     noise floor; the known-answer check demodulates them back to their transmitted bits."""
     M, P, D = 800, 8, 400
     n_in = 5000000
     frames = n_in // D
+    rate = int(getattr(args, "config5_rate", 36000))
+    if rate not in (36000, 50000):
+        raise SystemExit("--config5-rate: 36000 (the plugin's rate, through the 18/25 resampler) or 50000 (the bank's own rate)")
+    resample = rate == 36000
     carriers = {k: 500 + i for i, k in enumerate((3, 57, 101, 150, 199, 250, 313, 377, 423, 480, 531, 590, 644, 700, 751, 797))}
     x, tx = wideband_tetra(torch, pkg.synth, device, M, n_in, carriers)
     ch = pkg.Channeliser(M, P, D, max_in=n_in, device=local_rank)
-    dem = pkg.Demodulator(M, frames, layout=pkg.binding.LAYOUT_TIME_MAJOR, device=local_rank, samplerate=50000.0)
+    rs = pkg.Resampler(M, 18, 25, 16, max_in=frames, device=local_rank) if resample else None
+    n_dem = frames * 18 // 25 if resample else frames          # 9000 frames at 36 ksps
+    if resample:
+        dem = pkg.Demodulator(M, n_dem + 1, layout=pkg.binding.LAYOUT_TIME_MAJOR, device=local_rank)            # default configuration
+    else:
+        dem = pkg.Demodulator(M, frames, layout=pkg.binding.LAYOUT_TIME_MAJOR, device=local_rank, samplerate=50000.0)
     out = torch.zeros((frames, M), dtype=torch.complex64, device=device)
-    stride = dem.bits_stride(frames)
+    out36 = [torch.zeros((n_dem + 1, M), dtype=torch.complex64, device=device) for _ in range(2)] if resample else None
+    stride = dem.bits_stride(n_dem + 1)
     bits = torch.zeros((M, stride), dtype=torch.uint8, device=device)
     nbits = torch.zeros(M, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream(device)
 
-    def step():
-        nf = ch.process_device(x, n_in, out, stream)
-        dem.process_device(out, nf, bits, stride, nbits, None, stream)
+    def front(dst50, dst36, s):
+        """channeliser (+ resampler) of one block on stream s; returns (frame buffer for the demodulator, frames in it)"""
+        nf = ch.process_device(x, n_in, dst50, s)
+        if not resample:
+            return dst50, nf
+        return dst36, rs.process_device(dst50, nf, dst36, s)
 
-    for _ in range(args.warmup + 4 * RAMP_STEPS):      # a step is ~1.5 ms: this many bring the shader clock to its steady value
+    def step():
+        buf, n = front(out, out36[0] if resample else None, stream)
+        dem.process_device(buf, n, bits, stride, nbits, None, stream)
+
+    for _ in range(args.warmup + 4 * RAMP_STEPS):      # a step is ~1 ms: this many bring the shader clock to its steady value
         step()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -229,8 +248,9 @@ def wideband_config5(args, torch, pkg, device, local_rank):
     el = time.perf_counter() - t0
     k1 = dem.kernel_ms_history(1)
     ch_ms = ch.last_kernel_ms()
-    # steady-state streaming: the channeliser works on block k+1 (its own stream, the other frame buffer) while the
-    # demodulator -- 800 channels = 50 of the 256 CUs -- is on block k
+    rs_ms = rs.last_kernel_ms() if resample else None
+    # steady-state streaming: the front-end works on block k+1 (its own stream, the other frame buffers) while the
+    # demodulator -- 800 channels = 200 of the 256 CUs, latency-bound -- is on block k
     s_ch, s_dem = torch.cuda.Stream(device), torch.cuda.Stream(device)
     outs = [out, torch.zeros_like(out)]
     ev_ch = [torch.cuda.Event() for _ in range(2)]
@@ -240,10 +260,10 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         b = k & 1
         if k >= 2:
             s_ch.wait_event(ev_dem[b])
-        nf = ch.process_device(x, n_in, outs[b], s_ch)
+        buf, n = front(outs[b], out36[b] if resample else None, s_ch)
         ev_ch[b].record(s_ch)
         s_dem.wait_event(ev_ch[b])
-        dem.process_device(outs[b], nf, bits, stride, nbits, None, s_dem)
+        dem.process_device(buf, n, bits, stride, nbits, None, s_dem)
         ev_dem[b].record(s_dem)
 
     torch.cuda.synchronize(device)
@@ -273,36 +293,52 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         check = dict(carriers=len(tx), bits_compared_second_half=int(ncmp), bit_errors=int(errs), idle_channels=len(idle))
         if ncmp < 2000 * len(tx) or errs > 1e-3 * ncmp:
             raise SystemExit("config 5 known-answer check failed: %d bit errors in %d bits of %d carriers" % (errs, ncmp, len(tx)))
-    # Rooflines of the leg's two kernels.  Channeliser: algorithmic bytes = the capture read once + the frames written once
+    # Rooflines of the leg's kernels.  Channeliser: algorithmic bytes = the capture read once + the frames written once
     # (8 B per wideband sample in, 8 B per channel-sample out) -- HBM is what bounds the kernel since round 5; algorithmic flops =
-    # the weighted overlap-add (L = P M taps, 4 flop each) + an M-point complex FFT (5 M log2 M), per frame.  Demodulator: 9 B per
-    # channel-sample.
+    # the weighted overlap-add (L = P M taps, 4 flop each) + an M-point complex FFT (5 M log2 M), per frame.  Resampler: every input
+    # frame read once, every output frame written once (8 B per channel-sample each way); 4 T flop per complex output.  Demodulator:
+    # 9 B per channel-sample.
+    def hbm(nbytes, ms, **extra):
+        d = {"achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": nbytes}
+        d.update(extra)
+        return d
+
     ch_bytes = 8.0 * n_in + 8.0 * frames * M
     ch_flop = frames * (4.0 * P * M + 5.0 * M * math.log2(M))
-    dm_bytes = ALGO_BYTES_PER_SAMPLE * frames * M
+    dm_bytes = ALGO_BYTES_PER_SAMPLE * n_dem * M
     roof = {"channeliser": {"kernel": "k_channelise_fft", "kernel_ms": round(ch_ms, 4), "bound": "hbm",
-                            "hbm": {"achieved": round(ch_bytes / (ch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(ch_bytes / (ch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": ch_bytes,
-                                    "achievable_gbs": 6290.0,
-                                    "frac_of_achievable": round(ch_bytes / (ch_ms * 1e-3) / 1e9 / 6290.0, 4)},
+                            "hbm": hbm(ch_bytes, ch_ms, achievable_gbs=6290.0, frac_of_achievable=round(ch_bytes / (ch_ms * 1e-3) / 1e9 / 6290.0, 4)),
                             "fp32": {"achieved": round(ch_flop / (ch_ms * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(ch_flop / (ch_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), "algorithmic_flop": ch_flop,
                                      "note": "32 x 5 x 5 mixed-radix FFT in registers / LDS (round 4: 25 x 32 matrix products, 9.5x the flops)"}},
-            "demodulator": {"kernel": "k_fused<.., 4>", "kernel_ms": round(float(k1[0]), 4),
-                            "hbm": {"achieved": round(dm_bytes / (float(k1[0]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(dm_bytes / (float(k1[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "demodulator": {"kernel": "k_fused<.., 4>", "kernel_ms": round(float(k1[0]), 4), "hbm": hbm(dm_bytes, float(k1[0])),
                             "note": "800 channels = 200 four-channel workgroups: 200 of the 256 CUs, each at the per-sample recurrence's pace"}}
+    if resample:
+        rs_bytes = 8.0 * frames * M + 8.0 * n_dem * M
+        rs_flop = 4.0 * 16 * n_dem * M
+        roof["resampler"] = {"kernel": "k_resample<18, 25, 16, 4>", "kernel_ms": round(rs_ms, 4), "bound": "hbm",
+                             "hbm": hbm(rs_bytes, rs_ms, achievable_gbs=6290.0, frac_of_achievable=round(rs_bytes / (rs_ms * 1e-3) / 1e9 / 6290.0, 4)),
+                             "fp32": {"achieved": round(rs_flop / (rs_ms * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(rs_flop / (rs_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), "algorithmic_flop": rs_flop}}
+    workload = ("5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> 18/25 resampler -> "
+                "800 ch x 9000 frames @ 36 ksps (the plugin's rate, default demodulator parameters) -> bits") if resample else \
+               "5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> bits (demodulator at 50 ksps)"
     res = {"metric": "wideband IQ Msamples/s channelised and demodulated to bits (BASELINE config 5)",
            "value": round(args.steps * n_in / el / 1e6, 2), "unit": "Msamples/s (20 MHz capture)",
            "ms_per_step": round(el / args.steps * 1e3, 3), "realtime_factor": round(args.steps * n_in / el / 20e6, 1),
-           "channeliser_kernel_ms": round(ch_ms, 3), "demod_kernel_ms": round(float(k1[0]), 3),
+           "channeliser_kernel_ms": round(ch_ms, 3), "resampler_kernel_ms": None if rs_ms is None else round(rs_ms, 4),
+           "demod_kernel_ms": round(float(k1[0]), 3),
            "two_streams_ms_per_step": round(el2 / args.steps * 1e3, 3),
            "two_streams_realtime_factor": round(args.steps * n_in / el2 / 20e6, 1),
            "check": check, "roofline": roof,
-           "config": {"workload": "5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> bits",
-                      "channels": M, "taps_per_channel": P, "decimation": D}}
-    del outs
+           "config": {"workload": workload, "channels": M, "taps_per_channel": P, "decimation": D, "channel_rate_sps": rate,
+                      "resampler": {"interp": 18, "decim": 25, "taps_per_phase": 16} if resample else None,
+                      "input_format": "complex64"}}
+    del outs, out36
     ch.close()
+    if rs is not None:
+        rs.close()
     dem.close()
     del x, out, bits, nbits
     return res
@@ -335,6 +371,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--config5", action="store_true",
                     help="run BASELINE config 5 instead (wideband -> channeliser -> 800-channel demod); informational")
+    ap.add_argument("--config5-rate", type=int, default=36000,
+                    help="per-channel rate the config 5 demodulator instances run at: 36000 (default: the plugin's VFO_SAMPLERATE, through "
+                         "the 18/25 resampler) or 50000 (the 2x oversampled bank's own rate, round 5's route)")
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the PCIe-inclusive host-path legs (tetra_demod_process / tetra_demod_process_async on page-locked "
                          "buffers; informational fields host_path_*, never the metric value)")

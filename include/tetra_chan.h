@@ -68,6 +68,61 @@ int tetra_chan_get_prototype(tetra_chan_t* h, float* proto);
 /* GPU time (ms) of the channeliser kernel of the most recent process call (HIP events on its stream). */
 int tetra_chan_last_kernel_ms(tetra_chan_t* h, float* ms);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Rational resampler I / DN on time-major frames (round 6).  The reference instance runs at VFO_SAMPLERATE 36000 with 2 samples per
+ * symbol (src/main.cpp:35,75,84): SDR++'s VFO hands every plugin instance a 36 ksps stream.  The 2 x oversampled bank above emits
+ * 50 ksps per channel, so config 5's 800 demodulator instances get their frames through an 18 / 25 polyphase resampler (SURVEY.md
+ * section 8(f) #1: "PFB at 50 ksps + 18/25 rational resampler per channel") and are then created with the DEFAULT demodulator
+ * configuration -- the plugin's own operating point.
+ *
+ *   y[m][c] = sum_{j < T} h[r_m + I j] * x[q_m - j][c],     I q_m + r_m = DN m,  0 <= r_m < I
+ *
+ * = zero-stuff by I, low-pass with the real prototype h (I*T taps, DC gain I), keep every DN-th sample; the same filter for every
+ * channel.  Output m exists as soon as frame q_m = floor(DN m / I) has arrived: a call that brings the stream to n frames leaves
+ * ceil(I n / DN) outputs emitted in total.  The T - 1 newest frames and the output position are carried across calls (results are
+ * independent of the chunking).  float32 arithmetic, held to a tolerance against the double-precision definition
+ * (oracle/chan_oracle.c: resamp_oracle_process), see tests/test_resamp.py.  18 / 25 with 8 / 12 / 16 / 24 taps per phase (and
+ * 2 / 3, 3 / 2, 1 / 2 with 8) run a kernel specialised at compile time; every other ratio or length a generic one.
+ * --------------------------------------------------------------------------------------------------------------------------- */
+typedef struct tetra_resamp_config {
+    int32_t n_channels;        /* C: complex channels per frame (row = C complex64) */
+    int32_t interp;            /* I  >= 1 (18) */
+    int32_t decim;             /* DN >= 1 (25) */
+    int32_t taps_per_phase;    /* T: prototype length I*T (2..64) */
+    int32_t max_in;            /* largest n_in (frames) of one process call */
+    int32_t device;            /* HIP device ordinal, -1 = current */
+    int32_t flags;             /* TETRA_RESAMP_FLAG_* */
+    int32_t reserved;          /* must be 0 */
+    double cutoff_rel;         /* prototype cutoff relative to the narrower Nyquist band min(in, out) / 2; default 1.0 */
+    double kaiser_beta;        /* Kaiser window parameter of the designed prototype; default 6.0 */
+    const float* prototype;    /* optional caller-supplied prototype [I*T] (replaces the designed one); NULL = Kaiser-windowed sinc */
+} tetra_resamp_config_t;
+
+enum {
+    TETRA_RESAMP_FLAG_GENERIC = 1,      /* keep the generic (run-time ratio) kernel where a specialised one exists; A/B and tests */
+    TETRA_RESAMP_FLAG_NARROW_UNITS = 2  /* one channel (8 bytes) per lane even where a row divides into 16-byte units (the default for
+                                          an even channel count); same results; A/B and tests */
+};
+
+typedef struct tetra_resamp tetra_resamp_t;
+
+int tetra_resamp_default_config(tetra_resamp_config_t* cfg);   /* 800 channels, 18 / 25, 16 taps per phase, cutoff 1.0, beta 6 */
+int tetra_resamp_create(const tetra_resamp_config_t* cfg, tetra_resamp_t** out);
+int tetra_resamp_destroy(tetra_resamp_t* h);
+/* Frames the next process call with n_in input frames will emit. */
+int tetra_resamp_frames_for(tetra_resamp_t* h, int n_in);
+/* d_in: [n_in][C] complex64 frames (device pointer, 16-byte aligned, read IN PLACE by the work enqueued here: it must stay untouched
+ * until that work has run); d_out: [>= tetra_resamp_frames_for(n_in)][C] complex64 (device pointer, 16-byte aligned, must not overlap
+ * d_in); *n_out receives the frame count.  Enqueued on hip_stream, no sync. */
+int tetra_resamp_process_device(tetra_resamp_t* h, const float* d_in, int n_in, float* d_out, int* n_out, void* hip_stream);
+/* Host-pointer variant: copies in, runs, copies out, synchronises. */
+int tetra_resamp_process(tetra_resamp_t* h, const float* in, int n_in, float* out, int* n_out);
+int tetra_resamp_reset(tetra_resamp_t* h);
+/* Copy of the prototype [I*T]. */
+int tetra_resamp_get_prototype(tetra_resamp_t* h, float* proto);
+/* GPU time (ms) of the resampler kernel of the most recent process call (HIP events on its stream). */
+int tetra_resamp_last_kernel_ms(tetra_resamp_t* h, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

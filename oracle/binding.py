@@ -368,6 +368,11 @@ def chan_lib():
         L.chan_oracle_process_channels.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                                    C.c_int, vp, vp, C.c_int, vp]
         L.chan_oracle_process_channels.restype = C.c_int
+        L.resamp_oracle_prototype.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
+        L.resamp_oracle_prototype.restype = None
+        L.resamp_oracle_process.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                            C.c_int, vp, vp]
+        L.resamp_oracle_process.restype = C.c_int
         _chan = L
     return _chan
 
@@ -393,6 +398,35 @@ class ChanOracle:
         out = np.zeros((max(nf, 1), ncol), np.complex64)
         got = chan_lib().chan_oracle_process_channels(self.M, self.P, self.D, _ptr(self.h), _ptr(self.hist), C.byref(self.phase),
                                                       C.byref(self.frame), x.shape[0], _ptr(x), _ptr(out), ncol, _ptr(sel))
+        return out[:got]
+
+
+class ResampOracle:
+    """Definition-level rational resampler I / DN on time-major frames [n][C] complex64, double-precision sums
+    (oracle/chan_oracle.c: resamp_oracle_process).  Carries the T - 1 newest frames and the output position."""
+
+    def __init__(self, C_, I=18, DN=25, T=16, cutoff_rel=1.0, beta=6.0, prototype=None):
+        self.C, self.I, self.DN, self.T = C_, I, DN, T
+        if prototype is not None:
+            self.h = np.ascontiguousarray(prototype, np.float32)
+            assert self.h.size == I * T
+        else:
+            self.h = np.zeros(I * T, np.float32)
+            chan_lib().resamp_oracle_prototype(I, DN, T, cutoff_rel, beta, _ptr(self.h))
+        self.hist = np.zeros((T - 1, C_), np.complex64)
+        self.n_total = C.c_int64(0)
+        self.m_next = C.c_int64(0)
+
+    def frames_for(self, n_in):
+        return int(((self.n_total.value + n_in) * self.I + self.DN - 1) // self.DN - self.m_next.value)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.complex64).reshape(-1, self.C)
+        n_out = self.frames_for(x.shape[0])
+        out = np.zeros((max(n_out, 1), self.C), np.complex64)
+        got = chan_lib().resamp_oracle_process(self.I, self.DN, self.T, _ptr(self.h), self.C, _ptr(self.hist), C.byref(self.n_total),
+                                               C.byref(self.m_next), x.shape[0], _ptr(x), _ptr(out))
+        assert got == n_out
         return out[:got]
 
 

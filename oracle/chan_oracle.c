@@ -116,3 +116,67 @@ int chan_oracle_process_channels(int M, int P, int D, const float* h, float* his
     free(br);
     return n_frames;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Rational resampler I / DN on time-major frames -- the DEFINITION the GPU kernel (csrc/tetra_resamp.hip) is checked against.
+ * The reference has no resampler either: SDR++'s VFO hands every plugin instance a 36 ksps stream (src/main.cpp:35,75,
+ * VFO_SAMPLERATE 36000; the demodulator is initialised with 2 samples per symbol, :84).  Config 5's bank emits 50 ksps per
+ * channel; SURVEY.md section 8(f) #1 names the 18 / 25 rational resampler that brings the frames to the plugin's rate.
+ * Textbook form, evaluated in double precision: zero-stuff by I, filter with h (I*T taps), keep every DN-th sample:
+ *
+ *   u[I k] = x[k], 0 elsewhere;   v[p] = sum_i h[i] u[p - i];   y[m] = v[DN m]
+ *   =>  y[m] = sum_{j < T} h[r + I j] x[q - j],   DN m = I q + r,  0 <= r < I.
+ * --------------------------------------------------------------------------------------------------------------------------- */
+/* Kaiser(beta)-windowed sinc at the zero-stuffed rate, cutoff fc = cutoff_rel / (2 max(I, DN)) cycles per sample there, DC gain I.
+ * Same formula as design_prototype in csrc/tetra_resamp.hip. */
+void resamp_oracle_prototype(int I, int DN, int T, double cutoff_rel, double beta, float* h) {
+    const int L = I * T;
+    const double fc = cutoff_rel / (2.0 * (double)(I > DN ? I : DN));
+    double sum = 0.0;
+    double* t = (double*)malloc(sizeof(double) * (size_t)L);
+    for (int l = 0; l < L; l++) {
+        const double u = (double)l - 0.5 * (double)(L - 1);
+        const double sinc = (u == 0.0) ? 2.0 * fc : sin(2.0 * CH_PI * fc * u) / (CH_PI * u);
+        const double r = L > 1 ? 2.0 * u / (double)(L - 1) : 0.0;
+        const double w = bessel_i0(beta * sqrt(1.0 - r * r > 0 ? 1.0 - r * r : 0.0)) / bessel_i0(beta);
+        t[l] = sinc * w;
+        sum += t[l];
+    }
+    for (int l = 0; l < L; l++) h[l] = (float)(t[l] / sum * (double)I);
+    free(t);
+}
+
+/* x: [n_in][C] complex frames; hist: the T - 1 frames before x[0] (oldest first; [T-1][C] complex), updated on return;
+ * *n_total = frames consumed before this call, *m_next = outputs emitted before it (both updated).  Emits every output m whose newest
+ * input frame floor(DN m / I) has arrived; out: [..][C] complex.  Returns the number of output frames. */
+int resamp_oracle_process(int I, int DN, int T, const float* h, int C, float* hist, int64_t* n_total, int64_t* m_next,
+                          int n_in, const float* x, float* out) {
+    const int64_t n0 = *n_total, n1 = n0 + n_in;
+    const int64_t m0 = *m_next, m1 = (n1 * I + DN - 1) / DN;
+    const int H = T - 1;
+    const size_t row = (size_t)C * 2;
+    /* linear buffer of rows: hist (H) + x */
+    float* br = (float*)malloc(sizeof(float) * row * (size_t)(H + n_in + 1));
+    memcpy(br, hist, sizeof(float) * row * (size_t)H);
+    if (n_in > 0) memcpy(br + row * (size_t)H, x, sizeof(float) * row * (size_t)n_in);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t m = m0; m < m1; m++) {
+        const int64_t q = ((int64_t)DN * m) / I;
+        const int r = (int)((int64_t)DN * m - q * I);
+        for (size_t f = 0; f < row; f++) {
+            double acc = 0.0;
+            for (int j = 0; j < T; j++) {
+                const int64_t bi = (q - j) - n0 + H;      /* >= 0: the delay line holds what an output of this call reaches back to */
+                acc += (double)h[r + I * j] * (double)br[row * (size_t)bi + f];
+            }
+            out[row * (size_t)(m - m0) + f] = (float)acc;
+        }
+    }
+    memcpy(hist, br + row * (size_t)n_in, sizeof(float) * row * (size_t)H);
+    *n_total = n1;
+    *m_next = m1;
+    free(br);
+    return (int)(m1 - m0);
+}

@@ -7,4 +7,4 @@ only builds it (build.py), binds it with ctypes (binding.py) and generates synth
 """
 from . import build, binding, chan_binding, scan_binding, lmac_binding, bsync_binding, synth, shard  # noqa: F401
 from .binding import Demodulator, TetraDemodError, load_library  # noqa: F401
-from .chan_binding import Channeliser  # noqa: F401
+from .chan_binding import Channeliser, Resampler  # noqa: F401
