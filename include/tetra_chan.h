@@ -33,7 +33,7 @@ typedef struct tetra_chan_config {
     int32_t decimation;        /* D >= 1 */
     int32_t max_in;            /* largest n_in of one process call */
     int32_t device;            /* HIP device ordinal, -1 = current */
-    int32_t reserved;          /* flags: TETRA_CHAN_FLAG_* (0 = default) */
+    int32_t reserved;          /* flags: TETRA_CHAN_FLAG_* (0 = default); any other bit: TETRA_ERR_ARG */
     double cutoff_rel;         /* prototype cutoff relative to half the channel spacing (1.0 = Fs/(2M)); default 1.2 */
     const float* prototype;    /* optional caller-supplied prototype [P*M]; NULL = Kaiser(beta 9)-windowed sinc */
 } tetra_chan_config_t;
@@ -54,7 +54,7 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out);
 int tetra_chan_destroy(tetra_chan_t* h);
 /* Frames the next process call with n_in samples will emit (depends on the carried sub-frame phase). */
 int tetra_chan_frames_for(tetra_chan_t* h, int n_in);
-/* x: n_in wideband complex64 samples (device pointer); out: [frames][M] complex64 (device pointer, capacity >=
+/* x: n_in wideband complex64 samples (device pointer, 8-byte aligned: TETRA_ERR_ALIGN otherwise, also for out); out: [frames][M] complex64 (device pointer, capacity >=
  * tetra_chan_frames_for(n_in) frames); *n_frames receives the frame count.  Enqueued on hip_stream, no sync: d_x is read by the
  * work enqueued here (at M = 800, D = M / 2 the kernel reads it IN PLACE -- no staging copy, every sample crosses HBM once -- and
  * the last L - 1 samples are copied into the handle's delay line behind it), so it must stay untouched until that work has run.

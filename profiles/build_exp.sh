@@ -5,6 +5,7 @@
 #   sh profiles/build_exp.sh <name> "<-D flags>" [ENV=VALUE ...]      -> profiles/dbg/lib_<name>.so
 # e.g. sh profiles/build_exp.sh rrc9   "-DTETRA_EXP_ABLATE=2"
 #      sh profiles/build_exp.sh nomid  ""  TETRA_EXP_FLL_NO_MIDDLE=1
+#      sh profiles/build_exp.sh chanexp "-DTETRA_CHAN_EXPERIMENTS"      (the channeliser's ablation switches 0x100 / 0x200 / 0x400 of cfg.reserved)
 #      sh profiles/build_exp.sh cores2 "-DTETRA_EXP_XRING=128 -DTETRA_EXP_YRING=64 -DTETRA_EXP_SRING=32" TETRA_EXP_XRING=128
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -21,6 +22,6 @@ if [ -n "$EXP_ABLATE_MASK" ]; then
     sed -i 's/TETRA_EXP_ABLATE == 1/(TETRA_EXP_ABLATE \& 1)/; s/TETRA_EXP_ABLATE == 2/(TETRA_EXP_ABLATE \& 2)/; s/TETRA_EXP_ABLATE == 3/(TETRA_EXP_ABLATE \& 4)/; s/TETRA_EXP_ABLATE == 4/(TETRA_EXP_ABLATE \& 8)/' "$C/kernel_fused.hpp"
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $FLAGS \
-    -fPIC -shared -o "$HERE/dbg/lib_$NAME.so" "$C/tetra_demod.hip" "$C/tetra_chan.hip" "$C/tetra_burst_scan.hip" "$C/tetra_lmac.hip" "$C/tetra_burst_sync.hip"
+    -fPIC -shared -o "$HERE/dbg/lib_$NAME.so" "$C/tetra_demod.hip" "$C/tetra_chan.hip" "$C/tetra_resamp.hip" "$C/tetra_burst_scan.hip" "$C/tetra_lmac.hip" "$C/tetra_burst_sync.hip" "$C/tetra_rx.hip"
 rm -rf "$D"
 echo "built $HERE/dbg/lib_$NAME.so"

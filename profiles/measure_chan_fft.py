@@ -1,5 +1,6 @@
 """A/B of k_channelise_fft variants (experiment switches in cfg.reserved) on config 5's geometry: alternating launches on steady
-clocks, median of HIP-event times.  Usage: python profiles/measure_chan_fft.py [flags ...] (default: 0 and 0x100)"""
+clocks, median of HIP-event times.  Usage: python profiles/measure_chan_fft.py [flags ...] (default: 0 and 0x100).  The switches
+exist only in a library built with -DTETRA_CHAN_EXPERIMENTS (profiles/build_exp.sh); the product library refuses them."""
 import json
 import os
 import sys

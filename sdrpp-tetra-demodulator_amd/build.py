@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtetra_demod_hip.so")
-SOURCES = ["tetra_demod.hip", "tetra_chan.hip", "tetra_resamp.hip", "tetra_burst_scan.hip", "tetra_lmac.hip", "tetra_burst_sync.hip"]
-DEPS = ["tetra_burst_sync.hip", "bsync_core.hpp", "demux_core.hpp", os.path.join("..", "..", "include", "tetra_burst_sync.h"), "tetra_demod.hip", "tetra_chan.hip", "chan_fft_core.hpp", "tetra_resamp.hip", "resamp_core.hpp", "tetra_burst_scan.hip", "tetra_lmac.hip", "lmac_core.hpp", os.path.join("..", "..", "include", "tetra_lmac.h"), os.path.join("..", "..", "include", "tetra_burst_scan.h"), "demod_core.hpp", "constellation_core.hpp", "design.hpp", "kernel_fused.hpp", "kernel_generic.hpp", "fll_asm.inc", "fll4_asm.inc", "fll16_asm.inc", "fll16l_asm.inc", "fll8l_asm.inc", "gen_fll_asm.py",
+SOURCES = ["tetra_demod.hip", "tetra_chan.hip", "tetra_resamp.hip", "tetra_burst_scan.hip", "tetra_lmac.hip", "tetra_burst_sync.hip", "tetra_rx.hip"]
+DEPS = ["tetra_rx.hip", os.path.join("..", "..", "include", "tetra_rx.h"), "tetra_burst_sync.hip", "bsync_core.hpp", "demux_core.hpp", os.path.join("..", "..", "include", "tetra_burst_sync.h"), "tetra_demod.hip", "tetra_chan.hip", "chan_fft_core.hpp", "tetra_resamp.hip", "resamp_core.hpp", "tetra_burst_scan.hip", "tetra_lmac.hip", "lmac_core.hpp", os.path.join("..", "..", "include", "tetra_lmac.h"), os.path.join("..", "..", "include", "tetra_burst_scan.h"), "demod_core.hpp", "constellation_core.hpp", "design.hpp", "kernel_fused.hpp", "kernel_generic.hpp", "fll_asm.inc", "fll4_asm.inc", "fll16_asm.inc", "fll16l_asm.inc", "fll8l_asm.inc", "gen_fll_asm.py",
         os.path.join("..", "..", "include", "tetra_demod.h"), os.path.join("..", "..", "include", "tetra_chan.h")]
 
 # -ffp-contract=off + correctly rounded sqrt: the arithmetic contract shared with the oracle.

@@ -423,6 +423,7 @@ template <bool PACKED> int demux_compact_launch(const void* d_frames_v, const in
     if (longest == 0) return TETRA_ERR_ARG;                      // no burst type carries this (kind, block number)
     if (row_stride < longest) return TETRA_ERR_SIZE;
     if ((row_stride & 3) || ((uintptr_t)d_rows & 3)) return TETRA_ERR_ALIGN;
+    if (PACKED && ((uintptr_t)d_frames & 3)) return TETRA_ERR_ALIGN;          // packed frames are read as 32-bit words (as demux_launch<true> checks)
     const int nblocks = (n + 255) / 256;
     // the per-block counts / offsets of steps 1-3 live in the head of the row buffer itself (4 bytes per 256 frames of a buffer that
     // holds at least 30 bytes per frame; 4-byte aligned): the gather, which overwrites it, runs after their last reader in stream

@@ -301,7 +301,14 @@ template <int P, int EXP = 0> __global__ __launch_bounds__(kThreads, 2) void k_c
     load_twiddles(c, tid, tw);
     {
         c32 x[32];
-        if (phase_fft32_compute(tid, lds, x)) phase_fft32_store(tid, lds, x);
+        const bool live = phase_fft32_compute(tid, lds, x);
+        // The transpose is IN PLACE: every lane of the frame's wavefront must have its 32 reads back before any lane writes.  The
+        // data dependence (each output needs all 32 inputs) already orders a lane's own accesses; the wave-level fence states the
+        // cross-lane half for the compiler (free on wave64: the lanes of a wavefront execute in lockstep).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (live) phase_fft32_store(tid, lds, x);
     }
     __syncthreads();
     phase_dft25_store<EXP>(c, (long long)kBlockFrames * blk, tid, lds, tw);
@@ -467,6 +474,13 @@ int tetra_chan_create(const tetra_chan_config_t* cfg, tetra_chan_t** out) {
     if (cfg->n_channels < 2 || cfg->taps_per_channel < 1 || cfg->taps_per_channel > 32 || cfg->decimation < 1 ||
         cfg->max_in < 1 || !(cfg->cutoff_rel > 0))
         return TETRA_ERR_ARG;
+    {   // only the documented flags: a stray bit must not select anything (the ablation switches exist in the profiling build only)
+        int known = TETRA_CHAN_FLAG_VALU_DFT | TETRA_CHAN_FLAG_MATRIX_DFT;
+#ifdef TETRA_CHAN_EXPERIMENTS
+        known |= 0x700;
+#endif
+        if (cfg->reserved & ~known) return TETRA_ERR_ARG;
+    }
     int n1, n2;
     if (!factor(cfg->n_channels, n1, n2)) return TETRA_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -527,6 +541,8 @@ int tetra_chan_frames_for(tetra_chan_t* h, int n_in) {
 int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream) {
     if (!h || (!d_x && n_in > 0) || !d_out || !n_frames) return TETRA_ERR_ARG;
     if (n_in < 0 || n_in > h->max_in) return TETRA_ERR_SIZE;
+    // complex64 elements are moved as 8-byte units (the FFT kernel reads d_x in place with 8-byte loads; every kernel stores so)
+    if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 7)) return TETRA_ERR_ALIGN;
     Guard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)hip_stream;
@@ -543,13 +559,23 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
         p.frames = frames; p.blocks = (frames + chanfft::kBlockFrames - 1) / chanfft::kBlockFrames; p.n_in = n_in;
         p.ph0 = h->phase; p.abs0 = h->consumed;
         // one block of 8 frames per workgroup: the hardware hands the next block to whichever CU is through first
-        p.xcd_span = (h->cfg.reserved & 0x100) ? 0 : (p.blocks + 7) / 8;      // (0x100: experiment switch, no remap)
-        p.exp = (h->cfg.reserved >> 9) & 3;                                      // (0x200: one store per lane instead of 25, 0x400: no inter-stage twiddles)
+        p.xcd_span = (p.blocks + 7) / 8;
+        p.exp = 0;
+#ifdef TETRA_CHAN_EXPERIMENTS
+        // Ablation switches of the profiling build ONLY (profiles/build_exp.sh defines the macro; the product library rejects these
+        // bits in tetra_chan_create): 0x100 no XCD remap, 0x200 one store per lane instead of 25, 0x400 no inter-stage twiddles --
+        // the last two produce WRONG spectra by design.
+        if (h->cfg.reserved & 0x100) p.xcd_span = 0;
+        p.exp = (h->cfg.reserved >> 9) & 3;
+#endif
         const dim3 grid(p.xcd_span > 0 ? 8 * p.xcd_span : p.blocks);
+#ifdef TETRA_CHAN_EXPERIMENTS
         if (h->P == 8 && p.exp == 1) hipLaunchKernelGGL((k_channelise_fft<8, 1>), grid, dim3(kThreads), 0, s, p);
         else if (h->P == 8 && p.exp == 2) hipLaunchKernelGGL((k_channelise_fft<8, 2>), grid, dim3(kThreads), 0, s, p);
         else if (h->P == 8 && p.exp == 3) hipLaunchKernelGGL((k_channelise_fft<8, 3>), grid, dim3(kThreads), 0, s, p);
-        else if (h->P == 8) hipLaunchKernelGGL(k_channelise_fft<8>, grid, dim3(kThreads), 0, s, p);
+        else
+#endif
+        if (h->P == 8) hipLaunchKernelGGL(k_channelise_fft<8>, grid, dim3(kThreads), 0, s, p);
         else if (h->P == 6) hipLaunchKernelGGL(k_channelise_fft<6>, grid, dim3(kThreads), 0, s, p);
         else hipLaunchKernelGGL(k_channelise_fft<4>, grid, dim3(kThreads), 0, s, p);
         CH_TRY(h, hipGetLastError());

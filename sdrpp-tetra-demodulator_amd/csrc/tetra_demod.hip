@@ -1365,13 +1365,26 @@ int tetra_demod_set_tables(tetra_demod_t* h, const float* rrc_taps, int n_rrc, c
         if (rc != TETRA_OK) return rc;
     }
     const int old_ntaps = h->design.ntaps;
+    // commit, upload -- and take the commit back if the upload fails: the handle never stays half-updated (its host-side design is
+    // what the next setter re-designs from and what get_tables reports)
+    const host::Design old_design = h->design;
+    const host::DesignParams old_dp = h->dp;
+    const bool old_user_rrc = h->user_rrc, old_user_be = h->user_be;
     h->dp = np;
     h->design = nd;
     if (rrc_taps) h->user_rrc = true;
     if (bandedge_taps) h->user_be = true;
     (void)sync_generic_scratch(h);
     int rc = upload_tables(h);
-    if (rc != TETRA_OK) return rc;
+    if (rc != TETRA_OK) {
+        h->dp = old_dp;
+        h->design = old_design;
+        h->user_rrc = old_user_rrc;
+        h->user_be = old_user_be;
+        (void)sync_generic_scratch(h);
+        (void)upload_tables(h);
+        return rc;
+    }
     if (h->quirks && nd.ntaps > old_ntaps) {
         // FIR::setTaps with more taps keeps the RRC's old taps-1 history samples and zero-fills the newly visible part
         hipLaunchKernelGGL(k_min_i32, dim3((h->C + 255) / 256), dim3(256), 0, 0, h->rrc_valid, old_ntaps - 1, h->C);

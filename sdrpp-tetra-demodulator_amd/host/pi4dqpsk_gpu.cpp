@@ -178,11 +178,15 @@ bool PI4DQPSK::tablesFromSdrpp() {
 
 // The tail of the three re-designing setters (pi4dqpsk.cpp:37-39, 49-51, 62-64): new RRC taps, FIR::setTaps.  In an SDR++ build
 // the taps come from SDR++'s taps::rootRaisedCosine and go in as a caller table; called with ctrlMtx held and the block stopped.
-void PI4DQPSK::redesignRRC() {
+int PI4DQPSK::redesignRRC(int tapCount, double beta) {
 #ifdef TETRA_WITH_SDRPP
-    const std::vector<float> rrcTaps = sdrpp_tables::rrc(_rrcTapCount, _rrcBeta, _symbolrate, _samplerate);
+    const std::vector<float> rrcTaps = sdrpp_tables::rrc(tapCount, beta, _symbolrate, _samplerate);
     const int rc = tetra_demod_set_tables(h_, rrcTaps.data(), (int)rrcTaps.size(), nullptr, 0, nullptr);
     if (status_ == TETRA_OK) status_ = rc;
+    return rc;
+#else
+    (void)tapCount; (void)beta;
+    return TETRA_OK;
 #endif
 }
 
@@ -193,7 +197,7 @@ void PI4DQPSK::setSymbolrate(double v) {
     std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
     base_type::tempStop();
     status_ = tetra_demod_set_param(h_, TETRA_PARAM_SYMBOLRATE, v);
-    if (status_ == TETRA_OK) { _symbolrate = v; redesignRRC(); }
+    if (status_ == TETRA_OK) { _symbolrate = v; redesignRRC(_rrcTapCount, _rrcBeta); }
     resizeBuffers();
     base_type::tempStart();
 }
@@ -202,7 +206,7 @@ void PI4DQPSK::setSamplerate(double v) {
     std::lock_guard<std::recursive_mutex> lck(base_type::ctrlMtx);
     base_type::tempStop();
     status_ = tetra_demod_set_param(h_, TETRA_PARAM_SAMPLERATE, v);
-    if (status_ == TETRA_OK) { _samplerate = v; redesignRRC(); }
+    if (status_ == TETRA_OK) { _samplerate = v; redesignRRC(_rrcTapCount, _rrcBeta); }
     resizeBuffers();
     base_type::tempStart();
 }
@@ -213,7 +217,11 @@ void PI4DQPSK::setRRCParams(int n, double beta) {
     base_type::tempStop();
 #ifdef TETRA_WITH_SDRPP
     if (n < 2 || n > TETRA_DEMOD_MAX_TAPS) status_ = TETRA_ERR_UNSUPPORTED;      // (the library's own limit; nothing changes)
-    else { status_ = TETRA_OK; _rrcTapCount = n; _rrcBeta = beta; redesignRRC(); }
+    else {
+        // the mirror's members follow the handle: committed only once the handle has taken the new table
+        status_ = TETRA_OK;
+        if (redesignRRC(n, beta) == TETRA_OK) { _rrcTapCount = n; _rrcBeta = beta; }
+    }
 #else
     status_ = tetra_demod_set_rrc_params(h_, n, beta);
     if (status_ == TETRA_OK) { _rrcTapCount = n; _rrcBeta = beta; }

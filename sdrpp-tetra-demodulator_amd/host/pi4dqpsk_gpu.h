@@ -148,7 +148,7 @@ public:
 private:
     void set(int id, double v);
     void resizeBuffers();
-    void redesignRRC();          // setSymbolrate / setSamplerate / setRRCParams: taps::rootRaisedCosine + rrc.setTaps (pi4dqpsk.cpp:38-39,50-51,63-64)
+    int redesignRRC(int tapCount, double beta);          // returns the status of the table hand-over; setSymbolrate / setSamplerate / setRRCParams: taps::rootRaisedCosine + rrc.setTaps (pi4dqpsk.cpp:38-39,50-51,63-64)
     // what the reference keeps for its re-designs (pi4dqpsk.h:76-79)
     double _symbolrate = 0, _samplerate = 0, _rrcBeta = 0;
     int _rrcTapCount = 0;
