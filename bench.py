@@ -20,7 +20,11 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 channel-major headline (informational);
   host_path_*   PCIe-inclusive rates of the host entry points (informational);
   large_batch   the same call with twice the channels on this GPU (32-channel workgroup shape; informational);
-  config5       BASELINE config 5 (20 MHz wideband -> channeliser -> 800 channels -> bits; informational; also --config5 alone).
+  config5       BASELINE config 5 (20 MHz wideband -> channeliser -> 18/25 resampler -> 800 channels at the plugin's 36 ksps -> bits;
+                informational; also --config5 alone);
+  chain         the receive chain behind one handle (include/tetra_rx.h) on coded downlinks: steady-state ms per second of 4096
+                channels on two streams / one stream, stage times with rooflines, CRC-good and exact-block counters (informational;
+                also --chain-only).
 """
 import argparse
 import json
@@ -37,7 +41,7 @@ if ROOT not in sys.path:
 
 CHANNELS_PER_GPU = 4096
 SAMPLES = 36000
-BASE_CHANNELS = 64
+CHECK_CHANNELS = 256               # channels of every rank's bank the known-answer check demodulates back to their transmitted bits
 ALGO_BYTES_PER_SAMPLE = 9.0
 HBM_PEAK_GBS = 8000.0
 # Useful arithmetic of the chain per input sample at 2 samples/symbol and 65 taps, an fma counted as 2 (DESIGN.md section 4
@@ -49,26 +53,12 @@ VALU_PEAK_TFLOPS = 157.3          # MI355X FP32 vector peak (MI355X_MICROARCH.md
 RAMP_STEPS = 8                    # untimed passes that bring the shader clock up before warm-up (see main)
 
 
-def make_input(torch, synth, device, n_channels, n_samples, seed):
-    """Synthetic batch in HBM: BASE_CHANNELS independently modulated channels (numpy generator),
-    expanded on the GPU to n_channels by a per-channel amplitude, carrier offset and phase."""
-    base, txb, prm = synth.gen_batch(BASE_CHANNELS, n_samples, base_seed=seed, cfo=None, amp=1.0)
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    amp = torch.empty(n_channels).uniform_(0.05, 1.0, generator=g)
-    dw = torch.empty(n_channels).uniform_(-0.01, 0.01, generator=g)
-    ph = torch.empty(n_channels).uniform_(-3.14159, 3.14159, generator=g)
-    b = torch.from_numpy(base).to(device)
-    idx = torch.arange(n_channels, device=device) % BASE_CHANNELS
-    n = torch.arange(n_samples, device=device, dtype=torch.float64)
-    out = torch.empty((n_channels, n_samples), dtype=torch.complex64, device=device)
-    step = 256
-    for c0 in range(0, n_channels, step):
-        c1 = min(n_channels, c0 + step)
-        arg = dw[c0:c1, None].to(device).double() * n[None, :] + ph[c0:c1, None].to(device).double()
-        rot = torch.polar(amp[c0:c1, None].to(device).double().expand_as(arg).contiguous(), arg).to(torch.complex64)
-        out[c0:c1] = b[idx[c0:c1]] * rot
-    return out, txb
+def make_input(torch, pkg, device, n_channels, n_samples, seed):
+    """Synthetic batch in HBM, every channel from its OWN seed (seed + channel index; BASELINE.md's generator): bits and channel
+    parameters (carrier offset, timing offset, amplitude, phase) are a hash of (channel seed, position), shaped and rotated on the
+    GPU in float64 (synth_gpu.gen_bank = synth.gen_channel's signal model), AWGN at Es/N0 25 dB.  Returns (iq [C][N] complex64 on
+    device, seeds int64 [C]); synth.hash_bits(seeds[c], ..) regenerates channel c's transmitted bits on the CPU."""
+    return pkg.synth_gpu.gen_bank(torch, device, n_channels, n_samples, seed)
 
 
 KERNEL_SOURCES = ("kernel_fused.hpp", "demod_core.hpp", "fll_asm.inc", "fll4_asm.inc", "fll16_asm.inc", "fll16l_asm.inc", "fll8l_asm.inc")      # what k_fused is compiled from (+ the flags below)
@@ -344,6 +334,130 @@ def wideband_config5(args, torch, pkg, device, local_rank):
     return res
 
 
+CHAIN_DISTINCT = 64          # distinct coded downlinks (cells) of the chain leg, each used for C / 64 channels with its own rotation
+
+
+def receive_chain(args, torch, pkg, device, local_rank, C=CHANNELS_PER_GPU, N=SAMPLES, seconds=4):
+    """The receive chain behind the demodulator, through the ONE handle of include/tetra_rx.h (informational, NOT the metric line):
+    IQ -> demodulator || burst synchroniser -> SB1 -> SYNC-PDU tracker -> compact demux + counted decode of every block kind ->
+    labelled type-1 blocks (reference: tetra_burst_sync_in -> tetra_burst_rx_cb -> tp_sap_udata_ind, phy/tetra_burst_sync.c:54-155,
+    phy/tetra_burst.c:343-393, lower_mac/tetra_lower_mac.c:148-275).  Input: CODED continuous downlinks (synth.gen_downlink: SYNC
+    bursts with SB1 + AACH + SB2, two-channel normal bursts with NDB 1 + 2, one-channel normal bursts with SCH/F; every block carries
+    a CRC and its type-1 bits are known), CHAIN_DISTINCT cells x C / CHAIN_DISTINCT channels each with its own amplitude, carrier
+    offset and phase; `seconds` consecutive blocks of N samples per channel resident in HBM, streamed round and round with the state
+    carried.  Reports steady-state ms per block (= per second of C channels) with the tail overlapped on its own stream and on one
+    stream, the stage times of the one-stream run with their rooflines, and the known-answer counters of the last block."""
+    R, synth = pkg.rx_binding, pkg.synth
+    n_slots = seconds * N // 510 + 2
+    cells = [(200 + c, 3000 + 7 * c, (11 * c + 5) % 64) for c in range(CHAIN_DISTINCT)]
+    down = [synth.gen_downlink(n_slots, 7000 + c, cell=cells[c]) for c in range(CHAIN_DISTINCT)]
+    nb = synth.needed_bits(seconds * N)
+    bits = np.zeros((CHAIN_DISTINCT, nb), np.uint8)
+    for c in range(CHAIN_DISTINCT):
+        bits[c, : min(nb, down[c][0].size)] = down[c][0][:nb]
+    seeds = torch.arange(CHAIN_DISTINCT, dtype=torch.int64, device=device) + 31000
+    prm = pkg.synth_gpu.hash_params(torch, device, seeds)
+    one = torch.ones(CHAIN_DISTINCT, dtype=torch.float64, device=device)
+    base = pkg.synth_gpu.modulate_batch(torch, device, torch.from_numpy(bits).to(device), seconds * N, prm["tau"], 0 * one, one, 0 * one,
+                                        esn0_db=25.0, noise_seed=31000)          # unit amplitude, no rotation: applied per channel below
+    g = torch.Generator(device="cpu")
+    g.manual_seed(31001)
+    amp = torch.empty(C).uniform_(0.05, 1.0, generator=g).to(device).double()
+    dw = torch.empty(C).uniform_(-0.05, 0.05, generator=g).to(device).double()
+    ph = torch.empty(C).uniform_(-3.14159, 3.14159, generator=g).to(device).double()
+    idx = torch.arange(C, device=device) % CHAIN_DISTINCT
+    n = torch.arange(seconds * N, device=device, dtype=torch.float64)
+    d_iq = [torch.empty((C, N), dtype=torch.complex64, device=device) for _ in range(seconds)]
+    for c0 in range(0, C, 256):
+        c1 = min(C, c0 + 256)
+        rot = torch.polar(amp[c0:c1, None].expand(-1, seconds * N).contiguous(), dw[c0:c1, None] * n[None, :] + ph[c0:c1, None]).to(torch.complex64)
+        x = base[idx[c0:c1]] * rot
+        for k in range(seconds):
+            d_iq[k][c0:c1] = x[:, k * N:(k + 1) * N]
+    del base, x, rot
+    stream = torch.cuda.current_stream(device)
+    res = {"channels": C, "samples_per_channel": N, "blocks_resident": seconds,
+           "workload": "%d coded downlinks (cells) x %d channels each with its own amplitude / carrier offset / phase; every slot a burst: "
+                       "SYNC (SB1 + AACH + SB2) / NORM_2 (NDB 1 + 2 + AACH) / NORM_1 (SCH/F + AACH) x 2 per four slots; Es/N0 25 dB" % (CHAIN_DISTINCT, C // CHAIN_DISTINCT)}
+    reps = 2 * seconds
+
+    def run(rx, n_calls):
+        for k in range(n_calls):
+            rx.process_device(d_iq[k % seconds], N, stream)
+
+    stage = None
+    for name, flags in (("two_streams", 0), ("one_stream", R.FLAG_ONE_STREAM)):
+        rx = pkg.RxChain(C, N, device=local_rank, flags=flags)
+        run(rx, seconds + 2)                      # locks the loops and the synchronisers, fills the allocator pools, ramps the clock
+        rx.wait()
+        t0 = time.perf_counter()
+        run(rx, reps)
+        rx.wait()
+        ms = (time.perf_counter() - t0) * 1e3 / reps
+        res[name + "_ms_per_second"] = round(ms, 3)
+        res[name + "_x_real_time"] = round(1000.0 / ms, 1)
+        if flags:
+            stage = rx.stage_ms()
+        else:
+            # known answer on the last block of the overlapped run: every decoded block of every channel has a good CRC, and on the
+            # CHAIN_DISTINCT distinct streams the type-1 bits are those sent in the slot the block's TDMA time names
+            names = {R.KIND_SB1: "sb1", R.KIND_BBK: "bbk", R.KIND_SB2: "sb2", R.KIND_NDB1: "ndb1", R.KIND_NDB2: "ndb2", R.KIND_SCH_F: "schf"}
+            by_time = {}
+            for sl in range(n_slots):
+                tn, fn, mn = synth.tdma_time_of_slot(sl)
+                by_time[tn | fn << 8 | mn << 16] = sl
+            counters, rows_k = {}, {}
+            bad = 0
+            for k, nm in names.items():
+                blocks, t1 = rx.fetch(k)
+                rows_k[k] = len(blocks)
+                good = int((blocks["crc_ok"] != 0).sum())
+                sel = np.nonzero(blocks["channel"] < CHAIN_DISTINCT)[0]
+                exact = 0
+                sent = [{sl: v.tobytes() for sl, v in down[c][1][nm]} for c in range(CHAIN_DISTINCT)]
+                for j in sel:
+                    sl = by_time.get(int(blocks["tdma_time"][j]))
+                    exact += int(sl is not None and sent[int(blocks["channel"][j])].get(sl) == t1[j].tobytes())
+                counters[nm] = {"rows": len(blocks), "crc_good": good, "checked_rows": int(len(sel)), "type1_bits_and_tdma_slot_exact": exact}
+                bad += (len(blocks) - good) + (len(sel) - exact)
+            cellok = sum(1 for c, st in enumerate(rx.cells()) if (st.mcc, st.mnc, st.colour_code) == cells[c % CHAIN_DISTINCT])
+            locked = sum(1 for st in rx.sync_states() if st[0] == 2)
+            res["check"] = {"blocks": counters, "channels_locked": locked, "cells_read": cellok, "channels": C}
+            if bad or cellok != C or locked != C:
+                raise SystemExit("receive chain known-answer check failed: %s" % json.dumps(res["check"]))
+            res["rows_per_kind"] = {names[k]: v for k, v in rows_k.items()}
+        rx.close()
+    # Rooflines of the one-stream run's stages.  Bytes: demodulator 9 B per sample; synchroniser = the bit rows it scans + 64 B per
+    # packed frame + 8 B per frame slot; SB1 stage and the other kinds = per decoded row the packed frame window read (in / 8), the
+    # type-5 row written and read (2 x in), type-2 row + crc + label written (out + 28) + 4 B per frame slot and kind for the types;
+    # the decoder's add-compare-select recursion is integer vector work: trellis steps x 68 instructions per 64-block wave (its own
+    # model, DESIGN.md 8.3) against the chip's issue peak 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks = 614 G wave-instructions / s.
+    F = (4096 + pkg.binding.bits_stride(N)) // 510 + 2
+    geo = {"sb1": (120, 80, 84), "bbk": (32, 32, 0), "sb2": (216, 144, 148), "ndb1": (216, 144, 148), "ndb2": (216, 144, 148), "schf": (432, 288, 292)}
+    rows = res["rows_per_kind"]
+
+    def kind_bytes(nm):
+        i, o, _ = geo[nm]
+        return rows[nm] * (i / 8.0 + 2.0 * i + o + 28.0) + 4.0 * C * F
+
+    frames = sum(rows[k] for k in ("sb1", "ndb1", "schf"))          # every frame with a callback carries exactly one of these
+    by = [9.0 * C * N, float(C * N) + 64.0 * frames + 8.0 * C * F, kind_bytes("sb1") + 80.0 * rows["sb1"],
+          sum(kind_bytes(k) for k in geo if k != "sb1")]
+    steps = [0, 0, rows["sb1"] * geo["sb1"][2], sum(rows[k] * geo[k][2] for k in geo if k != "sb1")]
+    stages = {}
+    for i, nm in enumerate(("demodulator", "burst_sync", "sb1_demux_decode_track", "other_kinds_demux_decode_label")):
+        d = {"ms": round(stage[i], 4), "algorithmic_bytes": round(by[i]), "GBps": round(by[i] / (stage[i] * 1e-3) / 1e9, 1),
+             "frac_hbm_8TBps": round(by[i] / (stage[i] * 1e-3) / 8e12, 4)}
+        if steps[i]:
+            wi = 68.0 * steps[i] / 64.0
+            d.update(trellis_steps=int(steps[i]), frac_valu_issue_614G=round(wi / (stage[i] * 1e-3) / 614.4e9, 4), bound="valu-issue (integer add-compare-select)")
+        stages[nm] = d
+    res["stages_one_stream"] = stages
+    res["tail_ms_one_stream"] = round(sum(stage[1:]), 4)
+    del d_iq
+    return res
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command under
     torch.distributed.run (one process per GPU; on a box with fewer GPUs than ranks they share -- functional runs only) and
@@ -382,9 +496,11 @@ def main():
                     help="skip the informational BASELINE config 5 leg (wideband -> channeliser -> 800-channel demod, field config5)")
     ap.add_argument("--no-large-batch", action="store_true",
                     help="skip the informational leg with twice the channels per GPU (32-channel workgroup shape, field large_batch)")
-    ap.add_argument("--chain", action="store_true",
-                    help="also run the device-resident receive chain behind the demodulator (burst synchroniser -> demultiplexer "
-                         "-> lower-MAC decoder; profiles/measure_pipeline*.py) and attach its timings as \"chain\" (informational)")
+    ap.add_argument("--chain", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="skip the informational receive-chain leg (include/tetra_rx.h: demodulator || synchroniser -> demultiplexer -> "
+                         "lower-MAC decoder -> SYNC-PDU tracker on coded downlinks; field chain)")
+    ap.add_argument("--chain-only", action="store_true", help="run the receive-chain leg alone and print its object (profiling)")
     ap.add_argument("--force-dist", action="store_true",
                     help="build the torch.distributed group even for ONE rank: runs the RCCL set-up, barrier and MAX reduction of the "
                          "N > 1 path on a one-GPU box (RCCL refuses several ranks on one device, so this is how its half is exercised there)")
@@ -442,12 +558,15 @@ def main():
     if args.config5:
         print(json.dumps(wideband_config5(args, torch, pkg, device, local_rank)))
         return
+    if args.chain_only:
+        print(json.dumps(receive_chain(args, torch, pkg, device, local_rank)))
+        return
     C, N = args.channels, args.samples
     # rank r demodulates global channels [r*C, (r+1)*C) of a (world*C)-channel bank: independent channels,
     # per-GPU ranges, nothing exchanged on the data path
     ch_lo, ch_hi = pkg.shard.channel_range(C * world, world, rank)
     assert ch_hi - ch_lo == C
-    iq, txb = make_input(torch, pkg.synth, device, C, N, seed=20260000 + ch_lo)
+    iq, seeds = make_input(torch, pkg, device, C, N, seed=20260000 + ch_lo)
     stride = pkg.binding.bits_stride(N)
     bits = torch.zeros((C, stride), dtype=torch.uint8, device=device)
     nbits = torch.zeros(C, dtype=torch.int32, device=device)
@@ -493,11 +612,13 @@ def main():
         dem.reset()
         step()
         torch.cuda.synchronize(device)
-        hb = bits[:: max(1, C // 32)].cpu().numpy()
-        hn = nbits[:: max(1, C // 32)].cpu().numpy()
+        every = max(1, C // CHECK_CHANNELS)
+        hb = bits[::every].cpu().numpy()
+        hn = nbits[::every].cpu().numpy()
         errs, ncmp = 0, 0
-        for j, c in enumerate(range(0, C, max(1, C // 32))):
-            lag, e, n = pkg.synth.align_and_count_errors(hb[j][: hn[j]], txb[c % BASE_CHANNELS], skip=3 * hn[j] // 4)
+        for j, c in enumerate(range(0, C, every)):
+            txb = pkg.synth.hash_bits(int(seeds[c]), pkg.synth.needed_bits(N))          # channel c's own stream, regenerated from its seed
+            lag, e, n = pkg.synth.align_and_count_errors(hb[j][: hn[j]], txb, skip=3 * hn[j] // 4, max_lag=160)
             errs += e
             ncmp += n
         bad = int(errs > 1e-3 * ncmp or ncmp == 0)
@@ -645,8 +766,8 @@ def main():
             "warmup": args.warmup, "ramp_steps": RAMP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%d channels/GPU x %d complex64 samples (1 s @ 36 ksps), 65-tap RRC, "
-                                   "pi/4-DQPSK Es/N0 25 dB, state carried" % (C, N),
+            "config": {"workload": "%d channels/GPU x %d complex64 samples (1 s @ 36 ksps), 65-tap RRC, pi/4-DQPSK Es/N0 25 dB, every "
+                                   "channel from its own seed (bits, carrier / timing offset, amplitude, phase), state carried" % (C, N),
                        "channels_per_gpu": C, "samples_per_channel": N, "sharding": "channel ranges, no collective",
                        "pipeline": "fused"},
             "roofline": {"bound": "hbm", "kernel": "k_fused",
@@ -684,19 +805,12 @@ def main():
                 out["dist_backend_note"] = backend_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_baseline_fast"] = cpu_baseline(pkg.synth, N)
-        if args.chain and world == 1:
+        if not args.no_chain and world == 1 and C == CHANNELS_PER_GPU:
             if dem is not None:
                 dem.close()
             dem = None
-            import subprocess
-            chain = {}
-            # (frames handed on PACKED, 16 words per frame: the on-device chain's form since round 5; "stages_byte_frames" = round 4's)
-            for key, script, extra in (("stages", "measure_pipeline.py", ["packed"]), ("stages_byte_frames", "measure_pipeline.py", []),
-                                       ("overlapped", "measure_pipeline_overlap.py", ["packed"])):
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", script)] + extra, capture_output=True, text=True)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                chain[key] = json.loads(lines[-1]) if lines else {"error": r.stderr[-300:]}
-            out["chain"] = chain
+            del iq, bits, nbits
+            out["chain"] = receive_chain(args, torch, pkg, device, local_rank)      # informational, after the timed region
         print(json.dumps(out))
     if dem is not None:
         dem.close()

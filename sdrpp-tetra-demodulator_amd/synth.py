@@ -304,3 +304,33 @@ def gen_downlink(n_slots, seed, cell=(262, 1, 5), slot0=0):
             "ndb1": list(zip(s_ndb.tolist(), t1["ndb1"])), "ndb2": list(zip(s_ndb.tolist(), t1["ndb2"])),
             "schf": list(zip(s_schf.tolist(), t1["schf"])), "bbk": list(zip(slots.tolist(), t1["bbk"]))}
     return out.reshape(-1), sent
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Counter-based per-channel streams: channel c of a bank is fully determined by its own seed (base seed + global channel index) --
+# bits and channel parameters are a hash of (seed, position), so any channel can be regenerated on its own, on the CPU (here) or
+# for a whole bank on the GPU (synth_gpu.py, the same integer arithmetic in torch), in any order and any chunking.
+# ---------------------------------------------------------------------------------------------------------------------
+def hash_u32(seed, k):
+    """32-bit mix of (seed, k); seed a non-negative int < 2^31, k int64 array (or int) >= 0.  All intermediate values < 2^63."""
+    x = (np.asarray(seed, np.int64) * 2654435761 + np.asarray(k, np.int64) * 40503 + 12345) & 0xffffffff
+    for _ in range(3):
+        x ^= x >> 16
+        x = (x * 0x45d9f3b) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def hash_bits(seed, n):
+    """The n transmitted bits of the channel with this seed."""
+    return ((hash_u32(seed, np.arange(n, dtype=np.int64)) >> 7) & 1).astype(np.uint8)
+
+
+HASH_PARAM_BASE = 1 << 40          # positions of the channel parameters in the hash stream (far beyond any bit position)
+
+
+def hash_params(seed):
+    """Channel parameters of the channel with this seed, SURVEY.md 8(d) ranges: cfo U(-0.05, 0.05) rad/sample, tau U[0, 2) samples,
+    amp U(0.05, 1.0), phase0 U(-pi, pi)."""
+    u = hash_u32(seed, HASH_PARAM_BASE + np.arange(4, dtype=np.int64)).astype(np.float64) / 4294967296.0
+    return dict(cfo=-0.05 + 0.1 * u[0], tau=2.0 * u[1], amp=0.05 + 0.95 * u[2], phase0=-np.pi + 2.0 * np.pi * u[3])

@@ -73,3 +73,41 @@ def test_rank_count_must_equal_gpus_flag():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
                        env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "is running as one of 2 rank(s)" in r.stderr
+
+
+def test_default_line_carries_config5_at_the_plugins_rate_and_the_receive_chain():
+    """What the driver's plain `python bench.py` run reports beside the metric: config 5 through the 18/25
+    resampler at the plugin's 36 ksps by default, the receive chain (include/tetra_rx.h) unless --no-chain, per-channel seeds and a
+    known-answer check over >= 256 channels.  (Source-level pins: the line itself needs the GPU; tests/test_bench_ranks.py runs it.)"""
+    import inspect
+    src = inspect.getsource(bench.main)
+    assert 'out["chain"] = receive_chain(' in src and "args.no_chain" in src and 'out["config5"] = wideband_config5(' in src
+    assert bench.CHECK_CHANNELS >= 256 and "hash_bits(int(seeds[c])" in src
+    c5 = inspect.getsource(bench.wideband_config5)
+    assert "pkg.Resampler(M, 18, 25, 16" in c5 and '"resampler"' in c5 and "config5_rate" in c5
+    chain = inspect.getsource(bench.receive_chain)
+    for key in ("two_streams", "one_stream", "stages_one_stream", "crc_good", "type1_bits_and_tdma_slot_exact", "cells_read", "channels_locked"):
+        assert key in chain, key
+    ap = inspect.getsource(bench.main)
+    assert '"--config5-rate", type=int, default=36000' in ap
+
+
+def test_hashed_channel_streams_are_the_same_on_cpu_and_in_torch():
+    """bench.py's input: every channel from its own seed.  synth.hash_bits / hash_params (numpy) == synth_gpu's torch arithmetic, and
+    the torch modulator gives synth.gen_channel's samples (run on the CPU device here)."""
+    import numpy as np
+    import torch
+    import tetra_amd
+    pkg = tetra_amd.pkg
+    dev = torch.device("cpu")
+    iq, seeds = pkg.synth_gpu.gen_bank(torch, dev, 6, 1500, 20260000, esn0_db=None)
+    assert list(seeds) == list(range(20260000, 20260006))
+    for c in range(6):
+        sd = int(seeds[c])
+        bits = pkg.synth.hash_bits(sd, pkg.synth.needed_bits(1500))
+        assert 0.4 < bits.mean() < 0.6
+        ref = pkg.synth.gen_channel(1500, 0, bits=bits, esn0_db=None, **pkg.synth.hash_params(sd))[0]
+        assert np.abs(iq[c].numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    b = pkg.synth_gpu.hash_bits(torch, dev, seeds, 300).numpy()
+    assert all(np.array_equal(b[c], pkg.synth.hash_bits(int(seeds[c]), 300)) for c in range(6))
+    assert not np.array_equal(b[0], b[1])
