@@ -85,6 +85,11 @@ int tetra_lmac_decode_batch_device(int type, const uint8_t* d_type5, int n_block
 int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blocks, const int32_t* d_n_blocks, int in_stride,
                                      const uint32_t* d_scramb_init, const int32_t* d_init_index, uint8_t* d_type2, int out_stride,
                                      int32_t* d_crc_ok, void* hip_stream);
+/* Rows of plain bits (every byte 0 or 1 -- what this library's demultiplexers write) take a packed route inside the decoder (bytes ->
+ * bits, whole words of the scrambling sequence, ~6 x fewer instructions in the front end); a workgroup of 64 rows with any other byte
+ * value, or rows that are not 8-byte aligned (d_type5, in_stride), takes the byte route; the results are the same bit for bit.
+ * tetra_lmac_debug_force_byte_route(1) sends every row through the byte route (process-wide; tests and A/B); returns the old setting. */
+int tetra_lmac_debug_force_byte_route(int on);
 /* Host-pointer variant (copies in/out, synchronises; device = HIP ordinal or -1 for the current one). */
 int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
                             uint8_t* type2, int out_stride, int32_t* crc_ok, int device);

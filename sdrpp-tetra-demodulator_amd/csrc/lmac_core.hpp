@@ -54,6 +54,15 @@ LM_FN uint32_t lfsr_next(uint32_t& lfsr) {
     return bit;
 }
 
+// bit-field extracts (one instruction each on the device)
+#if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
+LM_FN uint32_t bfe_u(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+LM_FN uint32_t bfe_mask(uint32_t x, uint32_t off) { return (uint32_t)__builtin_amdgcn_sbfe((int)x, off, 1u); }     // bit -> 0 / 0xffffffff
+#else
+LM_FN uint32_t bfe_u(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((1u << width) - 1u); }
+LM_FN uint32_t bfe_mask(uint32_t x, uint32_t off) { return 0u - ((x >> off) & 1u); }
+#endif
+
 // 2-bit signed class of a descrambled byte: +1 (strong 0), 0 (erasure), -1 = 0b11 (strong 1)
 LM_FN uint32_t soft_class(uint32_t v) { return v == 0u ? 1u : (v == 0xffu ? 0u : 3u); }
 
@@ -83,6 +92,92 @@ LM_FN uint32_t descramble_chunk(int remaining, uint32_t lfsr, Ld4 ld4, St st) {
         }
     }
     return lfsr;
+}
+
+// ---- clean rows (every byte 0 or 1: what this library's own demultiplexer writes), round 6 -----------------------------------
+// The byte-serial route above costs ~12 vector instructions per type-5 bit (an LFSR step + a three-way classification per byte)
+// and is what ANY input needs.  A row of plain bits takes another route: pack the bytes 32 to a word, XOR whole words of the
+// scrambling sequence, and spread the bits to classes (+1 / -1, never an erasure) -- ~2 instructions per bit.  The sequence of a
+// 32-bit code is linear in the code (the LFSR has no constant term), so it is the XOR of four table rows indexed by the code's
+// bytes: seq_tab[t][byte][w] = word w of the sequence the code (byte << 8 t) generates (kSeqWords words = 448 bits, padded to
+// kSeqStride); the host fills the table once per device with scramb_sequence_words below.
+constexpr int kSeqWords = (kMaxType345 + 31) / 32;      // 14
+constexpr int kSeqStride = 16;
+// bit i of the sequence = bit (i & 31) of word i >> 5
+inline void scramb_sequence_words(uint32_t code, uint32_t* words) {
+    uint32_t lfsr = code;
+    for (int w = 0; w < kSeqWords; ++w) {
+        uint32_t v = 0;
+        for (int b = 0; b < 32; ++b) {
+            const uint32_t bit = (uint32_t)__builtin_popcount(lfsr & kScrambTaps) & 1u;
+            lfsr = (lfsr >> 1) | (bit << 31);
+            v |= bit << b;
+        }
+        words[w] = v;
+    }
+}
+inline void scramb_sequence_table(uint32_t* tab) {       // [4][256][kSeqStride]
+    for (int t = 0; t < 4; ++t)
+        for (int b = 0; b < 256; ++b) {
+            uint32_t* row = tab + ((size_t)t * 256 + b) * kSeqStride;
+            scramb_sequence_words((uint32_t)b << (8 * t), row);
+            for (int w = kSeqWords; w < kSeqStride; ++w) row[w] = 0;
+        }
+}
+// four bytes 0 / 1 -> a nibble, byte k at bit k
+LM_FN uint32_t pack4(uint32_t v) { return (v * 0x01020408u) >> 24; }
+// the low 16 bits of x, bit k moved to bit 2 k
+LM_FN uint32_t spread16(uint32_t x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+// 16 descrambled bits -> their class word (2 bits each, bit u at 2u..2u+1): 0 -> +1 = 0b01, 1 -> -1 = 0b11; positions at and beyond
+// `live` (bits of the row left from this word's first) get class 0 like the byte route gives them
+LM_FN uint32_t class_word(uint32_t bits16, int live) {
+    const uint32_t w = (spread16(bits16) << 1) | 0x55555555u;
+    return live >= 16 ? w : (live <= 0 ? 0u : (w & ((1u << (2 * live)) - 1u)));
+}
+
+struct U2 { uint32_t x, y; };
+// Packs the lane's own row, bytes -> bits (type-5 bit i at bit i & 31 of xb[i >> 5]); ld8(i) returns bytes 8i..8i+7 of the row.
+// Returns non-zero if any byte of the row is not 0 / 1 (then the byte route has to decode the row).  type345 is a multiple of 8
+// for every coded block kind.
+template <class Ld8>
+LM_FN uint32_t pack_row_bits(int type345, Ld8 ld8, uint32_t xb[kSeqWords]) {
+    uint32_t dirty = 0;
+#pragma unroll
+    for (int w = 0; w < kSeqWords; ++w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (32 * w + 8 * q < type345) {
+                const U2 d = ld8(4 * w + q);
+                dirty |= (d.x | d.y) & 0xfefefefeu;
+                v |= (pack4(d.x) | (pack4(d.y) << 4)) << (8 * q);
+            }
+        }
+        xb[w] = v;
+    }
+    return dirty;
+}
+// Descrambles the packed row and stores its class words: seq(t, byte, w) = seq_tab[t][byte][w]; st(i, word) = class word i
+// (classes of type-4 bits 16i..16i+15), the same words descramble_chunk produces for a row of plain bits.
+template <class Seq, class St>
+LM_FN void classes_from_bits(int type345, uint32_t code, const uint32_t xb[kSeqWords], Seq seq, St st) {
+#pragma unroll
+    for (int w = 0; w < kSeqWords; ++w) {
+        if (32 * w < type345) {
+            const uint32_t sw = seq(0, code & 0xffu, w) ^ seq(1, (code >> 8) & 0xffu, w) ^ seq(2, (code >> 16) & 0xffu, w) ^ seq(3, code >> 24, w);
+            const uint32_t x = xb[w] ^ sw;
+            const int live = type345 - 32 * w;
+            st(2 * w, class_word(x, live));
+            if (live > 16) st(2 * w + 1, class_word(x >> 16, live - 16));
+        }
+    }
 }
 
 // ---- packed 16-bit lanes: two path metrics per 32-bit register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16) --------
@@ -143,8 +238,10 @@ LM_FN uint32_t acs_pk(PathMetrics& pm, Pk M0, Pk M1, Pk M2, Pk M3) {
 
 LM_FN Pk pk_neg(Pk a) { return pk_sub(pk_make(0, 0), a); }
 
-// Forward recursion over n2 + 4 steps.  cls(idx) returns the soft class (-1, 0, +1) of type-4 bit idx (0-based);
-// st(t, mask) receives the decision mask of step t (state s at bit 15 - s).
+// Forward recursion over n2 + 4 steps, two steps per call-back (round 6: one 32-bit store per step pair instead of two 16-bit ones).
+// cls(idx) returns the soft class (-1, 0, +1) of type-4 bit idx (0-based); st(u, word) receives the decisions of steps 2u (low
+// half) and 2u + 1 (high half), INVERTED: state s at bit 15 - s of its half, 1 = the state kept its EVEN predecessor -- the form
+// the traceback consumes without a complement.  n2 is even for every block kind.
 template <class Cls, class St>
 LM_FN void viterbi_forward(int n2, int K, int a, Cls cls, St st) {
     PathMetrics pm;
@@ -159,56 +256,79 @@ LM_FN void viterbi_forward(int n2, int K, int a, Cls cls, St st) {
         pos += a; pos = pos >= K ? pos - K : pos;
         const int sc = cls(pos);
         pos += a; pos = pos >= K ? pos - K : pos;
-        {   // even step: g1 -> sa, g2 -> sb.  butterfly i = (d0 d1 d2): sign(g1) = d0, sign(g2) = d1 ^ d2, so with
-            // p = sa + sb, q = sa - sb the metrics are m_0..7 = p, q, q, p, -q, -p, -p, -q
-            const Pk pq = pk_make(sa + sb, sa - sb), qp = pk_swap(pq);
-            st(2 * u, acs_pk(pm, pq, qp, pk_neg(qp), pk_neg(pq)));
-        }
-        {   // odd step: g1 -> sc only: m_0..3 = sc, m_4..7 = -sc
-            const Pk cc = pk_make(sc, sc), nc = pk_neg(cc);
-            st(2 * u + 1, acs_pk(pm, cc, cc, nc, nc));
-        }
+        // even step: g1 -> sa, g2 -> sb.  butterfly i = (d0 d1 d2): sign(g1) = d0, sign(g2) = d1 ^ d2, so with
+        // p = sa + sb, q = sa - sb the metrics are m_0..7 = p, q, q, p, -q, -p, -p, -q
+        const Pk pq = pk_make(sa + sb, sa - sb), qp = pk_swap(pq);
+        const uint32_t even = acs_pk(pm, pq, qp, pk_neg(qp), pk_neg(pq));
+        // odd step: g1 -> sc only: m_0..3 = sc, m_4..7 = -sc
+        const Pk cc = pk_make(sc, sc), nc = pk_neg(cc);
+        const uint32_t odd = acs_pk(pm, cc, cc, nc, nc);
+        st(u, (even | (odd << 16)) ^ 0xffffffffu);
     }
 #pragma unroll
-    for (int f = 0; f < kFlush; ++f) {
+    for (int f = 0; f < kFlush / 2; ++f) {
         const Pk z = pk_make(0, 0);
-        st(n2 + f, acs_pk(pm, z, z, z, z));
+        const uint32_t even = acs_pk(pm, z, z, z, z);
+        const uint32_t odd = acs_pk(pm, z, z, z, z);
+        st(n2 / 2 + f, (even | (odd << 16)) ^ 0xffffffffu);
     }
 }
 
-// Traceback from state 0 after the flush steps.  ld(t) returns the decision mask of step t (state s at bit 15 - s);
-// st(h, half) receives decoded bits 16h..16h+15 (bit 16h+b at bit b).  n2 is a multiple of 16 for every coded block kind.
-template <class Ld, class St>
-LM_FN void viterbi_traceback(int n2, Ld ld, St st) {
-    uint32_t state = 0;
+// CRC16-CCITT (crc_simple.c:59-77, :103-106: x^16 + x^12 + x^5 + 1, start 0xffff, bits MSB first) is affine in the message: the
+// register after n bits = Z(n) ^ XOR over the 1 bits of T[distance of the bit from the end], T[j] = x^(16 + j) mod the polynomial,
+// Z(n) = the register after n zero bits.  The traceback meets the bits last to first, so it folds the CRC in: one AND + XOR per bit
+// with a wave-uniform constant instead of a five-instruction shift register step.
+constexpr int kCrcPad = 4;            // leading zero entries: the 4 tail bits behind the CRC field meet a zero constant, no branch
+struct CrcTable {
+    uint32_t t[kCrcPad + kMaxType2];   // t[kCrcPad + j] = T[j] (dwords: a wave-uniform index then loads through the scalar cache)
+};
+constexpr CrcTable make_crc_table() {
+    CrcTable c{};
+    uint32_t v = 0x1021u;                                  // one 1 bit into a zero register
+    for (int j = 0; j < kMaxType2; ++j) {
+        c.t[kCrcPad + j] = v;
+        v = (v & 0x8000u) ? (((v << 1) ^ 0x1021u) & 0xffffu) : ((v << 1) & 0xffffu);
+    }
+    return c;
+}
+// Z(n) ^ XOR of T[0 .. n - 1]: what the traceback's accumulator (XOR of T[j] over the ZERO bits) has to be XORed with
+constexpr uint32_t crc_fold_constant(const CrcTable& c, int n) {
+    uint32_t z = 0xffffu;
+    for (int i = 0; i < n; ++i) z = (z & 0x8000u) ? (((z << 1) ^ 0x1021u) & 0xffffu) : ((z << 1) & 0xffffu);
+    for (int j = 0; j < n; ++j) z ^= c.t[kCrcPad + j];
+    return z;
+}
+
+// Traceback from state 0 after the flush steps, CRC folded in.  ld(u) returns the decision word of step pair u as the forward pass
+// stored it; st(h, half) receives decoded bits 16h..16h+15 (bit 16h+b at bit b); tbl(k) = CrcTable::t[k] (wave-uniform index);
+// n_crc = type1 + 16 bits are covered by the CRC (n2 = n_crc + 4 tail bits), fold = crc_fold_constant(n_crc).  Returns the CRC
+// register.  n2 is a multiple of 16.
+// y = 15 - state runs in a shift register: y' = (y << 1 | inverted decision) & 15, and the decoded bit of a step is the complement
+// of bit 3 of y before the step, so after 16 steps the 16 decoded bits sit, complemented, at bits 4..19.
+template <class Ld, class St, class Tbl>
+LM_FN uint32_t viterbi_traceback(int n2, int n_crc, uint32_t fold, Ld ld, St st, Tbl tbl) {
+    uint32_t y = 15u;
 #pragma unroll
-    for (int f = kFlush - 1; f >= 0; --f) state = ((state << 1) & 0xfu) | ((ld(n2 + f) >> (state ^ 15u)) & 1u);
+    for (int f = kFlush / 2 - 1; f >= 0; --f) {
+        const uint32_t w = ld(n2 / 2 + f);
+        y = (y << 1) | bfe_u(w, (y & 15u) | 16u, 1);
+        y = (y << 1) | bfe_u(w, y & 15u, 1);
+    }
+    uint32_t acc = 0;
     for (int h = n2 / 16 - 1; h >= 0; --h) {
-        uint32_t half = 0;
+        const int k0 = n_crc - 1 + kCrcPad - 16 * h;          // table index of bit 16 h (>= 0 for every bit of the row)
 #pragma unroll
-        for (int b = 15; b >= 0; --b) {
-            half |= (state >> 3) << b;                                        // vals[state]: the newest input bit
-            state = ((state << 1) & 0xfu) | ((ld(16 * h + b) >> (state ^ 15u)) & 1u);
+        for (int b2 = 7; b2 >= 0; --b2) {
+            const uint32_t w = ld(8 * h + b2);
+            // step 16h + 2 b2 + 1, then step 16h + 2 b2: y bit 3 set <=> the decoded bit is 0
+            acc ^= tbl(k0 - 2 * b2 - 1) & bfe_mask(y, 3);
+            y = (y << 1) | bfe_u(w, (y & 15u) | 16u, 1);
+            acc ^= tbl(k0 - 2 * b2) & bfe_mask(y, 3);
+            y = (y << 1) | bfe_u(w, y & 15u, 1);
         }
-        st(h, half);
+        st(h, (~y >> 4) & 0xffffu);
     }
-}
-
-// CRC16-CCITT over decoded bits 0..nbits-1; ld(h) returns bits 16h..16h+15.
-template <class Ld>
-LM_FN uint32_t crc16_bits(int nbits, Ld ld) {
-    uint32_t crc = 0xffffu;
-    for (int h = 0; h * 16 < nbits; ++h) {
-        const uint32_t half = ld(h);
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            if (16 * h + b < nbits) {
-                crc ^= ((half >> b) & 1u) << 15;
-                crc = (crc & 0x8000u) ? (((crc << 1) ^ 0x1021u) & 0xffffu) : ((crc << 1) & 0xffffu);
-            }
-        }
-    }
-    return crc;
+    return (acc ^ fold) & 0xffffu;
 }
 
 // 4 decoded bits -> 4 bytes (one bit per byte, little endian)

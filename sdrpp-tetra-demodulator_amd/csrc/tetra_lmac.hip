@@ -2,23 +2,26 @@
 // tp_sap_udata_ind() decoding chain (src/decoder/src/lower_mac/tetra_lower_mac.c:181-236).
 //
 // One 64-lane workgroup (one wavefront) decodes 64 blocks, one block per lane (lane-level code: lmac_core.hpp):
-//   1. the 64 rows are read from HBM once, 64 bits per row at a time (coalesced 64-byte segments, 4 rows per load
-//      instruction), into a small LDS stage (row stride 17 dwords = odd, so that "every lane reads the same column of
-//      its own row" is bank-conflict free);
-//   2. each lane descrambles its row chunk (its own LFSR) and packs the soft classes 2 bits per type-4 bit into LDS
-//      words laid out [word][lane];
-//   3. forward recursion: 16 path metrics in registers, the three soft values of a step pair gathered from the class
-//      words at the deinterleaved positions, 16 decision bits per step stored as one ushort to a global scratch laid
-//      out [workgroup][step][lane] (one 128-byte line per step; written once, read once, normally from L2 / MALL);
-//   4. traceback from the scratch (the addresses do not depend on the surviving state, only the bit picked does, so the
-//      loads pipeline), decoded bits packed 16 per ushort into LDS [half][lane], CRC16 over them;
-//   5. the 64 decoded rows are written back with coalesced dword stores, 4 bits -> 4 bytes per lane.
-// LDS per workgroup: 4352 (stage) + 6912 (classes) + 2304 (decoded) = 13568 B, 70 VGPRs -> 11 workgroups per CU (the
-// first version kept the decisions in LDS: 46.6 KB, 3 waves per CU, 3x slower).  The work is integer
-// add/compare/select, VALU-bound.
+//   1. front end, rows of plain bits (every byte 0 / 1: what this library's demultiplexer writes; round 6): every lane reads ITS OWN
+//      row with 8-byte loads (the 64 rows of a workgroup are 64 strided streams that live in L1 while they are consumed), packs
+//      the bytes 32 to a register, XORs whole words of its scrambling sequence (linear in the code: four rows of a 64 KB table
+//      indexed by the code's bytes) and spreads the bits to soft classes -- ~2 vector instructions per type-5 bit;
+//      any other row (a byte that is not 0 / 1 anywhere in the workgroup's 64 rows): the byte route -- rows staged through LDS in
+//      coalesced 64-bit chunks, an LFSR step and a three-way classification (0 / erasure 0xff / 1) per byte, ~12 per bit;
+//      either way the classes end up 2 bits per type-4 bit in LDS words laid out [word][lane];
+//   2. forward recursion: 16 path metrics in registers (packed int16 pairs), the three soft values of a step pair gathered from
+//      the class words at the deinterleaved positions, the 2 x 16 decision bits of a step pair stored as one dword to a global
+//      scratch laid out [workgroup][step pair][lane] (one 256-byte line per pair; written once, read once, normally from L2 / MALL);
+//   3. traceback from the scratch (the addresses do not depend on the surviving state, only the bit picked does, so the loads
+//      pipeline) with the CRC16 folded in (affine in the message: one AND + XOR per bit with a wave-uniform constant), decoded bits
+//      packed 16 per ushort into LDS [half][lane];
+//   4. the 64 decoded rows are written back with coalesced dword stores, 4 bits -> 4 bytes per lane.
+// LDS per workgroup: 4352 (stage) + 6912 (classes) + 2304 (decoded) = 13568 B -> 11 workgroups per CU.  The work is integer
+// add / compare / select: bound by vector issue (67 instructions per trellis step and wave in the recursion itself).
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <vector>
 
 #include "../../include/tetra_lmac.h"
 #include "lmac_core.hpp"
@@ -32,6 +35,8 @@ constexpr int kChunkDwords = 16;                       // 64 type-5 bits per row
 constexpr int kSteps = kMaxType2 + kFlush;             // 292
 constexpr int kClsWords = (kMaxType345 + 15) / 16;     // 27
 constexpr int kOutHalves = kMaxType2 / 16;             // 18
+bool g_force_byte_route = false;                       // tests / A-B: tetra_lmac_debug_force_byte_route
+__constant__ CrcTable kCrcDev = make_crc_table();      // the traceback's CRC constants (constant address space: scalar loads)
 
 struct BlkParam { int type345, type2, type1, a, crc; };
 // tetra_blk_param[], tetra_lower_mac.c:58-105 (values of EN 300 392-2 table 8.x / 8.2.4.1)
@@ -48,10 +53,11 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                                         const uint32_t* __restrict__ scramb_init, int fixed_init,
                                                         int type345, int type2, int type1, int a,
                                                         uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
-                                                        uint16_t* __restrict__ dec_scratch, int dec_steps,
-                                                        const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index) {
+                                                        uint32_t* __restrict__ dec_scratch, int dec_pairs,
+                                                        const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index,
+                                                        const uint32_t* __restrict__ seq_tab, uint32_t crc_fold) {
     __shared__ uint32_t stage[kLanes][kChunkDwords + 1];     // +1: odd row stride, conflict-free column reads
-    __shared__ uint32_t cls[kClsWords][kLanes];
+    __shared__ uint32_t cls[kClsWords + 1][kLanes];
     __shared__ uint16_t outw[kOutHalves][kLanes];
     const int lane = threadIdx.x;
     const int blk0 = blockIdx.x * kLanes;
@@ -62,45 +68,86 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
         if (blk0 >= n_blocks) return;
     }
     const int rows_here = min(kLanes, n_blocks - blk0);
+    const uint32_t code = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[init_index ? init_index[blk] : blk];
 
-    // 1+2. rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
-    //      descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
-    uint32_t lfsr = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[init_index ? init_index[blk] : blk];
-    const int row_dw = type345 >> 2;
-    for (int c0 = 0; c0 < row_dw; c0 += kChunkDwords) {
+    // 1. front end.  Rows of plain bits: each lane packs its own row (8-byte loads) and descrambles whole words; the workgroup falls
+    //    back to the byte route if any of its rows holds another byte value, or if the rows are not 8-byte aligned.
+    bool byte_route = seq_tab == nullptr || (in_stride & 7) || ((uintptr_t)type5 & 7);
+    if (!byte_route) {
+        const U2* row = reinterpret_cast<const U2*>(type5 + (size_t)(blk < n_blocks ? blk : blk0) * in_stride);
+        uint32_t xb[kSeqWords];
+        const uint32_t dirty = pack_row_bits(type345, [&](int i) { return row[i]; }, xb);
+        byte_route = __builtin_amdgcn_ballot_w64(dirty != 0) != 0;          // wave-uniform
+        if (!byte_route)
+            classes_from_bits(type345, code, xb,
+                              [&](int t, uint32_t byte, int w) { return seq_tab[((size_t)t * 256 + byte) * kSeqStride + w]; },
+                              [&](int i, uint32_t word) { cls[i][lane] = word; });
+    }
+    if (byte_route) {
+        // rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
+        // descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
+        uint32_t lfsr = code;
+        const int row_dw = type345 >> 2;
+        for (int c0 = 0; c0 < row_dw; c0 += kChunkDwords) {
 #pragma unroll 4
-        for (int it = 0; it < kLanes * kChunkDwords / kLanes; ++it) {
-            const int q = it * (kLanes / kChunkDwords) + lane / kChunkDwords, d = lane % kChunkDwords;
-            uint32_t v = 0;
-            if (q < rows_here && c0 + d < row_dw)
-                v = reinterpret_cast<const uint32_t*>(type5 + (size_t)(blk0 + q) * in_stride)[c0 + d];
-            stage[q][d] = v;
+            for (int it = 0; it < kLanes * kChunkDwords / kLanes; ++it) {
+                const int q = it * (kLanes / kChunkDwords) + lane / kChunkDwords, d = lane % kChunkDwords;
+                uint32_t v = 0;
+                if (q < rows_here && c0 + d < row_dw)
+                    v = reinterpret_cast<const uint32_t*>(type5 + (size_t)(blk0 + q) * in_stride)[c0 + d];
+                stage[q][d] = v;
+            }
+            __syncthreads();
+            lfsr = descramble_chunk(type345 - 4 * c0, lfsr, [&](int d) { return stage[lane][d]; },
+                                    [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
+            __syncthreads();
         }
-        __syncthreads();
-        lfsr = descramble_chunk(type345 - 4 * c0, lfsr, [&](int d) { return stage[lane][d]; },
-                                [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
-        __syncthreads();
     }
 
-    // 3. forward recursion: decisions of step t of this workgroup's 64 blocks = one 128-byte line of the scratch
-    uint16_t* dec = dec_scratch + (size_t)blockIdx.x * dec_steps * kLanes + lane;
+    // 2. forward recursion: decisions of step pair u of this workgroup's 64 blocks = one 256-byte line of the scratch
+    uint32_t* dec = dec_scratch + (size_t)blockIdx.x * dec_pairs * kLanes + lane;
     viterbi_forward(type2, type345, a,
                     [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; },
-                    [&](int t, uint32_t mask) { dec[t * kLanes] = (uint16_t)mask; });
+                    [&](int u, uint32_t word) { dec[u * kLanes] = word; });
 
-    // 4. traceback + CRC (own lane's data only: program order is enough)
-    viterbi_traceback(type2, [&](int t) { return (uint32_t)dec[t * kLanes]; },
-                      [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; });
-    const uint32_t crc = crc16_bits(type1 + 16, [&](int h) { return (uint32_t)outw[h][lane]; });
+    // 3. traceback + CRC (own lane's data only: program order is enough)
+    const uint32_t crc = viterbi_traceback(type2, type1 + 16, crc_fold, [&](int u) { return dec[u * kLanes]; },
+                                           [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
+                                           [&](int k) { return kCrcDev.t[k]; });
     if (blk < n_blocks) crc_ok[blk] = crc == kCrcOk;
     __syncthreads();
 
-    // 5. decoded rows -> HBM
+    // 4. decoded rows -> HBM
     const int out_dw = type2 >> 2;
     for (int q = 0; q < rows_here; ++q) {
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)(blk0 + q) * out_stride);
         for (int d = lane; d < out_dw; d += kLanes) dst[d] = spread4(((uint32_t)outw[d >> 2][q] >> (4 * (d & 3))) & 0xfu);
     }
+}
+
+// Per-device constant of the decoder's packed route: the scrambling-sequence table (64 KB), built on the host once per device and
+// kept for the life of the process.
+std::mutex g_tab_mu;
+uint32_t* g_seq_tab[64] = {};
+// nullptr if the table cannot be set up (out of memory): the caller reports TETRA_ERR_NOMEM
+const uint32_t* seq_table() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_tab_mu);
+    if (!g_seq_tab[dev]) {
+        const size_t seq_words = (size_t)4 * 256 * kSeqStride;
+        std::vector<uint32_t> host(seq_words);
+        scramb_sequence_table(host.data());
+        uint32_t* d_seq = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d_seq), sizeof(uint32_t) * seq_words) != hipSuccess ||
+            hipMemcpy(d_seq, host.data(), sizeof(uint32_t) * seq_words, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            if (d_seq) (void)hipFree(d_seq);
+            return nullptr;
+        }
+        g_seq_tab[dev] = d_seq;
+    }
+    return g_seq_tab[dev];
 }
 
 // The decoder's decision scratch (up to 200 MB for a second of 4096 channels' SCH/F slots) comes from a stream-ordered pool of this
@@ -266,21 +313,31 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
         // decision scratch: (type2 + 4) steps x 64 lanes x u16 per workgroup, from the library's keeping pool (scratch_pool():
         // after the first call a free-list hit), released in stream order right behind the kernel
         const int groups = (n_blocks + kLanes - 1) / kLanes;
-        const int dec_steps = p.type2 + kFlush;
-        const size_t bytes = (size_t)groups * dec_steps * kLanes * sizeof(uint16_t);
-        uint16_t* scratch = nullptr;
+        const int dec_pairs = (p.type2 + kFlush) / 2;
+        const size_t bytes = (size_t)groups * dec_pairs * kLanes * sizeof(uint32_t);
+        const uint32_t* seq = seq_table();
+        if (!seq) return TETRA_ERR_NOMEM;
+        constexpr CrcTable crct = make_crc_table();
+        const uint32_t crc_fold = crc_fold_constant(crct, p.type1 + 16);
+        uint32_t* scratch = nullptr;
         hipMemPool_t pool = scratch_pool();
         const hipError_t got = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), bytes, pool, s)
                                     : hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s);
         if (got != hipSuccess) { (void)hipGetLastError(); return TETRA_ERR_NOMEM; }
         hipLaunchKernelGGL(k_lmac_decode, dim3(groups), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
                            type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride, d_crc_ok,
-                           scratch, dec_steps, d_n_blocks, d_init_index);
+                           scratch, dec_pairs, d_n_blocks, d_init_index, g_force_byte_route ? nullptr : seq, crc_fold);
         const hipError_t launch = hipGetLastError();
         if (hipFreeAsync(scratch, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
         return TETRA_OK;
     }
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_debug_force_byte_route(int on) {
+    const int was = g_force_byte_route ? 1 : 0;
+    g_force_byte_route = on != 0;
+    return was;
 }
 
 int tetra_lmac_track_scramb_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,

@@ -6,7 +6,8 @@ import numpy as np
 from .binding import TetraDemodError, load_library
 
 LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch",
-                "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device", "tetra_lmac_track_sync_device"]
+                "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device", "tetra_lmac_track_sync_device",
+                "tetra_lmac_debug_force_byte_route"]
 # enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
 TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
 
@@ -37,6 +38,14 @@ def _lib():
         L.tetra_lmac_track_scramb_device.restype = i32
         _ready = True
     return L
+
+
+def force_byte_route(on):
+    """tetra_lmac_debug_force_byte_route: every row through the decoder's byte route (process-wide).  Returns the old setting."""
+    L = _lib()
+    L.tetra_lmac_debug_force_byte_route.argtypes = [C.c_int]
+    L.tetra_lmac_debug_force_byte_route.restype = C.c_int
+    return bool(L.tetra_lmac_debug_force_byte_route(int(bool(on))))
 
 
 def blk_param(blk_type):

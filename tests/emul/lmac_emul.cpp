@@ -9,28 +9,59 @@
 
 using namespace tetra_lmac;
 
-extern "C" int lmac_emul_decode(int type345, int type2, int type1, int a, const uint8_t* type5, int n_blocks, int in_stride,
-                                const uint32_t* scramb_init, uint8_t* out, int out_stride, int32_t* crc_ok) {
-    if (type345 > kMaxType345 || type2 > kMaxType2 || (type345 & 3) || (type2 & 15) || (in_stride & 3)) return -1;
+namespace {
+const uint32_t* seq_table() {
+    static uint32_t* tab = nullptr;
+    if (!tab) {
+        tab = new uint32_t[(size_t)4 * 256 * kSeqStride];
+        scramb_sequence_table(tab);
+    }
+    return tab;
+}
+}  // namespace
+
+// route: 0 = like the kernel (rows of plain bits take the packed route, any other row the byte route), 1 = byte route always
+extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, const uint8_t* type5, int n_blocks, int in_stride,
+                                      const uint32_t* scramb_init, uint8_t* out, int out_stride, int32_t* crc_ok, int route, int32_t* fast_rows) {
+    if (type345 > kMaxType345 || type2 > kMaxType2 || (type345 & 7) || (type2 & 15) || (in_stride & 3)) return -1;
+    static const CrcTable crct = make_crc_table();
+    const uint32_t fold = crc_fold_constant(crct, type1 + 16);
+    const uint32_t* tab = seq_table();
+    int fast = 0;
     for (int blk = 0; blk < n_blocks; ++blk) {
         const uint8_t* row = type5 + (size_t)blk * in_stride;
-        uint32_t cls[(kMaxType345 + 15) / 16];
-        uint16_t dec[kMaxType2 + kFlush];
+        uint32_t cls[(kMaxType345 + 15) / 16 + 1];
+        uint32_t dec[(kMaxType2 + kFlush) / 2];
         uint16_t outw[kMaxType2 / 16];
-        uint32_t lfsr = scramb_init[blk];
-        for (int c0 = 0; c0 < type345 / 4; c0 += 16)      // the kernel's 64-bit staging chunks
-            lfsr = descramble_chunk(type345 - 4 * c0, lfsr,
-                                    [&](int d) { uint32_t v; std::memcpy(&v, row + 4 * (c0 + d), 4); return v; },
-                                    [&](int w, uint32_t word) { cls[c0 / 4 + w] = word; });
+        uint32_t xb[kSeqWords];
+        const uint32_t dirty = pack_row_bits(type345, [&](int i) { U2 d; std::memcpy(&d, row + 8 * i, 8); return d; }, xb);
+        if (route == 0 && !dirty) {
+            ++fast;
+            classes_from_bits(type345, scramb_init[blk], xb, [&](int t, uint32_t byte, int w) { return tab[((size_t)t * 256 + byte) * kSeqStride + w]; },
+                              [&](int i, uint32_t word) { cls[i] = word; });
+        } else {
+            uint32_t lfsr = scramb_init[blk];
+            for (int c0 = 0; c0 < type345 / 4; c0 += 16)      // the kernel's 64-bit staging chunks
+                lfsr = descramble_chunk(type345 - 4 * c0, lfsr,
+                                        [&](int d) { uint32_t v; std::memcpy(&v, row + 4 * (c0 + d), 4); return v; },
+                                        [&](int w, uint32_t word) { cls[c0 / 4 + w] = word; });
+        }
         viterbi_forward(type2, type345, a,
                         [&](int idx) { return (int)(cls[idx >> 4] << (30 - 2 * (idx & 15))) >> 30; },
-                        [&](int t, uint32_t mask) { dec[t] = (uint16_t)mask; });
-        viterbi_traceback(type2, [&](int t) { return (uint32_t)dec[t]; }, [&](int h, uint32_t half) { outw[h] = (uint16_t)half; });
-        crc_ok[blk] = crc16_bits(type1 + 16, [&](int h) { return (uint32_t)outw[h]; }) == kCrcOk;
+                        [&](int u, uint32_t word) { dec[u] = word; });
+        const uint32_t crc = viterbi_traceback(type2, type1 + 16, fold, [&](int u) { return dec[u]; },
+                                               [&](int h, uint32_t half) { outw[h] = (uint16_t)half; }, [&](int k) { return crct.t[k]; });
+        crc_ok[blk] = crc == kCrcOk;
         for (int t4 = 0; t4 < type2 / 4; ++t4) {
             const uint32_t v = spread4((outw[t4 >> 2] >> (4 * (t4 & 3))) & 0xfu);
             std::memcpy(out + (size_t)blk * out_stride + 4 * t4, &v, 4);
         }
     }
+    if (fast_rows) *fast_rows = fast;
     return 0;
+}
+
+extern "C" int lmac_emul_decode(int type345, int type2, int type1, int a, const uint8_t* type5, int n_blocks, int in_stride,
+                                const uint32_t* scramb_init, uint8_t* out, int out_stride, int32_t* crc_ok) {
+    return lmac_emul_decode_route(type345, type2, type1, a, type5, n_blocks, in_stride, scramb_init, out, out_stride, crc_ok, 0, nullptr);
 }

@@ -87,6 +87,32 @@ def test_lane_code_equals_reference(lref):
         assert 0 < want_ok.sum() < len(rows)
 
 
+def test_lane_code_packed_route_equals_byte_route(lref):
+    """Round 6: rows of plain bits (every byte 0 / 1) take a packed route through the decoder's front end (bytes -> bits, whole
+    words of the scrambling sequence from a table that is linear in the code, bit spreading to classes); any other row the byte
+    route (an LFSR step and a three-way classification per byte).  Same lane code as the kernel, on the host: the packed route IS
+    taken for the clean rows, gives the byte route's output bit for bit, and both equal the reference."""
+    import ctypes as C
+    from tests.emul import lmac_emul_bind
+    lmac_emul_bind.decode_batch(0, np.zeros((1, 120), np.uint8), np.zeros(1, np.uint32))          # builds / loads the library
+    L = lmac_emul_bind._lib
+    vp = C.c_void_p
+    for t in CODED:
+        n345, n2, n1, a, _ = lref.BLK_PARAM[t]
+        rows, si, _ = make_rows(lref, t, 200, 300 + t)
+        outs = []
+        for route in (0, 1):
+            out, ok, fast = np.zeros((len(rows), n2), np.uint8), np.zeros(len(rows), np.int32), C.c_int32(-1)
+            assert L.lmac_emul_decode_route(n345, n2, n1, a, rows.ctypes.data_as(vp), len(rows), rows.shape[1], si.ctypes.data_as(vp),
+                                            out.ctypes.data_as(vp), n2, ok.ctypes.data_as(vp), route, C.byref(fast)) == 0
+            outs.append((out, ok, fast.value))
+        clean = int(((rows[:, :n345] & 0xfe) == 0).all(1).sum())
+        assert outs[0][2] == clean >= 150 and outs[1][2] == 0
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        want, want_ok = ref_decode_rows(lref, t, rows, si)
+        assert np.array_equal(outs[0][0], want) and np.array_equal(outs[0][1], want_ok)
+
+
 def test_lane_code_equals_golden():
     """Same check against the committed fixture (inputs + reference outputs; tests/golden/make_lmac_golden.py)."""
     from tests.emul import lmac_emul_bind
@@ -121,6 +147,40 @@ def test_gpu_lmac_equals_reference(pkg, lref):
         tight = np.ascontiguousarray(rows[:200, :n345])
         got, got_ok = pkg.lmac_binding.decode_batch(t, tight, si[:200])
         assert np.array_equal(got[:, :n2], want[:200]) and np.array_equal(got_ok, want_ok[:200])
+
+
+@pytest.mark.gpu
+def test_gpu_lmac_packed_route_byte_route_and_mixed_workgroups(pkg, lref):
+    """The kernel's two front ends: all-clean batches (packed route), the same batches with the byte route forced
+    (tetra_lmac_debug_force_byte_route), batches where one row in every 64 holds an erasure byte (that workgroup falls back),
+    a row stride that is not a multiple of 8 (byte route by alignment) -- all bit for bit the reference."""
+    lb = pkg.lmac_binding
+    rng = np.random.default_rng(77)
+    for t in CODED:
+        n345, n2, n1, a, _ = lref.BLK_PARAM[t]
+        n = 300
+        si = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        if t == lref.TPSAP_T_SB1:
+            si[:] = lref.SCRAMB_INIT
+        for stride in (n345 + (-n345) % 8, n345 + 4 if (n345 + 4) % 8 else n345 + 12):
+            rows = rng.integers(0, 2, (n, stride), dtype=np.uint8)
+            for b in range(0, n, 3):
+                rows[b, :n345] = lref.lmac_encode(t, rng.integers(0, 2, n1).astype(np.uint8), int(si[b])) ^ (rng.random(n345) < 0.03)
+            want, want_ok = ref_decode_rows(lref, t, rows, si)
+            got, ok = lb.decode_batch(t, rows, si)
+            assert np.array_equal(got[:, :n2], want) and np.array_equal(ok, want_ok), (t, stride, "default")
+            assert lb.force_byte_route(True) is False
+            try:
+                got, ok = lb.decode_batch(t, rows, si)
+            finally:
+                lb.force_byte_route(False)
+            assert np.array_equal(got[:, :n2], want) and np.array_equal(ok, want_ok), (t, stride, "byte route")
+            mixed = rows.copy()
+            mixed[5::64, 7] = 0xff
+            mixed[70, n345 - 1] = 2
+            want, want_ok = ref_decode_rows(lref, t, mixed, si)
+            got, ok = lb.decode_batch(t, mixed, si)
+            assert np.array_equal(got[:, :n2], want) and np.array_equal(ok, want_ok), (t, stride, "mixed")
 
 
 @pytest.mark.gpu
