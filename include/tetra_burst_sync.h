@@ -125,6 +125,22 @@ int tetra_burst_demux_packed_device(const uint32_t* d_frames_packed, const int32
 int tetra_burst_demux_compact_packed_device(const uint32_t* d_frames_packed, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
                                             uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream);
 
+/*
+ * The frame lists of a call in one pass (round 6): which frame slots hold a SYNC / NORM_1 / NORM_2 burst, and which any of the
+ * three, each in frame order -- the d_row_frame of every block kind tetra_burst_rx_cb hands on (SYNC: SB1, SB2; NORM_1: SCH/F;
+ * NORM_2: NDB blk 1 + 2; any: BBK), for tetra_lmac_decode_frames_device.  Replaces the count / scan / index passes the compacting
+ * demultiplexer runs per kind (18 launches for the six kinds of a downlink) by three launches.
+ *   d_lists       [TETRA_N_LISTS][n] int32 out: list k holds indices into d_frame_type, ascending; entries past its count unspecified
+ *   d_counts      [TETRA_N_LISTS] int32 out
+ *   d_chan_first  [TETRA_N_LISTS][n / frames_per_channel] int32 out, may be NULL: position in list k of channel c's first entry
+ *                 (= entries of list k that belong to channels < c); frames_per_channel must divide n
+ *   d_work        [TETRA_N_LISTS * ((n + 255) / 256)] int32 scratch
+ * Enqueued on hip_stream; nothing is read back.
+ */
+enum { TETRA_LIST_SYNC = 0, TETRA_LIST_NORM_1 = 1, TETRA_LIST_NORM_2 = 2, TETRA_LIST_ANY = 3, TETRA_N_LISTS = 4 };
+int tetra_burst_index_device(const int32_t* d_frame_type, int n, int frames_per_channel, int32_t* d_lists, int32_t* d_counts,
+                             int32_t* d_chan_first, int32_t* d_work, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,57 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
  * value, or rows that are not 8-byte aligned (d_type5, in_stride), takes the byte route; the results are the same bit for bit.
  * tetra_lmac_debug_force_byte_route(1) sends every row through the byte route (process-wide; tests and A/B); returns the old setting. */
 int tetra_lmac_debug_force_byte_route(int on);
+/*
+ * Decoding straight from the burst synchroniser's PACKED frames, several block kinds in ONE launch (round 6).  The reference's
+ * tetra_burst_rx_cb (src/decoder/src/phy/tetra_burst.c:343-393) cuts a frame into its blocks and hands each to tp_sap_udata_ind;
+ * tetra_burst_demux_*_device + tetra_lmac_decode_*_device do the same through a byte row per block in HBM and one launch pair per
+ * kind.  Here the decoder's front end reads the frame itself (64 bytes per lane instead of up to 432), cuts the kind's bits out of
+ * the packed words with funnel shifts -- they are already the packed bits its trellis wants -- and one launch carries every job, so
+ * that the short kinds fill the machine while the long ones run.  Results are bit for bit those of the two-step route.
+ *
+ * src     the frames of a call: d_frames [n_frames][TETRA_FRAME_WORDS = 16] uint32 (first bit most significant) and d_frame_type
+ *         [n_frames] as tetra_bsync_process_packed_device writes them; for labels (optional, see d_labels): frames_per_channel and
+ *         the per-frame-slot arrays d_frame_bitnum (synchroniser), d_time_rx / d_time (tetra_lmac_track_sync_device)
+ * jobs    one per (type, blk_num): the rows are the frames listed in d_row_frame[0 .. *d_n_rows) (NULL count: max_rows), e.g. the
+ *         lists of tetra_burst_index_device; a listed frame whose burst type does not carry the kind decodes as an all-zero block.
+ *         d_frame_scramb [n_frames]: the scrambling code per FRAME SLOT (tetra_lmac_track_sync_device's d_row_scramb; NULL for
+ *         TETRA_TPSAP_T_SB1, which always uses SCRAMB_INIT).  d_type2 [max_rows][out_stride] (8-byte aligned, out_stride a multiple
+ *         of 8 and >= type2_bits; TETRA_TPSAP_T_BBK: 30 descrambled bits + 2 zero bytes, out_stride >= 32), d_crc_ok [max_rows].
+ *         d_labels [max_rows], may be NULL: (channel, frame slot, bit number, TDMA times, crc_ok) per row -- needs src's label arrays.
+ * Jobs run in the order given; put the long kinds first (SCH/F before SB2 / NDB before BBK).  At most TETRA_LMAC_MAX_JOBS.
+ */
+#define TETRA_LMAC_MAX_JOBS 8
+typedef struct tetra_lmac_label {
+    int32_t channel;
+    int32_t frame_slot;            /* frame index within its channel: frame / frames_per_channel, frame % frames_per_channel */
+    uint32_t bitnum;               /* d_frame_bitnum[frame] */
+    uint32_t tdma_time_rx;         /* d_time_rx[frame] */
+    uint32_t tdma_time;            /* d_time[frame] */
+    int32_t crc_ok;
+} tetra_lmac_label_t;
+typedef struct tetra_lmac_frames {
+    const uint32_t* d_frames;
+    const int32_t* d_frame_type;
+    int32_t n_frames;
+    int32_t frames_per_channel;            /* labels only */
+    const uint32_t* d_frame_bitnum;        /* labels only */
+    const uint32_t* d_time_rx;             /* labels only */
+    const uint32_t* d_time;                /* labels only */
+} tetra_lmac_frames_t;
+typedef struct tetra_lmac_job {
+    int32_t type;                          /* TETRA_TPSAP_T_x */
+    int32_t blk_num;                       /* 1 / 2 as tetra_burst_rx_cb numbers them (SB1: 1, SB2: 2, NDB: 1 or 2; BBK, SCH/F: ignored) */
+    const int32_t* d_row_frame;
+    const int32_t* d_n_rows;
+    int32_t max_rows;
+    int32_t out_stride;
+    const uint32_t* d_frame_scramb;
+    uint8_t* d_type2;
+    int32_t* d_crc_ok;
+    tetra_lmac_label_t* d_labels;
+} tetra_lmac_job_t;
+int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_lmac_job_t* jobs, int n_jobs, void* hip_stream);
+
 /* Host-pointer variant (copies in/out, synchronises; device = HIP ordinal or -1 for the current one). */
 int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,
                             uint8_t* type2, int out_stride, int32_t* crc_ok, int device);
@@ -143,6 +194,20 @@ typedef struct tetra_lmac_cell_state {
 int tetra_lmac_track_sync_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_valid,
                                  const int32_t* d_n_frames, int n_channels, int frames_per_channel, tetra_lmac_cell_state_t* d_cell,
                                  uint32_t* d_row_scramb, uint32_t* d_row_time_rx, uint32_t* d_row_time, void* hip_stream);
+
+/*
+ * The same read-out for SB1 rows that are COMPACT (round 6): d_sb1_type2 / d_crc_ok hold one row per entry of the SYNC list of
+ * tetra_burst_index_device (decoded by tetra_lmac_decode_frames_device), d_chan_first_sync[c] is the position in that list of
+ * channel c's first entry, and a frame slot is a SYNC burst where d_frame_type says so.  One wavefront per channel reads the
+ * channel's rows side by side and walks the frame slots from LDS (the slot-layout form above walks HBM: a dependent load per
+ * slot).  Outputs as above; with d_sb1_labels != NULL (needs d_frame_bitnum) also the label of every SB1 row, which the decode
+ * launch cannot write because the times come from here.  frames_per_channel <= TETRA_LMAC_TRACK_MAX_FRAMES (TETRA_ERR_SIZE).
+ */
+#define TETRA_LMAC_TRACK_MAX_FRAMES 2048
+int tetra_lmac_track_sync_lists_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_frame_type,
+                                       const int32_t* d_n_frames, const int32_t* d_chan_first_sync, int n_channels, int frames_per_channel,
+                                       tetra_lmac_cell_state_t* d_cell, uint32_t* d_row_scramb, uint32_t* d_row_time_rx, uint32_t* d_row_time,
+                                       const uint32_t* d_frame_bitnum, tetra_lmac_label_t* d_sb1_labels, void* hip_stream);
 
 #ifdef __cplusplus
 }

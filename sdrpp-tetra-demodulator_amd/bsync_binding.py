@@ -8,7 +8,8 @@ from .binding import TetraDemodError, load_library
 BSYNC_EXPORTS = ["tetra_bsync_create", "tetra_bsync_destroy", "tetra_bsync_reset", "tetra_bsync_max_frames",
                  "tetra_bsync_process_device", "tetra_bsync_process", "tetra_bsync_get_state", "tetra_burst_demux_device",
                  "tetra_burst_demux_compact_device", "tetra_bsync_process_packed_device", "tetra_burst_demux_packed_device",
-                 "tetra_burst_demux_compact_packed_device"]
+                 "tetra_burst_demux_compact_packed_device", "tetra_burst_index_device"]
+LIST_SYNC, LIST_NORM_1, LIST_NORM_2, LIST_ANY, N_LISTS = 0, 1, 2, 3, 4
 FRAME_WORDS = 16
 RX_S_UNLOCKED, RX_S_KNOW_FSTART, RX_S_LOCKED = 0, 1, 2
 FRAME_STRIDE, FRAME_NONE, BITS_PER_TS = 512, -2, 510
@@ -39,6 +40,7 @@ def _lib():
         L.tetra_bsync_process_packed_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.tetra_burst_demux_packed_device.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
         L.tetra_burst_demux_compact_packed_device.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
+        L.tetra_burst_index_device.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
         for n in BSYNC_EXPORTS:
             getattr(L, n).restype = i32
         _ready = True
@@ -139,3 +141,16 @@ def demux_device(d_frames, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, 
                                          vp(d_rows.data_ptr()), int(row_stride), vp(d_valid.data_ptr()), _stream(stream))
     if rc:
         raise TetraDemodError(rc, "tetra_burst_demux_device")
+
+
+def index_device(d_frame_type, frames_per_channel, d_lists, d_counts, d_chan_first=None, d_work=None, stream=None):
+    """tetra_burst_index_device: d_lists [4][n], d_counts [4], d_chan_first [4][n / frames_per_channel] or None (int32 tensors)."""
+    import torch
+    n = int(d_frame_type.numel())
+    if d_work is None:
+        d_work = torch.empty(N_LISTS * ((n + 255) // 256) + 1, dtype=torch.int32, device=d_frame_type.device)
+    vp = C.c_void_p
+    rc = _lib().tetra_burst_index_device(vp(d_frame_type.data_ptr()), n, int(frames_per_channel), vp(d_lists.data_ptr()), vp(d_counts.data_ptr()),
+                                         None if d_chan_first is None else vp(d_chan_first.data_ptr()), vp(d_work.data_ptr()), _stream(stream))
+    if rc:
+        raise TetraDemodError(rc, "tetra_burst_index_device")

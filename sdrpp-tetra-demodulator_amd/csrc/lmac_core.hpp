@@ -30,6 +30,8 @@
 
 #include <stdint.h>
 
+#include "demux_core.hpp"
+
 #if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
 #define LM_FN __device__ __forceinline__
 #else
@@ -57,10 +59,10 @@ LM_FN uint32_t lfsr_next(uint32_t& lfsr) {
 // bit-field extracts (one instruction each on the device)
 #if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
 LM_FN uint32_t bfe_u(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
-LM_FN uint32_t bfe_mask(uint32_t x, uint32_t off) { return (uint32_t)__builtin_amdgcn_sbfe((int)x, off, 1u); }     // bit -> 0 / 0xffffffff
+LM_FN uint32_t bfe_mask(uint32_t x, uint32_t off) { return (uint32_t)__builtin_amdgcn_sbfe((int)x, off, 1u); }     // bit (off & 31) -> 0 / 0xffffffff
 #else
 LM_FN uint32_t bfe_u(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((1u << width) - 1u); }
-LM_FN uint32_t bfe_mask(uint32_t x, uint32_t off) { return 0u - ((x >> off) & 1u); }
+LM_FN uint32_t bfe_mask(uint32_t x, uint32_t off) { return 0u - ((x >> (off & 31u)) & 1u); }
 #endif
 
 // 2-bit signed class of a descrambled byte: +1 (strong 0), 0 (erasure), -1 = 0b11 (strong 1)
@@ -96,14 +98,15 @@ LM_FN uint32_t descramble_chunk(int remaining, uint32_t lfsr, Ld4 ld4, St st) {
 
 // ---- clean rows (every byte 0 or 1: what this library's own demultiplexer writes), round 6 -----------------------------------
 // The byte-serial route above costs ~12 vector instructions per type-5 bit (an LFSR step + a three-way classification per byte)
-// and is what ANY input needs.  A row of plain bits takes another route: pack the bytes 32 to a word, XOR whole words of the
-// scrambling sequence, and spread the bits to classes (+1 / -1, never an erasure) -- ~2 instructions per bit.  The sequence of a
-// 32-bit code is linear in the code (the LFSR has no constant term), so it is the XOR of four table rows indexed by the code's
-// bytes: seq_tab[t][byte][w] = word w of the sequence the code (byte << 8 t) generates (kSeqWords words = 448 bits, padded to
-// kSeqStride); the host fills the table once per device with scramb_sequence_words below.
+// and is what ANY input needs.  A row of plain bits stays bits: pack the bytes 32 to a word, XOR whole words of the scrambling
+// sequence, and let the forward recursion pick its three bits per step pair straight from those words (no classes, no erasures).
+// The sequence of a 32-bit code is linear in the code (the LFSR has no constant term), so it is the XOR of four table rows indexed
+// by the code's bytes: seq_tab[t][byte][w] = word w of the sequence the code (byte << 8 t) generates (kSeqWords words = 448 bits,
+// padded to kSeqStride); the host fills the table once per device with scramb_sequence_table below.
+// Bit order: type-5 bit i sits at bit 31 - (i & 31) of word i >> 5 -- the order of the burst synchroniser's packed frames, so that
+// a block cut out of a packed frame (decode straight from frames) needs no reversal.
 constexpr int kSeqWords = (kMaxType345 + 31) / 32;      // 14
 constexpr int kSeqStride = 16;
-// bit i of the sequence = bit (i & 31) of word i >> 5
 inline void scramb_sequence_words(uint32_t code, uint32_t* words) {
     uint32_t lfsr = code;
     for (int w = 0; w < kSeqWords; ++w) {
@@ -111,7 +114,7 @@ inline void scramb_sequence_words(uint32_t code, uint32_t* words) {
         for (int b = 0; b < 32; ++b) {
             const uint32_t bit = (uint32_t)__builtin_popcount(lfsr & kScrambTaps) & 1u;
             lfsr = (lfsr >> 1) | (bit << 31);
-            v |= bit << b;
+            v |= bit << (31 - b);
         }
         words[w] = v;
     }
@@ -124,28 +127,12 @@ inline void scramb_sequence_table(uint32_t* tab) {       // [4][256][kSeqStride]
             for (int w = kSeqWords; w < kSeqStride; ++w) row[w] = 0;
         }
 }
-// four bytes 0 / 1 -> a nibble, byte k at bit k
-LM_FN uint32_t pack4(uint32_t v) { return (v * 0x01020408u) >> 24; }
-// the low 16 bits of x, bit k moved to bit 2 k
-LM_FN uint32_t spread16(uint32_t x) {
-    x &= 0xffffu;
-    x = (x | (x << 8)) & 0x00ff00ffu;
-    x = (x | (x << 4)) & 0x0f0f0f0fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-// 16 descrambled bits -> their class word (2 bits each, bit u at 2u..2u+1): 0 -> +1 = 0b01, 1 -> -1 = 0b11; positions at and beyond
-// `live` (bits of the row left from this word's first) get class 0 like the byte route gives them
-LM_FN uint32_t class_word(uint32_t bits16, int live) {
-    const uint32_t w = (spread16(bits16) << 1) | 0x55555555u;
-    return live >= 16 ? w : (live <= 0 ? 0u : (w & ((1u << (2 * live)) - 1u)));
-}
+// four bytes 0 / 1 -> a nibble, byte 0 (the first bit) at bit 3
+LM_FN uint32_t pack4(uint32_t v) { return (v * 0x08040201u) >> 24; }
 
 struct U2 { uint32_t x, y; };
-// Packs the lane's own row, bytes -> bits (type-5 bit i at bit i & 31 of xb[i >> 5]); ld8(i) returns bytes 8i..8i+7 of the row.
-// Returns non-zero if any byte of the row is not 0 / 1 (then the byte route has to decode the row).  type345 is a multiple of 8
-// for every coded block kind.
+// Packs the lane's own row, bytes -> bits; ld8(i) returns bytes 8i..8i+7 of the row.  Returns non-zero if any byte of the row is
+// not 0 / 1 (then the byte route has to decode the row).  type345 is a multiple of 8 for every coded block kind.
 template <class Ld8>
 LM_FN uint32_t pack_row_bits(int type345, Ld8 ld8, uint32_t xb[kSeqWords]) {
     uint32_t dirty = 0;
@@ -157,120 +144,218 @@ LM_FN uint32_t pack_row_bits(int type345, Ld8 ld8, uint32_t xb[kSeqWords]) {
             if (32 * w + 8 * q < type345) {
                 const U2 d = ld8(4 * w + q);
                 dirty |= (d.x | d.y) & 0xfefefefeu;
-                v |= (pack4(d.x) | (pack4(d.y) << 4)) << (8 * q);
+                v |= ((pack4(d.x) << 4) | pack4(d.y)) << (24 - 8 * q);
             }
         }
         xb[w] = v;
     }
     return dirty;
 }
-// Descrambles the packed row and stores its class words: seq(t, byte, w) = seq_tab[t][byte][w]; st(i, word) = class word i
-// (classes of type-4 bits 16i..16i+15), the same words descramble_chunk produces for a row of plain bits.
+// Descrambles the packed row: seq(t, byte, w) = seq_tab[t][byte][w]; st(w, word) = type-4 bits 32w..32w+31.
 template <class Seq, class St>
-LM_FN void classes_from_bits(int type345, uint32_t code, const uint32_t xb[kSeqWords], Seq seq, St st) {
+LM_FN void descramble_bits(int type345, uint32_t code, const uint32_t xb[kSeqWords], Seq seq, St st) {
 #pragma unroll
-    for (int w = 0; w < kSeqWords; ++w) {
-        if (32 * w < type345) {
-            const uint32_t sw = seq(0, code & 0xffu, w) ^ seq(1, (code >> 8) & 0xffu, w) ^ seq(2, (code >> 16) & 0xffu, w) ^ seq(3, code >> 24, w);
-            const uint32_t x = xb[w] ^ sw;
-            const int live = type345 - 32 * w;
-            st(2 * w, class_word(x, live));
-            if (live > 16) st(2 * w + 1, class_word(x >> 16, live - 16));
+    for (int w = 0; w < kSeqWords; ++w)
+        if (32 * w < type345)
+            st(w, xb[w] ^ seq(0, code & 0xffu, w) ^ seq(1, (code >> 8) & 0xffu, w) ^ seq(2, (code >> 16) & 0xffu, w) ^ seq(3, code >> 24, w));
+}
+
+// ---- blocks straight from the burst synchroniser's packed frames (16 words, first bit most significant) ---------------------------
+constexpr int kFrameWords = 16;
+// 32 bits of a frame from burst bit s on; bits past the 512th read as zero.  (s is a constant wherever this is called: the block
+// kind of a job selects one of a handful of literal layouts, and the loops around it are unrolled.)
+LM_FN uint32_t frame_window(const uint32_t fw[kFrameWords], int s) {
+    const int w = s >> 5, sh = s & 31;
+    const uint32_t hi = w < kFrameWords ? fw[w] : 0u, lo = w + 1 < kFrameWords ? fw[w + 1] : 0u;
+    return sh ? (hi << sh) | (lo >> (32 - sh)) : hi;
+}
+// the type-5 bits of a block = burst bits [off0, off0 + len0) then [off1, off1 + len1) (tetra_burst.c:343-393), as packed words
+// (bit i at bit 31 - (i & 31) of word i >> 5), zero behind the block
+LM_FN void extract_block(const uint32_t fw[kFrameWords], int off0, int len0, int off1, int len1, uint32_t xb[kSeqWords]) {
+    const int total = len0 + len1;
+#pragma unroll
+    for (int v = 0; v < kSeqWords; ++v) {
+        const int start = 32 * v;
+        uint32_t x = 0;
+        if (start < total) {
+            if (start + 32 <= len0) x = frame_window(fw, off0 + start);
+            else if (start >= len0) x = frame_window(fw, off1 + start - len0);
+            else x = (frame_window(fw, off0 + start) & ~(0xffffffffu >> (len0 - start))) | (frame_window(fw, off1) >> (len0 - start));
+            if (total - start < 32) x &= ~(0xffffffffu >> (total - start));
         }
+        xb[v] = x;
     }
 }
 
+// where a kind's bits sit in its burst (demux_core::pieces_for), as literal layouts so that every shift is a constant
+enum { kLayoutSb1 = 0, kLayoutSb2, kLayoutNdb1, kLayoutNdb2, kLayoutSchF, kLayoutBbk, kLayoutNone };
+template <int TRAIN, int TPSAP, int BLK>
+LM_FN void cut(const uint32_t fw[kFrameWords], int frame_type, uint32_t xb[kSeqWords]) {
+    const demux_core::Pieces p = demux_core::pieces_for(TRAIN, TPSAP, BLK);
+    extract_block(fw, p.off0, p.len0, p.off1, p.len1, xb);
+    if (frame_type != TRAIN) {          // a listed frame of another burst type: the demultiplexer's all-zero row
+#pragma unroll
+        for (int v = 0; v < kSeqWords; ++v) xb[v] = 0;
+    }
+}
+LM_FN void frame_block(int layout, const uint32_t fw[kFrameWords], int frame_type, uint32_t xb[kSeqWords]) {
+    switch (layout) {
+        case kLayoutSb1: cut<TETRA_TRAIN_SYNC, TETRA_TPSAP_T_SB1, 1>(fw, frame_type, xb); break;
+        case kLayoutSb2: cut<TETRA_TRAIN_SYNC, TETRA_TPSAP_T_SB2, 2>(fw, frame_type, xb); break;
+        case kLayoutNdb1: cut<TETRA_TRAIN_NORM_2, TETRA_TPSAP_T_NDB, 1>(fw, frame_type, xb); break;
+        case kLayoutNdb2: cut<TETRA_TRAIN_NORM_2, TETRA_TPSAP_T_NDB, 2>(fw, frame_type, xb); break;
+        case kLayoutSchF: cut<TETRA_TRAIN_NORM_1, TETRA_TPSAP_T_SCH_F, 0>(fw, frame_type, xb); break;
+        default:
+#pragma unroll
+            for (int v = 0; v < kSeqWords; ++v) xb[v] = 0;
+    }
+}
+// the 30 AACH bits of a frame (SYNC: one piece, NORM_1 / NORM_2: two), first bit most significant; 0 for any other frame type
+LM_FN uint32_t bbk_bits(const uint32_t fw[kFrameWords], int frame_type) {
+    uint32_t xs[kSeqWords], xn[kSeqWords];
+    const demux_core::Pieces ps = demux_core::pieces_for(TETRA_TRAIN_SYNC, TETRA_TPSAP_T_BBK, 0);
+    const demux_core::Pieces pn = demux_core::pieces_for(TETRA_TRAIN_NORM_1, TETRA_TPSAP_T_BBK, 0);
+    extract_block(fw, ps.off0, ps.len0, ps.off1, ps.len1, xs);
+    extract_block(fw, pn.off0, pn.len0, pn.off1, pn.len1, xn);
+    return frame_type == TETRA_TRAIN_SYNC ? xs[0] : ((frame_type == TETRA_TRAIN_NORM_1 || frame_type == TETRA_TRAIN_NORM_2) ? xn[0] : 0u);
+}
+LM_FN uint32_t rev32(uint32_t x) {
+#if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
+    return __builtin_bitreverse32(x);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+#endif
+}
+LM_FN uint32_t spread4(uint32_t nib);
+// bits 4k..4k+3 of a first-bit-most-significant word as four bytes, first bit in the low byte
+LM_FN uint32_t bbk_bytes(uint32_t y, int k) { return spread4(rev32(y << (4 * k)) & 0xfu); }
+
 // ---- packed 16-bit lanes: two path metrics per 32-bit register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16) --------
 // In units of 127 a path metric never leaves [-2*292, 20 + 2*292], so int16 needs no renormalisation at all.
+// pk_lo2 / pk_hi2 / pk_swap feed a packed operation and cost nothing on the device: the compiler folds them into the operation's
+// op_sel / op_sel_hi operand modifiers.
 #if defined(__HIPCC__) && !defined(TETRA_HOST_EMUL)
 typedef short Pk __attribute__((ext_vector_type(2)));
 LM_FN Pk pk_make(int lo, int hi) { Pk r; r.x = (short)lo; r.y = (short)hi; return r; }
 LM_FN Pk pk_add(Pk a, Pk b) { return a + b; }
 LM_FN Pk pk_sub(Pk a, Pk b) { return a - b; }
 LM_FN Pk pk_max(Pk a, Pk b) { return __builtin_elementwise_max(a, b); }
-LM_FN Pk pk_lolo(Pk x, Pk y) { return __builtin_shufflevector(x, y, 0, 2); }
-LM_FN Pk pk_hihi(Pk x, Pk y) { return __builtin_shufflevector(x, y, 1, 3); }
+LM_FN Pk pk_lo2(Pk x) { return __builtin_shufflevector(x, x, 0, 0); }
+LM_FN Pk pk_hi2(Pk x) { return __builtin_shufflevector(x, x, 1, 1); }
 LM_FN Pk pk_swap(Pk x) { return __builtin_shufflevector(x, x, 1, 0); }
 LM_FN uint32_t pk_bits(Pk a) { return __builtin_bit_cast(uint32_t, a); }
+LM_FN Pk pk_from_bits(uint32_t v) { return __builtin_bit_cast(Pk, v); }
+// v_perm_b32: byte k of the result = byte sel[k] of the eight bytes { hi (7..4), lo (3..0) }
+LM_FN uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 #else
 struct Pk { int16_t x, y; };
 LM_FN Pk pk_make(int lo, int hi) { return Pk{ (int16_t)lo, (int16_t)hi }; }
 LM_FN Pk pk_add(Pk a, Pk b) { return Pk{ (int16_t)(a.x + b.x), (int16_t)(a.y + b.y) }; }
 LM_FN Pk pk_sub(Pk a, Pk b) { return Pk{ (int16_t)(a.x - b.x), (int16_t)(a.y - b.y) }; }
 LM_FN Pk pk_max(Pk a, Pk b) { return Pk{ a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y }; }
-LM_FN Pk pk_lolo(Pk x, Pk y) { return Pk{ x.x, y.x }; }
-LM_FN Pk pk_hihi(Pk x, Pk y) { return Pk{ x.y, y.y }; }
+LM_FN Pk pk_lo2(Pk x) { return Pk{ x.x, x.x }; }
+LM_FN Pk pk_hi2(Pk x) { return Pk{ x.y, x.y }; }
 LM_FN Pk pk_swap(Pk x) { return Pk{ x.y, x.x }; }
 LM_FN uint32_t pk_bits(Pk a) { return (uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16); }
+LM_FN Pk pk_from_bits(uint32_t v) { return Pk{ (int16_t)(v & 0xffffu), (int16_t)(v >> 16) }; }
+LM_FN uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t all = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) r |= (uint32_t)((all >> (8 * ((sel >> (8 * k)) & 7u))) & 0xffu) << (8 * k);
+    return r;
+}
 #endif
 
-// Path metrics of the 16 states, packed for the butterflies: butterfly j has predecessors 2j (even) and 2j+1 (odd) and
-// produces states j and j+8.  E[k] = (S[4k], S[4k+2]) and O[k] = (S[4k+1], S[4k+3]) are the even / odd predecessors of
-// butterflies 2k (low half) and 2k+1 (high half).
-struct PathMetrics { Pk E[4], O[4]; };
+// Path metrics of the 16 states: R[i] = (S[i], S[i + 8]).  Butterfly i has predecessors 2i (even) and 2i + 1 (odd) and produces
+// states i and i + 8 -- exactly one register -- from one half each of R[2i & 7] and R[(2i + 1) & 7]: with the halves broadcast by
+// operand modifiers a step is 8 x (add, subtract, maximum, difference) and not one move (round 6; until then (S[4k], S[4k+2]) /
+// (S[4k+1], S[4k+3]) pairs and eight permutes per step to re-pair the results).
+struct PathMetrics { Pk R[8]; };
 
-// One add-compare-select step.  Mk = (m_2k, m_2k+1) are the branch metrics of butterflies 2k and 2k+1.  Returns the 16
-// decision bits, state s at bit 15 - s (1 = state s took its odd predecessor).
-LM_FN uint32_t acs_pk(PathMetrics& pm, Pk M0, Pk M1, Pk M2, Pk M3) {
-    const Pk M[4] = { M0, M1, M2, M3 };
-    Pk NN[8];      // NN[j] = (S'[2j], S'[2j+1])
-    Pk D[8];       // sign bits = decisions of states (2r, 2r+1)
+// One add-compare-select step.  Mm[i] = (m_i, -m_i), m_i = branch metric of the transition 2i --0--> i (the other three transitions
+// of the butterfly are -m, -m, +m).  D[i] = (difference into state i, into state i + 8): negative <=> the odd predecessor is
+// strictly better (ties keep the even one).
+LM_FN void acs_step(PathMetrics& pm, const Pk Mm[8], Pk D[8]) {
+    Pk N[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const Pk e0 = pk_add(pm.E[k], M[k]), o0 = pk_sub(pm.O[k], M[k]);   // into states 2k, 2k+1
-        const Pk e1 = pk_sub(pm.E[k], M[k]), o1 = pk_add(pm.O[k], M[k]);   // into states 2k+8, 2k+9
-        NN[k] = pk_max(e0, o0);
-        NN[k + 4] = pk_max(e1, o1);
-        D[k] = pk_sub(e0, o0);          // negative <=> odd predecessor strictly better (ties keep the even one)
-        D[k + 4] = pk_sub(e1, o1);
+    for (int i = 0; i < 8; ++i) {
+        const Pk a = pm.R[(2 * i) & 7], b = pm.R[(2 * i + 1) & 7];
+        const Pk e = pk_add(i < 4 ? pk_lo2(a) : pk_hi2(a), Mm[i]);      // S[2i] + m, S[2i] - m
+        const Pk o = pk_sub(i < 4 ? pk_lo2(b) : pk_hi2(b), Mm[i]);      // S[2i+1] - m, S[2i+1] + m
+        N[i] = pk_max(e, o);
+        D[i] = pk_sub(e, o);
     }
-    uint32_t acc = 0;
 #pragma unroll
-    for (int r = 7; r >= 0; --r) acc = (acc >> 2) | (pk_bits(D[r]) & 0x80008000u);
-    // low-half sign of D[r] (state 2r) now sits at bit 15 - 2r, high-half sign (state 2r+1) at bit 31 - 2r
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        pm.E[k] = pk_lolo(NN[2 * k], NN[2 * k + 1]);
-        pm.O[k] = pk_hihi(NN[2 * k], NN[2 * k + 1]);
-    }
-    return (acc & 0xaaaau) | ((acc >> 17) & 0x5555u);
+    for (int i = 0; i < 8; ++i) pm.R[i] = N[i];
 }
 
-LM_FN Pk pk_neg(Pk a) { return pk_sub(pk_make(0, 0), a); }
+// The 2 x 16 decisions of a step pair as one word: state s of the even step at bit 2 (15 - s) + 1, of the odd step at bit
+// 2 (15 - s); 1 = the state took its odd predecessor.  A permute gathers the four sign bytes of D[k] and D[k + 4] (states k, k + 4,
+// k + 8, k + 12 -> bytes 3, 2, 1, 0); the eight gathered words are then merged from bit 7 of every byte downwards, a shift and a
+// bit-field insert each: 22 instructions per step pair (until round 6 a shift and a masked OR per difference register: 38).
+LM_FN uint32_t decision_word(const Pk De[8], const Pk Do[8]) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t pe = perm_b32(pk_bits(De[k]), pk_bits(De[k + 4]), 0x05010703u);
+        const uint32_t po = perm_b32(pk_bits(Do[k]), pk_bits(Do[k + 4]), 0x05010703u);
+        const uint32_t keep_e = 0x01010101u * (0xffu & ~(0xffu >> (2 * k))), keep_o = 0x01010101u * (0xffu & ~(0xffu >> (2 * k + 1)));
+        w = (w & keep_e) | ((pe >> (2 * k)) & ~keep_e);          // bits 7 - 2k and below of every byte from pe (below: overwritten next)
+        w = (w & keep_o) | ((po >> (2 * k + 1)) & ~keep_o);
+    }
+    return w;
+}
 
-// Forward recursion over n2 + 4 steps, two steps per call-back (round 6: one 32-bit store per step pair instead of two 16-bit ones).
-// cls(idx) returns the soft class (-1, 0, +1) of type-4 bit idx (0-based); st(u, word) receives the decisions of steps 2u (low
-// half) and 2u + 1 (high half), INVERTED: state s at bit 15 - s of its half, 1 = the state kept its EVEN predecessor -- the form
-// the traceback consumes without a complement.  n2 is even for every block kind.
-template <class Cls, class St>
-LM_FN void viterbi_forward(int n2, int K, int a, Cls cls, St st) {
+// Branch metrics of a step pair: P = (p, -p), Q = (q, -q) for the even step (g1 -> sa, g2 -> sb; butterfly i = (d0 d1 d2):
+// sign(g1) = d0, sign(g2) = d1 ^ d2, so with p = sa + sb, q = sa - sb the metrics are m_0..7 = p, q, q, p, -q, -p, -p, -q),
+// C = (sc, -sc) for the odd step (g1 -> sc only: m_0..3 = sc, m_4..7 = -sc).
+struct Bm { Pk P, Q, C; };
+LM_FN Bm bm_from_classes(int sa, int sb, int sc) {
+    return Bm{ pk_make(sa + sb, -(sa + sb)), pk_make(sa - sb, sb - sa), pk_make(sc, -sc) };
+}
+// the same from three plain bits given as masks (0 -> class +1, all ones -> class -1): five + two instructions
+LM_FN Bm bm_from_masks(uint32_t ma, uint32_t mb, uint32_t mc) {
+    const uint32_t k = 0xfffe0002u;                                     // (2, -2)
+    const Pk A = pk_from_bits(ma & k), B = pk_from_bits(mb & k);
+    return Bm{ pk_sub(pk_sub(pk_from_bits(k), A), B), pk_sub(B, A), pk_from_bits(0xffff0001u ^ (mc & 0xfffefffeu)) };
+}
+
+// the interleaver's running index (a * i) % K, i = 1, 2, ...: returns the current position and advances (a < K for every kind)
+LM_FN int interleave_next(int& pos, int a, int K) {
+    const int p = pos;
+    pos += a;
+    pos = pos >= K ? pos - K : pos;
+    return p;
+}
+
+// Forward recursion over n2 + 4 steps, two steps per call-back.  next() returns the branch metrics of the next step pair (the
+// soft values of type-4 bits at three consecutive interleaver positions); st(u, word) receives decision_word of steps 2u, 2u + 1.
+// n2 is even for every block kind.
+template <class Next, class St>
+LM_FN void viterbi_forward(int n2, Next next, St st) {
     PathMetrics pm;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { pm.E[k] = pk_make(0, 0); pm.O[k] = pk_make(0, 0); }
-    pm.E[0] = pk_make(4 * 5, 0);       // S[0] = 127 * N * K in units of 127
-    int pos = a;                       // (a * i) % K for i = 1 (a < K for every block kind)
+    for (int i = 0; i < 8; ++i) pm.R[i] = pk_make(0, 0);
+    pm.R[0] = pk_make(4 * 5, 0);       // S[0] = 127 * N * K in units of 127
     for (int u = 0; u < n2 / 2; ++u) {
-        const int sa = cls(pos);
-        pos += a; pos = pos >= K ? pos - K : pos;
-        const int sb = cls(pos);
-        pos += a; pos = pos >= K ? pos - K : pos;
-        const int sc = cls(pos);
-        pos += a; pos = pos >= K ? pos - K : pos;
-        // even step: g1 -> sa, g2 -> sb.  butterfly i = (d0 d1 d2): sign(g1) = d0, sign(g2) = d1 ^ d2, so with
-        // p = sa + sb, q = sa - sb the metrics are m_0..7 = p, q, q, p, -q, -p, -p, -q
-        const Pk pq = pk_make(sa + sb, sa - sb), qp = pk_swap(pq);
-        const uint32_t even = acs_pk(pm, pq, qp, pk_neg(qp), pk_neg(pq));
-        // odd step: g1 -> sc only: m_0..3 = sc, m_4..7 = -sc
-        const Pk cc = pk_make(sc, sc), nc = pk_neg(cc);
-        const uint32_t odd = acs_pk(pm, cc, cc, nc, nc);
-        st(u, (even | (odd << 16)) ^ 0xffffffffu);
+        const Bm m = next();
+        Pk De[8], Do[8];
+        const Pk Me[8] = { m.P, m.Q, m.Q, m.P, pk_swap(m.Q), pk_swap(m.P), pk_swap(m.P), pk_swap(m.Q) };
+        acs_step(pm, Me, De);
+        const Pk Mo[8] = { m.C, m.C, m.C, m.C, pk_swap(m.C), pk_swap(m.C), pk_swap(m.C), pk_swap(m.C) };
+        acs_step(pm, Mo, Do);
+        st(u, decision_word(De, Do));
     }
 #pragma unroll
     for (int f = 0; f < kFlush / 2; ++f) {
         const Pk z = pk_make(0, 0);
-        const uint32_t even = acs_pk(pm, z, z, z, z);
-        const uint32_t odd = acs_pk(pm, z, z, z, z);
-        st(n2 / 2 + f, (even | (odd << 16)) ^ 0xffffffffu);
+        const Pk Mz[8] = { z, z, z, z, z, z, z, z };
+        Pk De[8], Do[8];
+        acs_step(pm, Mz, De);
+        acs_step(pm, Mz, Do);
+        st(n2 / 2 + f, decision_word(De, Do));
     }
 }
 
@@ -303,16 +388,20 @@ constexpr uint32_t crc_fold_constant(const CrcTable& c, int n) {
 // stored it; st(h, half) receives decoded bits 16h..16h+15 (bit 16h+b at bit b); tbl(k) = CrcTable::t[k] (wave-uniform index);
 // n_crc = type1 + 16 bits are covered by the CRC (n2 = n_crc + 4 tail bits), fold = crc_fold_constant(n_crc).  Returns the CRC
 // register.  n2 is a multiple of 16.
-// y = 15 - state runs in a shift register: y' = (y << 1 | inverted decision) & 15, and the decoded bit of a step is the complement
-// of bit 3 of y before the step, so after 16 steps the 16 decoded bits sit, complemented, at bits 4..19.
+// y = 15 - state runs in a shift register: the predecessor of state s under decision d is (2 s + d) & 15, so y' = 2 y + 1 - d, and
+// the decision of state s sits at bit 2 y (odd step) or 2 y + 1 (even step) of the word: a shift, a one-bit signed extract (= -d)
+// and an add per step.  The decoded bit of a step is the complement of bit 3 of y before the step, so after 16 steps the 16 decoded
+// bits sit, complemented, at bits 4..19.
 template <class Ld, class St, class Tbl>
 LM_FN uint32_t viterbi_traceback(int n2, int n_crc, uint32_t fold, Ld ld, St st, Tbl tbl) {
     uint32_t y = 15u;
 #pragma unroll
     for (int f = kFlush / 2 - 1; f >= 0; --f) {
         const uint32_t w = ld(n2 / 2 + f);
-        y = (y << 1) | bfe_u(w, (y & 15u) | 16u, 1);
-        y = (y << 1) | bfe_u(w, y & 15u, 1);
+        uint32_t t = y << 1;
+        y = t + 1u + bfe_mask(w, t);
+        t = (y << 1) | 1u;
+        y = t + bfe_mask(w, t);
     }
     uint32_t acc = 0;
     for (int h = n2 / 16 - 1; h >= 0; --h) {
@@ -322,9 +411,11 @@ LM_FN uint32_t viterbi_traceback(int n2, int n_crc, uint32_t fold, Ld ld, St st,
             const uint32_t w = ld(8 * h + b2);
             // step 16h + 2 b2 + 1, then step 16h + 2 b2: y bit 3 set <=> the decoded bit is 0
             acc ^= tbl(k0 - 2 * b2 - 1) & bfe_mask(y, 3);
-            y = (y << 1) | bfe_u(w, (y & 15u) | 16u, 1);
+            uint32_t t = y << 1;
+            y = t + 1u + bfe_mask(w, t);
             acc ^= tbl(k0 - 2 * b2) & bfe_mask(y, 3);
-            y = (y << 1) | bfe_u(w, y & 15u, 1);
+            t = (y << 1) | 1u;
+            y = t + bfe_mask(w, t);
         }
         st(h, (~y >> 4) & 0xffffu);
     }

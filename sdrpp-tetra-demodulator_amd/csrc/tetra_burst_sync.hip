@@ -243,6 +243,71 @@ template <bool GATHER> __global__ __launch_bounds__(256) void k_demux_rows(const
     demux_core::rows_thread<GATHER>(blockIdx.x, threadIdx.x, frames, frame_type, row_frame, have, lut, row_u, rows_per_wave, inv_row_u, rows, valid);
 }
 
+// ---- the frame lists of a call (tetra_burst_index_device): SYNC / NORM_1 / NORM_2 / any, frame order ----------------------------
+__device__ __forceinline__ unsigned list_mask(int t) {      // bit k set <=> a frame of type t belongs to list k
+    return t == TETRA_TRAIN_SYNC ? (1u << TETRA_LIST_SYNC) | (1u << TETRA_LIST_ANY)
+         : t == TETRA_TRAIN_NORM_1 ? (1u << TETRA_LIST_NORM_1) | (1u << TETRA_LIST_ANY)
+         : t == TETRA_TRAIN_NORM_2 ? (1u << TETRA_LIST_NORM_2) | (1u << TETRA_LIST_ANY) : 0u;
+}
+// 1. entries per 256 frames and list
+__global__ __launch_bounds__(256) void k_index_count(const int* __restrict__ frame_type, int n, int nblocks, int* __restrict__ work) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const unsigned m = r < n ? list_mask(frame_type[r]) : 0u;
+#pragma unroll
+    for (int k = 0; k < TETRA_N_LISTS; ++k) {
+        const int c = __syncthreads_count((m >> k) & 1u);
+        if (threadIdx.x == 0) work[k * nblocks + blockIdx.x] = c;
+    }
+}
+// 2. exclusive scan of each list's block counts (one workgroup), totals -> counts
+__global__ __launch_bounds__(1024) void k_index_scan(int* __restrict__ work, int nblocks, int* __restrict__ counts) {
+    __shared__ int part[1024];
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(nblocks, lo + per);
+    for (int k = 0; k < TETRA_N_LISTS; ++k) {
+        int* cnt = work + k * nblocks;
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += cnt[i];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan
+            const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+        for (int i = lo; i < hi; ++i) { const int c = cnt[i]; cnt[i] = run; run += c; }
+        if (threadIdx.x == 1023) counts[k] = part[1023];
+        __syncthreads();
+    }
+}
+// 3. the lists themselves, and per channel the position of its first entry
+__global__ __launch_bounds__(256) void k_index_write(const int* __restrict__ frame_type, int n, int nblocks, int frames_per_channel,
+                                                     const int* __restrict__ work, int* __restrict__ lists, int* __restrict__ chan_first) {
+    __shared__ int wave_cnt[TETRA_N_LISTS][4];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const unsigned m = r < n ? list_mask(frame_type[r]) : 0u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long b[TETRA_N_LISTS];
+#pragma unroll
+    for (int k = 0; k < TETRA_N_LISTS; ++k) {
+        b[k] = __ballot((m >> k) & 1u);
+        if (lane == 0) wave_cnt[k][w] = __popcll(b[k]);
+    }
+    __syncthreads();
+    const bool first_of_channel = chan_first && r < n && r % frames_per_channel == 0;
+    const int chans = first_of_channel ? n / frames_per_channel : 0;
+#pragma unroll
+    for (int k = 0; k < TETRA_N_LISTS; ++k) {
+        int at = work[k * nblocks + blockIdx.x];
+        for (int i = 0; i < w; ++i) at += wave_cnt[k][i];
+        at += __popcll(b[k] & ((1ull << lane) - 1ull));
+        if ((m >> k) & 1u) lists[(size_t)k * n + at] = r;
+        if (first_of_channel) chan_first[(size_t)k * chans + r / frames_per_channel] = at;
+    }
+}
+
 size_t lds_bytes(int max_bits, int max_frames) { return (size_t)stream_words(max_bits) * 5 * sizeof(uint32_t) + (size_t)max_frames * sizeof(FrameRec); }
 
 }  // namespace
@@ -464,6 +529,20 @@ int tetra_burst_demux_compact_device(const uint8_t* d_frames, const int32_t* d_f
 int tetra_burst_demux_compact_packed_device(const uint32_t* d_frames_packed, const int32_t* d_frame_type, int n, int tpsap, int blk_num,
                                             uint8_t* d_rows, int row_stride, int32_t* d_row_frame, int32_t* d_n_rows, void* hip_stream) {
     return demux_compact_launch<true>(d_frames_packed, d_frame_type, n, tpsap, blk_num, d_rows, row_stride, d_row_frame, d_n_rows, hip_stream);
+}
+
+int tetra_burst_index_device(const int32_t* d_frame_type, int n, int frames_per_channel, int32_t* d_lists, int32_t* d_counts,
+                             int32_t* d_chan_first, int32_t* d_work, void* hip_stream) {
+    if (!d_frame_type || !d_lists || !d_counts || !d_work || n < 0) return TETRA_ERR_ARG;
+    if (d_chan_first && (frames_per_channel < 1 || n % frames_per_channel)) return TETRA_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (n == 0) return hipMemsetAsync(d_counts, 0, sizeof(int32_t) * TETRA_N_LISTS, s) == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+    const int nblocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_index_count, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, nblocks, d_work);
+    hipLaunchKernelGGL(k_index_scan, dim3(1), dim3(1024), 0, s, d_work, nblocks, d_counts);
+    hipLaunchKernelGGL(k_index_write, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, nblocks, d_chan_first ? frames_per_channel : 1, d_work,
+                       d_lists, d_chan_first);
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 
 }  // extern "C"

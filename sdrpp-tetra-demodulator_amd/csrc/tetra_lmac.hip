@@ -2,28 +2,32 @@
 // tp_sap_udata_ind() decoding chain (src/decoder/src/lower_mac/tetra_lower_mac.c:181-236).
 //
 // One 64-lane workgroup (one wavefront) decodes 64 blocks, one block per lane (lane-level code: lmac_core.hpp):
-//   1. front end, rows of plain bits (every byte 0 / 1: what this library's demultiplexer writes; round 6): every lane reads ITS OWN
-//      row with 8-byte loads (the 64 rows of a workgroup are 64 strided streams that live in L1 while they are consumed), packs
-//      the bytes 32 to a register, XORs whole words of its scrambling sequence (linear in the code: four rows of a 64 KB table
-//      indexed by the code's bytes) and spreads the bits to soft classes -- ~2 vector instructions per type-5 bit;
-//      any other row (a byte that is not 0 / 1 anywhere in the workgroup's 64 rows): the byte route -- rows staged through LDS in
-//      coalesced 64-bit chunks, an LFSR step and a three-way classification (0 / erasure 0xff / 1) per byte, ~12 per bit;
-//      either way the classes end up 2 bits per type-4 bit in LDS words laid out [word][lane];
-//   2. forward recursion: 16 path metrics in registers (packed int16 pairs), the three soft values of a step pair gathered from
-//      the class words at the deinterleaved positions, the 2 x 16 decision bits of a step pair stored as one dword to a global
-//      scratch laid out [workgroup][step pair][lane] (one 256-byte line per pair; written once, read once, normally from L2 / MALL);
+//   1. front end -> the descrambled type-4 bits of the lane's block as packed words in LDS, [word][lane]:
+//      * from PACKED FRAMES (k_lmac_frames, round 6): the lane reads its frame (four 16-byte loads), cuts the kind's one or two bit
+//        ranges out with funnel shifts and XORs whole words of its scrambling sequence (linear in the code: four rows of a 64 KB
+//        table indexed by the code's bytes);
+//      * from byte rows of plain bits (k_lmac_decode; every byte 0 / 1): the lane reads ITS OWN row with 8-byte loads, packs the
+//        bytes 32 to a register, then the same;
+//      * from byte rows with any other byte value anywhere in the workgroup's 64 rows (erasures), or rows that are not 8-byte
+//        aligned: the byte route -- rows staged through LDS in coalesced 64-bit chunks, an LFSR step and a three-way classification
+//        (0 / erasure 0xff / 1) per byte, soft classes 2 bits per type-4 bit in LDS;
+//   2. forward recursion: 16 path metrics in 8 registers (packed int16: states i and i + 8), the three soft values of a step pair
+//      gathered from LDS at the deinterleaved positions (wave-uniform addresses), a butterfly = add, subtract, maximum, difference
+//      with the halves picked by operand modifiers (no moves), the 2 x 16 decision bits of a step pair gathered with byte permutes
+//      and stored as one dword to a global scratch laid out [workgroup][step pair][lane] (one 256-byte line per pair; written
+//      once, read once, normally from L2 / MALL): 99 vector instructions per step pair;
 //   3. traceback from the scratch (the addresses do not depend on the surviving state, only the bit picked does, so the loads
 //      pipeline) with the CRC16 folded in (affine in the message: one AND + XOR per bit with a wave-uniform constant), decoded bits
 //      packed 16 per ushort into LDS [half][lane];
-//   4. the 64 decoded rows are written back with coalesced dword stores, 4 bits -> 4 bytes per lane.
-// LDS per workgroup: 4352 (stage) + 6912 (classes) + 2304 (decoded) = 13568 B -> 11 workgroups per CU.  The work is integer
-// add / compare / select: bound by vector issue (67 instructions per trellis step and wave in the recursion itself).
+//   4. the 64 decoded rows are written back with coalesced 8-byte stores, 8 bits -> 8 bytes per lane.
+// The work is integer add / compare / select: bound by vector issue.
 #include <hip/hip_runtime.h>
 
 #include <mutex>
 #include <vector>
 
 #include "../../include/tetra_lmac.h"
+#include "demux_core.hpp"
 #include "lmac_core.hpp"
 
 namespace {
@@ -35,6 +39,7 @@ constexpr int kChunkDwords = 16;                       // 64 type-5 bits per row
 constexpr int kSteps = kMaxType2 + kFlush;             // 292
 constexpr int kClsWords = (kMaxType345 + 15) / 16;     // 27
 constexpr int kOutHalves = kMaxType2 / 16;             // 18
+constexpr int kOutPad = 2;                             // outw rows of 66 ushorts = 33 banks: the write-back's column reads do not collide
 bool g_force_byte_route = false;                       // tests / A-B: tetra_lmac_debug_force_byte_route
 __constant__ CrcTable kCrcDev = make_crc_table();      // the traceback's CRC constants (constant address space: scalar loads)
 
@@ -49,6 +54,79 @@ const BlkParam kBlk[6] = {
     { 432, 288, 268, 103, 1 },  // SCH/F
 };
 
+typedef uint16_t OutW[kOutHalves][kLanes + kOutPad];
+
+// steps 2-4 for a workgroup whose type-4 bits (BITS) or soft classes are in `cls`; returns the lane's CRC verdict
+template <bool BITS>
+__device__ __forceinline__ bool decode_core(const uint32_t (*cls)[kLanes], OutW& outw, int lane, int type345, int type2, int type1, int a,
+                                            uint32_t crc_fold, uint32_t* __restrict__ dec) {
+    int pos = a;                       // (a * i) % K for i = 1
+    if (BITS) {
+        auto bit = [&](int p) { return bfe_mask(cls[p >> 5][lane], 31u - (uint32_t)(p & 31)); };
+        viterbi_forward(type2,
+                        [&] {
+                            const uint32_t ma = bit(interleave_next(pos, a, type345)), mb = bit(interleave_next(pos, a, type345));
+                            return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
+                        },
+                        [&](int u, uint32_t word) { dec[u * kLanes] = word; });
+    } else {
+        auto soft = [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; };
+        viterbi_forward(type2,
+                        [&] {
+                            const int sa = soft(interleave_next(pos, a, type345)), sb = soft(interleave_next(pos, a, type345));
+                            return bm_from_classes(sa, sb, soft(interleave_next(pos, a, type345)));
+                        },
+                        [&](int u, uint32_t word) { dec[u * kLanes] = word; });
+    }
+    // traceback + CRC (own lane's data only: program order is enough)
+    const uint32_t crc = viterbi_traceback(type2, type1 + 16, crc_fold, [&](int u) { return dec[u * kLanes]; },
+                                           [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
+                                           [&](int k) { return kCrcDev.t[k]; });
+    return crc == kCrcOk;
+}
+
+// step 4: decoded rows -> HBM.  WIDE: rows a multiple of 8 bytes and 8-byte aligned -- 8 bits -> 8 bytes per lane, the (row, unit)
+// index space flattened so that every lane stores in every round (q = i / units by a multiply: exact for i < 64 * 36).
+__device__ __forceinline__ void write_rows(const OutW& outw, int lane, int rows_here, int type2, uint8_t* __restrict__ out0, int out_stride) {
+    if (!(out_stride & 7) && !((uintptr_t)out0 & 7)) {
+        const int units = type2 >> 3, total = rows_here * units;
+        const uint32_t inv = ((1u << 20) + (uint32_t)units - 1u) / (uint32_t)units;
+        for (int i = lane; i < total; i += kLanes) {
+            const int q = (int)(((uint32_t)i * inv) >> 20), d = i - q * units;
+            const uint32_t byte = ((uint32_t)outw[d >> 1][q] >> (8 * (d & 1))) & 0xffu;
+            demux_core::U2 v;
+            v.x = spread4(byte & 0xfu);
+            v.y = spread4(byte >> 4);
+            reinterpret_cast<demux_core::U2*>(out0 + (size_t)q * out_stride)[d] = v;
+        }
+    } else {
+        const int out_dw = type2 >> 2;
+        for (int q = 0; q < rows_here; ++q) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(out0 + (size_t)q * out_stride);
+            for (int d = lane; d < out_dw; d += kLanes) dst[d] = spread4(((uint32_t)outw[d >> 2][q] >> (4 * (d & 3))) & 0xfu);
+        }
+    }
+}
+
+// the lane's scrambling sequence words XORed onto its packed row, result to LDS (sequence rows as 16-byte loads)
+__device__ __forceinline__ void descramble_to_lds(int type345, uint32_t code, const uint32_t xb[kSeqWords], const uint32_t* __restrict__ seq_tab,
+                                                  uint32_t (*cls)[kLanes], int lane) {
+    const uint4* r0 = reinterpret_cast<const uint4*>(seq_tab + ((size_t)0 * 256 + (code & 0xffu)) * kSeqStride);
+    const uint4* r1 = reinterpret_cast<const uint4*>(seq_tab + ((size_t)1 * 256 + ((code >> 8) & 0xffu)) * kSeqStride);
+    const uint4* r2 = reinterpret_cast<const uint4*>(seq_tab + ((size_t)2 * 256 + ((code >> 16) & 0xffu)) * kSeqStride);
+    const uint4* r3 = reinterpret_cast<const uint4*>(seq_tab + ((size_t)3 * 256 + (code >> 24)) * kSeqStride);
+#pragma unroll
+    for (int g = 0; g < (kSeqWords + 3) / 4; ++g) {
+        if (128 * g < type345) {
+            const uint4 s0 = r0[g], s1 = r1[g], s2 = r2[g], s3 = r3[g];
+            const uint32_t w[4] = { s0.x ^ s1.x ^ s2.x ^ s3.x, s0.y ^ s1.y ^ s2.y ^ s3.y, s0.z ^ s1.z ^ s2.z ^ s3.z, s0.w ^ s1.w ^ s2.w ^ s3.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * g + k < kSeqWords && 32 * (4 * g + k) < type345) cls[4 * g + k][lane] = xb[4 * g + k] ^ w[k];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restrict__ type5, int n_blocks, int in_stride,
                                                         const uint32_t* __restrict__ scramb_init, int fixed_init,
                                                         int type345, int type2, int type1, int a,
@@ -58,7 +136,7 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                                         const uint32_t* __restrict__ seq_tab, uint32_t crc_fold) {
     __shared__ uint32_t stage[kLanes][kChunkDwords + 1];     // +1: odd row stride, conflict-free column reads
     __shared__ uint32_t cls[kClsWords + 1][kLanes];
-    __shared__ uint16_t outw[kOutHalves][kLanes];
+    __shared__ OutW outw;
     const int lane = threadIdx.x;
     const int blk0 = blockIdx.x * kLanes;
     const int blk = blk0 + lane;
@@ -69,21 +147,23 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
     }
     const int rows_here = min(kLanes, n_blocks - blk0);
     const uint32_t code = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[init_index ? init_index[blk] : blk];
+    uint32_t* dec = dec_scratch + (size_t)blockIdx.x * dec_pairs * kLanes + lane;
 
-    // 1. front end.  Rows of plain bits: each lane packs its own row (8-byte loads) and descrambles whole words; the workgroup falls
-    //    back to the byte route if any of its rows holds another byte value, or if the rows are not 8-byte aligned.
+    // 1. front end.  Rows of plain bits: each lane packs its own row (8-byte loads), descrambles whole words and leaves the type-4
+    //    bits in LDS (cls rows 0..13 as [word][lane]); the workgroup falls back to the byte route if any of its rows holds another
+    //    byte value, or if the rows are not 8-byte aligned.
     bool byte_route = seq_tab == nullptr || (in_stride & 7) || ((uintptr_t)type5 & 7);
     if (!byte_route) {
         const U2* row = reinterpret_cast<const U2*>(type5 + (size_t)(blk < n_blocks ? blk : blk0) * in_stride);
         uint32_t xb[kSeqWords];
         const uint32_t dirty = pack_row_bits(type345, [&](int i) { return row[i]; }, xb);
         byte_route = __builtin_amdgcn_ballot_w64(dirty != 0) != 0;          // wave-uniform
-        if (!byte_route)
-            classes_from_bits(type345, code, xb,
-                              [&](int t, uint32_t byte, int w) { return seq_tab[((size_t)t * 256 + byte) * kSeqStride + w]; },
-                              [&](int i, uint32_t word) { cls[i][lane] = word; });
+        if (!byte_route) descramble_to_lds(type345, code, xb, seq_tab, cls, lane);
     }
-    if (byte_route) {
+    bool good;
+    if (!byte_route) {
+        good = decode_core<true>(cls, outw, lane, type345, type2, type1, a, crc_fold, dec);
+    } else {
         // rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
         // descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
         uint32_t lfsr = code;
@@ -102,26 +182,104 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                     [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
             __syncthreads();
         }
+        good = decode_core<false>(cls, outw, lane, type345, type2, type1, a, crc_fold, dec);
     }
-
-    // 2. forward recursion: decisions of step pair u of this workgroup's 64 blocks = one 256-byte line of the scratch
-    uint32_t* dec = dec_scratch + (size_t)blockIdx.x * dec_pairs * kLanes + lane;
-    viterbi_forward(type2, type345, a,
-                    [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; },
-                    [&](int u, uint32_t word) { dec[u * kLanes] = word; });
-
-    // 3. traceback + CRC (own lane's data only: program order is enough)
-    const uint32_t crc = viterbi_traceback(type2, type1 + 16, crc_fold, [&](int u) { return dec[u * kLanes]; },
-                                           [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
-                                           [&](int k) { return kCrcDev.t[k]; });
-    if (blk < n_blocks) crc_ok[blk] = crc == kCrcOk;
+    if (blk < n_blocks) crc_ok[blk] = good;
     __syncthreads();
+    write_rows(outw, lane, rows_here, type2, out + (size_t)blk0 * out_stride, out_stride);
+}
 
-    // 4. decoded rows -> HBM
-    const int out_dw = type2 >> 2;
-    for (int q = 0; q < rows_here; ++q) {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)(blk0 + q) * out_stride);
-        for (int d = lane; d < out_dw; d += kLanes) dst[d] = spread4(((uint32_t)outw[d >> 2][q] >> (4 * (d & 3))) & 0xfu);
+// ---- straight from packed frames, several kinds per launch (tetra_lmac_decode_frames_device) ----------------------------------
+struct DevJob {
+    const int* row_frame;
+    const int* n_rows_dev;
+    const uint32_t* frame_scramb;
+    uint8_t* out;
+    int* crc_ok;
+    tetra_lmac_label_t* labels;
+    long long scratch_base;            // first word of the job's decision scratch
+    int n_rows, out_stride, first_group, dec_pairs;
+    int layout;                        // kLayout*
+    int type345, type2, type1, a;
+    uint32_t crc_fold;
+};
+struct DevFrames {
+    const uint32_t* frames;
+    const int* frame_type;
+    const uint32_t* bitnum;
+    const uint32_t* time_rx;
+    const uint32_t* time;
+    int frames_per_channel;
+};
+struct JobTable {
+    DevJob job[TETRA_LMAC_MAX_JOBS];
+    DevFrames src;
+    int n;
+};
+__global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint32_t* __restrict__ dec_scratch,
+                                                        const uint32_t* __restrict__ seq_tab) {
+    __shared__ uint32_t cls[kSeqWords][kLanes];
+    __shared__ OutW outw;
+    const int lane = threadIdx.x;
+    int ji = 0;
+    for (int i = 1; i < tab.n; ++i) ji = (int)blockIdx.x >= tab.job[i].first_group ? i : ji;
+    const DevJob& J = tab.job[ji];
+    const int group = (int)blockIdx.x - J.first_group;
+    const int blk0 = group * kLanes, blk = blk0 + lane;
+    int n_blocks = J.n_rows;
+    if (J.n_rows_dev) {
+        const int have = *J.n_rows_dev;
+        n_blocks = have < n_blocks ? have : n_blocks;
+    }
+    if (blk0 >= n_blocks) return;
+    const int rows_here = min(kLanes, n_blocks - blk0);
+    const int f = J.row_frame[blk < n_blocks ? blk : blk0];
+    const uint32_t code = J.frame_scramb ? J.frame_scramb[f] : kScrambInitSb1;
+    const int ft = tab.src.frame_type[f];
+    uint32_t fw[kFrameWords];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(tab.src.frames + (size_t)f * kFrameWords);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 v = src[g];
+            fw[4 * g] = v.x; fw[4 * g + 1] = v.y; fw[4 * g + 2] = v.z; fw[4 * g + 3] = v.w;
+        }
+    }
+    bool good = true;
+    if (J.layout == kLayoutBbk) {
+        // TPSAP_T_BBK: the reference only descrambles (tetra_lower_mac.c:231-236): 30 bits -> 30 bytes (+ 2 zero bytes), a row per lane
+        const uint32_t x = bbk_bits(fw, ft);
+        const uint32_t seq = seq_tab[((size_t)0 * 256 + (code & 0xffu)) * kSeqStride] ^ seq_tab[((size_t)1 * 256 + ((code >> 8) & 0xffu)) * kSeqStride] ^
+                             seq_tab[((size_t)2 * 256 + ((code >> 16) & 0xffu)) * kSeqStride] ^ seq_tab[((size_t)3 * 256 + (code >> 24)) * kSeqStride];
+        const uint32_t y = (x ^ seq) & 0xfffffffcu;          // 30 bits, first bit most significant
+        if (blk < n_blocks) {
+            demux_core::U2* dst = reinterpret_cast<demux_core::U2*>(J.out + (size_t)blk * J.out_stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k] = demux_core::U2{ bbk_bytes(y, 2 * k), bbk_bytes(y, 2 * k + 1) };
+        }
+    } else {
+        uint32_t xb[kSeqWords];
+        frame_block(J.layout, fw, ft, xb);
+        descramble_to_lds(J.type345, code, xb, seq_tab, cls, lane);
+        uint32_t* dec = dec_scratch + J.scratch_base + (size_t)group * J.dec_pairs * kLanes + lane;
+        good = decode_core<true>(cls, outw, lane, J.type345, J.type2, J.type1, J.a, J.crc_fold, dec);
+    }
+    if (blk < n_blocks) {
+        J.crc_ok[blk] = good;
+        if (J.labels) {
+            tetra_lmac_label_t lb;
+            lb.channel = f / tab.src.frames_per_channel;
+            lb.frame_slot = f - lb.channel * tab.src.frames_per_channel;
+            lb.bitnum = tab.src.bitnum[f];
+            lb.tdma_time_rx = tab.src.time_rx[f];
+            lb.tdma_time = tab.src.time[f];
+            lb.crc_ok = good;
+            J.labels[blk] = lb;
+        }
+    }
+    if (J.layout != kLayoutBbk) {
+        __syncthreads();
+        write_rows(outw, lane, rows_here, J.type2, J.out + (size_t)blk0 * J.out_stride, J.out_stride);
     }
 }
 
@@ -260,6 +418,97 @@ __global__ __launch_bounds__(256) void k_track_sync(const uint8_t* __restrict__ 
     cell[c] = st;
 }
 
+// tetra_lmac_track_sync_lists_device: k_track_sync's walk with the channel's SB1 rows compact and read side by side.  One
+// wavefront per channel: lanes over frame slots gather (valid, crc, SYNC-PDU fields) into LDS, lane 0 walks the slots there, all
+// lanes write the three per-slot arrays (and the SB1 rows' labels) back.
+__global__ __launch_bounds__(kLanes) void k_track_sync_lists(const uint8_t* __restrict__ sb1, int stride, const int* __restrict__ crc_ok,
+                                                             const int* __restrict__ frame_type, const int* __restrict__ n_frames,
+                                                             const int* __restrict__ chan_first, int frames,
+                                                             tetra_lmac_cell_state_t* __restrict__ cell, uint32_t* __restrict__ row_scramb,
+                                                             uint32_t* __restrict__ row_time_rx, uint32_t* __restrict__ row_time,
+                                                             const uint32_t* __restrict__ frame_bitnum, tetra_lmac_label_t* __restrict__ labels) {
+    extern __shared__ uint32_t sm[];
+    uint32_t* in_a = sm;                     // bit 0 valid, bit 1 crc ok, colour << 2, tn << 8, fn << 11, mn << 16
+    uint32_t* in_b = sm + frames;            // mcc | mnc << 10
+    uint32_t* in_j = sm + 2 * frames;        // compact row index
+    uint32_t* o_scr = sm + 3 * frames;       // the code in force for the slot's other blocks
+    uint32_t* o_rx = sm + 4 * frames;        // time on entry
+    uint32_t* o_t = sm + 5 * frames;         // time after the slot's SB1
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int nf = n_frames ? min(n_frames[c], frames) : frames;
+    int base = chan_first[c];
+    for (int f0 = 0; f0 < frames; f0 += kLanes) {
+        const int f = f0 + lane;
+        const bool is_sync = f < frames && frame_type[(size_t)c * frames + f] == TETRA_TRAIN_SYNC;
+        const unsigned long long m = __ballot(is_sync);
+        const int j = base + __popcll(m & ((1ull << lane) - 1ull));
+        base += __popcll(m);
+        if (f < frames) {
+            uint32_t a = 0, b = 0;
+            if (is_sync && f < nf) {
+                a = 1u;
+                if (crc_ok[j]) {
+                    const uint32_t* t2 = reinterpret_cast<const uint32_t*>(sb1 + (size_t)j * stride);
+                    uint64_t v = 0;                               // type-2 bits 0..55, first bit most significant
+#pragma unroll
+                    for (int k = 0; k < 14; ++k) v |= (uint64_t)pack4(t2[k] & 0x01010101u) << (60 - 4 * k);
+                    auto field = [&](int first, int len) { return (uint32_t)(v >> (64 - first - len)) & ((1u << len) - 1u); };
+                    a |= 2u | (field(4, 6) << 2) | ((field(10, 2) + 1u) << 8) | (field(12, 5) << 11) | (field(17, 6) << 16);
+                    b = field(31, 10) | (field(41, 14) << 10);
+                }
+            }
+            in_a[f] = a; in_b[f] = b; in_j[f] = (uint32_t)j;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        tetra_lmac_cell_state_t st = cell[c];
+        for (int f = 0; f < frames; ++f) {
+            uint32_t t_rx = 0, t_after = 0;
+            if (f < nf) {
+                tdma_add_tn(st.phy_tn, st.phy_fn, st.phy_mn);
+                t_rx = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
+                const uint32_t a = in_a[f];
+                if (a & 1u) {
+                    if (a & 2u) {
+                        const uint32_t b = in_b[f];
+                        st.colour_code = (a >> 2) & 0x3fu;
+                        st.tcd_tn = (a >> 8) & 7u;
+                        st.tcd_fn = (a >> 11) & 0x1fu;
+                        st.tcd_mn = (a >> 16) & 0x3fu;
+                        st.mcc = b & 0x3ffu;
+                        st.mnc = b >> 10;
+                        st.scramb_init = (((st.colour_code & 0x3f) | ((st.mnc & 0x3fff) << 6) | ((st.mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1;
+                    }
+                    st.phy_tn = st.tcd_tn; st.phy_fn = st.tcd_fn; st.phy_mn = st.tcd_mn;
+                }
+                t_after = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
+            }
+            o_scr[f] = st.scramb_init;
+            o_rx[f] = t_rx;
+            o_t[f] = t_after;
+        }
+        cell[c] = st;
+    }
+    __syncthreads();
+    for (int f = lane; f < frames; f += kLanes) {
+        const size_t r = (size_t)c * frames + f;
+        row_scramb[r] = o_scr[f];
+        if (row_time_rx) row_time_rx[r] = o_rx[f];
+        if (row_time) row_time[r] = o_t[f];
+        if (labels && (in_a[f] & 1u)) {
+            tetra_lmac_label_t lb;
+            lb.channel = c;
+            lb.frame_slot = f;
+            lb.bitnum = frame_bitnum[r];
+            lb.tdma_time_rx = o_rx[f];
+            lb.tdma_time = o_t[f];
+            lb.crc_ok = (in_a[f] >> 1) & 1u;
+            labels[in_j[f]] = lb;
+        }
+    }
+}
+
 int check_args(int type, const void* in, int n_blocks, int in_stride, const void* init, const void* out, int out_stride,
                const void* ok, bool device_ptrs) {
     if (type < 0 || type > 5 || n_blocks < 0) return TETRA_ERR_ARG;
@@ -334,6 +583,75 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 
+int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_lmac_job_t* jobs, int n_jobs, void* hip_stream) {
+    if (!src || !jobs || n_jobs < 0 || n_jobs > TETRA_LMAC_MAX_JOBS) return TETRA_ERR_ARG;
+    if (n_jobs == 0) return TETRA_OK;
+    if (!src->d_frames || !src->d_frame_type || src->n_frames < 0) return TETRA_ERR_ARG;
+    if ((uintptr_t)src->d_frames & 15) return TETRA_ERR_ALIGN;
+    JobTable tab = {};
+    tab.src = DevFrames{ src->d_frames, src->d_frame_type, src->d_frame_bitnum, src->d_time_rx, src->d_time, src->frames_per_channel };
+    constexpr CrcTable crct = make_crc_table();
+    long long groups_total = 0, scratch_words = 0;
+    int n = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const tetra_lmac_job_t& j = jobs[i];
+        if (j.type < 0 || j.type > 5 || j.max_rows < 0) return TETRA_ERR_ARG;
+        if (j.max_rows == 0) continue;
+        if (!j.d_row_frame || !j.d_type2 || !j.d_crc_ok) return TETRA_ERR_ARG;
+        if (j.type != TETRA_TPSAP_T_SB1 && !j.d_frame_scramb) return TETRA_ERR_ARG;
+        if (j.d_labels && (!src->d_frame_bitnum || !src->d_time_rx || !src->d_time || src->frames_per_channel < 1)) return TETRA_ERR_ARG;
+        int layout = kLayoutNone;
+        switch (j.type) {
+            case TETRA_TPSAP_T_SB1: layout = j.blk_num == 1 ? kLayoutSb1 : kLayoutNone; break;
+            case TETRA_TPSAP_T_SB2: layout = j.blk_num == 2 ? kLayoutSb2 : kLayoutNone; break;
+            case TETRA_TPSAP_T_NDB: layout = j.blk_num == 1 ? kLayoutNdb1 : j.blk_num == 2 ? kLayoutNdb2 : kLayoutNone; break;
+            case TETRA_TPSAP_T_BBK: layout = kLayoutBbk; break;
+            case TETRA_TPSAP_T_SCH_F: layout = kLayoutSchF; break;
+            default: break;                                    // SCH/HU: an uplink block, no downlink burst carries it
+        }
+        if (layout == kLayoutNone) return TETRA_ERR_ARG;       // no burst type carries this (kind, block number)
+        const BlkParam& p = kBlk[j.type];
+        if (j.out_stride < (layout == kLayoutBbk ? 32 : p.type2)) return TETRA_ERR_SIZE;
+        if ((j.out_stride & 7) || ((uintptr_t)j.d_type2 & 7)) return TETRA_ERR_ALIGN;
+        DevJob& d = tab.job[n++];
+        d.row_frame = j.d_row_frame;
+        d.n_rows_dev = j.d_n_rows;
+        d.frame_scramb = j.type == TETRA_TPSAP_T_SB1 ? nullptr : j.d_frame_scramb;
+        d.out = j.d_type2;
+        d.crc_ok = j.d_crc_ok;
+        d.labels = j.d_labels;
+        d.n_rows = j.max_rows;
+        d.out_stride = j.out_stride;
+        d.layout = layout;
+        d.type345 = p.type345; d.type2 = p.type2; d.type1 = p.type1; d.a = p.a;
+        d.crc_fold = p.crc ? crc_fold_constant(crct, p.type1 + 16) : 0u;
+        d.dec_pairs = layout == kLayoutBbk ? 0 : (p.type2 + kFlush) / 2;
+        const long long groups = ((long long)j.max_rows + kLanes - 1) / kLanes;
+        d.first_group = (int)groups_total;
+        d.scratch_base = scratch_words;
+        groups_total += groups;
+        scratch_words += groups * d.dec_pairs * kLanes;
+        if (groups_total > 0x7fffffffLL) return TETRA_ERR_SIZE;
+    }
+    tab.n = n;
+    if (n == 0) return TETRA_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const uint32_t* seq = seq_table();
+    if (!seq) return TETRA_ERR_NOMEM;
+    uint32_t* scratch = nullptr;
+    if (scratch_words) {
+        hipMemPool_t pool = scratch_pool();
+        const size_t bytes = (size_t)scratch_words * sizeof(uint32_t);
+        const hipError_t got = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), bytes, pool, s)
+                                    : hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s);
+        if (got != hipSuccess) { (void)hipGetLastError(); return TETRA_ERR_NOMEM; }
+    }
+    hipLaunchKernelGGL(k_lmac_frames, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, scratch, seq);
+    const hipError_t launch = hipGetLastError();
+    if ((scratch && hipFreeAsync(scratch, s) != hipSuccess) || launch != hipSuccess) return TETRA_ERR_HIP;
+    return TETRA_OK;
+}
+
 int tetra_lmac_debug_force_byte_route(int on) {
     const int was = g_force_byte_route ? 1 : 0;
     g_force_byte_route = on != 0;
@@ -358,6 +676,21 @@ int tetra_lmac_track_sync_device(const uint8_t* d_sb1_type2, int type2_stride, c
     hipLaunchKernelGGL(k_track_sync, dim3((n_channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2,
                        type2_stride, d_crc_ok, d_valid, d_n_frames, n_channels, frames_per_channel, d_cell, d_row_scramb, d_row_time_rx,
                        d_row_time);
+    return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+}
+
+int tetra_lmac_track_sync_lists_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_frame_type,
+                                       const int32_t* d_n_frames, const int32_t* d_chan_first_sync, int n_channels, int frames_per_channel,
+                                       tetra_lmac_cell_state_t* d_cell, uint32_t* d_row_scramb, uint32_t* d_row_time_rx, uint32_t* d_row_time,
+                                       const uint32_t* d_frame_bitnum, tetra_lmac_label_t* d_sb1_labels, void* hip_stream) {
+    if (!d_sb1_type2 || !d_crc_ok || !d_frame_type || !d_chan_first_sync || !d_cell || !d_row_scramb) return TETRA_ERR_ARG;
+    if (n_channels < 1 || frames_per_channel < 0 || type2_stride < 60 || (d_sb1_labels && !d_frame_bitnum)) return TETRA_ERR_ARG;
+    if ((type2_stride & 3) || ((uintptr_t)d_sb1_type2 & 3)) return TETRA_ERR_ALIGN;
+    if (frames_per_channel > TETRA_LMAC_TRACK_MAX_FRAMES) return TETRA_ERR_SIZE;
+    if (frames_per_channel == 0) return TETRA_OK;
+    hipLaunchKernelGGL(k_track_sync_lists, dim3(n_channels), dim3(kLanes), sizeof(uint32_t) * 6 * (size_t)frames_per_channel,
+                       static_cast<hipStream_t>(hip_stream), d_sb1_type2, type2_stride, d_crc_ok, d_frame_type, d_n_frames, d_chan_first_sync,
+                       frames_per_channel, d_cell, d_row_scramb, d_row_time_rx, d_row_time, d_frame_bitnum, d_sb1_labels);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }
 

@@ -1,18 +1,20 @@
 // tetra_rx.hip -- the device-resident receive chain behind one handle (include/tetra_rx.h): the ordering, buffers, streams and
-// events around this library's own stage entry points, plus two small kernels of its own (SB1 rows back into slot layout for the
-// SYNC-PDU tracker; per-row labels).
+// events around this library's own stage entry points.
 //
 // Reference chain per receiver: tetra_burst_sync_in (phy/tetra_burst_sync.c:54-155) -> tetra_burst_rx_cb (phy/tetra_burst.c:343-393)
 // -> tp_sap_udata_ind (lower_mac/tetra_lower_mac.c:148-237) with the cell state fed back at :246-275.  Here, per process call k:
 //
 //   caller's stream  [wait: tail k-2 has read bit rows k & 1]  demodulator -> bits[k & 1]                          (event D_k)
 //   tail stream      [wait D_k]  synchroniser (packed frames, types, bit numbers, counts)
-//                    SB1:   compact demux -> counted decode -> rows scattered to slot layout -> tracker: cell state, per-slot
-//                           scrambling code, TDMA time before / after the slot's SB1
-//                    every other configured kind: compact demux -> counted decode with the TRACKER's per-slot codes
-//                    labels: (channel, slot, bit number, times, crc) per row                                      (event T_k)
+//                    frame lists (SYNC / NORM_1 / NORM_2 / any) in one pass
+//                    SB1:   decode straight from the SYNC frames -> tracker: cell state, per-slot scrambling code, TDMA time
+//                           before / after the slot's SB1, the SB1 rows' labels
+//                    every other configured kind: ONE launch that decodes them all straight from the frames with the TRACKER's
+//                           per-slot codes and labels every row (channel, slot, bit number, times, crc)            (event T_k)
 //
 // so the demodulator of call k+1 runs beside the tail of call k; results and bit rows are double buffered by call parity.
+// (Until round 6: per kind a compacting demultiplexer into byte rows (4 launches), a counted decode and a label kernel -- 40 launches
+// and 0.36 GB of byte rows per second of 4096 channels; now 7 launches and no byte rows.)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -23,54 +25,21 @@
 namespace {
 
 struct KindInfo {
-    int tpsap, blk, in_stride, out_stride, type1_bits;
+    int tpsap, blk, list, out_stride, type1_bits;
 };
-// rows as the demultiplexer lays them out / the decoder writes them (tetra_lower_mac.c:58-105: type345 / type2 / type1 bits)
+// rows as the decoder writes them (tetra_lower_mac.c:58-105: type2 / type1 bits) and the frame list a kind's rows come from
 constexpr KindInfo kKinds[TETRA_RX_N_KINDS] = {
-    { TETRA_TPSAP_T_SB1, 1, 120, 80, 60 },     // SB1
-    { TETRA_TPSAP_T_BBK, 0, 32, 32, 30 },      // BBK
-    { TETRA_TPSAP_T_SB2, 2, 216, 144, 124 },   // SB2
-    { TETRA_TPSAP_T_NDB, 1, 216, 144, 124 },   // NDB blk 1
-    { TETRA_TPSAP_T_NDB, 2, 216, 144, 124 },   // NDB blk 2
-    { TETRA_TPSAP_T_SCH_F, 0, 432, 288, 268 }, // SCH/F
+    { TETRA_TPSAP_T_SB1, 1, TETRA_LIST_SYNC, 80, 60 },       // SB1
+    { TETRA_TPSAP_T_BBK, 0, TETRA_LIST_ANY, 32, 30 },        // BBK
+    { TETRA_TPSAP_T_SB2, 2, TETRA_LIST_SYNC, 144, 124 },     // SB2
+    { TETRA_TPSAP_T_NDB, 1, TETRA_LIST_NORM_2, 144, 124 },   // NDB blk 1
+    { TETRA_TPSAP_T_NDB, 2, TETRA_LIST_NORM_2, 144, 124 },   // NDB blk 2
+    { TETRA_TPSAP_T_SCH_F, 0, TETRA_LIST_NORM_1, 288, 268 }, // SCH/F
 };
-constexpr int kScratchStride = 432;            // the longest type-5 row: one scratch serves every kind (they run one after the other)
-constexpr int kSb1SlotStride = 64;             // bytes of a decoded SB1 row the tracker reads (fields up to bit 54), slot layout
+// the second decode launch's job order: long blocks first, so that the short ones fill the machine while the long ones finish
+constexpr int kJobOrder[] = { TETRA_RX_KIND_SCH_F, TETRA_RX_KIND_SB2, TETRA_RX_KIND_NDB1, TETRA_RX_KIND_NDB2, TETRA_RX_KIND_BBK };
 
-// decoded SB1 rows (compact, frame order) back into the slot layout tetra_lmac_track_sync_device walks
-__global__ __launch_bounds__(256) void k_rx_scatter_sb1(const uint8_t* __restrict__ t2, const int32_t* __restrict__ crc_ok,
-                                                        const int32_t* __restrict__ row_frame, const int32_t* __restrict__ n_rows,
-                                                        uint8_t* __restrict__ slot_t2, int32_t* __restrict__ slot_ok,
-                                                        int32_t* __restrict__ slot_valid) {
-    const int n = *n_rows;
-    const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, part = threadIdx.x & 3;      // four lanes per row, 16 bytes each
-    if (j >= n) return;
-    const int f = row_frame[j];
-    const uint4 v = *reinterpret_cast<const uint4*>(t2 + (size_t)j * kKinds[TETRA_RX_KIND_SB1].out_stride + 16 * part);
-    *reinterpret_cast<uint4*>(slot_t2 + (size_t)f * kSb1SlotStride + 16 * part) = v;
-    if (part == 0) {
-        slot_ok[f] = crc_ok[j];
-        slot_valid[f] = 1;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_rx_label(const int32_t* __restrict__ row_frame, const int32_t* __restrict__ n_rows,
-                                                  const int32_t* __restrict__ crc_ok, const uint32_t* __restrict__ frame_bitnum,
-                                                  const uint32_t* __restrict__ row_time_rx, const uint32_t* __restrict__ row_time,
-                                                  int frames_per_channel, tetra_rx_block_t* __restrict__ blocks) {
-    const int n = *n_rows;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int f = row_frame[j];
-    tetra_rx_block_t b;
-    b.channel = f / frames_per_channel;
-    b.frame_slot = f - b.channel * frames_per_channel;
-    b.bitnum = frame_bitnum[f];
-    b.tdma_time_rx = row_time_rx[f];
-    b.tdma_time = row_time[f];
-    b.crc_ok = crc_ok[j];
-    blocks[j] = b;
-}
+static_assert(sizeof(tetra_rx_block_t) == sizeof(tetra_lmac_label_t), "tetra_rx_block_t is the decoder's row label");
 
 struct Guard {
     int prev = -1;
@@ -82,9 +51,10 @@ struct Guard {
 struct KindBufs {                 // one parity's results of one kind
     uint8_t* t2 = nullptr;        // [rows][out_stride]
     int32_t* ok = nullptr;        // [rows]
-    int32_t* row_frame = nullptr; // [rows]
-    int32_t* n_rows = nullptr;    // [1]
     tetra_rx_block_t* blocks = nullptr;   // [rows]
+    // into the parity's frame lists (not owned): the kind's rows are the frames row_frame[0 .. *n_rows)
+    const int32_t* row_frame = nullptr;
+    const int32_t* n_rows = nullptr;
 };
 
 }  // namespace
@@ -101,15 +71,16 @@ struct tetra_rx {
     uint8_t* bits[2] = { nullptr, nullptr };
     int32_t* nbits[2] = { nullptr, nullptr };
     KindBufs res[2][TETRA_RX_N_KINDS];
+    int32_t* lists[2] = { nullptr, nullptr };         // [TETRA_N_LISTS][rows] frame lists
+    int32_t* counts[2] = { nullptr, nullptr };        // [TETRA_N_LISTS]
     hipEvent_t ev_demod[2] = { nullptr, nullptr }, ev_tail[2] = { nullptr, nullptr };
     // the tail's working set (one: tails run one after the other on one stream)
     uint32_t* frames = nullptr;           // [rows][16] packed frames
     int32_t* ft = nullptr;                // [rows] frame types
     uint32_t* fb = nullptr;               // [rows] frame bit numbers
     int32_t* nf = nullptr;                // [C]
-    uint8_t* scratch = nullptr;           // [rows][432] type-5 rows of the kind in work
-    uint8_t* slot_t2 = nullptr;           // [rows][64] decoded SB1 rows, slot layout
-    int32_t *slot_ok = nullptr, *slot_valid = nullptr;
+    int32_t* chan_first = nullptr;        // [TETRA_N_LISTS][C] position in each list of a channel's first entry
+    int32_t* index_work = nullptr;        // tetra_burst_index_device's scratch
     uint32_t *row_scramb = nullptr, *row_time_rx = nullptr, *row_time = nullptr;
     tetra_lmac_cell_state_t* cell = nullptr;   // [C]
     float* st_iq = nullptr;               // host-path staging
@@ -137,12 +108,12 @@ namespace {
 void free_all(tetra_rx* h) {
     if (h->dem) (void)tetra_demod_destroy(h->dem);
     if (h->bs) (void)tetra_bsync_destroy(h->bs);
-    void* ptrs[] = { h->bits[0], h->bits[1], h->nbits[0], h->nbits[1], h->frames, h->ft, h->fb, h->nf, h->scratch, h->slot_t2,
-                     h->slot_ok, h->slot_valid, h->row_scramb, h->row_time_rx, h->row_time, h->cell, h->st_iq };
+    void* ptrs[] = { h->bits[0], h->bits[1], h->nbits[0], h->nbits[1], h->lists[0], h->lists[1], h->counts[0], h->counts[1], h->frames, h->ft,
+                     h->fb, h->nf, h->chan_first, h->index_work, h->row_scramb, h->row_time_rx, h->row_time, h->cell, h->st_iq };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& par : h->res)
         for (auto& k : par) {
-            void* q[] = { k.t2, k.ok, k.row_frame, k.n_rows, k.blocks };
+            void* q[] = { k.t2, k.ok, k.blocks };
             for (void* p : q) if (p) (void)hipFree(p);
         }
     for (auto* evs : { h->ev_demod, h->ev_tail })
@@ -154,9 +125,7 @@ void free_all(tetra_rx* h) {
 template <typename T> bool dalloc(T*& p, size_t count) { return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1)) == hipSuccess; }
 
 int zero_results(tetra_rx* h) {
-    for (auto& par : h->res)
-        for (int k = 0; k < TETRA_RX_N_KINDS; k++)
-            if (par[k].n_rows) RX_TRY(h, hipMemset(par[k].n_rows, 0, sizeof(int32_t)));
+    for (int b = 0; b < 2; b++) RX_TRY(h, hipMemset(h->counts[b], 0, sizeof(int32_t) * TETRA_N_LISTS));
     RX_TRY(h, hipMemset(h->cell, 0, sizeof(tetra_lmac_cell_state_t) * (size_t)h->C));
     for (int b = 0; b < 2; b++) RX_TRY(h, hipMemset(h->nbits[b], 0, sizeof(int32_t) * (size_t)h->C));
     return TETRA_OK;
@@ -168,32 +137,45 @@ int enqueue_tail(tetra_rx* h, int b, hipStream_t s) {
     RX_TRY(h, hipEventRecord(h->ev_stage[0], s));
     RX_OK(tetra_bsync_process_packed_device(h->bs, h->bits[b], h->stride, h->nbits[b], h->frames, h->ft, h->fb, h->nf, s));
     RX_TRY(h, hipEventRecord(h->ev_stage[1], s));
+    RX_OK(tetra_burst_index_device(h->ft, n, h->F, h->lists[b], h->counts[b], h->chan_first, h->index_work, s));
+    tetra_lmac_frames_t src = {};
+    src.d_frames = h->frames;
+    src.d_frame_type = h->ft;
+    src.n_frames = n;
+    src.frames_per_channel = h->F;
+    src.d_frame_bitnum = h->fb;
+    src.d_time_rx = h->row_time_rx;
+    src.d_time = h->row_time;
+    auto job_of = [&](int k, bool labels) {
+        const KindInfo& ki = kKinds[k];
+        const KindBufs& r = h->res[b][k];
+        tetra_lmac_job_t j = {};
+        j.type = ki.tpsap;
+        j.blk_num = ki.blk;
+        j.d_row_frame = r.row_frame;
+        j.d_n_rows = r.n_rows;
+        j.max_rows = n;
+        j.out_stride = ki.out_stride;
+        j.d_frame_scramb = h->row_scramb;
+        j.d_type2 = r.t2;
+        j.d_crc_ok = r.ok;
+        j.d_labels = labels ? reinterpret_cast<tetra_lmac_label_t*>(r.blocks) : nullptr;
+        return j;
+    };
     {   // SB1 first: its SYNC PDUs set the code and the clock for everything else in the same burst (tetra_lower_mac.c:246-275)
-        const KindInfo& ki = kKinds[TETRA_RX_KIND_SB1];
-        KindBufs& r = h->res[b][TETRA_RX_KIND_SB1];
-        RX_OK(tetra_burst_demux_compact_packed_device(h->frames, h->ft, n, ki.tpsap, ki.blk, h->scratch, ki.in_stride, r.row_frame, r.n_rows, s));
-        RX_OK(tetra_lmac_decode_counted_device(ki.tpsap, h->scratch, n, r.n_rows, ki.in_stride, nullptr, nullptr, r.t2, ki.out_stride, r.ok, s));
-        RX_TRY(h, hipMemsetAsync(h->slot_valid, 0, sizeof(int32_t) * (size_t)n, s));
-        hipLaunchKernelGGL(k_rx_scatter_sb1, dim3((unsigned)((4 * (size_t)n + 255) / 256)), dim3(256), 0, s, r.t2, r.ok, r.row_frame, r.n_rows,
-                           h->slot_t2, h->slot_ok, h->slot_valid);
-        RX_TRY(h, hipGetLastError());
-        RX_OK(tetra_lmac_track_sync_device(h->slot_t2, kSb1SlotStride, h->slot_ok, h->slot_valid, h->nf, h->C, h->F, h->cell, h->row_scramb,
-                                           h->row_time_rx, h->row_time, s));
+        const KindBufs& r = h->res[b][TETRA_RX_KIND_SB1];
+        const tetra_lmac_job_t j = job_of(TETRA_RX_KIND_SB1, false);
+        RX_OK(tetra_lmac_decode_frames_device(&src, &j, 1, s));
+        RX_OK(tetra_lmac_track_sync_lists_device(r.t2, kKinds[TETRA_RX_KIND_SB1].out_stride, r.ok, h->ft, h->nf,
+                                                 h->chan_first + (size_t)TETRA_LIST_SYNC * h->C, h->C, h->F, h->cell, h->row_scramb, h->row_time_rx,
+                                                 h->row_time, h->fb, reinterpret_cast<tetra_lmac_label_t*>(r.blocks), s));
     }
     RX_TRY(h, hipEventRecord(h->ev_stage[2], s));
-    for (int k = 0; k < TETRA_RX_N_KINDS; k++) {
-        if (!(h->kinds & (1 << k))) continue;
-        const KindInfo& ki = kKinds[k];
-        KindBufs& r = h->res[b][k];
-        if (k != TETRA_RX_KIND_SB1) {
-            RX_OK(tetra_burst_demux_compact_packed_device(h->frames, h->ft, n, ki.tpsap, ki.blk, h->scratch, ki.in_stride, r.row_frame, r.n_rows, s));
-            RX_OK(tetra_lmac_decode_counted_device(ki.tpsap, h->scratch, n, r.n_rows, ki.in_stride, h->row_scramb, r.row_frame, r.t2, ki.out_stride,
-                                                   r.ok, s));
-        }
-        hipLaunchKernelGGL(k_rx_label, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r.row_frame, r.n_rows, r.ok, h->fb, h->row_time_rx,
-                           h->row_time, h->F, r.blocks);
-        RX_TRY(h, hipGetLastError());
-    }
+    tetra_lmac_job_t jobs[TETRA_RX_N_KINDS];
+    int nj = 0;
+    for (int k : kJobOrder)
+        if (h->kinds & (1 << k)) jobs[nj++] = job_of(k, true);
+    RX_OK(tetra_lmac_decode_frames_device(&src, jobs, nj, s));
     RX_TRY(h, hipEventRecord(h->ev_stage[3], s));
     return TETRA_OK;
 }
@@ -242,27 +224,27 @@ int tetra_rx_create(const tetra_rx_config_t* cfg, tetra_rx_t** out) {
     if (rc != TETRA_OK) { free_all(h); delete h; return rc; }
     h->F = tetra_bsync_max_frames(h->bs);
     const long long rows = (long long)h->C * h->F;
-    if (rows > 0x7fffffffLL / kScratchStride * 8) { free_all(h); delete h; return TETRA_ERR_SIZE; }      // 32-bit row indices downstream
+    if (rows > 0x7fffffffLL / 512 || h->F > TETRA_LMAC_TRACK_MAX_FRAMES) { free_all(h); delete h; return TETRA_ERR_SIZE; }      // 32-bit row / byte indices downstream
     h->rows = (int)rows;
     const size_t n = (size_t)rows;
     bool ok = hipStreamCreateWithFlags(&h->tail, hipStreamNonBlocking) == hipSuccess;
     for (int b = 0; b < 2 && ok; b++) {
-        ok = dalloc(h->bits[b], (size_t)h->C * h->stride) && dalloc(h->nbits[b], (size_t)h->C) &&
-             hipEventCreateWithFlags(&h->ev_demod[b], hipEventDisableTiming) == hipSuccess &&
+        ok = dalloc(h->bits[b], (size_t)h->C * h->stride) && dalloc(h->nbits[b], (size_t)h->C) && dalloc(h->lists[b], (size_t)TETRA_N_LISTS * n) &&
+             dalloc(h->counts[b], (size_t)TETRA_N_LISTS) && hipEventCreateWithFlags(&h->ev_demod[b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&h->ev_tail[b], hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < TETRA_RX_N_KINDS && ok; k++) {
             if (!(h->kinds & (1 << k))) continue;
             KindBufs& r = h->res[b][k];
-            ok = dalloc(r.t2, n * kKinds[k].out_stride) && dalloc(r.ok, n) && dalloc(r.row_frame, n) && dalloc(r.n_rows, 1) && dalloc(r.blocks, n);
+            ok = dalloc(r.t2, n * kKinds[k].out_stride) && dalloc(r.ok, n) && dalloc(r.blocks, n);
+            r.row_frame = h->lists[b] + (size_t)kKinds[k].list * n;
+            r.n_rows = h->counts[b] + kKinds[k].list;
         }
     }
     ok = ok && dalloc(h->frames, n * TETRA_FRAME_WORDS) && dalloc(h->ft, n) && dalloc(h->fb, n) && dalloc(h->nf, (size_t)h->C) &&
-         dalloc(h->scratch, n * kScratchStride) && dalloc(h->slot_t2, n * kSb1SlotStride) && dalloc(h->slot_ok, n) && dalloc(h->slot_valid, n) &&
+         dalloc(h->chan_first, (size_t)TETRA_N_LISTS * h->C) && dalloc(h->index_work, (size_t)TETRA_N_LISTS * ((n + 255) / 256)) &&
          dalloc(h->row_scramb, n) && dalloc(h->row_time_rx, n) && dalloc(h->row_time, n) && dalloc(h->cell, (size_t)h->C);
     for (auto& e : h->ev_stage) ok = ok && hipEventCreate(&e) == hipSuccess;
     rc = ok ? zero_results(h) : TETRA_ERR_NOMEM;
-    if (rc == TETRA_OK && (hipMemset(h->slot_t2, 0, n * kSb1SlotStride) != hipSuccess || hipMemset(h->slot_ok, 0, sizeof(int32_t) * n) != hipSuccess))
-        rc = TETRA_ERR_HIP;
     if (rc != TETRA_OK) { free_all(h); delete h; return rc; }
     *out = h;
     return TETRA_OK;

@@ -7,9 +7,28 @@ from .binding import TetraDemodError, load_library
 
 LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch",
                 "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device", "tetra_lmac_track_sync_device",
-                "tetra_lmac_debug_force_byte_route"]
+                "tetra_lmac_debug_force_byte_route", "tetra_lmac_decode_frames_device", "tetra_lmac_track_sync_lists_device"]
 # enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
 TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
+
+
+class Label(C.Structure):
+    """tetra_lmac_label_t (= tetra_rx_block_t)."""
+    _fields_ = [("channel", C.c_int32), ("frame_slot", C.c_int32), ("bitnum", C.c_uint32), ("tdma_time_rx", C.c_uint32),
+                ("tdma_time", C.c_uint32), ("crc_ok", C.c_int32)]
+
+
+class Frames(C.Structure):
+    """tetra_lmac_frames_t."""
+    _fields_ = [("d_frames", C.c_void_p), ("d_frame_type", C.c_void_p), ("n_frames", C.c_int32), ("frames_per_channel", C.c_int32),
+                ("d_frame_bitnum", C.c_void_p), ("d_time_rx", C.c_void_p), ("d_time", C.c_void_p)]
+
+
+class Job(C.Structure):
+    """tetra_lmac_job_t."""
+    _fields_ = [("type", C.c_int32), ("blk_num", C.c_int32), ("d_row_frame", C.c_void_p), ("d_n_rows", C.c_void_p), ("max_rows", C.c_int32),
+                ("out_stride", C.c_int32), ("d_frame_scramb", C.c_void_p), ("d_type2", C.c_void_p), ("d_crc_ok", C.c_void_p),
+                ("d_labels", C.c_void_p)]
 
 
 class BlkParam(C.Structure):
@@ -140,3 +159,44 @@ def track_sync_device(d_sb1_type2, type2_stride, d_crc_ok, d_valid, d_n_frames, 
                                         int(frames_per_channel), p(d_cell), p(d_row_scramb), p(d_row_time_rx), p(d_row_time), s)
     if rc:
         raise TetraDemodError(rc, "tetra_lmac_track_sync_device")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def decode_frames_device(d_frames, d_frame_type, jobs, frames_per_channel=0, d_frame_bitnum=None, d_time_rx=None, d_time=None, stream=None):
+    """tetra_lmac_decode_frames_device.  jobs: dicts with type, blk_num, row_frame, n_rows (tensor or None), max_rows, out_stride,
+    frame_scramb (tensor or None), type2, crc_ok, labels (int32 tensor [rows][6] or None)."""
+    L = _lib()
+    L.tetra_lmac_decode_frames_device.argtypes = [C.POINTER(Frames), C.POINTER(Job), C.c_int, C.c_void_p]
+    L.tetra_lmac_decode_frames_device.restype = C.c_int
+    src = Frames(_ptr(d_frames), _ptr(d_frame_type), int(d_frame_type.numel()), int(frames_per_channel), _ptr(d_frame_bitnum), _ptr(d_time_rx),
+                 _ptr(d_time))
+    arr = (Job * max(1, len(jobs)))()
+    for i, j in enumerate(jobs):
+        arr[i] = Job(int(j["type"]), int(j.get("blk_num", 0)), _ptr(j["row_frame"]), _ptr(j.get("n_rows")), int(j["max_rows"]),
+                     int(j["out_stride"]), _ptr(j.get("frame_scramb")), _ptr(j["type2"]), _ptr(j["crc_ok"]), _ptr(j.get("labels")))
+    s = None
+    if stream is not None:
+        s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+    rc = L.tetra_lmac_decode_frames_device(C.byref(src), arr, len(jobs), s)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_decode_frames_device")
+
+
+def track_sync_lists_device(d_sb1_type2, type2_stride, d_crc_ok, d_frame_type, d_n_frames, d_chan_first_sync, n_channels, frames_per_channel,
+                            d_cell, d_row_scramb, d_row_time_rx=None, d_row_time=None, d_frame_bitnum=None, d_sb1_labels=None, stream=None):
+    """tetra_lmac_track_sync_lists_device (compact SB1 rows = the SYNC list's)."""
+    vp = C.c_void_p
+    L = _lib()
+    L.tetra_lmac_track_sync_lists_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.tetra_lmac_track_sync_lists_device.restype = C.c_int
+    s = None
+    if stream is not None:
+        s = vp(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+    rc = L.tetra_lmac_track_sync_lists_device(_ptr(d_sb1_type2), int(type2_stride), _ptr(d_crc_ok), _ptr(d_frame_type), _ptr(d_n_frames),
+                                              _ptr(d_chan_first_sync), int(n_channels), int(frames_per_channel), _ptr(d_cell), _ptr(d_row_scramb),
+                                              _ptr(d_row_time_rx), _ptr(d_row_time), _ptr(d_frame_bitnum), _ptr(d_sb1_labels), s)
+    if rc:
+        raise TetraDemodError(rc, "tetra_lmac_track_sync_lists_device")

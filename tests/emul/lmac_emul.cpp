@@ -35,20 +35,32 @@ extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, 
         uint16_t outw[kMaxType2 / 16];
         uint32_t xb[kSeqWords];
         const uint32_t dirty = pack_row_bits(type345, [&](int i) { U2 d; std::memcpy(&d, row + 8 * i, 8); return d; }, xb);
+        int pos = a;
         if (route == 0 && !dirty) {
             ++fast;
-            classes_from_bits(type345, scramb_init[blk], xb, [&](int t, uint32_t byte, int w) { return tab[((size_t)t * 256 + byte) * kSeqStride + w]; },
-                              [&](int i, uint32_t word) { cls[i] = word; });
+            descramble_bits(type345, scramb_init[blk], xb, [&](int t, uint32_t byte, int w) { return tab[((size_t)t * 256 + byte) * kSeqStride + w]; },
+                            [&](int w, uint32_t word) { cls[w] = word; });
+            auto bit = [&](int p) { return bfe_mask(cls[p >> 5], 31u - (uint32_t)(p & 31)); };
+            viterbi_forward(type2,
+                            [&] {
+                                const uint32_t ma = bit(interleave_next(pos, a, type345)), mb = bit(interleave_next(pos, a, type345));
+                                return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
+                            },
+                            [&](int u, uint32_t word) { dec[u] = word; });
         } else {
             uint32_t lfsr = scramb_init[blk];
             for (int c0 = 0; c0 < type345 / 4; c0 += 16)      // the kernel's 64-bit staging chunks
                 lfsr = descramble_chunk(type345 - 4 * c0, lfsr,
                                         [&](int d) { uint32_t v; std::memcpy(&v, row + 4 * (c0 + d), 4); return v; },
                                         [&](int w, uint32_t word) { cls[c0 / 4 + w] = word; });
+            auto soft = [&](int idx) { return (int)(cls[idx >> 4] << (30 - 2 * (idx & 15))) >> 30; };
+            viterbi_forward(type2,
+                            [&] {
+                                const int sa = soft(interleave_next(pos, a, type345)), sb = soft(interleave_next(pos, a, type345));
+                                return bm_from_classes(sa, sb, soft(interleave_next(pos, a, type345)));
+                            },
+                            [&](int u, uint32_t word) { dec[u] = word; });
         }
-        viterbi_forward(type2, type345, a,
-                        [&](int idx) { return (int)(cls[idx >> 4] << (30 - 2 * (idx & 15))) >> 30; },
-                        [&](int u, uint32_t word) { dec[u] = word; });
         const uint32_t crc = viterbi_traceback(type2, type1 + 16, fold, [&](int u) { return dec[u]; },
                                                [&](int h, uint32_t half) { outw[h] = (uint16_t)half; }, [&](int k) { return crct.t[k]; });
         crc_ok[blk] = crc == kCrcOk;
@@ -64,4 +76,57 @@ extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, 
 extern "C" int lmac_emul_decode(int type345, int type2, int type1, int a, const uint8_t* type5, int n_blocks, int in_stride,
                                 const uint32_t* scramb_init, uint8_t* out, int out_stride, int32_t* crc_ok) {
     return lmac_emul_decode_route(type345, type2, type1, a, type5, n_blocks, in_stride, scramb_init, out, out_stride, crc_ok, 0, nullptr);
+}
+
+// tetra_lmac_decode_frames_device, one job: the lane code of k_lmac_frames for every listed frame.  frames [n_frames][16] packed,
+// frame_scramb per frame slot (NULL: SCRAMB_INIT).  out rows: type2 bits (BBK: 30 bits + 2 zero bytes).
+extern "C" int lmac_emul_decode_frames(int tpsap, int blk_num, const uint32_t* frames, const int32_t* frame_type, const int32_t* row_frame,
+                                       int n_rows, const uint32_t* frame_scramb, uint8_t* out, int out_stride, int32_t* crc_ok) {
+    int layout = kLayoutNone, type345 = 0, type2 = 0, type1 = 0, a = 0;
+    switch (tpsap) {
+        case TETRA_TPSAP_T_SB1: layout = blk_num == 1 ? kLayoutSb1 : kLayoutNone; type345 = 120; type2 = 80; type1 = 60; a = 11; break;
+        case TETRA_TPSAP_T_SB2: layout = blk_num == 2 ? kLayoutSb2 : kLayoutNone; type345 = 216; type2 = 144; type1 = 124; a = 101; break;
+        case TETRA_TPSAP_T_NDB: layout = blk_num == 1 ? kLayoutNdb1 : blk_num == 2 ? kLayoutNdb2 : kLayoutNone; type345 = 216; type2 = 144; type1 = 124; a = 101; break;
+        case TETRA_TPSAP_T_BBK: layout = kLayoutBbk; break;
+        case TETRA_TPSAP_T_SCH_F: layout = kLayoutSchF; type345 = 432; type2 = 288; type1 = 268; a = 103; break;
+        default: break;
+    }
+    if (layout == kLayoutNone) return -1;
+    static const CrcTable crct = make_crc_table();
+    const uint32_t* tab = seq_table();
+    auto seq = [&](int t, uint32_t byte, int w) { return tab[((size_t)t * 256 + byte) * kSeqStride + w]; };
+    for (int blk = 0; blk < n_rows; ++blk) {
+        const int f = row_frame[blk];
+        const uint32_t code = frame_scramb && tpsap != TETRA_TPSAP_T_SB1 ? frame_scramb[f] : kScrambInitSb1;
+        const uint32_t* fw = frames + (size_t)f * kFrameWords;
+        uint8_t* row = out + (size_t)blk * out_stride;
+        if (layout == kLayoutBbk) {
+            const uint32_t x = bbk_bits(fw, frame_type[f]);
+            const uint32_t sw = seq(0, code & 0xffu, 0) ^ seq(1, (code >> 8) & 0xffu, 0) ^ seq(2, (code >> 16) & 0xffu, 0) ^ seq(3, code >> 24, 0);
+            const uint32_t y = (x ^ sw) & 0xfffffffcu;
+            for (int k = 0; k < 8; ++k) { const uint32_t v = bbk_bytes(y, k); std::memcpy(row + 4 * k, &v, 4); }
+            crc_ok[blk] = 1;
+            continue;
+        }
+        uint32_t xb[kSeqWords], cls[kSeqWords], dec[(kMaxType2 + kFlush) / 2];
+        uint16_t outw[kMaxType2 / 16];
+        frame_block(layout, fw, frame_type[f], xb);
+        descramble_bits(type345, code, xb, seq, [&](int w, uint32_t word) { cls[w] = word; });
+        int pos = a;
+        auto bit = [&](int p) { return bfe_mask(cls[p >> 5], 31u - (uint32_t)(p & 31)); };
+        viterbi_forward(type2,
+                        [&] {
+                            const uint32_t ma = bit(interleave_next(pos, a, type345)), mb = bit(interleave_next(pos, a, type345));
+                            return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
+                        },
+                        [&](int u, uint32_t word) { dec[u] = word; });
+        const uint32_t crc = viterbi_traceback(type2, type1 + 16, crc_fold_constant(crct, type1 + 16), [&](int u) { return dec[u]; },
+                                               [&](int h, uint32_t half) { outw[h] = (uint16_t)half; }, [&](int k) { return crct.t[k]; });
+        crc_ok[blk] = crc == kCrcOk;
+        for (int t4 = 0; t4 < type2 / 4; ++t4) {
+            const uint32_t v = spread4((outw[t4 >> 2] >> (4 * (t4 & 3))) & 0xfu);
+            std::memcpy(row + 4 * t4, &v, 4);
+        }
+    }
+    return 0;
 }

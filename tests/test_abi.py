@@ -74,7 +74,7 @@ def test_lmac_header_symbols_all_exported_and_host_helpers(pkg):
 def test_burst_sync_header_symbols_all_exported(pkg):
     src = open(os.path.join(ROOT, "include", "tetra_burst_sync.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = sorted(set(re.findall(r"\b(tetra_bsync_[a-z0-9_]+|tetra_burst_demux_[a-z_]*device)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(tetra_bsync_[a-z0-9_]+|tetra_burst_demux_[a-z_]*device|tetra_burst_index_device)\s*\(", src)))
     L = pkg.load_library()
     assert set(names) == set(pkg.bsync_binding.BSYNC_EXPORTS)
     for n in names:

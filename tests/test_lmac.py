@@ -113,6 +113,68 @@ def test_lane_code_packed_route_equals_byte_route(lref):
         assert np.array_equal(outs[0][0], want) and np.array_equal(outs[0][1], want_ok)
 
 
+FRAME_KINDS = ((0, 1, 3), (1, 2, 3), (2, 1, 1), (2, 2, 1), (5, 0, 0), (3, 0, None))      # (tpsap, blk_num, carrying burst type)
+
+
+def make_frames(lref, oracle, n, seed):
+    """n packed frames of random burst types (NORM_1 / NORM_2 / SYNC, a few that carry nothing), each block position holding --
+    in turn -- a block made with the reference's encoder (clean / with bit errors) under the frame's own scrambling code or random
+    bits.  Returns (frames [n][512] bytes, packed [n][16], types, codes)."""
+    from tests.emul import bsync_emul_bind as E
+    rng = np.random.default_rng(seed)
+    types = rng.choice(np.array([0, 1, 3, 3, 0, 1, 2, -1, -2], np.int32), n)
+    codes = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    frames = np.zeros((n, 512), np.uint8)
+    frames[:, :510] = rng.integers(0, 2, (n, 510))
+    place = {(0, 1): [(94, 120)], (1, 2): [(282, 216)], (2, 1): [(14, 216)], (2, 2): [(282, 216)], (5, 0): [(14, 216), (282, 216)]}
+    for r in range(n):
+        for tpsap, blk, train in FRAME_KINDS[:5]:
+            if types[r] != train or r % 3 == 2:
+                continue
+            n1 = lref.BLK_PARAM[tpsap][2]
+            code = lref.SCRAMB_INIT if tpsap == 0 else int(codes[r])
+            t5 = lref.lmac_encode(tpsap, rng.integers(0, 2, n1).astype(np.uint8), code)
+            if r % 3 == 1:
+                t5 = t5 ^ (rng.random(t5.size) < 0.05)
+            at = 0
+            for off, ln in place[(tpsap, blk)]:
+                frames[r, off:off + ln] = t5[at:at + ln]
+                at += ln
+    return frames, E.pack_frames(frames), types, codes
+
+
+def test_lane_code_from_frames_equals_demultiplexer_then_reference(lref, oracle):
+    """tetra_lmac_decode_frames_device's lane code (round 6: the decoder's front end cuts its block out of the packed frame) on the
+    host: for every kind, the frames that carry it -- and a few that do not (all-zero block) -- give exactly what the restated
+    tetra_burst_rx_cb split (tetra_burst.c:343-393) followed by the REFERENCE's decoding chain gives."""
+    from tests.emul import lmac_emul_bind
+    frames, packed, types, codes = make_frames(lref, oracle, 400, 21)
+    rng = np.random.default_rng(4)
+    good_total = 0
+    for tpsap, blk, train in FRAME_KINDS:
+        carrying = [r for r in range(len(types)) if (types[r] == train if train is not None else types[r] in (0, 1, 3))]
+        others = [r for r in range(len(types)) if r not in carrying][:7]
+        listed = np.array(carrying + others, np.int32)
+        rng.shuffle(listed)
+        n2 = 32 if tpsap == 3 else lref.BLK_PARAM[tpsap][1]
+        got, ok = lmac_emul_bind.decode_frames(tpsap, blk, packed, types, listed, None if tpsap == 0 else codes, n2 + 8)
+        assert not got[:, n2:].any()
+        for j, r in enumerate(listed):
+            row = oracle.bsync_demux(frames[r], int(types[r]), tpsap, blk) if types[r] >= 0 else np.zeros(0, np.uint8)
+            n345 = 30 if tpsap == 3 else lref.BLK_PARAM[tpsap][0]
+            t5 = np.zeros(n345, np.uint8)
+            t5[:row.size] = row
+            code = lref.SCRAMB_INIT if tpsap == 0 else int(codes[r])
+            want, want_ok = lref.lmac_decode(tpsap, t5, code)
+            if tpsap == 3:
+                want = np.concatenate([want, np.zeros(2, np.uint8)])          # the row's two padding bytes are written as zeros
+            assert np.array_equal(got[j, :n2], want) and ok[j] == want_ok, (tpsap, blk, j, r)
+            good_total += int(want_ok) if tpsap != 3 else 0
+    assert good_total > 100
+    with pytest.raises(ValueError):
+        lmac_emul_bind.decode_frames(4, 0, packed, types, np.zeros(1, np.int32), codes, 112)      # SCH/HU: no downlink burst carries it
+
+
 def test_lane_code_equals_golden():
     """Same check against the committed fixture (inputs + reference outputs; tests/golden/make_lmac_golden.py)."""
     from tests.emul import lmac_emul_bind
@@ -409,3 +471,135 @@ def test_gpu_track_sync_equals_the_reference_rule_and_clock(pkg, lref, ref):
             w = want[c]
             assert list(got[c]) == [w["scr"], w["cc"], w["mcc"], w["mnc"], *w["tcd"], w["phy"].tn, w["phy"].fn, w["phy"].mn], (call, c)
     assert max(w["phy"].mn for w in want) > 0 and any(w["scr"] for w in want)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_frames_all_kinds_in_one_launch(pkg, lref, oracle):
+    """tetra_burst_index_device + tetra_lmac_decode_frames_device on the GPU: the four frame lists equal numpy's, and ONE launch with
+    a job per kind (SCH/F, SB2, NDB 1 + 2, BBK, SB1; counted rows, labels) gives, row for row, what the restated tetra_burst_rx_cb
+    split followed by the REFERENCE's decoding chain gives for the listed frames -- incl. workgroups that end inside a list."""
+    import torch
+    lb, bb = pkg.lmac_binding, pkg.bsync_binding
+    dev = torch.device("cuda", 0)
+    F = 25
+    n = 40 * F
+    frames, packed, types, codes = make_frames(lref, oracle, n, 33)
+    d_fr = torch.from_numpy(packed.astype(np.int64)).to(dev).to(torch.int32).contiguous()        # uint32 bit patterns
+    d_ft = torch.from_numpy(types).to(dev)
+    d_codes = torch.from_numpy(codes.astype(np.int64)).to(dev).to(torch.int32)
+    lists = torch.full((4, n), -7, dtype=torch.int32, device=dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    chan_first = torch.zeros((4, n // F), dtype=torch.int32, device=dev)
+    bb.index_device(d_ft, F, lists, counts, chan_first)
+    torch.cuda.synchronize()
+    want_lists = [np.flatnonzero(types == 3), np.flatnonzero(types == 0), np.flatnonzero(types == 1), np.flatnonzero(np.isin(types, (0, 1, 3)))]
+    for k in range(4):
+        assert int(counts[k]) == want_lists[k].size and np.array_equal(lists[k, :want_lists[k].size].cpu().numpy(), want_lists[k])
+        assert np.array_equal(chan_first[k].cpu().numpy(), np.searchsorted(want_lists[k], np.arange(0, n, F)))
+    bitnum = torch.arange(n, dtype=torch.int32, device=dev) * 510 + 7
+    t_rx = torch.arange(n, dtype=torch.int32, device=dev) + 1000
+    t_af = torch.arange(n, dtype=torch.int32, device=dev) + 5000
+    kinds = ((5, 0, 1), (1, 2, 0), (2, 1, 2), (2, 2, 2), (3, 0, 3), (0, 1, 0))       # (tpsap, blk, list)
+    jobs, outs = [], []
+    for tpsap, blk, li in kinds:
+        n2 = 32 if tpsap == 3 else lref.BLK_PARAM[tpsap][1]
+        t2 = torch.full((n, n2 + 8), 5, dtype=torch.uint8, device=dev)
+        ok = torch.full((n,), -3, dtype=torch.int32, device=dev)
+        lab = torch.full((n, 6), -1, dtype=torch.int32, device=dev)
+        outs.append((t2, ok, lab))
+        jobs.append(dict(type=tpsap, blk_num=blk, row_frame=lists[li], n_rows=counts[li:li + 1], max_rows=n, out_stride=n2 + 8,
+                         frame_scramb=None if tpsap == 0 else d_codes, type2=t2, crc_ok=ok, labels=lab))
+    lb.decode_frames_device(d_fr, d_ft, jobs, F, bitnum, t_rx, t_af)
+    torch.cuda.synchronize()
+    good = 0
+    for (tpsap, blk, li), (t2, ok, lab) in zip(kinds, outs):
+        rows = want_lists[li]
+        n2 = 32 if tpsap == 3 else lref.BLK_PARAM[tpsap][1]
+        n345 = 30 if tpsap == 3 else lref.BLK_PARAM[tpsap][0]
+        t2, ok, lab = t2.cpu().numpy(), ok.cpu().numpy(), lab.cpu().numpy()
+        assert (t2[rows.size:] == 5).all() and (ok[rows.size:] == -3).all() and (lab[rows.size:] == -1).all()      # rows past the count: untouched
+        assert (t2[:rows.size, n2:] == 5).all()                                                                   # and the rows' padding
+        for j, r in enumerate(rows):
+            row = oracle.bsync_demux(frames[r], int(types[r]), tpsap, blk)
+            t5 = np.zeros(n345, np.uint8)
+            t5[:row.size] = row
+            want, want_ok = lref.lmac_decode(tpsap, t5, lref.SCRAMB_INIT if tpsap == 0 else int(codes[r]))
+            if tpsap == 3:
+                want = np.concatenate([want, np.zeros(2, np.uint8)])
+            assert np.array_equal(t2[j, :n2], want) and ok[j] == want_ok, (tpsap, blk, j)
+            assert list(lab[j]) == [r // F, r % F, r * 510 + 7, r + 1000, r + 5000, want_ok]
+            good += int(want_ok) if tpsap != 3 else 0
+    assert good > 150
+    # argument errors: statuses, not launches
+    from ctypes import byref
+    L = pkg.binding.load_library()
+    src = lb.Frames(d_fr.data_ptr(), d_ft.data_ptr(), n, F, None, None, None)
+    t2, ok, lab = outs[0]
+    def one(**kw):
+        base = dict(type=5, blk_num=0, d_row_frame=lists[1].data_ptr(), d_n_rows=None, max_rows=n, out_stride=296, d_frame_scramb=d_codes.data_ptr(),
+                    d_type2=t2.data_ptr(), d_crc_ok=ok.data_ptr(), d_labels=None)
+        base.update(kw)
+        return L.tetra_lmac_decode_frames_device(byref(src), byref(lb.Job(*[base[f] for f, _ in lb.Job._fields_])), 1, None)
+    ERR_ARG, ERR_SIZE, ERR_ALIGN = -1, -6, -7                           # include/tetra_demod.h
+    assert one(type=4) == ERR_ARG                    # SCH/HU: no downlink burst carries it
+    assert one(type=0, blk_num=2) == ERR_ARG         # SB1 is block 1
+    assert one(out_stride=280) == ERR_SIZE
+    assert one(out_stride=292) == ERR_ALIGN
+    assert one(d_frame_scramb=None) == ERR_ARG
+    assert one(d_labels=lab.data_ptr()) == ERR_ARG   # labels without the per-frame arrays
+    assert one(max_rows=0) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_gpu_track_sync_lists_equals_the_slot_layout_tracker(pkg, lref):
+    """tetra_lmac_track_sync_lists_device (compact SB1 rows, a wavefront per channel) == tetra_lmac_track_sync_device (slot layout,
+    itself checked against the reference's field read-out and TDMA arithmetic in tests/test_burst_sync.py): cell state, per-slot
+    codes and times, over two calls with carried state, channels without any SYNC burst, bad CRCs, short frame counts; plus the
+    SB1 rows' labels."""
+    import torch
+    lb, bb = pkg.lmac_binding, pkg.bsync_binding
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    C_, F = 37, 70
+    n = C_ * F
+    cell_a = torch.zeros((C_, 10), dtype=torch.int32, device=dev)
+    cell_b = torch.zeros((C_, 10), dtype=torch.int32, device=dev)
+    for call in range(2):
+        types = rng.choice(np.array([0, 1, 3, 3, -1, -2], np.int32), n)
+        types.reshape(C_, F)[5] = 0                                     # a channel without SYNC bursts
+        nf = rng.integers(F - 6, F + 1, C_).astype(np.int32)
+        nf[3] = 0
+        sync = np.flatnonzero(types == 3)
+        t2c = rng.integers(0, 2, (sync.size, 80), dtype=np.uint8)
+        okc = (rng.random(sync.size) < 0.8).astype(np.int32)
+        # slot layout for the old tracker
+        slot_t2 = np.zeros((n, 80), np.uint8)
+        slot_ok = np.zeros(n, np.int32)
+        slot_valid = np.zeros(n, np.int32)
+        slot_t2[sync], slot_ok[sync], slot_valid[sync] = t2c, okc, 1
+        d = lambda a: torch.from_numpy(a).to(dev)
+        outs_a = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+        outs_b = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+        lb.track_sync_device(d(slot_t2), 80, d(slot_ok), d(slot_valid), d(nf), C_, F, cell_a, *outs_a)
+        d_ft = d(types)
+        lists = torch.zeros((4, n), dtype=torch.int32, device=dev)
+        counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        chan_first = torch.zeros((4, C_), dtype=torch.int32, device=dev)
+        bb.index_device(d_ft, F, lists, counts, chan_first)
+        bitnum = torch.arange(n, dtype=torch.int32, device=dev) * 3
+        labels = torch.full((n, 6), -1, dtype=torch.int32, device=dev)
+        lb.track_sync_lists_device(d(t2c), 80, d(okc), d_ft, d(nf), chan_first[0], C_, F, cell_b, *outs_b, d_frame_bitnum=bitnum, d_sb1_labels=labels)
+        torch.cuda.synchronize()
+        assert torch.equal(cell_a, cell_b)
+        for a, b in zip(outs_a, outs_b):
+            assert torch.equal(a, b)
+        lab = labels.cpu().numpy()
+        trx, taf = outs_b[1].cpu().numpy(), outs_b[2].cpu().numpy()
+        for j, r in enumerate(sync):
+            c, f = divmod(int(r), F)
+            if f < nf[c]:
+                assert list(lab[j]) == [c, f, 3 * r, trx[r], taf[r], okc[j]]
+            else:
+                assert (lab[j] == -1).all()              # a SYNC-typed slot past the channel's frame count is not a frame
+        assert (lab[sync.size:] == -1).all()
