@@ -1,5 +1,5 @@
 set -x
-O=$GRAFT_REPO_ROOT/gpurun_out/r06e
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r06e}
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o p -- python $GRAFT_REPO_ROOT/bench.py --chain-only > $O/chain.json 2> $O/chain.err

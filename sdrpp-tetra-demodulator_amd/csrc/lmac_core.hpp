@@ -359,41 +359,42 @@ LM_FN void viterbi_forward(int n2, Next next, St st) {
     }
 }
 
-// CRC16-CCITT (crc_simple.c:59-77, :103-106: x^16 + x^12 + x^5 + 1, start 0xffff, bits MSB first) is affine in the message: the
-// register after n bits = Z(n) ^ XOR over the 1 bits of T[distance of the bit from the end], T[j] = x^(16 + j) mod the polynomial,
-// Z(n) = the register after n zero bits.  The traceback meets the bits last to first, so it folds the CRC in: one AND + XOR per bit
-// with a wave-uniform constant instead of a five-instruction shift register step.
-constexpr int kCrcPad = 4;            // leading zero entries: the 4 tail bits behind the CRC field meet a zero constant, no branch
-struct CrcTable {
-    uint32_t t[kCrcPad + kMaxType2];   // t[kCrcPad + j] = T[j] (dwords: a wave-uniform index then loads through the scalar cache)
-};
-constexpr CrcTable make_crc_table() {
-    CrcTable c{};
-    uint32_t v = 0x1021u;                                  // one 1 bit into a zero register
-    for (int j = 0; j < kMaxType2; ++j) {
-        c.t[kCrcPad + j] = v;
-        v = (v & 0x8000u) ? (((v << 1) ^ 0x1021u) & 0xffffu) : ((v << 1) & 0xffffu);
+// CRC16-CCITT (crc_simple.c:59-77, :103-106: x^16 + x^12 + x^5 + 1, start 0xffff, bits MSB first, good = 0x1d0f over type1 + 16
+// bits).  The traceback meets the bits last to first, so it runs the register BACKWARDS from the good value and checks that it
+// arrives at the start value: the shift register step is invertible (the polynomial's constant term is 1),
+//     forward   fb = msb(r) ^ d;  r = (r << 1) ^ (fb ? 0x1021 : 0)            inverse   fb = r & 1;  r = ((r ^ fb * 0x1021) >> 1) | (fb ^ d) << 15
+// and eight inverse steps are one table look-up: r = (r >> 8) ^ Tinv[r & 0xff] ^ (the eight bits, first one most significant, << 8)
+// (the data bits enter at bit 15 and only shift right afterwards).  Until round 6 the CRC was folded in bit by bit (an AND + XOR with
+// a position constant per bit, three instructions); this is five instructions and a look-up per eight bits.
+// The register is carried shifted left by two (r4 = r << 2; whatever lands in its two low bits is never looked at) and the table
+// holds Tinv << 2, so that r4 & 0x3fc is the byte offset of the table entry: one AND makes the LDS address.
+struct CrcInvTable { uint32_t t[256]; };
+constexpr uint32_t crc_inv_step(uint32_t r, uint32_t d) {
+    const uint32_t fb = r & 1u;
+    return ((r ^ (fb ? 0x1021u : 0u)) >> 1) | ((fb ^ d) << 15);
+}
+constexpr CrcInvTable make_crc_inv_table() {
+    CrcInvTable c{};
+    for (uint32_t b = 0; b < 256; ++b) {
+        uint32_t r = b;
+        for (int k = 0; k < 8; ++k) r = crc_inv_step(r, 0u);
+        c.t[b] = r << 2;
     }
     return c;
 }
-// Z(n) ^ XOR of T[0 .. n - 1]: what the traceback's accumulator (XOR of T[j] over the ZERO bits) has to be XORed with
-constexpr uint32_t crc_fold_constant(const CrcTable& c, int n) {
-    uint32_t z = 0xffffu;
-    for (int i = 0; i < n; ++i) z = (z & 0x8000u) ? (((z << 1) ^ 0x1021u) & 0xffffu) : ((z << 1) & 0xffffu);
-    for (int j = 0; j < n; ++j) z ^= c.t[kCrcPad + j];
-    return z;
-}
 
-// Traceback from state 0 after the flush steps, CRC folded in.  ld(u) returns the decision word of step pair u as the forward pass
-// stored it; st(h, half) receives decoded bits 16h..16h+15 (bit 16h+b at bit b); tbl(k) = CrcTable::t[k] (wave-uniform index);
-// n_crc = type1 + 16 bits are covered by the CRC (n2 = n_crc + 4 tail bits), fold = crc_fold_constant(n_crc).  Returns the CRC
-// register.  n2 is a multiple of 16.
+// Traceback from state 0 after the flush steps with the CRC check run backwards alongside.  ld(u) returns the decision word of step
+// pair u as the forward pass stored it; st(h, half) receives decoded bits 16h..16h+15 (bit 16h+b at bit b); tinv(off) = the entry of
+// make_crc_inv_table at BYTE offset off (per-lane).  n2 = type1 + 16 CRC-covered bits + 4 tail bits, a multiple of 16.  Returns whether the CRC
+// over the first n2 - 4 decoded bits is good.
 // y = 15 - state runs in a shift register: the predecessor of state s under decision d is (2 s + d) & 15, so y' = 2 y + 1 - d, and
 // the decision of state s sits at bit 2 y (odd step) or 2 y + 1 (even step) of the word: a shift, a one-bit signed extract (= -d)
-// and an add per step.  The decoded bit of a step is the complement of bit 3 of y before the step, so after 16 steps the 16 decoded
-// bits sit, complemented, at bits 4..19.
-template <class Ld, class St, class Tbl>
-LM_FN uint32_t viterbi_traceback(int n2, int n_crc, uint32_t fold, Ld ld, St st, Tbl tbl) {
+// and an add per step.  The decoded bit of a step is the complement of bit 3 of y before the step, and the register only ever
+// shifts, so after the 16 steps of group h bits 4..31 of ~y are the decoded bits 16h .. 16h+27: the CRC bytes, which end 4 bits
+// before a group boundary, are cut from there -- bits 16h+12..16h+19 (not in the top group: tail bits) and 16h+4..16h+11; the four
+// bits 0..3 left at the end take four single steps.
+template <class Ld, class St, class Tinv>
+LM_FN bool viterbi_traceback(int n2, Ld ld, St st, Tinv tinv) {
     uint32_t y = 15u;
 #pragma unroll
     for (int f = kFlush / 2 - 1; f >= 0; --f) {
@@ -403,23 +404,27 @@ LM_FN uint32_t viterbi_traceback(int n2, int n_crc, uint32_t fold, Ld ld, St st,
         t = (y << 1) | 1u;
         y = t + bfe_mask(w, t);
     }
-    uint32_t acc = 0;
-    for (int h = n2 / 16 - 1; h >= 0; --h) {
-        const int k0 = n_crc - 1 + kCrcPad - 16 * h;          // table index of bit 16 h (>= 0 for every bit of the row)
+    uint32_t r4 = kCrcOk << 2;
+    const int top = n2 / 16 - 1;
+    for (int h = top; h >= 0; --h) {
 #pragma unroll
         for (int b2 = 7; b2 >= 0; --b2) {
             const uint32_t w = ld(8 * h + b2);
-            // step 16h + 2 b2 + 1, then step 16h + 2 b2: y bit 3 set <=> the decoded bit is 0
-            acc ^= tbl(k0 - 2 * b2 - 1) & bfe_mask(y, 3);
             uint32_t t = y << 1;
             y = t + 1u + bfe_mask(w, t);
-            acc ^= tbl(k0 - 2 * b2) & bfe_mask(y, 3);
             t = (y << 1) | 1u;
             y = t + bfe_mask(w, t);
         }
-        st(h, (~y >> 4) & 0xffffu);
+        const uint32_t bits = ~y;
+        st(h, (bits >> 4) & 0xffffu);
+        const uint32_t rev = rev32(bits);                 // decoded bit 16h + k at bit 27 - k
+        if (h != top) r4 = (r4 >> 8) ^ tinv(r4 & 0x3fcu) ^ ((rev << 2) & 0x3fc00u);          // bits 16h+12 .. 16h+19
+        r4 = (r4 >> 8) ^ tinv(r4 & 0x3fcu) ^ ((rev >> 6) & 0x3fc00u);                        // bits 16h+4 .. 16h+11
     }
-    return (acc ^ fold) & 0xffffu;
+    uint32_t r = (r4 >> 2) & 0xffffu;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) r = crc_inv_step(r, (~y >> (4 + k)) & 1u);                         // bits 3 .. 0
+    return r == 0xffffu;
 }
 
 // 4 decoded bits -> 4 bytes (one bit per byte, little endian)

@@ -259,27 +259,33 @@ __global__ __launch_bounds__(256) void k_index_count(const int* __restrict__ fra
         if (threadIdx.x == 0) work[k * nblocks + blockIdx.x] = c;
     }
 }
-// 2. exclusive scan of each list's block counts (one workgroup), totals -> counts
+// 2. exclusive scan of each list's block counts (one workgroup: a run of blocks per thread, shuffles within a wavefront, one
+//    exchange between the 16 wavefronts), totals -> counts
 __global__ __launch_bounds__(1024) void k_index_scan(int* __restrict__ work, int nblocks, int* __restrict__ counts) {
-    __shared__ int part[1024];
+    __shared__ int wave_sum[TETRA_N_LISTS][16];
     const int per = (nblocks + 1023) / 1024;
     const int lo = threadIdx.x * per, hi = min(nblocks, lo + per);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int sum[TETRA_N_LISTS], inc[TETRA_N_LISTS];
+#pragma unroll
     for (int k = 0; k < TETRA_N_LISTS; ++k) {
-        int* cnt = work + k * nblocks;
-        int sum = 0;
-        for (int i = lo; i < hi; ++i) sum += cnt[i];
-        part[threadIdx.x] = sum;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan
-            const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
+        sum[k] = 0;
+        for (int i = lo; i < hi; ++i) sum[k] += work[k * nblocks + i];
+        inc[k] = sum[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(inc[k], d);
+            inc[k] += lane >= d ? v : 0;
         }
-        int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-        for (int i = lo; i < hi; ++i) { const int c = cnt[i]; cnt[i] = run; run += c; }
-        if (threadIdx.x == 1023) counts[k] = part[1023];
-        __syncthreads();
+        if (lane == 63) wave_sum[k][w] = inc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TETRA_N_LISTS; ++k) {
+        int run = inc[k] - sum[k];
+        for (int i = 0; i < w; ++i) run += wave_sum[k][i];
+        for (int i = lo; i < hi; ++i) { const int c = work[k * nblocks + i]; work[k * nblocks + i] = run; run += c; }
+        if (threadIdx.x == 1023) counts[k] = run;
     }
 }
 // 3. the lists themselves, and per channel the position of its first entry

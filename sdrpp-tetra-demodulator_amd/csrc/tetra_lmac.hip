@@ -41,7 +41,7 @@ constexpr int kClsWords = (kMaxType345 + 15) / 16;     // 27
 constexpr int kOutHalves = kMaxType2 / 16;             // 18
 constexpr int kOutPad = 2;                             // outw rows of 66 ushorts = 33 banks: the write-back's column reads do not collide
 bool g_force_byte_route = false;                       // tests / A-B: tetra_lmac_debug_force_byte_route
-__constant__ CrcTable kCrcDev = make_crc_table();      // the traceback's CRC constants (constant address space: scalar loads)
+__constant__ CrcInvTable kCrcInvDev = make_crc_inv_table();      // the traceback's backward CRC table; every workgroup copies it to LDS
 
 struct BlkParam { int type345, type2, type1, a, crc; };
 // tetra_blk_param[], tetra_lower_mac.c:58-105 (values of EN 300 392-2 table 8.x / 8.2.4.1)
@@ -58,8 +58,8 @@ typedef uint16_t OutW[kOutHalves][kLanes + kOutPad];
 
 // steps 2-4 for a workgroup whose type-4 bits (BITS) or soft classes are in `cls`; returns the lane's CRC verdict
 template <bool BITS>
-__device__ __forceinline__ bool decode_core(const uint32_t (*cls)[kLanes], OutW& outw, int lane, int type345, int type2, int type1, int a,
-                                            uint32_t crc_fold, uint32_t* __restrict__ dec) {
+__device__ __forceinline__ bool decode_core(const uint32_t (*cls)[kLanes], OutW& outw, const uint32_t* crc_inv, int lane, int type345, int type2,
+                                            int a, uint32_t* __restrict__ dec) {
     int pos = a;                       // (a * i) % K for i = 1
     if (BITS) {
         auto bit = [&](int p) { return bfe_mask(cls[p >> 5][lane], 31u - (uint32_t)(p & 31)); };
@@ -79,10 +79,14 @@ __device__ __forceinline__ bool decode_core(const uint32_t (*cls)[kLanes], OutW&
                         [&](int u, uint32_t word) { dec[u * kLanes] = word; });
     }
     // traceback + CRC (own lane's data only: program order is enough)
-    const uint32_t crc = viterbi_traceback(type2, type1 + 16, crc_fold, [&](int u) { return dec[u * kLanes]; },
-                                           [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
-                                           [&](int k) { return kCrcDev.t[k]; });
-    return crc == kCrcOk;
+    return viterbi_traceback(type2, [&](int u) { return dec[u * kLanes]; }, [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
+                             [&](uint32_t off) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crc_inv) + off); });
+}
+
+// the backward CRC table into LDS (4 entries per lane); the caller's next barrier makes it visible
+__device__ __forceinline__ void load_crc_inv(uint32_t* crc_inv, int lane) {
+#pragma unroll
+    for (int k = 0; k < 256 / kLanes; ++k) crc_inv[k * kLanes + lane] = kCrcInvDev.t[k * kLanes + lane];
 }
 
 // step 4: decoded rows -> HBM.  WIDE: rows a multiple of 8 bytes and 8-byte aligned -- 8 bits -> 8 bytes per lane, the (row, unit)
@@ -133,10 +137,11 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                                         uint8_t* __restrict__ out, int out_stride, int* __restrict__ crc_ok,
                                                         uint32_t* __restrict__ dec_scratch, int dec_pairs,
                                                         const int* __restrict__ n_blocks_dev, const int* __restrict__ init_index,
-                                                        const uint32_t* __restrict__ seq_tab, uint32_t crc_fold) {
+                                                        const uint32_t* __restrict__ seq_tab) {
     __shared__ uint32_t stage[kLanes][kChunkDwords + 1];     // +1: odd row stride, conflict-free column reads
     __shared__ uint32_t cls[kClsWords + 1][kLanes];
     __shared__ OutW outw;
+    __shared__ uint32_t crc_inv[256];
     const int lane = threadIdx.x;
     const int blk0 = blockIdx.x * kLanes;
     const int blk = blk0 + lane;
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
     const int rows_here = min(kLanes, n_blocks - blk0);
     const uint32_t code = (fixed_init || blk >= n_blocks) ? kScrambInitSb1 : scramb_init[init_index ? init_index[blk] : blk];
     uint32_t* dec = dec_scratch + (size_t)blockIdx.x * dec_pairs * kLanes + lane;
+    load_crc_inv(crc_inv, lane);
 
     // 1. front end.  Rows of plain bits: each lane packs its own row (8-byte loads), descrambles whole words and leaves the type-4
     //    bits in LDS (cls rows 0..13 as [word][lane]); the workgroup falls back to the byte route if any of its rows holds another
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
     }
     bool good;
     if (!byte_route) {
-        good = decode_core<true>(cls, outw, lane, type345, type2, type1, a, crc_fold, dec);
+        __syncthreads();
+        good = decode_core<true>(cls, outw, crc_inv, lane, type345, type2, a, dec);
     } else {
         // rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
         // descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                     [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
             __syncthreads();
         }
-        good = decode_core<false>(cls, outw, lane, type345, type2, type1, a, crc_fold, dec);
+        good = decode_core<false>(cls, outw, crc_inv, lane, type345, type2, a, dec);
     }
     if (blk < n_blocks) crc_ok[blk] = good;
     __syncthreads();
@@ -200,8 +207,7 @@ struct DevJob {
     long long scratch_base;            // first word of the job's decision scratch
     int n_rows, out_stride, first_group, dec_pairs;
     int layout;                        // kLayout*
-    int type345, type2, type1, a;
-    uint32_t crc_fold;
+    int type345, type2, a;
 };
 struct DevFrames {
     const uint32_t* frames;
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint
                                                         const uint32_t* __restrict__ seq_tab) {
     __shared__ uint32_t cls[kSeqWords][kLanes];
     __shared__ OutW outw;
+    __shared__ uint32_t crc_inv[256];
     const int lane = threadIdx.x;
     int ji = 0;
     for (int i = 1; i < tab.n; ++i) ji = (int)blockIdx.x >= tab.job[i].first_group ? i : ji;
@@ -261,8 +268,10 @@ __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint
         uint32_t xb[kSeqWords];
         frame_block(J.layout, fw, ft, xb);
         descramble_to_lds(J.type345, code, xb, seq_tab, cls, lane);
+        load_crc_inv(crc_inv, lane);
+        __syncthreads();
         uint32_t* dec = dec_scratch + J.scratch_base + (size_t)group * J.dec_pairs * kLanes + lane;
-        good = decode_core<true>(cls, outw, lane, J.type345, J.type2, J.type1, J.a, J.crc_fold, dec);
+        good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, dec);
     }
     if (blk < n_blocks) {
         J.crc_ok[blk] = good;
@@ -419,94 +428,87 @@ __global__ __launch_bounds__(256) void k_track_sync(const uint8_t* __restrict__ 
 }
 
 // tetra_lmac_track_sync_lists_device: k_track_sync's walk with the channel's SB1 rows compact and read side by side.  One
-// wavefront per channel: lanes over frame slots gather (valid, crc, SYNC-PDU fields) into LDS, lane 0 walks the slots there, all
-// lanes write the three per-slot arrays (and the SB1 rows' labels) back.
+// wavefront per channel, 64 frame slots at a time: every lane gathers its slot's (valid, crc, SYNC-PDU fields); the walk over the
+// slots then runs on WAVE-UNIFORM values -- a slot's words fetched with v_readlane, the cell state and the clock in scalar
+// registers, the three results per slot selected into their lane -- so it costs scalar instructions and four vector ones per
+// slot, no LDS and no dependent loads; the lanes write the results back coalesced.
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __global__ __launch_bounds__(kLanes) void k_track_sync_lists(const uint8_t* __restrict__ sb1, int stride, const int* __restrict__ crc_ok,
                                                              const int* __restrict__ frame_type, const int* __restrict__ n_frames,
                                                              const int* __restrict__ chan_first, int frames,
                                                              tetra_lmac_cell_state_t* __restrict__ cell, uint32_t* __restrict__ row_scramb,
                                                              uint32_t* __restrict__ row_time_rx, uint32_t* __restrict__ row_time,
                                                              const uint32_t* __restrict__ frame_bitnum, tetra_lmac_label_t* __restrict__ labels) {
-    extern __shared__ uint32_t sm[];
-    uint32_t* in_a = sm;                     // bit 0 valid, bit 1 crc ok, colour << 2, tn << 8, fn << 11, mn << 16
-    uint32_t* in_b = sm + frames;            // mcc | mnc << 10
-    uint32_t* in_j = sm + 2 * frames;        // compact row index
-    uint32_t* o_scr = sm + 3 * frames;       // the code in force for the slot's other blocks
-    uint32_t* o_rx = sm + 4 * frames;        // time on entry
-    uint32_t* o_t = sm + 5 * frames;         // time after the slot's SB1
     const int c = blockIdx.x, lane = threadIdx.x;
     const int nf = n_frames ? min(n_frames[c], frames) : frames;
     int base = chan_first[c];
+    tetra_lmac_cell_state_t st = cell[c];
     for (int f0 = 0; f0 < frames; f0 += kLanes) {
         const int f = f0 + lane;
-        const bool is_sync = f < frames && frame_type[(size_t)c * frames + f] == TETRA_TRAIN_SYNC;
+        const size_t r = (size_t)c * frames + f;
+        const bool is_sync = f < frames && frame_type[r] == TETRA_TRAIN_SYNC;
         const unsigned long long m = __ballot(is_sync);
         const int j = base + __popcll(m & ((1ull << lane) - 1ull));
         base += __popcll(m);
-        if (f < frames) {
-            uint32_t a = 0, b = 0;
-            if (is_sync && f < nf) {
-                a = 1u;
-                if (crc_ok[j]) {
-                    const uint32_t* t2 = reinterpret_cast<const uint32_t*>(sb1 + (size_t)j * stride);
-                    uint64_t v = 0;                               // type-2 bits 0..55, first bit most significant
+        // a: bit 0 valid, bit 1 crc ok, colour << 2, tn << 8, fn << 11, mn << 16;  b: mcc | mnc << 10
+        uint32_t a = 0, b = 0;
+        if (is_sync && f < nf) {
+            a = 1u;
+            if (crc_ok[j]) {
+                const uint32_t* t2 = reinterpret_cast<const uint32_t*>(sb1 + (size_t)j * stride);
+                uint64_t v = 0;                               // type-2 bits 0..55, first bit most significant
 #pragma unroll
-                    for (int k = 0; k < 14; ++k) v |= (uint64_t)pack4(t2[k] & 0x01010101u) << (60 - 4 * k);
-                    auto field = [&](int first, int len) { return (uint32_t)(v >> (64 - first - len)) & ((1u << len) - 1u); };
-                    a |= 2u | (field(4, 6) << 2) | ((field(10, 2) + 1u) << 8) | (field(12, 5) << 11) | (field(17, 6) << 16);
-                    b = field(31, 10) | (field(41, 14) << 10);
-                }
+                for (int k = 0; k < 14; ++k) v |= (uint64_t)pack4(t2[k] & 0x01010101u) << (60 - 4 * k);
+                auto field = [&](int first, int len) { return (uint32_t)(v >> (64 - first - len)) & ((1u << len) - 1u); };
+                a |= 2u | (field(4, 6) << 2) | ((field(10, 2) + 1u) << 8) | (field(12, 5) << 11) | (field(17, 6) << 16);
+                b = field(31, 10) | (field(41, 14) << 10);
             }
-            in_a[f] = a; in_b[f] = b; in_j[f] = (uint32_t)j;
         }
-    }
-    __syncthreads();
-    if (lane == 0) {
-        tetra_lmac_cell_state_t st = cell[c];
-        for (int f = 0; f < frames; ++f) {
+        uint32_t o_scr = 0, o_rx = 0, o_t = 0;
+        const int lim = min(kLanes, frames - f0);
+        for (int i = 0; i < lim; ++i) {
             uint32_t t_rx = 0, t_after = 0;
-            if (f < nf) {
+            if (f0 + i < nf) {
                 tdma_add_tn(st.phy_tn, st.phy_fn, st.phy_mn);
                 t_rx = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
-                const uint32_t a = in_a[f];
-                if (a & 1u) {
-                    if (a & 2u) {
-                        const uint32_t b = in_b[f];
-                        st.colour_code = (a >> 2) & 0x3fu;
-                        st.tcd_tn = (a >> 8) & 7u;
-                        st.tcd_fn = (a >> 11) & 0x1fu;
-                        st.tcd_mn = (a >> 16) & 0x3fu;
-                        st.mcc = b & 0x3ffu;
-                        st.mnc = b >> 10;
+                const uint32_t ai = lane_get(a, i);
+                if (ai & 1u) {
+                    if (ai & 2u) {
+                        const uint32_t bi = lane_get(b, i);
+                        st.colour_code = (ai >> 2) & 0x3fu;
+                        st.tcd_tn = (ai >> 8) & 7u;
+                        st.tcd_fn = (ai >> 11) & 0x1fu;
+                        st.tcd_mn = (ai >> 16) & 0x3fu;
+                        st.mcc = bi & 0x3ffu;
+                        st.mnc = bi >> 10;
                         st.scramb_init = (((st.colour_code & 0x3f) | ((st.mnc & 0x3fff) << 6) | ((st.mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1;
                     }
                     st.phy_tn = st.tcd_tn; st.phy_fn = st.tcd_fn; st.phy_mn = st.tcd_mn;
                 }
                 t_after = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
             }
-            o_scr[f] = st.scramb_init;
-            o_rx[f] = t_rx;
-            o_t[f] = t_after;
+            const bool mine = lane == i;
+            o_scr = mine ? st.scramb_init : o_scr;
+            o_rx = mine ? t_rx : o_rx;
+            o_t = mine ? t_after : o_t;
         }
-        cell[c] = st;
-    }
-    __syncthreads();
-    for (int f = lane; f < frames; f += kLanes) {
-        const size_t r = (size_t)c * frames + f;
-        row_scramb[r] = o_scr[f];
-        if (row_time_rx) row_time_rx[r] = o_rx[f];
-        if (row_time) row_time[r] = o_t[f];
-        if (labels && (in_a[f] & 1u)) {
-            tetra_lmac_label_t lb;
-            lb.channel = c;
-            lb.frame_slot = f;
-            lb.bitnum = frame_bitnum[r];
-            lb.tdma_time_rx = o_rx[f];
-            lb.tdma_time = o_t[f];
-            lb.crc_ok = (in_a[f] >> 1) & 1u;
-            labels[in_j[f]] = lb;
+        if (f < frames) {
+            row_scramb[r] = o_scr;
+            if (row_time_rx) row_time_rx[r] = o_rx;
+            if (row_time) row_time[r] = o_t;
+            if (labels && (a & 1u)) {
+                tetra_lmac_label_t lb;
+                lb.channel = c;
+                lb.frame_slot = f;
+                lb.bitnum = frame_bitnum[r];
+                lb.tdma_time_rx = o_rx;
+                lb.tdma_time = o_t;
+                lb.crc_ok = (a >> 1) & 1u;
+                labels[j] = lb;
+            }
         }
     }
+    if (lane == 0) cell[c] = st;
 }
 
 int check_args(int type, const void* in, int n_blocks, int in_stride, const void* init, const void* out, int out_stride,
@@ -566,8 +568,6 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
         const size_t bytes = (size_t)groups * dec_pairs * kLanes * sizeof(uint32_t);
         const uint32_t* seq = seq_table();
         if (!seq) return TETRA_ERR_NOMEM;
-        constexpr CrcTable crct = make_crc_table();
-        const uint32_t crc_fold = crc_fold_constant(crct, p.type1 + 16);
         uint32_t* scratch = nullptr;
         hipMemPool_t pool = scratch_pool();
         const hipError_t got = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), bytes, pool, s)
@@ -575,7 +575,7 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
         if (got != hipSuccess) { (void)hipGetLastError(); return TETRA_ERR_NOMEM; }
         hipLaunchKernelGGL(k_lmac_decode, dim3(groups), dim3(kLanes), 0, s, d_type5, n_blocks, in_stride, d_scramb_init,
                            type == TETRA_TPSAP_T_SB1 ? 1 : 0, p.type345, p.type2, p.type1, p.a, d_type2, out_stride, d_crc_ok,
-                           scratch, dec_pairs, d_n_blocks, d_init_index, g_force_byte_route ? nullptr : seq, crc_fold);
+                           scratch, dec_pairs, d_n_blocks, d_init_index, g_force_byte_route ? nullptr : seq);
         const hipError_t launch = hipGetLastError();
         if (hipFreeAsync(scratch, s) != hipSuccess || launch != hipSuccess) return TETRA_ERR_HIP;
         return TETRA_OK;
@@ -590,7 +590,6 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
     if ((uintptr_t)src->d_frames & 15) return TETRA_ERR_ALIGN;
     JobTable tab = {};
     tab.src = DevFrames{ src->d_frames, src->d_frame_type, src->d_frame_bitnum, src->d_time_rx, src->d_time, src->frames_per_channel };
-    constexpr CrcTable crct = make_crc_table();
     long long groups_total = 0, scratch_words = 0;
     int n = 0;
     for (int i = 0; i < n_jobs; ++i) {
@@ -623,8 +622,7 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
         d.n_rows = j.max_rows;
         d.out_stride = j.out_stride;
         d.layout = layout;
-        d.type345 = p.type345; d.type2 = p.type2; d.type1 = p.type1; d.a = p.a;
-        d.crc_fold = p.crc ? crc_fold_constant(crct, p.type1 + 16) : 0u;
+        d.type345 = p.type345; d.type2 = p.type2; d.a = p.a;
         d.dec_pairs = layout == kLayoutBbk ? 0 : (p.type2 + kFlush) / 2;
         const long long groups = ((long long)j.max_rows + kLanes - 1) / kLanes;
         d.first_group = (int)groups_total;
@@ -688,8 +686,7 @@ int tetra_lmac_track_sync_lists_device(const uint8_t* d_sb1_type2, int type2_str
     if ((type2_stride & 3) || ((uintptr_t)d_sb1_type2 & 3)) return TETRA_ERR_ALIGN;
     if (frames_per_channel > TETRA_LMAC_TRACK_MAX_FRAMES) return TETRA_ERR_SIZE;
     if (frames_per_channel == 0) return TETRA_OK;
-    hipLaunchKernelGGL(k_track_sync_lists, dim3(n_channels), dim3(kLanes), sizeof(uint32_t) * 6 * (size_t)frames_per_channel,
-                       static_cast<hipStream_t>(hip_stream), d_sb1_type2, type2_stride, d_crc_ok, d_frame_type, d_n_frames, d_chan_first_sync,
+    hipLaunchKernelGGL(k_track_sync_lists, dim3(n_channels), dim3(kLanes), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2, type2_stride, d_crc_ok, d_frame_type, d_n_frames, d_chan_first_sync,
                        frames_per_channel, d_cell, d_row_scramb, d_row_time_rx, d_row_time, d_frame_bitnum, d_sb1_labels);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
 }

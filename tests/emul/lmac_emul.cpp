@@ -24,8 +24,8 @@ const uint32_t* seq_table() {
 extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, const uint8_t* type5, int n_blocks, int in_stride,
                                       const uint32_t* scramb_init, uint8_t* out, int out_stride, int32_t* crc_ok, int route, int32_t* fast_rows) {
     if (type345 > kMaxType345 || type2 > kMaxType2 || (type345 & 7) || (type2 & 15) || (in_stride & 3)) return -1;
-    static const CrcTable crct = make_crc_table();
-    const uint32_t fold = crc_fold_constant(crct, type1 + 16);
+    static const CrcInvTable crci = make_crc_inv_table();
+    (void)type1;                  // n2 = type1 + 16 + 4 for every coded kind: the traceback derives the CRC span from n2
     const uint32_t* tab = seq_table();
     int fast = 0;
     for (int blk = 0; blk < n_blocks; ++blk) {
@@ -61,9 +61,8 @@ extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, 
                             },
                             [&](int u, uint32_t word) { dec[u] = word; });
         }
-        const uint32_t crc = viterbi_traceback(type2, type1 + 16, fold, [&](int u) { return dec[u]; },
-                                               [&](int h, uint32_t half) { outw[h] = (uint16_t)half; }, [&](int k) { return crct.t[k]; });
-        crc_ok[blk] = crc == kCrcOk;
+        crc_ok[blk] = viterbi_traceback(type2, [&](int u) { return dec[u]; }, [&](int h, uint32_t half) { outw[h] = (uint16_t)half; },
+                                        [&](uint32_t off) { return crci.t[off >> 2]; });
         for (int t4 = 0; t4 < type2 / 4; ++t4) {
             const uint32_t v = spread4((outw[t4 >> 2] >> (4 * (t4 & 3))) & 0xfu);
             std::memcpy(out + (size_t)blk * out_stride + 4 * t4, &v, 4);
@@ -92,7 +91,7 @@ extern "C" int lmac_emul_decode_frames(int tpsap, int blk_num, const uint32_t* f
         default: break;
     }
     if (layout == kLayoutNone) return -1;
-    static const CrcTable crct = make_crc_table();
+    static const CrcInvTable crci = make_crc_inv_table();
     const uint32_t* tab = seq_table();
     auto seq = [&](int t, uint32_t byte, int w) { return tab[((size_t)t * 256 + byte) * kSeqStride + w]; };
     for (int blk = 0; blk < n_rows; ++blk) {
@@ -120,9 +119,9 @@ extern "C" int lmac_emul_decode_frames(int tpsap, int blk_num, const uint32_t* f
                             return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
                         },
                         [&](int u, uint32_t word) { dec[u] = word; });
-        const uint32_t crc = viterbi_traceback(type2, type1 + 16, crc_fold_constant(crct, type1 + 16), [&](int u) { return dec[u]; },
-                                               [&](int h, uint32_t half) { outw[h] = (uint16_t)half; }, [&](int k) { return crct.t[k]; });
-        crc_ok[blk] = crc == kCrcOk;
+        (void)type1;
+        crc_ok[blk] = viterbi_traceback(type2, [&](int u) { return dec[u]; }, [&](int h, uint32_t half) { outw[h] = (uint16_t)half; },
+                                        [&](uint32_t off) { return crci.t[off >> 2]; });
         for (int t4 = 0; t4 < type2 / 4; ++t4) {
             const uint32_t v = spread4((outw[t4 >> 2] >> (4 * (t4 & 3))) & 0xfu);
             std::memcpy(row + 4 * t4, &v, 4);
