@@ -203,6 +203,14 @@ def wideband_config5(args, torch, pkg, device, local_rank):
     resample = rate == 36000
     carriers = {k: 500 + i for i, k in enumerate((3, 57, 101, 150, 199, 250, 313, 377, 423, 480, 531, 590, 644, 700, 751, 797))}
     x, tx = wideband_tetra(torch, pkg.synth, device, M, n_in, carriers)
+    # what the SDR's DMA delivers: interleaved int16 (int8) I / Q pairs, read by the channeliser in place (tetra_chan_process_device_cs16 /
+    # _cs8); the capture is scaled to a quarter of full scale at its largest component.  --config5-input complex64 keeps the float capture.
+    in_fmt = getattr(args, "config5_input", "cs16")
+    in_bytes = {"complex64": 8.0, "cs16": 4.0, "cs8": 2.0}[in_fmt]
+    if in_fmt != "complex64":
+        full = 32768.0 if in_fmt == "cs16" else 128.0
+        peak = float(torch.view_as_real(x).abs().max())
+        x = torch.clamp(torch.round(torch.view_as_real(x) * (0.25 * full / peak)), -full, full - 1).to(torch.int16 if in_fmt == "cs16" else torch.int8).contiguous()
     ch = pkg.Channeliser(M, P, D, max_in=n_in, device=local_rank)
     rs = pkg.Resampler(M, 18, 25, 16, max_in=frames, device=local_rank) if resample else None
     n_dem = frames * 18 // 25 if resample else frames          # 9000 frames at 36 ksps
@@ -284,7 +292,7 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         if ncmp < 2000 * len(tx) or errs > 1e-3 * ncmp:
             raise SystemExit("config 5 known-answer check failed: %d bit errors in %d bits of %d carriers" % (errs, ncmp, len(tx)))
     # Rooflines of the leg's kernels.  Channeliser: algorithmic bytes = the capture read once + the frames written once
-    # (8 B per wideband sample in, 8 B per channel-sample out) -- HBM is what bounds the kernel since round 5; algorithmic flops =
+    # (8 / 4 / 2 B per wideband sample in for complex64 / cs16 / cs8, 8 B per channel-sample out) -- HBM is what bounds the kernel since round 5; algorithmic flops =
     # the weighted overlap-add (L = P M taps, 4 flop each) + an M-point complex FFT (5 M log2 M), per frame.  Resampler: every input
     # frame read once, every output frame written once (8 B per channel-sample each way); 4 T flop per complex output.  Demodulator:
     # 9 B per channel-sample.
@@ -294,7 +302,7 @@ def wideband_config5(args, torch, pkg, device, local_rank):
         d.update(extra)
         return d
 
-    ch_bytes = 8.0 * n_in + 8.0 * frames * M
+    ch_bytes = in_bytes * n_in + 8.0 * frames * M
     ch_flop = frames * (4.0 * P * M + 5.0 * M * math.log2(M))
     dm_bytes = ALGO_BYTES_PER_SAMPLE * n_dem * M
     roof = {"channeliser": {"kernel": "k_channelise_fft", "kernel_ms": round(ch_ms, 4), "bound": "hbm",
@@ -311,9 +319,9 @@ def wideband_config5(args, torch, pkg, device, local_rank):
                              "hbm": hbm(rs_bytes, rs_ms, achievable_gbs=6290.0, frac_of_achievable=round(rs_bytes / (rs_ms * 1e-3) / 1e9 / 6290.0, 4)),
                              "fp32": {"achieved": round(rs_flop / (rs_ms * 1e-3) / 1e12, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(rs_flop / (rs_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), "algorithmic_flop": rs_flop}}
-    workload = ("5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> 18/25 resampler -> "
-                "800 ch x 9000 frames @ 36 ksps (the plugin's rate, default demodulator parameters) -> bits") if resample else \
-               "5e6 samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> bits (demodulator at 50 ksps)"
+    workload = ("5e6 %s samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> 18/25 resampler -> "
+                "800 ch x 9000 frames @ 36 ksps (the plugin's rate, default demodulator parameters) -> bits") % in_fmt if resample else \
+               "5e6 %s samples @ 20 MHz (16 TETRA carriers over a noise floor) -> 800 ch x 12500 frames @ 50 ksps -> bits (demodulator at 50 ksps)" % in_fmt
     res = {"metric": "wideband IQ Msamples/s channelised and demodulated to bits (BASELINE config 5)",
            "value": round(args.steps * n_in / el / 1e6, 2), "unit": "Msamples/s (20 MHz capture)",
            "ms_per_step": round(el / args.steps * 1e3, 3), "realtime_factor": round(args.steps * n_in / el / 20e6, 1),
@@ -324,7 +332,8 @@ def wideband_config5(args, torch, pkg, device, local_rank):
            "check": check, "roofline": roof,
            "config": {"workload": workload, "channels": M, "taps_per_channel": P, "decimation": D, "channel_rate_sps": rate,
                       "resampler": {"interp": 18, "decim": 25, "taps_per_phase": 16} if resample else None,
-                      "input_format": "complex64"}}
+                      "input_format": {"complex64": "complex64", "cs16": "interleaved int16 I/Q (4 B per sample), read in place by the channeliser's fold",
+                                       "cs8": "interleaved int8 I/Q (2 B per sample), read in place by the channeliser's fold"}[in_fmt]}}
     del outs, out36
     ch.close()
     if rs is not None:
@@ -488,6 +497,8 @@ def main():
     ap.add_argument("--config5-rate", type=int, default=36000,
                     help="per-channel rate the config 5 demodulator instances run at: 36000 (default: the plugin's VFO_SAMPLERATE, through "
                          "the 18/25 resampler) or 50000 (the 2x oversampled bank's own rate, round 5's route)")
+    ap.add_argument("--config5-input", choices=["cs16", "cs8", "complex64"], default="cs16",
+                    help="sample format of config 5's wideband capture (default: int16 I/Q pairs, what an SDR delivers)")
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the PCIe-inclusive host-path legs (tetra_demod_process / tetra_demod_process_async on page-locked "
                          "buffers; informational fields host_path_*, never the metric value)")

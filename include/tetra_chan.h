@@ -60,6 +60,13 @@ int tetra_chan_frames_for(tetra_chan_t* h, int n_in);
  * the last L - 1 samples are copied into the handle's delay line behind it), so it must stay untouched until that work has run.
  * The filter history and the sub-frame phase are carried across calls (results independent of the chunking). */
 int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream);
+/* The same for what an SDR's DMA delivers (round 6; the plugin's VFO reads the device's native stream, src/main.cpp:75): interleaved
+ * int16 / int8 I, Q pairs, sample value = integer / 32768 (/ 128) -- exact in binary32, so the result equals tetra_chan_process_device
+ * on the converted samples bit for bit.  At M = 800, D = M / 2 the kernel converts in its fold's loads: the capture is read in
+ * place at 4 (2) bytes per sample instead of 8 and no float copy of it ever exists; the other kernels convert into their staging
+ * buffer.  d_x: 4-byte (2-byte) aligned.  Calls of different formats may be mixed on one handle (the delay line is complex64). */
+int tetra_chan_process_device_cs16(tetra_chan_t* h, const int16_t* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream);
+int tetra_chan_process_device_cs8(tetra_chan_t* h, const int8_t* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream);
 /* Host-pointer variant: copies in, runs, copies out, synchronises. */
 int tetra_chan_process(tetra_chan_t* h, const float* x, int n_in, float* out, int* n_frames);
 int tetra_chan_reset(tetra_chan_t* h);

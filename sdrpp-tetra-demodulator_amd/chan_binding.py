@@ -7,7 +7,7 @@ from .binding import TetraDemodError, load_library
 
 CHAN_EXPORTS = ["tetra_chan_default_config", "tetra_chan_create", "tetra_chan_destroy", "tetra_chan_frames_for",
                 "tetra_chan_process_device", "tetra_chan_process", "tetra_chan_reset", "tetra_chan_get_prototype",
-                "tetra_chan_last_kernel_ms"]
+                "tetra_chan_last_kernel_ms", "tetra_chan_process_device_cs16", "tetra_chan_process_device_cs8"]
 RESAMP_EXPORTS = ["tetra_resamp_default_config", "tetra_resamp_create", "tetra_resamp_destroy", "tetra_resamp_frames_for",
                   "tetra_resamp_process_device", "tetra_resamp_process", "tetra_resamp_reset", "tetra_resamp_get_prototype",
                   "tetra_resamp_last_kernel_ms"]
@@ -39,6 +39,8 @@ def _lib():
         L.tetra_chan_frames_for.argtypes = [vp, i32]
         L.tetra_chan_process_device.argtypes = [vp, vp, i32, vp, C.POINTER(i32), vp]
         L.tetra_chan_process.argtypes = [vp, vp, i32, vp, C.POINTER(i32)]
+        L.tetra_chan_process_device_cs16.argtypes = [vp, vp, i32, vp, C.POINTER(i32), vp]
+        L.tetra_chan_process_device_cs8.argtypes = [vp, vp, i32, vp, C.POINTER(i32), vp]
         L.tetra_chan_reset.argtypes = [vp]
         L.tetra_chan_get_prototype.argtypes = [vp, vp]
         L.tetra_chan_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -118,9 +120,12 @@ class Channeliser:
         if stream is not None:
             s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
         got = C.c_int(0)
-        rc = self._lib.tetra_chan_process_device(self._h, p(d_x), int(n_in), p(d_out), C.byref(got), s)
+        # the input format follows the tensor: complex64, or interleaved I / Q pairs [n][2] int16 / int8 (tetra_chan_process_device_cs16 / _cs8)
+        name = {"torch.int16": "tetra_chan_process_device_cs16", "torch.int8": "tetra_chan_process_device_cs8"}.get(str(getattr(d_x, "dtype", "")),
+                                                                                                                  "tetra_chan_process_device")
+        rc = getattr(self._lib, name)(self._h, p(d_x), int(n_in), p(d_out), C.byref(got), s)
         if rc:
-            raise TetraDemodError(rc, "tetra_chan_process_device")
+            raise TetraDemodError(rc, name)
         return got.value
 
     def reset(self):

@@ -169,8 +169,26 @@ template <int P> CHAN_HD void fold_load_coef(const float* ht, int u, FoldCoef<P>
     }
 }
 // ---- one block of kBlockFrames frames on a workgroup of 256 threads: three phases, a barrier after each ------------------
+// Sample formats of the wideband input (round 6): complex64, or what an SDR's DMA delivers -- interleaved int16 / int8 I, Q pairs,
+// converted in the fold's load (value / 32768, value / 128: exact in binary32), so that an integer capture crosses HBM once at 4 or
+// 2 bytes per sample instead of 8.
+enum { kFmtC32 = 0, kFmtCs16 = 1, kFmtCs8 = 2 };
+struct cs16 { int16_t x, y; };
+struct cs8 { int8_t x, y; };
+template <int FMT> CHAN_HD c32 load_sample(const void* x, long long s) {
+    if (FMT == kFmtCs16) {
+        const cs16 v = reinterpret_cast<const cs16*>(x)[s];
+        return mk((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
+    }
+    if (FMT == kFmtCs8) {
+        const cs8 v = reinterpret_cast<const cs8*>(x)[s];
+        return mk((float)v.x * (1.0f / 128.0f), (float)v.y * (1.0f / 128.0f));
+    }
+    return reinterpret_cast<const c32*>(x)[s];
+}
+
 struct BlockCtx {
-    const c32* x;         // the call's n_in NEW samples, where the caller left them (read in place: no staging copy)
+    const void* x;        // the call's n_in NEW samples in the format the kernel is compiled for, where the caller left them (read in place: no staging copy)
     const c32* hist;      // the L - 1 samples before them, oldest first (the handle's carried delay line)
     int n_in;
     c32* out;             // [frames][800]
@@ -186,10 +204,10 @@ struct BlockCtx {
 // index the caller's buffer directly (CAREFUL = false).  The first two blocks reach back into the delay line (s < 0), and the last
 // block of a call whose frame count is not a multiple of 8 asks for samples past the call's end for the frames it does not store:
 // those read the last sample instead (any value would do: it only reaches results that are never stored).
-template <bool CAREFUL> CHAN_HD c32 sample_at(const BlockCtx& c, long long s) {
-    if (!CAREFUL) return c.x[s];
+template <bool CAREFUL, int FMT> CHAN_HD c32 sample_at(const BlockCtx& c, long long s) {
+    if (!CAREFUL) return load_sample<FMT>(c.x, s);
     if (s < 0) return c.hist[(c.L - 1) + s];
-    return c.x[s < c.n_in ? s : c.n_in - 1];
+    return load_sample<FMT>(c.x, s < c.n_in ? s : c.n_in - 1);
 }
 // does a block with its first frame's newest sample at index newest0 need the careful accessor?  (it reads
 // [newest0 - (L - 1), newest0 + 7 * 400])
@@ -197,12 +215,12 @@ CHAN_HD bool block_is_careful(const BlockCtx& c, long long newest0) {
     return newest0 < c.L - 1 || newest0 + (kBlockFrames - 1) * (kM / 2) > c.n_in - 1;
 }
 
-template <int P, int CLS, bool CAREFUL> CHAN_HD void fold_slot(const BlockCtx& c, long long s0, const FoldCoef<P>& k, c32 out[kBlockFrames]) {
+template <int P, int CLS, bool CAREFUL, int FMT> CHAN_HD void fold_slot(const BlockCtx& c, long long s0, const FoldCoef<P>& k, c32 out[kBlockFrames]) {
     CHAN_FP_FAST
     constexpr int kS = P + 3 + CLS;                   // class 0 frames reach sample m = 3, class 1 frames m = 4
     c32 S[kS];                                        // S[j] = sample m = j - (P - 1) = stream sample s0 + 800 m  (s0 = newest0 - u)
 #pragma unroll
-    for (int j = 0; j < kS; j++) S[j] = sample_at<CAREFUL>(c, s0 + kM * (j - (P - 1)));
+    for (int j = 0; j < kS; j++) S[j] = sample_at<CAREFUL, FMT>(c, s0 + kM * (j - (P - 1)));
 #pragma unroll
     for (int t = 0; t < kBlockFrames; t++) {
         const int s = (t + CLS) >> 1;
@@ -220,7 +238,7 @@ template <int P, int CLS, bool CAREFUL> CHAN_HD void fold_slot(const BlockCtx& c
 
 // phase 1 (threads < kFoldThreads): fold the block's 8 frames, v_t[r] -> lds[t][r].  Slot after slot: a slot's 2 P coefficients and
 // P + 4 samples live only while its 8 frames are summed.
-template <int P, bool CAREFUL> CHAN_HD void phase_fold_t(const BlockCtx& c, int blk, int tid, c32* lds) {
+template <int P, bool CAREFUL, int FMT> CHAN_HD void phase_fold_t(const BlockCtx& c, int blk, int tid, c32* lds) {
     if (tid >= kFoldThreads) return;
     const long long newest0 = (long long)(kBlockFrames * blk + 1) * (kM / 2) - 1 - c.ph0;     // index of the block's first frame's newest sample among the new samples
     const int a = (int)((c.abs0 + newest0) % kM);
@@ -230,8 +248,8 @@ template <int P, bool CAREFUL> CHAN_HD void phase_fold_t(const BlockCtx& c, int 
         FoldCoef<P> k;
         fold_load_coef<P>(c.h, u, k);
         c32 v[kBlockFrames];
-        if (i < 2) fold_slot<P, 0, CAREFUL>(c, newest0 - u, k, v);
-        else fold_slot<P, 1, CAREFUL>(c, newest0 - u, k, v);
+        if (i < 2) fold_slot<P, 0, CAREFUL, FMT>(c, newest0 - u, k, v);
+        else fold_slot<P, 1, CAREFUL, FMT>(c, newest0 - u, k, v);
         int r = a - u;
         r += r < 0 ? kM : 0;
 #pragma unroll
@@ -243,10 +261,10 @@ template <int P, bool CAREFUL> CHAN_HD void phase_fold_t(const BlockCtx& c, int 
 #endif
     }
 }
-template <int P> CHAN_HD void phase_fold(const BlockCtx& c, int blk, int tid, c32* lds) {
+template <int P, int FMT = kFmtC32> CHAN_HD void phase_fold(const BlockCtx& c, int blk, int tid, c32* lds) {
     const long long newest0 = (long long)(kBlockFrames * blk + 1) * (kM / 2) - 1 - c.ph0;
-    if (block_is_careful(c, newest0)) phase_fold_t<P, true>(c, blk, tid, lds);      // (uniform over the workgroup)
-    else phase_fold_t<P, false>(c, blk, tid, lds);
+    if (block_is_careful(c, newest0)) phase_fold_t<P, true, FMT>(c, blk, tid, lds);      // (uniform over the workgroup)
+    else phase_fold_t<P, false, FMT>(c, blk, tid, lds);
 }
 
 // phase 2 (lanes n1 < 25 of each half-wave; wave w, half f -> frame 2 w + f): 32-point FFT over n2, result transposed IN PLACE:

@@ -259,7 +259,7 @@ template <int P> __global__ __launch_bounds__(kThreads, 3) void k_channelise_mfm
 // The lane-level code is chan_fft_core.hpp (also compiled for the host: tests/emul/chan_emul.cpp).
 // ---------------------------------------------------------------------------------------------------------------------
 struct ChanFftParams {
-    const float2* x;       // the call's new samples (the caller's buffer)
+    const void* x;         // the call's new samples (the caller's buffer) in the kernel's sample format
     const float2* hist;    // the L - 1 samples before them
     float2* out;
     const float* h;        // the prototype re-ordered for the fold [800][2][P]
@@ -271,12 +271,12 @@ struct ChanFftParams {
     long long abs0;
 };
 
-template <int P, int EXP = 0> __global__ __launch_bounds__(kThreads, 2) void k_channelise_fft(ChanFftParams p) {
+template <int P, int EXP = 0, int FMT = chanfft::kFmtC32> __global__ __launch_bounds__(kThreads, 2) void k_channelise_fft(ChanFftParams p) {
     using namespace chanfft;
     __shared__ c32 lds[kBlockFrames * kFrameLds];          // 52.8 KB: three workgroups per CU
     const int tid = threadIdx.x;
     BlockCtx c;
-    c.x = reinterpret_cast<const c32*>(p.x);
+    c.x = p.x;
     c.hist = reinterpret_cast<const c32*>(p.hist);
     c.n_in = p.n_in;
     c.L = kM * P;
@@ -295,7 +295,7 @@ template <int P, int EXP = 0> __global__ __launch_bounds__(kThreads, 2) void k_c
         blk = (int)(blockIdx.x & 7) * p.xcd_span + (int)(blockIdx.x >> 3);
         if (blk >= p.blocks || (int)(blockIdx.x >> 3) >= p.xcd_span) return;
     }
-    phase_fold<P>(c, blk, tid, lds);
+    phase_fold<P, FMT>(c, blk, tid, lds);
     __syncthreads();
     c32 tw[kN1 - 1];
     load_twiddles(c, tid, tw);
@@ -312,6 +312,14 @@ template <int P, int EXP = 0> __global__ __launch_bounds__(kThreads, 2) void k_c
     }
     __syncthreads();
     phase_dft25_store<EXP>(c, (long long)kBlockFrames * blk, tid, lds, tw);
+}
+
+// integer samples -> complex64 (the staging buffer of the kernels that read [history | new] contiguously, and the delay line)
+template <int FMT> __global__ __launch_bounds__(256) void k_chan_convert(const void* __restrict__ x, long long first, int n, float2* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const chanfft::c32 v = chanfft::load_sample<FMT>(x, first + i);
+    out[i] = make_float2(v.x, v.y);
 }
 
 }  // namespace
@@ -538,11 +546,30 @@ int tetra_chan_frames_for(tetra_chan_t* h, int n_in) {
     return (h->phase + n_in) / h->D;
 }
 
-int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream) {
+}  // extern "C"
+
+namespace {
+// bytes per sample of a format; copy `n` samples starting at `first` of the caller's buffer into a complex64 buffer
+constexpr int kFmtBytes[3] = { 8, 4, 2 };
+int copy_samples(tetra_chan* h, int fmt, const void* d_x, size_t first, size_t n, float2* dst, hipStream_t s) {
+    if (n == 0) return TETRA_OK;
+    if (fmt == chanfft::kFmtC32) {
+        CH_TRY(h, hipMemcpyAsync(dst, static_cast<const float2*>(d_x) + first, sizeof(float2) * n, hipMemcpyDeviceToDevice, s));
+        return TETRA_OK;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (fmt == chanfft::kFmtCs16) hipLaunchKernelGGL(k_chan_convert<chanfft::kFmtCs16>, grid, dim3(256), 0, s, d_x, (long long)first, (int)n, dst);
+    else hipLaunchKernelGGL(k_chan_convert<chanfft::kFmtCs8>, grid, dim3(256), 0, s, d_x, (long long)first, (int)n, dst);
+    CH_TRY(h, hipGetLastError());
+    return TETRA_OK;
+}
+template <int FMT> void launch_fft(tetra_chan* h, const ChanFftParams& p, dim3 grid, hipStream_t s);
+
+int process_any(tetra_chan_t* h, int fmt, const void* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream) {
     if (!h || (!d_x && n_in > 0) || !d_out || !n_frames) return TETRA_ERR_ARG;
     if (n_in < 0 || n_in > h->max_in) return TETRA_ERR_SIZE;
-    // complex64 elements are moved as 8-byte units (the FFT kernel reads d_x in place with 8-byte loads; every kernel stores so)
-    if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 7)) return TETRA_ERR_ALIGN;
+    // samples are moved as whole units (the FFT kernel reads d_x in place with 8- / 4- / 2-byte loads; every kernel stores 8-byte units)
+    if (((uintptr_t)d_x & (kFmtBytes[fmt] - 1)) || ((uintptr_t)d_out & 7)) return TETRA_ERR_ALIGN;
     Guard g(h->device);
     if (!g.ok) return TETRA_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)hip_stream;
@@ -551,11 +578,14 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     const size_t hist = (size_t)h->L - 1;
     // The FFT kernel reads the new samples where the caller left them (and the L - 1 before them from the handle's delay line): no
     // staging copy -- every sample crosses HBM once.  The other two kernels index one contiguous [history | new] buffer.
-    if (n_in > 0 && !h->fft) CH_TRY(h, hipMemcpyAsync(h->xbuf + hist, d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
+    if (n_in > 0 && !h->fft) {
+        const int rc = copy_samples(h, fmt, d_x, 0, (size_t)n_in, h->xbuf + hist, s);
+        if (rc != TETRA_OK) return rc;
+    }
     CH_TRY(h, hipEventRecord(h->ev[0], s));
     if (frames > 0 && h->fft) {
         ChanFftParams p;
-        p.x = reinterpret_cast<const float2*>(d_x); p.hist = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_ht; p.tw = h->d_tw;
+        p.x = d_x; p.hist = h->xbuf; p.out = reinterpret_cast<float2*>(d_out); p.h = h->d_ht; p.tw = h->d_tw;
         p.frames = frames; p.blocks = (frames + chanfft::kBlockFrames - 1) / chanfft::kBlockFrames; p.n_in = n_in;
         p.ph0 = h->phase; p.abs0 = h->consumed;
         // one block of 8 frames per workgroup: the hardware hands the next block to whichever CU is through first
@@ -570,14 +600,14 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
 #endif
         const dim3 grid(p.xcd_span > 0 ? 8 * p.xcd_span : p.blocks);
 #ifdef TETRA_CHAN_EXPERIMENTS
-        if (h->P == 8 && p.exp == 1) hipLaunchKernelGGL((k_channelise_fft<8, 1>), grid, dim3(kThreads), 0, s, p);
-        else if (h->P == 8 && p.exp == 2) hipLaunchKernelGGL((k_channelise_fft<8, 2>), grid, dim3(kThreads), 0, s, p);
-        else if (h->P == 8 && p.exp == 3) hipLaunchKernelGGL((k_channelise_fft<8, 3>), grid, dim3(kThreads), 0, s, p);
+        if (fmt == chanfft::kFmtC32 && h->P == 8 && p.exp == 1) hipLaunchKernelGGL((k_channelise_fft<8, 1>), grid, dim3(kThreads), 0, s, p);
+        else if (fmt == chanfft::kFmtC32 && h->P == 8 && p.exp == 2) hipLaunchKernelGGL((k_channelise_fft<8, 2>), grid, dim3(kThreads), 0, s, p);
+        else if (fmt == chanfft::kFmtC32 && h->P == 8 && p.exp == 3) hipLaunchKernelGGL((k_channelise_fft<8, 3>), grid, dim3(kThreads), 0, s, p);
         else
 #endif
-        if (h->P == 8) hipLaunchKernelGGL(k_channelise_fft<8>, grid, dim3(kThreads), 0, s, p);
-        else if (h->P == 6) hipLaunchKernelGGL(k_channelise_fft<6>, grid, dim3(kThreads), 0, s, p);
-        else hipLaunchKernelGGL(k_channelise_fft<4>, grid, dim3(kThreads), 0, s, p);
+        if (fmt == chanfft::kFmtCs16) launch_fft<chanfft::kFmtCs16>(h, p, grid, s);
+        else if (fmt == chanfft::kFmtCs8) launch_fft<chanfft::kFmtCs8>(h, p, grid, s);
+        else launch_fft<chanfft::kFmtC32>(h, p, grid, s);
         CH_TRY(h, hipGetLastError());
     } else if (frames > 0 && h->mfma) {
         ChanMfmaParams p;
@@ -608,8 +638,8 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
         // the same from the two places the samples live in: what is left of the old delay line, then the tail of the caller's buffer
         const size_t from_x = (size_t)n_in < hist ? (size_t)n_in : hist, keep = hist - from_x;
         if (keep) CH_TRY(h, hipMemcpyAsync(h->xalt, h->xbuf + n_in, sizeof(float2) * keep, hipMemcpyDeviceToDevice, s));
-        CH_TRY(h, hipMemcpyAsync(h->xalt + keep, reinterpret_cast<const float2*>(d_x) + ((size_t)n_in - from_x), sizeof(float2) * from_x,
-                                 hipMemcpyDeviceToDevice, s));
+        const int rc = copy_samples(h, fmt, d_x, (size_t)n_in - from_x, from_x, h->xalt + keep, s);
+        if (rc != TETRA_OK) return rc;
         float2* t = h->xbuf; h->xbuf = h->xalt; h->xalt = t;
     } else if (n_in > 0) {
         CH_TRY(h, hipMemcpyAsync(h->xalt, h->xbuf + n_in, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
@@ -618,6 +648,24 @@ int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float
     h->phase = (h->phase + n_in) % h->D;
     h->consumed += n_in;
     return TETRA_OK;
+}
+template <int FMT> void launch_fft(tetra_chan* h, const ChanFftParams& p, dim3 grid, hipStream_t s) {
+    if (h->P == 8) hipLaunchKernelGGL((k_channelise_fft<8, 0, FMT>), grid, dim3(kThreads), 0, s, p);
+    else if (h->P == 6) hipLaunchKernelGGL((k_channelise_fft<6, 0, FMT>), grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((k_channelise_fft<4, 0, FMT>), grid, dim3(kThreads), 0, s, p);
+}
+}  // namespace
+
+extern "C" {
+
+int tetra_chan_process_device(tetra_chan_t* h, const float* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream) {
+    return process_any(h, chanfft::kFmtC32, d_x, n_in, d_out, n_frames, hip_stream);
+}
+int tetra_chan_process_device_cs16(tetra_chan_t* h, const int16_t* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream) {
+    return process_any(h, chanfft::kFmtCs16, d_x, n_in, d_out, n_frames, hip_stream);
+}
+int tetra_chan_process_device_cs8(tetra_chan_t* h, const int8_t* d_x, int n_in, float* d_out, int* n_frames, void* hip_stream) {
+    return process_any(h, chanfft::kFmtCs8, d_x, n_in, d_out, n_frames, hip_stream);
 }
 
 int tetra_chan_process(tetra_chan_t* h, const float* x, int n_in, float* out, int* n_frames) {

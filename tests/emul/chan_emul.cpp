@@ -13,7 +13,8 @@ using namespace chanfft;
 extern "C" {
 
 // hist: the L - 1 samples before the call (oldest first); x: the call's n_in new samples -- two separate buffers, like the kernel sees them; out: [frames][800] complex.  P in {4, 6, 8}.  Returns frames.
-int chan_fft_emul(const float* hist, const float* x, int n_in, int P, int ph0, long long abs0, const float* h, float* out) {
+// fmt: the format of x (kFmtC32 / kFmtCs16 / kFmtCs8: interleaved float / int16 / int8 I, Q pairs); hist is always complex64.
+int chan_fft_emul_fmt(const float* hist, const void* x, int fmt, int n_in, int P, int ph0, long long abs0, const float* h, float* out) {
     const int L = kM * P, D = kM / 2;
     const int frames = (ph0 + n_in) / D;
     std::vector<c32> tw((size_t)kN1 * kN2);
@@ -24,7 +25,7 @@ int chan_fft_emul(const float* hist, const float* x, int n_in, int P, int ph0, l
             tw[(size_t)n1 * kN2 + k2] = mk((float)std::cos(a), (float)std::sin(a));
         }
     BlockCtx c;
-    c.x = reinterpret_cast<const c32*>(x);
+    c.x = x;
     c.hist = reinterpret_cast<const c32*>(hist);
     c.n_in = n_in;
     c.out = reinterpret_cast<c32*>(out);
@@ -40,7 +41,11 @@ int chan_fft_emul(const float* hist, const float* x, int n_in, int P, int ph0, l
         std::vector<Regs> regs(256);
         std::vector<char> live(256);
         for (int blk = 0; blk < blocks; blk++) {
-            for (int tid = 0; tid < 256; tid++) phase_fold<PP>(c, blk, tid, lds.data());
+            for (int tid = 0; tid < 256; tid++) {
+                if (fmt == kFmtCs16) phase_fold<PP, kFmtCs16>(c, blk, tid, lds.data());
+                else if (fmt == kFmtCs8) phase_fold<PP, kFmtCs8>(c, blk, tid, lds.data());
+                else phase_fold<PP, kFmtC32>(c, blk, tid, lds.data());
+            }
             for (int tid = 0; tid < 256; tid++) live[tid] = phase_fft32_compute(tid, lds.data(), regs[tid].x);      // every lane reads ...
             for (int tid = 0; tid < 256; tid++) if (live[tid]) phase_fft32_store(tid, lds.data(), regs[tid].x);       // ... before any lane writes
             for (int tid = 0; tid < 256; tid++) { c32 tw[kN1 - 1]; load_twiddles(c, tid, tw); phase_dft25_store(c, (long long)kBlockFrames * blk, tid, lds.data(), tw); }
@@ -51,6 +56,10 @@ int chan_fft_emul(const float* hist, const float* x, int n_in, int P, int ph0, l
     else if (P == 4) run(std::integral_constant<int, 4>());
     else return -1;
     return frames;
+}
+
+int chan_fft_emul(const float* hist, const float* x, int n_in, int P, int ph0, long long abs0, const float* h, float* out) {
+    return chan_fft_emul_fmt(hist, x, kFmtC32, n_in, P, ph0, abs0, h, out);
 }
 
 // the two register-level transforms on their own (natural order in and out)

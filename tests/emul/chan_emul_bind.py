@@ -24,6 +24,8 @@ def lib():
         L = C.CDLL(build())
         L.chan_fft_emul.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
         L.chan_fft_emul.restype = C.c_int
+        L.chan_fft_emul_fmt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.chan_fft_emul_fmt.restype = C.c_int
         L.chan_fft32.argtypes = [C.c_void_p, C.c_void_p]
         L.chan_dft25.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
@@ -40,14 +42,22 @@ class ChanFftEmul:
         self.phase, self.consumed = 0, 0
 
     def process(self, x):
-        x = np.ascontiguousarray(x, np.complex64)
+        """x: complex64 samples, or integer I / Q pairs [n][2] int16 / int8 (tetra_chan_process_device_cs16 / _cs8)."""
+        x = np.ascontiguousarray(x)
+        if x.dtype == np.int16 or x.dtype == np.int8:
+            fmt = 1 if x.dtype == np.int16 else 2
+            xc = (x[:, 0].astype(np.float32) + 1j * x[:, 1].astype(np.float32)).astype(np.complex64) / np.float32(32768 if fmt == 1 else 128)
+        else:
+            fmt, x = 0, np.ascontiguousarray(x, np.complex64)
+            xc = x
         frames = (self.phase + len(x)) // 400
         out = np.zeros((max(frames, 1), 800), np.complex64)
         # exact-size buffers in their own allocations (no slack behind the new samples: the kernel must not read past them)
-        xs = x.copy() if len(x) else np.zeros(1, np.complex64)
-        got = lib().chan_fft_emul(self.hist.ctypes.data, xs.ctypes.data, len(x), self.P, self.phase, self.consumed, self.h.ctypes.data,
-                                  out.ctypes.data)
+        xs = x.copy() if len(x) else np.zeros((1, 2), x.dtype) if fmt else np.zeros(1, np.complex64)
+        got = lib().chan_fft_emul_fmt(self.hist.ctypes.data, xs.ctypes.data, fmt, len(x), self.P, self.phase, self.consumed, self.h.ctypes.data,
+                                      out.ctypes.data)
         assert got == frames
+        x = xc
         self.hist = np.concatenate([self.hist, x])[len(x):].copy()
         self.phase = (self.phase + len(x)) % 400
         self.consumed += len(x)

@@ -31,7 +31,7 @@ def test_channeliser_header_symbols_all_exported(pkg):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(tetra_chan_[a-z0-9_]+)\s*\(", src)))
     L = pkg.load_library()
-    assert len(names) == 9 and set(names) == set(pkg.chan_binding.CHAN_EXPORTS)
+    assert len(names) == 11 and set(names) == set(pkg.chan_binding.CHAN_EXPORTS)
     for n in names:
         assert hasattr(L, n), n
 

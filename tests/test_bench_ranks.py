@@ -73,7 +73,7 @@ def test_bench_gpus_8_folded_onto_the_box(tmp_path):
         assert d["value"] is None and d["value_functional"] > 0 and "NOT an 8-GPU measurement" in d["functional_note"]
         assert d["dist_backend"] == "gloo" and "RCCL needs one GPU per rank" in d["dist_backend_note"]
     ck = d["check"]
-    assert ck["ranks_checked"] == 8 and ck["ranks_green"] == 8 and ck["channels_checked"] == 8 * 32
+    assert ck["ranks_checked"] == 8 and ck["ranks_green"] == 8 and ck["channels_checked"] == 8 * 256          # bench.CHECK_CHANNELS of every rank
     assert ck["bit_errors"] <= 1e-3 * ck["bits_compared_last_quarter"] and ck["bits_compared_last_quarter"] > 8 * 32 * 8000
     assert d["config"]["channels_per_gpu"] == 512
 

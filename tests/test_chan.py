@@ -94,6 +94,71 @@ def test_fft_kernel_lane_code_on_the_host_matches_the_definition(oracle):
                 assert np.isfinite(ye).all() and np.abs(yo - ye).max() / np.abs(yo).max() < 2e-6, (P, a, b)
 
 
+def _quantise(x, dtype):
+    """complex samples of roughly unit scale -> integer I / Q pairs [n][2] and the complex64 values they stand for (integer / 32768 or / 128)."""
+    full = 32768 if dtype == np.int16 else 128
+    q = np.stack([np.clip(np.round(x.real * full / 6), -full, full - 1), np.clip(np.round(x.imag * full / 6), -full, full - 1)], axis=1).astype(dtype)
+    return q, (q[:, 0].astype(np.float32) + 1j * q[:, 1].astype(np.float32)).astype(np.complex64) / np.float32(full)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int8])
+def test_fft_kernel_lane_code_with_integer_samples(oracle, dtype):
+    """Round 6: the FFT kernel's fold reading what an SDR delivers -- interleaved int16 / int8 I, Q pairs, converted in the load
+    (tetra_chan_process_device_cs16 / _cs8).  Same lane code on the host: against the definition fed the quantised samples, and EQUAL
+    to the complex64 route on the converted samples (the conversion is exact in binary32), with ragged chunks and carried history."""
+    from tests.emul import chan_emul_bind as ce
+    rng = np.random.default_rng(5)
+    co = oracle.ChanOracle(800, 8, 400)
+    em_i, em_f = ce.ChanFftEmul(8, co.h), ce.ChanFftEmul(8, co.h)
+    nin = 400 * 21 + 77
+    q, xq = _quantise(rng.standard_normal(nin) + 1j * rng.standard_normal(nin), dtype)
+    cuts = [0, 9, 9 + 399, nin // 2, nin]
+    for a, b in zip(cuts, cuts[1:]):
+        yo, yi, yf = co.process(xq[a:b]), em_i.process(q[a:b]), em_f.process(xq[a:b])
+        assert yo.shape == yi.shape and np.array_equal(yi, yf)
+        if len(yo):
+            assert np.abs(yo - yi).max() / np.abs(yo).max() < 2e-6, (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["int16", "int8"])
+@pytest.mark.parametrize("M,P,D,flags", [(800, 8, 400, 0), (800, 6, 400, 0), (800, 8, 400, 2), (800, 8, 400, 1), (32, 8, 16, 0)])
+def test_gpu_integer_input_matches_definition_and_the_float_route(pkg, oracle, M, P, D, flags, dtype):
+    """tetra_chan_process_device_cs16 / _cs8 on the GPU: the FFT kernel reads the integer capture in place, the
+    matrix / direct-sum kernels through a converting staging copy; against the double-precision definition on the quantised samples
+    (2e-5) and bit for bit the complex64 entry point on the converted samples; ragged chunks, formats mixed on one handle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    np_dtype = np.int16 if dtype == "int16" else np.int8
+    rng = np.random.default_rng(M + P)
+    nin = D * 150 + 11
+    q, xq = _quantise(rng.standard_normal(nin) + 1j * rng.standard_normal(nin), np_dtype)
+    ch_i = pkg.Channeliser(M, P, D, max_in=nin, flags=flags)
+    ch_f = pkg.Channeliser(M, P, D, max_in=nin, flags=flags)
+    co = oracle.ChanOracle(M, P, D)
+    d_q = torch.from_numpy(q).to(dev)
+    d_x = torch.from_numpy(xq).to(dev)
+    cuts = [0, 5, 5 + D - 1, nin // 3, nin // 3 + 2, nin]
+    for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        yo = co.process(xq[a:b])
+        out_i = torch.zeros((max(1, ch_i.frames_for(b - a)), M), dtype=torch.complex64, device=dev)
+        out_f = torch.zeros_like(out_i)
+        # one chunk of the integer handle goes in as complex64: formats may be mixed (the delay line is complex64)
+        n_i = ch_i.process_device(d_x[a:b] if i == 3 else d_q[a:b], b - a, out_i)
+        n_f = ch_f.process_device(d_x[a:b], b - a, out_f)
+        torch.cuda.synchronize()
+        assert n_i == n_f == len(yo)
+        if n_i:
+            assert torch.equal(out_i[:n_i], out_f[:n_f]), (a, b)
+            yg = out_i[:n_i].cpu().numpy()
+            scale = np.abs(yo).max() + 1e-12
+            assert np.abs(yg - yo).max() / scale < 2e-5, (a, b)
+    with pytest.raises(pkg.TetraDemodError):
+        ch_i.process_device(d_q.reshape(-1)[1:], 4, out_i)      # a pointer into the middle of an I / Q pair: TETRA_ERR_ALIGN
+    ch_i.close()
+    ch_f.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,P,D,nin,flags", [(32, 8, 16, 3000, 0), (800, 8, 400, 800 * 5, 0), (800, 8, 400, 800 * 5, 1), (800, 8, 400, 800 * 5, 2), (60, 4, 20, 1234, 0),
                                              (32, 4, 32, 1000, 0), (800, 8, 400, 400 * 1000 + 123, 0), (800, 8, 400, 400 * 120 + 7, 1),
