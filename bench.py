@@ -348,8 +348,8 @@ CHAIN_DISTINCT = 64          # distinct coded downlinks (cells) of the chain leg
 
 def receive_chain(args, torch, pkg, device, local_rank, C=CHANNELS_PER_GPU, N=SAMPLES, seconds=4):
     """The receive chain behind the demodulator, through the ONE handle of include/tetra_rx.h (informational, NOT the metric line):
-    IQ -> demodulator || burst synchroniser -> SB1 -> SYNC-PDU tracker -> compact demux + counted decode of every block kind ->
-    labelled type-1 blocks (reference: tetra_burst_sync_in -> tetra_burst_rx_cb -> tp_sap_udata_ind, phy/tetra_burst_sync.c:54-155,
+    IQ -> demodulator || burst synchroniser -> frame lists -> SB1 decoded straight from the frames -> SYNC-PDU tracker -> every other
+    block kind decoded straight from the frames in one launch -> labelled type-1 blocks (reference: tetra_burst_sync_in -> tetra_burst_rx_cb -> tp_sap_udata_ind, phy/tetra_burst_sync.c:54-155,
     phy/tetra_burst.c:343-393, lower_mac/tetra_lower_mac.c:148-275).  Input: CODED continuous downlinks (synth.gen_downlink: SYNC
     bursts with SB1 + AACH + SB2, two-channel normal bursts with NDB 1 + 2, one-channel normal bursts with SCH/F; every block carries
     a CRC and its type-1 bits are known), CHAIN_DISTINCT cells x C / CHAIN_DISTINCT channels each with its own amplitude, carrier
@@ -436,30 +436,32 @@ def receive_chain(args, torch, pkg, device, local_rank, C=CHANNELS_PER_GPU, N=SA
                 raise SystemExit("receive chain known-answer check failed: %s" % json.dumps(res["check"]))
             res["rows_per_kind"] = {names[k]: v for k, v in rows_k.items()}
         rx.close()
-    # Rooflines of the one-stream run's stages.  Bytes: demodulator 9 B per sample; synchroniser = the bit rows it scans + 64 B per
-    # packed frame + 8 B per frame slot; SB1 stage and the other kinds = per decoded row the packed frame window read (in / 8), the
-    # type-5 row written and read (2 x in), type-2 row + crc + label written (out + 28) + 4 B per frame slot and kind for the types;
-    # the decoder's add-compare-select recursion is integer vector work: trellis steps x 68 instructions per 64-block wave (its own
-    # model) against the chip's issue peak 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks = 614 G wave-instructions / s.
+    # Rooflines of the one-stream run's stages (round 6 chain: no byte rows between the stages).  Bytes: demodulator 9 B per sample;
+    # synchroniser = the bit rows it scans + 64 B per packed frame + 8 B per frame slot; SB1 stage = the frame-list pass (frame types
+    # read twice, 4 B per list entry written) + per SB1 row (frame 64, list entry 4, type-2 row 80 + crc 4 written, then read by the
+    # tracker with the label 24 written) + the tracker's 12 B per frame slot; other kinds = per decoded row (frame 64, list entry 4,
+    # code 4, times + bit number 12 read; type-2 row + crc + label out + 28 written).  The decoder's decision scratch (2 B per trellis
+    # step and block, written once and read once) normally lives in L2 / MALL and is not counted.  The decoder is integer vector work:
+    # 99 vector instructions per step PAIR in the forward recursion + 6.1 per step in the traceback (ISA of k_lmac_frames,
+    # DESIGN.md 8.3) = 55.6 per trellis step per 64-block wave, against the chip's issue peak 256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks
+    # = 614 G wave-instructions / s.
     F = (4096 + pkg.binding.bits_stride(N)) // 510 + 2
-    geo = {"sb1": (120, 80, 84), "bbk": (32, 32, 0), "sb2": (216, 144, 148), "ndb1": (216, 144, 148), "ndb2": (216, 144, 148), "schf": (432, 288, 292)}
+    geo = {"sb1": (80, 84), "bbk": (32, 0), "sb2": (144, 148), "ndb1": (144, 148), "ndb2": (144, 148), "schf": (288, 292)}      # type-2 row bytes, trellis steps
     rows = res["rows_per_kind"]
-
-    def kind_bytes(nm):
-        i, o, _ = geo[nm]
-        return rows[nm] * (i / 8.0 + 2.0 * i + o + 28.0) + 4.0 * C * F
-
     frames = sum(rows[k] for k in ("sb1", "ndb1", "schf"))          # every frame with a callback carries exactly one of these
-    by = [9.0 * C * N, float(C * N) + 64.0 * frames + 8.0 * C * F, kind_bytes("sb1") + 80.0 * rows["sb1"],
-          sum(kind_bytes(k) for k in geo if k != "sb1")]
-    steps = [0, 0, rows["sb1"] * geo["sb1"][2], sum(rows[k] * geo[k][2] for k in geo if k != "sb1")]
+    lists = rows["sb1"] + rows["ndb1"] + rows["schf"] + rows["bbk"]
+    by = [9.0 * C * N, float(C * N) + 64.0 * frames + 8.0 * C * F,
+          8.0 * C * F + 4.0 * lists + rows["sb1"] * (64.0 + 4.0 + 2 * 84.0 + 24.0) + 12.0 * C * F,
+          sum(rows[k] * (64.0 + 4.0 + 4.0 + 12.0 + geo[k][0] + 28.0) for k in geo if k != "sb1")]
+    steps = [0, 0, rows["sb1"] * geo["sb1"][1], sum(rows[k] * geo[k][1] for k in geo if k != "sb1")]
     stages = {}
-    for i, nm in enumerate(("demodulator", "burst_sync", "sb1_demux_decode_track", "other_kinds_demux_decode_label")):
+    for i, nm in enumerate(("demodulator", "burst_sync", "frame_lists_sb1_decode_track", "other_kinds_decode_label")):
         d = {"ms": round(stage[i], 4), "algorithmic_bytes": round(by[i]), "GBps": round(by[i] / (stage[i] * 1e-3) / 1e9, 1),
              "frac_hbm_8TBps": round(by[i] / (stage[i] * 1e-3) / 8e12, 4)}
         if steps[i]:
-            wi = 68.0 * steps[i] / 64.0
-            d.update(trellis_steps=int(steps[i]), frac_valu_issue_614G=round(wi / (stage[i] * 1e-3) / 614.4e9, 4), bound="valu-issue (integer add-compare-select)")
+            wi = 55.6 * steps[i] / 64.0
+            d.update(trellis_steps=int(steps[i]), vector_instructions_per_step_and_wave=55.6,
+                     frac_valu_issue_614G=round(wi / (stage[i] * 1e-3) / 614.4e9, 4), bound="valu-issue (integer add-compare-select)")
         stages[nm] = d
     res["stages_one_stream"] = stages
     res["tail_ms_one_stream"] = round(sum(stage[1:]), 4)

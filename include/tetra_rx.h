@@ -13,9 +13,10 @@
  * cell state out -- for C channels at once:
  *
  *     tetra_rx_process_device(h, d_iq, n)      enqueue:  demodulator (block k) on the caller's stream  ||  on the handle's own
- *                                              stream, for block k: synchroniser -> SB1 (demux, decode) -> SYNC-PDU tracker (cell,
- *                                              per-slot scrambling code + TDMA time) -> every other block kind (compact demux,
- *                                              counted decode with the tracker's codes) -> row labels
+ *                                              stream, for block k: synchroniser -> frame lists -> SB1 decoded straight from the
+ *                                              packed frames -> SYNC-PDU tracker (cell, per-slot scrambling code + TDMA time) ->
+ *                                              every other block kind decoded straight from the frames with the tracker's codes,
+ *                                              labelled, in ONE launch (7 launches per call; no byte rows between the stages)
  *     tetra_rx_fetch(h, which, kind, ...)      the decoded blocks of one kind of the latest (which = 0) or the previous (1) call
  *     tetra_rx_get_cell(h, first, count, ..)   tcd / t_phy_state of channels (tetra_lmac_cell_state_t)
  *
@@ -91,7 +92,9 @@ int tetra_rx_process(tetra_rx_t* h, const float* iq, int n_samples);
 /* Blocks until everything enqueued has run.  TETRA_ERR_OVERRUN if the demodulator cut a channel off (tetra_demod.h). */
 int tetra_rx_wait(tetra_rx_t* h);
 
-/* Upper bound of the rows a fetch of one kind can return: n_channels x frames per call ((4096 + bits per call) / 510 + 2). */
+/* Upper bound of the rows a fetch of one kind can return: n_channels x frames per call ((4096 + bits per call) / 510 + 2).
+ * (tetra_rx_create refuses configurations with more than TETRA_LMAC_TRACK_MAX_FRAMES = 2048 frames per channel and call -- about
+ * 29 s of signal per call -- with TETRA_ERR_SIZE.) */
 int tetra_rx_max_rows(tetra_rx_t* h);
 /* type-1 bits per block of a kind (60 / 30 / 124 / 124 / 124 / 268); < 0: TETRA_ERR_ARG. */
 int tetra_rx_type1_bits(int kind);
@@ -123,7 +126,7 @@ int tetra_rx_bits_device(tetra_rx_t* h, int which, const uint8_t** d_bits, int* 
  * _get_quality, _get_state ...).  Call tetra_rx_wait first; never destroy it. */
 tetra_demod_t* tetra_rx_demod(tetra_rx_t* h);
 /* GPU time (ms) of the latest call's stages from HIP events on their streams: ms[0] demodulator launch, ms[1] synchroniser,
- * ms[2] SB1 demux + decode + tracker, ms[3] the other kinds + labels (waits for the tail). */
+ * ms[2] frame lists + SB1 decode + tracker, ms[3] the other kinds' decode + labels (waits for the tail). */
 int tetra_rx_stage_ms(tetra_rx_t* h, float ms[4]);
 
 #ifdef __cplusplus

@@ -106,4 +106,6 @@ def test_bench_under_the_driver_s_own_launcher():
     d = _line(r)
     import torch
     assert d["n_ranks"] == 2 and d["n_gpus"] == min(2, torch.cuda.device_count()) and d["dist_backend"] == "gloo"
-    assert d["functional_only"] == (torch.cuda.device_count() < 2) and d["check"]["bit_errors"] == 0
+    assert d["functional_only"] == (torch.cuda.device_count() < 2)
+    # 256 channels per rank from their own seeds at 25 dB: a few true channel errors among millions of bits (bench.py's own bound)
+    assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
