@@ -26,6 +26,7 @@
 #ifndef TETRA_LMAC_H
 #define TETRA_LMAC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "tetra_demod.h"
@@ -126,6 +127,9 @@ typedef struct tetra_lmac_frames {
     const uint32_t* d_frame_bitnum;        /* labels only */
     const uint32_t* d_time_rx;             /* labels only */
     const uint32_t* d_time;                /* labels only */
+    void* d_workspace;                     /* optional: the launch's decision scratch (tetra_lmac_decode_frames_workspace_bytes of the jobs;
+                                              4-byte aligned); NULL: taken from / returned to the library's stream-ordered pool around the launch */
+    size_t workspace_bytes;
 } tetra_lmac_frames_t;
 typedef struct tetra_lmac_job {
     int32_t type;                          /* TETRA_TPSAP_T_x */
@@ -140,6 +144,10 @@ typedef struct tetra_lmac_job {
     tetra_lmac_label_t* d_labels;
 } tetra_lmac_job_t;
 int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_lmac_job_t* jobs, int n_jobs, void* hip_stream);
+/* Bytes of decision scratch a launch of these jobs needs (2 bytes per trellis step and row of max_rows; 0 for a launch of SB1 / AACH
+ * jobs only, whose decisions stay in LDS).  A caller that hands the scratch in (d_workspace) saves the two stream-ordered pool
+ * operations around the launch -- the receive chain does. */
+size_t tetra_lmac_decode_frames_workspace_bytes(const tetra_lmac_job_t* jobs, int n_jobs);
 
 /* Host-pointer variant (copies in/out, synchronises; device = HIP ordinal or -1 for the current one). */
 int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in_stride, const uint32_t* scramb_init,

@@ -28,3 +28,4 @@ d=json.load(open('$O/chain.json'))
 print(d['two_streams_ms_per_second'], d['one_stream_ms_per_second'], d['tail_ms_one_stream'], json.dumps({k:v['ms'] for k,v in d['stages_one_stream'].items()}))
 print(sum(v['rows']-v['crc_good'] for v in d['check']['blocks'].values()), d['check']['channels_locked'], d['check']['cells_read'])
 "
+cd $GRAFT_REPO_ROOT; timeout 300 python profiles/measure_lmac_frames.py > $O/measure_lmac_frames.json 2> $O/measure_lmac_frames.err; cat $O/measure_lmac_frames.json; tail -3 $O/measure_lmac_frames.err

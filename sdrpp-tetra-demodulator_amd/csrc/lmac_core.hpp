@@ -330,17 +330,21 @@ LM_FN int interleave_next(int& pos, int a, int K) {
     return p;
 }
 
-// Forward recursion over n2 + 4 steps, two steps per call-back.  next() returns the branch metrics of the next step pair (the
-// soft values of type-4 bits at three consecutive interleaver positions); st(u, word) receives decision_word of steps 2u, 2u + 1.
-// n2 is even for every block kind.
-template <class Next, class St>
-LM_FN void viterbi_forward(int n2, Next next, St st) {
+// Forward recursion over n2 + 4 steps, two steps per round.  fetch() starts the loads of the next step pair's three soft values
+// (type-4 bits at three consecutive interleaver positions) and returns what make(raw) needs to turn them into branch metrics;
+// st(u, word) receives decision_word of steps 2u, 2u + 1.  The loads of pair u + 1 are issued BEFORE the add-compare-select of pair
+// u and consumed after it (software pipelining by one round): a wavefront that has its SIMD to itself -- the last long blocks of a
+// launch, every wave of a small one -- does not wait for LDS.  n2 is even for every block kind.
+template <class Fetch, class Make, class St>
+LM_FN void viterbi_forward(int n2, Fetch fetch, Make make, St st) {
     PathMetrics pm;
 #pragma unroll
     for (int i = 0; i < 8; ++i) pm.R[i] = pk_make(0, 0);
     pm.R[0] = pk_make(4 * 5, 0);       // S[0] = 127 * N * K in units of 127
+    auto raw = fetch();
     for (int u = 0; u < n2 / 2; ++u) {
-        const Bm m = next();
+        const Bm m = make(raw);
+        if (u + 1 < n2 / 2) raw = fetch();
         Pk De[8], Do[8];
         const Pk Me[8] = { m.P, m.Q, m.Q, m.P, pk_swap(m.Q), pk_swap(m.P), pk_swap(m.P), pk_swap(m.Q) };
         acs_step(pm, Me, De);
@@ -358,6 +362,8 @@ LM_FN void viterbi_forward(int n2, Next next, St st) {
         st(n2 / 2 + f, decision_word(De, Do));
     }
 }
+// what fetch() hands to make(): the three LDS words that hold a step pair's soft values and where in them
+struct Raw3 { uint32_t w[3]; uint32_t at[3]; };
 
 // CRC16-CCITT (crc_simple.c:59-77, :103-106: x^16 + x^12 + x^5 + 1, start 0xffff, bits MSB first, good = 0x1d0f over type1 + 16
 // bits).  The traceback meets the bits last to first, so it runs the register BACKWARDS from the good value and checks that it
@@ -406,10 +412,18 @@ LM_FN bool viterbi_traceback(int n2, Ld ld, St st, Tinv tinv) {
     }
     uint32_t r4 = kCrcOk << 2;
     const int top = n2 / 16 - 1;
+    // the eight decision words of a group are requested one group ahead of their use (the scratch is in L2 / HBM: ~2000 clocks)
+    uint32_t cur[8], nxt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int b2 = 0; b2 < 8; ++b2) cur[b2] = ld(8 * top + b2);
     for (int h = top; h >= 0; --h) {
+        if (h > 0) {
+#pragma unroll
+            for (int b2 = 0; b2 < 8; ++b2) nxt[b2] = ld(8 * (h - 1) + b2);
+        }
 #pragma unroll
         for (int b2 = 7; b2 >= 0; --b2) {
-            const uint32_t w = ld(8 * h + b2);
+            const uint32_t w = cur[b2];
             uint32_t t = y << 1;
             y = t + 1u + bfe_mask(w, t);
             t = (y << 1) | 1u;
@@ -420,6 +434,8 @@ LM_FN bool viterbi_traceback(int n2, Ld ld, St st, Tinv tinv) {
         const uint32_t rev = rev32(bits);                 // decoded bit 16h + k at bit 27 - k
         if (h != top) r4 = (r4 >> 8) ^ tinv(r4 & 0x3fcu) ^ ((rev << 2) & 0x3fc00u);          // bits 16h+12 .. 16h+19
         r4 = (r4 >> 8) ^ tinv(r4 & 0x3fcu) ^ ((rev >> 6) & 0x3fc00u);                        // bits 16h+4 .. 16h+11
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) cur[b2] = nxt[b2];
     }
     uint32_t r = (r4 >> 2) & 0xffffu;
 #pragma unroll

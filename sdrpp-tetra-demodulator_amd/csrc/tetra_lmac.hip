@@ -56,30 +56,33 @@ const BlkParam kBlk[6] = {
 
 typedef uint16_t OutW[kOutHalves][kLanes + kOutPad];
 
-// steps 2-4 for a workgroup whose type-4 bits (BITS) or soft classes are in `cls`; returns the lane's CRC verdict
-template <bool BITS>
+// steps 2-3 for a workgroup whose type-4 bits (BITS) or soft classes are in `cls`; dec_st(u, word) / dec_ld(u) = the lane's decision
+// word of step pair u (global scratch, or LDS for a launch of short blocks); returns the lane's CRC verdict
+template <bool BITS, class DecSt, class DecLd>
 __device__ __forceinline__ bool decode_core(const uint32_t (*cls)[kLanes], OutW& outw, const uint32_t* crc_inv, int lane, int type345, int type2,
-                                            int a, uint32_t* __restrict__ dec) {
+                                            int a, DecSt dec_st, DecLd dec_ld) {
     int pos = a;                       // (a * i) % K for i = 1
+    auto fetch = [&] {
+        Raw3 r;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = interleave_next(pos, a, type345);
+            r.w[k] = cls[BITS ? p >> 5 : p >> 4][lane];
+            r.at[k] = BITS ? 31u - (uint32_t)(p & 31) : (uint32_t)(30 - 2 * (p & 15));
+        }
+        return r;
+    };
     if (BITS) {
-        auto bit = [&](int p) { return bfe_mask(cls[p >> 5][lane], 31u - (uint32_t)(p & 31)); };
-        viterbi_forward(type2,
-                        [&] {
-                            const uint32_t ma = bit(interleave_next(pos, a, type345)), mb = bit(interleave_next(pos, a, type345));
-                            return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
-                        },
-                        [&](int u, uint32_t word) { dec[u * kLanes] = word; });
+        viterbi_forward(type2, fetch,
+                        [&](const Raw3& r) { return bm_from_masks(bfe_mask(r.w[0], r.at[0]), bfe_mask(r.w[1], r.at[1]), bfe_mask(r.w[2], r.at[2])); },
+                        dec_st);
     } else {
-        auto soft = [&](int idx) { return (int)(cls[idx >> 4][lane] << (30 - 2 * (idx & 15))) >> 30; };
-        viterbi_forward(type2,
-                        [&] {
-                            const int sa = soft(interleave_next(pos, a, type345)), sb = soft(interleave_next(pos, a, type345));
-                            return bm_from_classes(sa, sb, soft(interleave_next(pos, a, type345)));
-                        },
-                        [&](int u, uint32_t word) { dec[u * kLanes] = word; });
+        viterbi_forward(type2, fetch,
+                        [&](const Raw3& r) { return bm_from_classes((int)(r.w[0] << r.at[0]) >> 30, (int)(r.w[1] << r.at[1]) >> 30, (int)(r.w[2] << r.at[2]) >> 30); },
+                        dec_st);
     }
     // traceback + CRC (own lane's data only: program order is enough)
-    return viterbi_traceback(type2, [&](int u) { return dec[u * kLanes]; }, [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
+    return viterbi_traceback(type2, dec_ld, [&](int h, uint32_t half) { outw[h][lane] = (uint16_t)half; },
                              [&](uint32_t off) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(crc_inv) + off); });
 }
 
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
     bool good;
     if (!byte_route) {
         __syncthreads();
-        good = decode_core<true>(cls, outw, crc_inv, lane, type345, type2, a, dec);
+        good = decode_core<true>(cls, outw, crc_inv, lane, type345, type2, a, [&](int u, uint32_t w) { dec[u * kLanes] = w; },
+                                 [&](int u) { return dec[u * kLanes]; });
     } else {
         // rows -> LDS in chunks of 64 bits per row (coalesced 64-byte segments, 4 rows per load instruction), each lane
         // descrambles its own row chunk by chunk (its LFSR carried in a register) and packs the soft classes
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
                                     [&](int w, uint32_t word) { cls[c0 / 4 + w][lane] = word; });
             __syncthreads();
         }
-        good = decode_core<false>(cls, outw, crc_inv, lane, type345, type2, a, dec);
+        good = decode_core<false>(cls, outw, crc_inv, lane, type345, type2, a, [&](int u, uint32_t w) { dec[u * kLanes] = w; },
+                                  [&](int u) { return dec[u * kLanes]; });
     }
     if (blk < n_blocks) crc_ok[blk] = good;
     __syncthreads();
@@ -222,8 +227,13 @@ struct JobTable {
     DevFrames src;
     int n;
 };
+// DEC_LDS: the decisions of the launch's blocks fit LDS (kDecLdsPairs step pairs: a launch of SB1 blocks) -- no scratch round trip,
+// for launches that are too small to hide it behind other waves
+constexpr int kDecLdsPairs = 44;
+template <bool DEC_LDS>
 __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint32_t* __restrict__ dec_scratch,
                                                         const uint32_t* __restrict__ seq_tab) {
+    __shared__ uint32_t dec_lds[DEC_LDS ? kDecLdsPairs : 1][kLanes];
     __shared__ uint32_t cls[kSeqWords][kLanes];
     __shared__ OutW outw;
     __shared__ uint32_t crc_inv[256];
@@ -270,8 +280,14 @@ __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint
         descramble_to_lds(J.type345, code, xb, seq_tab, cls, lane);
         load_crc_inv(crc_inv, lane);
         __syncthreads();
-        uint32_t* dec = dec_scratch + J.scratch_base + (size_t)group * J.dec_pairs * kLanes + lane;
-        good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, dec);
+        if (DEC_LDS) {
+            good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, [&](int u, uint32_t w) { dec_lds[u][lane] = w; },
+                                     [&](int u) { return dec_lds[u][lane]; });
+        } else {
+            uint32_t* dec = dec_scratch + J.scratch_base + (size_t)group * J.dec_pairs * kLanes + lane;
+            good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, [&](int u, uint32_t w) { dec[u * kLanes] = w; },
+                                     [&](int u) { return dec[u * kLanes]; });
+        }
     }
     if (blk < n_blocks) {
         J.crc_ok[blk] = good;
@@ -427,12 +443,37 @@ __global__ __launch_bounds__(256) void k_track_sync(const uint8_t* __restrict__ 
     cell[c] = st;
 }
 
-// tetra_lmac_track_sync_lists_device: k_track_sync's walk with the channel's SB1 rows compact and read side by side.  One
-// wavefront per channel, 64 frame slots at a time: every lane gathers its slot's (valid, crc, SYNC-PDU fields); the walk over the
-// slots then runs on WAVE-UNIFORM values -- a slot's words fetched with v_readlane, the cell state and the clock in scalar
-// registers, the three results per slot selected into their lane -- so it costs scalar instructions and four vector ones per
-// slot, no LDS and no dependent loads; the lanes write the results back coalesced.
-__device__ __forceinline__ uint32_t lane_get(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// tetra_lmac_track_sync_lists_device: k_track_sync's walk with the channel's SB1 rows compact, WITHOUT the walk.  One wavefront per
+// channel, 64 frame slots at a time, a slot per lane.  What a slot needs from its past is (1) the last SYNC frame before it -- the
+// PHY clock was set to tcd's time there -- and how many slots ago that was, (2) the last SYNC frame with a good CRC up to there /
+// up to the slot itself -- that is what tcd holds.  Both are "highest set bit below my lane" of two ballots; the fields travel
+// with two lane shuffles; and the clock k slots after a reset is one literal tetra_tdma_time_add_tn step (tetra_tdma.c:28-78: any
+// state lands in tn 0..4, fn 0..18, mn 0..60 -- the wrap tests run on every call) followed by k - 1 steps in closed form
+// (three counters that run 1..4, 1..18, 1..60, a zero taking one step to become 1).  Nothing is serial but the carry from one
+// 64-slot group to the next.  (The first version walked the slots on the scalar unit: 2577 scalar instructions per wave, 29 us.)
+struct Tdma { uint32_t tn, fn, mn; };
+__device__ __forceinline__ Tdma tdma_advance(Tdma t, uint32_t k) {       // k >= 1 calls of tetra_tdma_time_add_tn(t, 1)
+    tdma_add_tn(t.tn, t.fn, t.mn);
+    k -= 1;
+    if (k) {
+        const uint32_t p1 = t.tn + k - 1u;                                // t.tn in 0..4: a zero needs one step to become 1
+        const uint32_t c1 = p1 >> 2;
+        t.tn = (p1 & 3u) + 1u;
+        if (c1) {
+            const uint32_t p2 = t.fn + c1 - 1u, c2 = p2 / 18u;
+            t.fn = p2 - 18u * c2 + 1u;
+            if (c2) t.mn = (t.mn + c2 - 1u) % 60u + 1u;
+        }
+    }
+    return t;
+}
+__device__ __forceinline__ uint32_t tdma_pack(Tdma t) { return t.tn | (t.fn << 8) | (t.mn << 16); }
+// highest set bit of m at or below position `upto` (-1: none; upto = -1: none)
+__device__ __forceinline__ int last_set_upto(unsigned long long m, int upto) {
+    if (upto < 0) return -1;
+    const unsigned long long x = m & (upto >= 63 ? ~0ull : ((2ull << upto) - 1ull));
+    return x ? 63 - __clzll((long long)x) : -1;
+}
 __global__ __launch_bounds__(kLanes) void k_track_sync_lists(const uint8_t* __restrict__ sb1, int stride, const int* __restrict__ crc_ok,
                                                              const int* __restrict__ frame_type, const int* __restrict__ n_frames,
                                                              const int* __restrict__ chan_first, int frames,
@@ -442,7 +483,7 @@ __global__ __launch_bounds__(kLanes) void k_track_sync_lists(const uint8_t* __re
     const int c = blockIdx.x, lane = threadIdx.x;
     const int nf = n_frames ? min(n_frames[c], frames) : frames;
     int base = chan_first[c];
-    tetra_lmac_cell_state_t st = cell[c];
+    tetra_lmac_cell_state_t st = cell[c];                 // wave-uniform; carried from group to group
     for (int f0 = 0; f0 < frames; f0 += kLanes) {
         const int f = f0 + lane;
         const size_t r = (size_t)c * frames + f;
@@ -450,62 +491,76 @@ __global__ __launch_bounds__(kLanes) void k_track_sync_lists(const uint8_t* __re
         const unsigned long long m = __ballot(is_sync);
         const int j = base + __popcll(m & ((1ull << lane) - 1ull));
         base += __popcll(m);
-        // a: bit 0 valid, bit 1 crc ok, colour << 2, tn << 8, fn << 11, mn << 16;  b: mcc | mnc << 10
+        // a: colour << 2, tn << 8, fn << 11, mn << 16;  b: mcc | mnc << 10  (of a SYNC frame with a good CRC)
+        const bool valid = is_sync && f < nf;
+        bool good = false;
         uint32_t a = 0, b = 0;
-        if (is_sync && f < nf) {
-            a = 1u;
-            if (crc_ok[j]) {
-                const uint32_t* t2 = reinterpret_cast<const uint32_t*>(sb1 + (size_t)j * stride);
-                uint64_t v = 0;                               // type-2 bits 0..55, first bit most significant
+        if (valid && crc_ok[j]) {
+            good = true;
+            const uint32_t* t2 = reinterpret_cast<const uint32_t*>(sb1 + (size_t)j * stride);
+            uint64_t v = 0;                               // type-2 bits 0..55, first bit most significant
 #pragma unroll
-                for (int k = 0; k < 14; ++k) v |= (uint64_t)pack4(t2[k] & 0x01010101u) << (60 - 4 * k);
-                auto field = [&](int first, int len) { return (uint32_t)(v >> (64 - first - len)) & ((1u << len) - 1u); };
-                a |= 2u | (field(4, 6) << 2) | ((field(10, 2) + 1u) << 8) | (field(12, 5) << 11) | (field(17, 6) << 16);
-                b = field(31, 10) | (field(41, 14) << 10);
-            }
+            for (int k = 0; k < 14; ++k) v |= (uint64_t)pack4(t2[k] & 0x01010101u) << (60 - 4 * k);
+            auto field = [&](int first, int len) { return (uint32_t)(v >> (64 - first - len)) & ((1u << len) - 1u); };
+            a = (field(4, 6) << 2) | ((field(10, 2) + 1u) << 8) | (field(12, 5) << 11) | (field(17, 6) << 16);
+            b = field(31, 10) | (field(41, 14) << 10);
         }
-        uint32_t o_scr = 0, o_rx = 0, o_t = 0;
-        const int lim = min(kLanes, frames - f0);
-        for (int i = 0; i < lim; ++i) {
-            uint32_t t_rx = 0, t_after = 0;
-            if (f0 + i < nf) {
-                tdma_add_tn(st.phy_tn, st.phy_fn, st.phy_mn);
-                t_rx = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
-                const uint32_t ai = lane_get(a, i);
-                if (ai & 1u) {
-                    if (ai & 2u) {
-                        const uint32_t bi = lane_get(b, i);
-                        st.colour_code = (ai >> 2) & 0x3fu;
-                        st.tcd_tn = (ai >> 8) & 7u;
-                        st.tcd_fn = (ai >> 11) & 0x1fu;
-                        st.tcd_mn = (ai >> 16) & 0x3fu;
-                        st.mcc = bi & 0x3ffu;
-                        st.mnc = bi >> 10;
-                        st.scramb_init = (((st.colour_code & 0x3f) | ((st.mnc & 0x3fff) << 6) | ((st.mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1;
-                    }
-                    st.phy_tn = st.tcd_tn; st.phy_fn = st.tcd_fn; st.phy_mn = st.tcd_mn;
-                }
-                t_after = st.phy_tn | (st.phy_fn << 8) | (st.phy_mn << 16);
+        const unsigned long long mv = __ballot(valid), mg = __ballot(good);
+        // tcd as a slot sees it: the fields of good frame h (ah, bh = its words, fetched by every lane: a shuffle reads active lanes
+        // only), or what the group started with
+        auto tcd_of = [&](int h, uint32_t ah, uint32_t bh, uint32_t& colour, uint32_t& mcc, uint32_t& mnc) {
+            Tdma t = { st.tcd_tn, st.tcd_fn, st.tcd_mn };
+            colour = st.colour_code; mcc = st.mcc; mnc = st.mnc;
+            if (h >= 0) {
+                t = Tdma{ (ah >> 8) & 7u, (ah >> 11) & 0x1fu, (ah >> 16) & 0x3fu };
+                colour = (ah >> 2) & 0x3fu; mcc = bh & 0x3ffu; mnc = bh >> 10;
             }
-            const bool mine = lane == i;
-            o_scr = mine ? st.scramb_init : o_scr;
-            o_rx = mine ? t_rx : o_rx;
-            o_t = mine ? t_after : o_t;
-        }
+            return t;
+        };
+        const int gp = last_set_upto(mv, lane - 1);                          // the last SYNC frame before this slot
+        const int hp = gp >= 0 ? last_set_upto(mg, gp) : -1;                 // ... and the good one tcd held there
+        const int hs = last_set_upto(mg, lane);                              // the good one tcd holds after this slot
+        const uint32_t ap = (uint32_t)__shfl((int)a, hp < 0 ? 0 : hp), bp = (uint32_t)__shfl((int)b, hp < 0 ? 0 : hp);
+        const uint32_t as = (uint32_t)__shfl((int)a, hs < 0 ? 0 : hs), bs = (uint32_t)__shfl((int)b, hs < 0 ? 0 : hs);
+        uint32_t cc, mcc, mnc;
+        // time on entry: k slots after the last SYNC frame before this one (the clock was set to tcd's time there), or after the group's start
+        Tdma from = tcd_of(hp, ap, bp, cc, mcc, mnc);
+        if (gp < 0) from = Tdma{ st.phy_tn, st.phy_fn, st.phy_mn };
+        const Tdma t_rx = tdma_advance(from, (uint32_t)(lane - gp));
+        // after the slot's SB1: tcd as of this slot if it is a SYNC frame, else unchanged
+        const Tdma tcd_now = tcd_of(hs, as, bs, cc, mcc, mnc);
+        const Tdma t_after = valid ? tcd_now : t_rx;
+        const uint32_t scramb = hs >= 0 ? ((((cc & 0x3f) | ((mnc & 0x3fff) << 6) | ((mcc & 0x3ff) << 20)) << 2) | kScrambInitSb1) : st.scramb_init;
+        const bool live = f < nf;
+        // the group's last live slot is the state the next group (and the next call) starts from; slots past the channel's frame
+        // count carry the code in force at its end
+        const int last_live = min(nf - f0, kLanes) - 1;                       // < 0: no live slot in this group
+        const int src = last_live < 0 ? 0 : last_live;
+        const uint32_t code_end = last_live < 0 ? st.scramb_init : (uint32_t)__shfl((int)scramb, src);
+        const Tdma end_phy = { (uint32_t)__shfl((int)t_after.tn, src), (uint32_t)__shfl((int)t_after.fn, src), (uint32_t)__shfl((int)t_after.mn, src) };
+        const Tdma end_tcd = { (uint32_t)__shfl((int)tcd_now.tn, src), (uint32_t)__shfl((int)tcd_now.fn, src), (uint32_t)__shfl((int)tcd_now.mn, src) };
+        const uint32_t end_cc = (uint32_t)__shfl((int)cc, src), end_mcc = (uint32_t)__shfl((int)mcc, src), end_mnc = (uint32_t)__shfl((int)mnc, src);
         if (f < frames) {
-            row_scramb[r] = o_scr;
+            const uint32_t o_rx = live ? tdma_pack(t_rx) : 0u, o_t = live ? tdma_pack(t_after) : 0u;
+            row_scramb[r] = live ? scramb : code_end;
             if (row_time_rx) row_time_rx[r] = o_rx;
             if (row_time) row_time[r] = o_t;
-            if (labels && (a & 1u)) {
+            if (labels && valid) {
                 tetra_lmac_label_t lb;
                 lb.channel = c;
                 lb.frame_slot = f;
                 lb.bitnum = frame_bitnum[r];
                 lb.tdma_time_rx = o_rx;
                 lb.tdma_time = o_t;
-                lb.crc_ok = (a >> 1) & 1u;
+                lb.crc_ok = good;
                 labels[j] = lb;
             }
+        }
+        if (last_live >= 0) {
+            st.phy_tn = end_phy.tn; st.phy_fn = end_phy.fn; st.phy_mn = end_phy.mn;
+            st.tcd_tn = end_tcd.tn; st.tcd_fn = end_tcd.fn; st.tcd_mn = end_tcd.mn;
+            st.colour_code = end_cc; st.mcc = end_mcc; st.mnc = end_mnc;
+            st.scramb_init = code_end;
         }
     }
     if (lane == 0) cell[c] = st;
@@ -591,7 +646,7 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
     JobTable tab = {};
     tab.src = DevFrames{ src->d_frames, src->d_frame_type, src->d_frame_bitnum, src->d_time_rx, src->d_time, src->frames_per_channel };
     long long groups_total = 0, scratch_words = 0;
-    int n = 0;
+    int n = 0, max_pairs = 0;
     for (int i = 0; i < n_jobs; ++i) {
         const tetra_lmac_job_t& j = jobs[i];
         if (j.type < 0 || j.type > 5 || j.max_rows < 0) return TETRA_ERR_ARG;
@@ -624,6 +679,7 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
         d.layout = layout;
         d.type345 = p.type345; d.type2 = p.type2; d.a = p.a;
         d.dec_pairs = layout == kLayoutBbk ? 0 : (p.type2 + kFlush) / 2;
+        max_pairs = d.dec_pairs > max_pairs ? d.dec_pairs : max_pairs;
         const long long groups = ((long long)j.max_rows + kLanes - 1) / kLanes;
         d.first_group = (int)groups_total;
         d.scratch_base = scratch_words;
@@ -636,18 +692,44 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uint32_t* seq = seq_table();
     if (!seq) return TETRA_ERR_NOMEM;
-    uint32_t* scratch = nullptr;
-    if (scratch_words) {
-        hipMemPool_t pool = scratch_pool();
-        const size_t bytes = (size_t)scratch_words * sizeof(uint32_t);
-        const hipError_t got = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), bytes, pool, s)
-                                    : hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s);
-        if (got != hipSuccess) { (void)hipGetLastError(); return TETRA_ERR_NOMEM; }
+    if (max_pairs <= kDecLdsPairs) {                      // short blocks only (an SB1 launch): decisions in LDS
+        hipLaunchKernelGGL(k_lmac_frames<true>, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, nullptr, seq);
+        return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
     }
-    hipLaunchKernelGGL(k_lmac_frames, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, scratch, seq);
+    const size_t bytes = (size_t)scratch_words * sizeof(uint32_t);
+    uint32_t* scratch = nullptr;
+    bool pooled = false;
+    if (scratch_words) {
+        if (src->d_workspace) {
+            if (src->workspace_bytes < bytes) return TETRA_ERR_SIZE;
+            if ((uintptr_t)src->d_workspace & 3) return TETRA_ERR_ALIGN;
+            scratch = static_cast<uint32_t*>(src->d_workspace);
+        } else {
+            hipMemPool_t pool = scratch_pool();
+            const hipError_t got = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(&scratch), bytes, pool, s)
+                                        : hipMallocAsync(reinterpret_cast<void**>(&scratch), bytes, s);
+            if (got != hipSuccess) { (void)hipGetLastError(); return TETRA_ERR_NOMEM; }
+            pooled = true;
+        }
+    }
+    hipLaunchKernelGGL(k_lmac_frames<false>, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, scratch, seq);
     const hipError_t launch = hipGetLastError();
-    if ((scratch && hipFreeAsync(scratch, s) != hipSuccess) || launch != hipSuccess) return TETRA_ERR_HIP;
+    if ((pooled && hipFreeAsync(scratch, s) != hipSuccess) || launch != hipSuccess) return TETRA_ERR_HIP;
     return TETRA_OK;
+}
+
+size_t tetra_lmac_decode_frames_workspace_bytes(const tetra_lmac_job_t* jobs, int n_jobs) {
+    if (!jobs || n_jobs < 0) return 0;
+    size_t words = 0;
+    int max_pairs = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const tetra_lmac_job_t& j = jobs[i];
+        if (j.type < 0 || j.type > 5 || j.type == TETRA_TPSAP_T_BBK || j.max_rows <= 0) continue;
+        const int pairs = (kBlk[j.type].type2 + kFlush) / 2;
+        max_pairs = pairs > max_pairs ? pairs : max_pairs;
+        words += (size_t)(((long long)j.max_rows + kLanes - 1) / kLanes) * pairs * kLanes;
+    }
+    return max_pairs <= kDecLdsPairs ? 0 : words * sizeof(uint32_t);
 }
 
 int tetra_lmac_debug_force_byte_route(int on) {

@@ -81,6 +81,8 @@ struct tetra_rx {
     int32_t* nf = nullptr;                // [C]
     int32_t* chan_first = nullptr;        // [TETRA_N_LISTS][C] position in each list of a channel's first entry
     int32_t* index_work = nullptr;        // tetra_burst_index_device's scratch
+    void* lmac_ws = nullptr;              // the decoder's decision scratch for the launch of every other kind
+    size_t lmac_ws_bytes = 0;
     uint32_t *row_scramb = nullptr, *row_time_rx = nullptr, *row_time = nullptr;
     tetra_lmac_cell_state_t* cell = nullptr;   // [C]
     float* st_iq = nullptr;               // host-path staging
@@ -109,7 +111,7 @@ void free_all(tetra_rx* h) {
     if (h->dem) (void)tetra_demod_destroy(h->dem);
     if (h->bs) (void)tetra_bsync_destroy(h->bs);
     void* ptrs[] = { h->bits[0], h->bits[1], h->nbits[0], h->nbits[1], h->lists[0], h->lists[1], h->counts[0], h->counts[1], h->frames, h->ft,
-                     h->fb, h->nf, h->chan_first, h->index_work, h->row_scramb, h->row_time_rx, h->row_time, h->cell, h->st_iq };
+                     h->fb, h->nf, h->chan_first, h->index_work, h->lmac_ws, h->row_scramb, h->row_time_rx, h->row_time, h->cell, h->st_iq };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& par : h->res)
         for (auto& k : par) {
@@ -146,6 +148,8 @@ int enqueue_tail(tetra_rx* h, int b, hipStream_t s) {
     src.d_frame_bitnum = h->fb;
     src.d_time_rx = h->row_time_rx;
     src.d_time = h->row_time;
+    src.d_workspace = h->lmac_ws;
+    src.workspace_bytes = h->lmac_ws_bytes;
     auto job_of = [&](int k, bool labels) {
         const KindInfo& ki = kKinds[k];
         const KindBufs& r = h->res[b][k];
@@ -244,6 +248,14 @@ int tetra_rx_create(const tetra_rx_config_t* cfg, tetra_rx_t** out) {
          dalloc(h->chan_first, (size_t)TETRA_N_LISTS * h->C) && dalloc(h->index_work, (size_t)TETRA_N_LISTS * ((n + 255) / 256)) &&
          dalloc(h->row_scramb, n) && dalloc(h->row_time_rx, n) && dalloc(h->row_time, n) && dalloc(h->cell, (size_t)h->C);
     for (auto& e : h->ev_stage) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (ok) {      // the decision scratch of the second decode launch, sized for the worst case (every frame slot a row of every kind)
+        tetra_lmac_job_t jobs[TETRA_RX_N_KINDS] = {};
+        int nj = 0;
+        for (int k : kJobOrder)
+            if (h->kinds & (1 << k)) { jobs[nj].type = kKinds[k].tpsap; jobs[nj].blk_num = kKinds[k].blk; jobs[nj].max_rows = h->rows; nj++; }
+        h->lmac_ws_bytes = tetra_lmac_decode_frames_workspace_bytes(jobs, nj);
+        ok = h->lmac_ws_bytes == 0 || hipMalloc(&h->lmac_ws, h->lmac_ws_bytes) == hipSuccess;
+    }
     rc = ok ? zero_results(h) : TETRA_ERR_NOMEM;
     if (rc != TETRA_OK) { free_all(h); delete h; return rc; }
     *out = h;

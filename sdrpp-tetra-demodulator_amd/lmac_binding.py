@@ -7,7 +7,8 @@ from .binding import TetraDemodError, load_library
 
 LMAC_EXPORTS = ["tetra_lmac_blk_param", "tetra_lmac_scramb_init", "tetra_lmac_decode_batch_device", "tetra_lmac_decode_batch",
                 "tetra_lmac_track_scramb_device", "tetra_lmac_decode_counted_device", "tetra_lmac_track_sync_device",
-                "tetra_lmac_debug_force_byte_route", "tetra_lmac_decode_frames_device", "tetra_lmac_track_sync_lists_device"]
+                "tetra_lmac_debug_force_byte_route", "tetra_lmac_decode_frames_device", "tetra_lmac_track_sync_lists_device",
+                "tetra_lmac_decode_frames_workspace_bytes"]
 # enum tp_sap_data_type (src/decoder/src/phy/tetra_burst.h:9-16)
 TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F = range(6)
 
@@ -21,7 +22,8 @@ class Label(C.Structure):
 class Frames(C.Structure):
     """tetra_lmac_frames_t."""
     _fields_ = [("d_frames", C.c_void_p), ("d_frame_type", C.c_void_p), ("n_frames", C.c_int32), ("frames_per_channel", C.c_int32),
-                ("d_frame_bitnum", C.c_void_p), ("d_time_rx", C.c_void_p), ("d_time", C.c_void_p)]
+                ("d_frame_bitnum", C.c_void_p), ("d_time_rx", C.c_void_p), ("d_time", C.c_void_p), ("d_workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
 
 
 class Job(C.Structure):
@@ -165,18 +167,32 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def decode_frames_device(d_frames, d_frame_type, jobs, frames_per_channel=0, d_frame_bitnum=None, d_time_rx=None, d_time=None, stream=None):
+def _job_array(jobs):
+    arr = (Job * max(1, len(jobs)))()
+    for i, j in enumerate(jobs):
+        arr[i] = Job(int(j["type"]), int(j.get("blk_num", 0)), _ptr(j.get("row_frame")), _ptr(j.get("n_rows")), int(j["max_rows"]),
+                     int(j.get("out_stride", 0)), _ptr(j.get("frame_scramb")), _ptr(j.get("type2")), _ptr(j.get("crc_ok")), _ptr(j.get("labels")))
+    return arr
+
+
+def decode_frames_workspace_bytes(jobs):
+    """tetra_lmac_decode_frames_workspace_bytes (jobs as for decode_frames_device; only type and max_rows matter)."""
+    L = _lib()
+    L.tetra_lmac_decode_frames_workspace_bytes.argtypes = [C.POINTER(Job), C.c_int]
+    L.tetra_lmac_decode_frames_workspace_bytes.restype = C.c_size_t
+    return int(L.tetra_lmac_decode_frames_workspace_bytes(_job_array(jobs), len(jobs)))
+
+
+def decode_frames_device(d_frames, d_frame_type, jobs, frames_per_channel=0, d_frame_bitnum=None, d_time_rx=None, d_time=None, stream=None,
+                         d_workspace=None):
     """tetra_lmac_decode_frames_device.  jobs: dicts with type, blk_num, row_frame, n_rows (tensor or None), max_rows, out_stride,
-    frame_scramb (tensor or None), type2, crc_ok, labels (int32 tensor [rows][6] or None)."""
+    frame_scramb (tensor or None), type2, crc_ok, labels (int32 tensor [rows][6] or None); d_workspace: uint8 tensor or None (pool)."""
     L = _lib()
     L.tetra_lmac_decode_frames_device.argtypes = [C.POINTER(Frames), C.POINTER(Job), C.c_int, C.c_void_p]
     L.tetra_lmac_decode_frames_device.restype = C.c_int
     src = Frames(_ptr(d_frames), _ptr(d_frame_type), int(d_frame_type.numel()), int(frames_per_channel), _ptr(d_frame_bitnum), _ptr(d_time_rx),
-                 _ptr(d_time))
-    arr = (Job * max(1, len(jobs)))()
-    for i, j in enumerate(jobs):
-        arr[i] = Job(int(j["type"]), int(j.get("blk_num", 0)), _ptr(j["row_frame"]), _ptr(j.get("n_rows")), int(j["max_rows"]),
-                     int(j["out_stride"]), _ptr(j.get("frame_scramb")), _ptr(j["type2"]), _ptr(j["crc_ok"]), _ptr(j.get("labels")))
+                 _ptr(d_time), _ptr(d_workspace), 0 if d_workspace is None else int(d_workspace.numel() * d_workspace.element_size()))
+    arr = _job_array(jobs)
     s = None
     if stream is not None:
         s = C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))

@@ -36,31 +36,35 @@ extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, 
         uint32_t xb[kSeqWords];
         const uint32_t dirty = pack_row_bits(type345, [&](int i) { U2 d; std::memcpy(&d, row + 8 * i, 8); return d; }, xb);
         int pos = a;
-        if (route == 0 && !dirty) {
+        const bool bits_route = route == 0 && !dirty;
+        if (bits_route) {
             ++fast;
             descramble_bits(type345, scramb_init[blk], xb, [&](int t, uint32_t byte, int w) { return tab[((size_t)t * 256 + byte) * kSeqStride + w]; },
                             [&](int w, uint32_t word) { cls[w] = word; });
-            auto bit = [&](int p) { return bfe_mask(cls[p >> 5], 31u - (uint32_t)(p & 31)); };
-            viterbi_forward(type2,
-                            [&] {
-                                const uint32_t ma = bit(interleave_next(pos, a, type345)), mb = bit(interleave_next(pos, a, type345));
-                                return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
-                            },
-                            [&](int u, uint32_t word) { dec[u] = word; });
         } else {
             uint32_t lfsr = scramb_init[blk];
             for (int c0 = 0; c0 < type345 / 4; c0 += 16)      // the kernel's 64-bit staging chunks
                 lfsr = descramble_chunk(type345 - 4 * c0, lfsr,
                                         [&](int d) { uint32_t v; std::memcpy(&v, row + 4 * (c0 + d), 4); return v; },
                                         [&](int w, uint32_t word) { cls[c0 / 4 + w] = word; });
-            auto soft = [&](int idx) { return (int)(cls[idx >> 4] << (30 - 2 * (idx & 15))) >> 30; };
-            viterbi_forward(type2,
-                            [&] {
-                                const int sa = soft(interleave_next(pos, a, type345)), sb = soft(interleave_next(pos, a, type345));
-                                return bm_from_classes(sa, sb, soft(interleave_next(pos, a, type345)));
-                            },
-                            [&](int u, uint32_t word) { dec[u] = word; });
         }
+        auto fetch = [&] {                                    // as decode_core in tetra_lmac.hip
+            Raw3 r;
+            for (int k = 0; k < 3; ++k) {
+                const int p = interleave_next(pos, a, type345);
+                r.w[k] = cls[bits_route ? p >> 5 : p >> 4];
+                r.at[k] = bits_route ? 31u - (uint32_t)(p & 31) : (uint32_t)(30 - 2 * (p & 15));
+            }
+            return r;
+        };
+        auto dec_st = [&](int u, uint32_t word) { dec[u] = word; };
+        if (bits_route)
+            viterbi_forward(type2, fetch,
+                            [&](const Raw3& r) { return bm_from_masks(bfe_mask(r.w[0], r.at[0]), bfe_mask(r.w[1], r.at[1]), bfe_mask(r.w[2], r.at[2])); }, dec_st);
+        else
+            viterbi_forward(type2, fetch,
+                            [&](const Raw3& r) { return bm_from_classes((int)(r.w[0] << r.at[0]) >> 30, (int)(r.w[1] << r.at[1]) >> 30, (int)(r.w[2] << r.at[2]) >> 30); },
+                            dec_st);
         crc_ok[blk] = viterbi_traceback(type2, [&](int u) { return dec[u]; }, [&](int h, uint32_t half) { outw[h] = (uint16_t)half; },
                                         [&](uint32_t off) { return crci.t[off >> 2]; });
         for (int t4 = 0; t4 < type2 / 4; ++t4) {
@@ -112,12 +116,17 @@ extern "C" int lmac_emul_decode_frames(int tpsap, int blk_num, const uint32_t* f
         frame_block(layout, fw, frame_type[f], xb);
         descramble_bits(type345, code, xb, seq, [&](int w, uint32_t word) { cls[w] = word; });
         int pos = a;
-        auto bit = [&](int p) { return bfe_mask(cls[p >> 5], 31u - (uint32_t)(p & 31)); };
-        viterbi_forward(type2,
-                        [&] {
-                            const uint32_t ma = bit(interleave_next(pos, a, type345)), mb = bit(interleave_next(pos, a, type345));
-                            return bm_from_masks(ma, mb, bit(interleave_next(pos, a, type345)));
-                        },
+        auto fetch = [&] {
+            Raw3 r;
+            for (int k = 0; k < 3; ++k) {
+                const int p = interleave_next(pos, a, type345);
+                r.w[k] = cls[p >> 5];
+                r.at[k] = 31u - (uint32_t)(p & 31);
+            }
+            return r;
+        };
+        viterbi_forward(type2, fetch,
+                        [&](const Raw3& r) { return bm_from_masks(bfe_mask(r.w[0], r.at[0]), bfe_mask(r.w[1], r.at[1]), bfe_mask(r.w[2], r.at[2])); },
                         [&](int u, uint32_t word) { dec[u] = word; });
         (void)type1;
         crc_ok[blk] = viterbi_traceback(type2, [&](int u) { return dec[u]; }, [&](int h, uint32_t half) { outw[h] = (uint16_t)half; },

@@ -511,6 +511,21 @@ def test_gpu_decode_frames_all_kinds_in_one_launch(pkg, lref, oracle):
                          frame_scramb=None if tpsap == 0 else d_codes, type2=t2, crc_ok=ok, labels=lab))
     lb.decode_frames_device(d_fr, d_ft, jobs, F, bitnum, t_rx, t_af)
     torch.cuda.synchronize()
+    # the same launch with the caller's decision scratch instead of the library's pool, and an SB1-only launch (decisions in LDS, no scratch)
+    need = lb.decode_frames_workspace_bytes(jobs[:5])
+    assert need == 2 * sum((lref.BLK_PARAM[t][1] + 4) * 64 * ((n + 63) // 64) for t, _, _ in kinds[:5] if t != 3) and lb.decode_frames_workspace_bytes(jobs[5:]) == 0
+    again = [tuple(torch.full_like(x, 9) for x in o) for o in outs]
+    jobs2 = [dict(j, type2=o[0], crc_ok=o[1], labels=o[2]) for j, o in zip(jobs, again)]
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    lb.decode_frames_device(d_fr, d_ft, jobs2[:5], F, bitnum, t_rx, t_af, d_workspace=ws)
+    lb.decode_frames_device(d_fr, d_ft, jobs2[5:], F, bitnum, t_rx, t_af)
+    with pytest.raises(pkg.TetraDemodError):
+        lb.decode_frames_device(d_fr, d_ft, jobs2[:5], F, bitnum, t_rx, t_af, d_workspace=ws[: need - 256])       # TETRA_ERR_SIZE
+    torch.cuda.synchronize()
+    for (tpsap, blk, li), o, o2 in zip(kinds, outs, again):
+        cnt = want_lists[li].size
+        for x, y in zip(o, o2):
+            assert torch.equal(x[:cnt], y[:cnt]), (tpsap, blk)
     good = 0
     for (tpsap, blk, li), (t2, ok, lab) in zip(kinds, outs):
         rows = want_lists[li]
@@ -533,7 +548,7 @@ def test_gpu_decode_frames_all_kinds_in_one_launch(pkg, lref, oracle):
     # argument errors: statuses, not launches
     from ctypes import byref
     L = pkg.binding.load_library()
-    src = lb.Frames(d_fr.data_ptr(), d_ft.data_ptr(), n, F, None, None, None)
+    src = lb.Frames(d_fr.data_ptr(), d_ft.data_ptr(), n, F, None, None, None, None, 0)
     t2, ok, lab = outs[0]
     def one(**kw):
         base = dict(type=5, blk_num=0, d_row_frame=lists[1].data_ptr(), d_n_rows=None, max_rows=n, out_stride=296, d_frame_scramb=d_codes.data_ptr(),
@@ -561,15 +576,18 @@ def test_gpu_track_sync_lists_equals_the_slot_layout_tracker(pkg, lref):
     lb, bb = pkg.lmac_binding, pkg.bsync_binding
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(9)
-    C_, F = 37, 70
+    C_, F = 37, 150                                      # three 64-slot groups per channel, the last one ragged
     n = C_ * F
-    cell_a = torch.zeros((C_, 10), dtype=torch.int32, device=dev)
-    cell_b = torch.zeros((C_, 10), dtype=torch.int32, device=dev)
+    cell0 = np.zeros((C_, 10), np.int32)
+    cell0[7:20] = rng.integers(0, 70, (13, 10))          # arbitrary carried states (clock digits out of range): the wrap tests normalise them
+    cell0[20, 4:] = [100, 200, 500, 7, 36, 121]
+    cell_a = torch.from_numpy(cell0).to(dev)
+    cell_b = torch.from_numpy(cell0.copy()).to(dev)
     for call in range(2):
         types = rng.choice(np.array([0, 1, 3, 3, -1, -2], np.int32), n)
         types.reshape(C_, F)[5] = 0                                     # a channel without SYNC bursts
         nf = rng.integers(F - 6, F + 1, C_).astype(np.int32)
-        nf[3] = 0
+        nf[3], nf[4], nf[6] = 0, 64, 70
         sync = np.flatnonzero(types == 3)
         t2c = rng.integers(0, 2, (sync.size, 80), dtype=np.uint8)
         okc = (rng.random(sync.size) < 0.8).astype(np.int32)
