@@ -144,8 +144,7 @@ typedef struct tetra_lmac_job {
     tetra_lmac_label_t* d_labels;
 } tetra_lmac_job_t;
 int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_lmac_job_t* jobs, int n_jobs, void* hip_stream);
-/* Bytes of decision scratch a launch of these jobs needs (2 bytes per trellis step and row of max_rows; 0 for a launch of SB1 / AACH
- * jobs only, whose decisions stay in LDS).  A caller that hands the scratch in (d_workspace) saves the two stream-ordered pool
+/* Bytes of decision scratch a launch of these jobs needs (2 bytes per trellis step and row of max_rows; 0 for AACH jobs).  A caller that hands the scratch in (d_workspace) saves the two stream-ordered pool
  * operations around the launch -- the receive chain does. */
 size_t tetra_lmac_decode_frames_workspace_bytes(const tetra_lmac_job_t* jobs, int n_jobs);
 

@@ -1,0 +1,6 @@
+# quick GPU check: lmac / rx / bsync parity tests, then the chain leg twice
+TAG=${1:-r06x}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O; cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_lmac.py tests/test_rx.py tests/test_burst_sync.py -x -q -m gpu > $O/pytest.log 2>&1; tail -2 $O/pytest.log
+for i in 1 2; do timeout 300 python bench.py --chain-only > $O/chain_$i.json 2>> $O/chain.err; python -c "
+import json
+d=json.load(open('$O/chain_$i.json')); print(d['two_streams_ms_per_second'], d['one_stream_ms_per_second'], d['tail_ms_one_stream'], {k:v['ms'] for k,v in d['stages_one_stream'].items()})"; done

@@ -259,11 +259,15 @@ __global__ __launch_bounds__(256) void k_index_count(const int* __restrict__ fra
         if (threadIdx.x == 0) work[k * nblocks + blockIdx.x] = c;
     }
 }
-// 2. exclusive scan of each list's block counts (one workgroup: a run of blocks per thread, shuffles within a wavefront, one
-//    exchange between the 16 wavefronts), totals -> counts
-__global__ __launch_bounds__(1024) void k_index_scan(int* __restrict__ work, int nblocks, int* __restrict__ counts) {
-    __shared__ int wave_sum[TETRA_N_LISTS][16];
-    const int per = (nblocks + 1023) / 1024;
+// 2. exclusive scan of each list's block counts, totals -> counts.  One workgroup of FOUR wavefronts (a run of blocks per thread,
+//    shuffles within a wavefront, one exchange between the four): a workgroup has to find ONE compute unit with room for all its
+//    waves, and beside the demodulator -- whose 199-register waves leave 112 registers on two of a CU's four SIMDs -- the
+//    1024-thread form of this kernel (four waves of 32 registers per SIMD) found none until the demodulator's launch was over: the
+//    tail of the receive chain then ran BEHIND the demodulator it was meant to overlap (two-stream chain 4.17 instead of 3.98 ms).
+constexpr int kScanThreads = 256;
+__global__ __launch_bounds__(kScanThreads) void k_index_scan(int* __restrict__ work, int nblocks, int* __restrict__ counts) {
+    __shared__ int wave_sum[TETRA_N_LISTS][kScanThreads / 64];
+    const int per = (nblocks + kScanThreads - 1) / kScanThreads;
     const int lo = threadIdx.x * per, hi = min(nblocks, lo + per);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int sum[TETRA_N_LISTS], inc[TETRA_N_LISTS];
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_index_scan(int* __restrict__ work, int
         int run = inc[k] - sum[k];
         for (int i = 0; i < w; ++i) run += wave_sum[k][i];
         for (int i = lo; i < hi; ++i) { const int c = work[k * nblocks + i]; work[k * nblocks + i] = run; run += c; }
-        if (threadIdx.x == 1023) counts[k] = run;
+        if (threadIdx.x == kScanThreads - 1) counts[k] = run;
     }
 }
 // 3. the lists themselves, and per channel the position of its first entry
@@ -545,7 +549,7 @@ int tetra_burst_index_device(const int32_t* d_frame_type, int n, int frames_per_
     if (n == 0) return hipMemsetAsync(d_counts, 0, sizeof(int32_t) * TETRA_N_LISTS, s) == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
     const int nblocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_index_count, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, nblocks, d_work);
-    hipLaunchKernelGGL(k_index_scan, dim3(1), dim3(1024), 0, s, d_work, nblocks, d_counts);
+    hipLaunchKernelGGL(k_index_scan, dim3(1), dim3(kScanThreads), 0, s, d_work, nblocks, d_counts);
     hipLaunchKernelGGL(k_index_write, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, nblocks, d_chan_first ? frames_per_channel : 1, d_work,
                        d_lists, d_chan_first);
     return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;

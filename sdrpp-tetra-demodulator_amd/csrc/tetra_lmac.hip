@@ -227,15 +227,19 @@ struct JobTable {
     DevFrames src;
     int n;
 };
-// DEC_LDS: the decisions of the launch's blocks fit LDS (kDecLdsPairs step pairs: a launch of SB1 blocks) -- no scratch round trip,
-// for launches that are too small to hide it behind other waves
-constexpr int kDecLdsPairs = 44;
-template <bool DEC_LDS>
+// LDS per workgroup: 3584 (type-4 bits; the decoded halves reuse the space once the forward recursion is through with them) + 1024
+// (backward CRC table) = 4608 B <= 5120: LDS never caps the kernel below 8 waves per SIMD -- which matters beside the demodulator:
+// the compiler sizes a kernel's register allocation for the occupancy its LDS allows (6992 B -> 6 waves -> 80 registers where 54 are
+// used), and next to k_fused's 199-register waves every 8 registers decide how many of this kernel's waves fit a SIMD.
 __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint32_t* __restrict__ dec_scratch,
                                                         const uint32_t* __restrict__ seq_tab) {
-    __shared__ uint32_t dec_lds[DEC_LDS ? kDecLdsPairs : 1][kLanes];
-    __shared__ uint32_t cls[kSeqWords][kLanes];
-    __shared__ OutW outw;
+    __shared__ union {
+        uint32_t cls[kSeqWords][kLanes];
+        OutW outw;
+    } sm;
+    static_assert(sizeof(OutW) <= sizeof(uint32_t) * kSeqWords * kLanes, "the decoded halves fit the type-4 words' space");
+    uint32_t (&cls)[kSeqWords][kLanes] = sm.cls;
+    OutW& outw = sm.outw;
     __shared__ uint32_t crc_inv[256];
     const int lane = threadIdx.x;
     int ji = 0;
@@ -280,14 +284,9 @@ __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint
         descramble_to_lds(J.type345, code, xb, seq_tab, cls, lane);
         load_crc_inv(crc_inv, lane);
         __syncthreads();
-        if (DEC_LDS) {
-            good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, [&](int u, uint32_t w) { dec_lds[u][lane] = w; },
-                                     [&](int u) { return dec_lds[u][lane]; });
-        } else {
-            uint32_t* dec = dec_scratch + J.scratch_base + (size_t)group * J.dec_pairs * kLanes + lane;
-            good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, [&](int u, uint32_t w) { dec[u * kLanes] = w; },
-                                     [&](int u) { return dec[u * kLanes]; });
-        }
+        uint32_t* dec = dec_scratch + J.scratch_base + (size_t)group * J.dec_pairs * kLanes + lane;
+        good = decode_core<true>(cls, outw, crc_inv, lane, J.type345, J.type2, J.a, [&](int u, uint32_t w) { dec[u * kLanes] = w; },
+                                 [&](int u) { return dec[u * kLanes]; });
     }
     if (blk < n_blocks) {
         J.crc_ok[blk] = good;
@@ -692,10 +691,6 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uint32_t* seq = seq_table();
     if (!seq) return TETRA_ERR_NOMEM;
-    if (max_pairs <= kDecLdsPairs) {                      // short blocks only (an SB1 launch): decisions in LDS
-        hipLaunchKernelGGL(k_lmac_frames<true>, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, nullptr, seq);
-        return hipGetLastError() == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
-    }
     const size_t bytes = (size_t)scratch_words * sizeof(uint32_t);
     uint32_t* scratch = nullptr;
     bool pooled = false;
@@ -712,7 +707,7 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
             pooled = true;
         }
     }
-    hipLaunchKernelGGL(k_lmac_frames<false>, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, scratch, seq);
+    hipLaunchKernelGGL(k_lmac_frames, dim3((unsigned)groups_total), dim3(kLanes), 0, s, tab, scratch, seq);
     const hipError_t launch = hipGetLastError();
     if ((pooled && hipFreeAsync(scratch, s) != hipSuccess) || launch != hipSuccess) return TETRA_ERR_HIP;
     return TETRA_OK;
@@ -721,15 +716,12 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
 size_t tetra_lmac_decode_frames_workspace_bytes(const tetra_lmac_job_t* jobs, int n_jobs) {
     if (!jobs || n_jobs < 0) return 0;
     size_t words = 0;
-    int max_pairs = 0;
     for (int i = 0; i < n_jobs; ++i) {
         const tetra_lmac_job_t& j = jobs[i];
         if (j.type < 0 || j.type > 5 || j.type == TETRA_TPSAP_T_BBK || j.max_rows <= 0) continue;
-        const int pairs = (kBlk[j.type].type2 + kFlush) / 2;
-        max_pairs = pairs > max_pairs ? pairs : max_pairs;
-        words += (size_t)(((long long)j.max_rows + kLanes - 1) / kLanes) * pairs * kLanes;
+        words += (size_t)(((long long)j.max_rows + kLanes - 1) / kLanes) * ((kBlk[j.type].type2 + kFlush) / 2) * kLanes;
     }
-    return max_pairs <= kDecLdsPairs ? 0 : words * sizeof(uint32_t);
+    return words * sizeof(uint32_t);
 }
 
 int tetra_lmac_debug_force_byte_route(int on) {

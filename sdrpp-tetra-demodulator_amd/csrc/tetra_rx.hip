@@ -248,12 +248,16 @@ int tetra_rx_create(const tetra_rx_config_t* cfg, tetra_rx_t** out) {
          dalloc(h->chan_first, (size_t)TETRA_N_LISTS * h->C) && dalloc(h->index_work, (size_t)TETRA_N_LISTS * ((n + 255) / 256)) &&
          dalloc(h->row_scramb, n) && dalloc(h->row_time_rx, n) && dalloc(h->row_time, n) && dalloc(h->cell, (size_t)h->C);
     for (auto& e : h->ev_stage) ok = ok && hipEventCreate(&e) == hipSuccess;
-    if (ok) {      // the decision scratch of the second decode launch, sized for the worst case (every frame slot a row of every kind)
+    if (ok) {      // the decision scratch of the two decode launches (they run one after the other), sized for the worst case (every frame slot a row of every kind)
         tetra_lmac_job_t jobs[TETRA_RX_N_KINDS] = {};
         int nj = 0;
         for (int k : kJobOrder)
             if (h->kinds & (1 << k)) { jobs[nj].type = kKinds[k].tpsap; jobs[nj].blk_num = kKinds[k].blk; jobs[nj].max_rows = h->rows; nj++; }
         h->lmac_ws_bytes = tetra_lmac_decode_frames_workspace_bytes(jobs, nj);
+        tetra_lmac_job_t sb1 = {};
+        sb1.type = TETRA_TPSAP_T_SB1; sb1.blk_num = 1; sb1.max_rows = h->rows;
+        const size_t sb1_bytes = tetra_lmac_decode_frames_workspace_bytes(&sb1, 1);
+        h->lmac_ws_bytes = sb1_bytes > h->lmac_ws_bytes ? sb1_bytes : h->lmac_ws_bytes;
         ok = h->lmac_ws_bytes == 0 || hipMalloc(&h->lmac_ws, h->lmac_ws_bytes) == hipSuccess;
     }
     rc = ok ? zero_results(h) : TETRA_ERR_NOMEM;
