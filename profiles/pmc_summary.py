@@ -87,7 +87,7 @@ def main(prof, out, tag, C=4096, N=36000):
     with open(os.path.join(out, "pmc_traffic_fused_%dx%d.json" % (C, N)), "w") as f:
         json.dump(d, f, indent=1)
     with open(os.path.join(out, tag + "_rocprof_summary.md"), "w") as f:
-        f.write("# %s: rocprofv3 summary of `python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-large-batch --no-config5 --no-time-major --channels %d`\n\n" % (tag, C))
+        f.write("# %s: rocprofv3 summary of `python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-large-batch --no-config5 --no-time-major --no-chain --channels %d`\n\n" % (tag, C))
         f.write("kernel sources sha256 `%s`\n\n" % d["kernel_source_sha256"])
         f.write("## --kernel-trace --stats (top rows; full table in %s_kernel_stats.csv)\n\n| kernel | calls | avg ms | %% |\n|---|---|---|---|\n" % tag)
         for row in stats_rows[:6]:

@@ -8,7 +8,7 @@ CH=${2:-4096}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof
 rm -rf $O && mkdir -p $O $GRAFT_REPO_ROOT/gpurun_out/prof_out
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-large-batch --no-config5 --no-time-major --channels $CH"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-check --no-host-path --no-large-batch --no-config5 --no-time-major --no-chain --channels $CH"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r02 -- $B > $O/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o r02 -- $B > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o r02 -- $B > $O/pmc_write.log 2>&1
