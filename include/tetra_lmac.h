@@ -205,12 +205,12 @@ int tetra_lmac_track_sync_device(const uint8_t* d_sb1_type2, int type2_stride, c
 /*
  * The same read-out for SB1 rows that are COMPACT (round 6): d_sb1_type2 / d_crc_ok hold one row per entry of the SYNC list of
  * tetra_burst_index_device (decoded by tetra_lmac_decode_frames_device), d_chan_first_sync[c] is the position in that list of
- * channel c's first entry, and a frame slot is a SYNC burst where d_frame_type says so.  One wavefront per channel reads the
- * channel's rows side by side and walks the frame slots from LDS (the slot-layout form above walks HBM: a dependent load per
- * slot).  Outputs as above; with d_sb1_labels != NULL (needs d_frame_bitnum) also the label of every SB1 row, which the decode
- * launch cannot write because the times come from here.  frames_per_channel <= TETRA_LMAC_TRACK_MAX_FRAMES (TETRA_ERR_SIZE).
+ * channel c's first entry, and a frame slot is a SYNC burst where d_frame_type says so.  One wavefront per channel, a frame slot
+ * per lane, no walk over the slots: the last SYNC frame before a slot and the last one with a good CRC are found with two ballots,
+ * their fields fetched by lane shuffle, and the clock k slots after it was set is one literal tetra_tdma_time_add_tn step plus
+ * k - 1 in closed form (the slot-layout form above walks HBM: a dependent load per slot).  Outputs as above; with d_sb1_labels != NULL (needs d_frame_bitnum) also the label of every SB1 row, which the decode
+ * launch cannot write because the times come from here.  Any frames_per_channel (64 slots at a time, the state carried in between).
  */
-#define TETRA_LMAC_TRACK_MAX_FRAMES 2048
 int tetra_lmac_track_sync_lists_device(const uint8_t* d_sb1_type2, int type2_stride, const int32_t* d_crc_ok, const int32_t* d_frame_type,
                                        const int32_t* d_n_frames, const int32_t* d_chan_first_sync, int n_channels, int frames_per_channel,
                                        tetra_lmac_cell_state_t* d_cell, uint32_t* d_row_scramb, uint32_t* d_row_time_rx, uint32_t* d_row_time,

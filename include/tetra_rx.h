@@ -92,9 +92,7 @@ int tetra_rx_process(tetra_rx_t* h, const float* iq, int n_samples);
 /* Blocks until everything enqueued has run.  TETRA_ERR_OVERRUN if the demodulator cut a channel off (tetra_demod.h). */
 int tetra_rx_wait(tetra_rx_t* h);
 
-/* Upper bound of the rows a fetch of one kind can return: n_channels x frames per call ((4096 + bits per call) / 510 + 2).
- * (tetra_rx_create refuses configurations with more than TETRA_LMAC_TRACK_MAX_FRAMES = 2048 frames per channel and call -- about
- * 29 s of signal per call -- with TETRA_ERR_SIZE.) */
+/* Upper bound of the rows a fetch of one kind can return: n_channels x frames per call ((4096 + bits per call) / 510 + 2). */
 int tetra_rx_max_rows(tetra_rx_t* h);
 /* type-1 bits per block of a kind (60 / 30 / 124 / 124 / 124 / 268); < 0: TETRA_ERR_ARG. */
 int tetra_rx_type1_bits(int kind);

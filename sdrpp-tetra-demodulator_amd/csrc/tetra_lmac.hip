@@ -758,7 +758,6 @@ int tetra_lmac_track_sync_lists_device(const uint8_t* d_sb1_type2, int type2_str
     if (!d_sb1_type2 || !d_crc_ok || !d_frame_type || !d_chan_first_sync || !d_cell || !d_row_scramb) return TETRA_ERR_ARG;
     if (n_channels < 1 || frames_per_channel < 0 || type2_stride < 60 || (d_sb1_labels && !d_frame_bitnum)) return TETRA_ERR_ARG;
     if ((type2_stride & 3) || ((uintptr_t)d_sb1_type2 & 3)) return TETRA_ERR_ALIGN;
-    if (frames_per_channel > TETRA_LMAC_TRACK_MAX_FRAMES) return TETRA_ERR_SIZE;
     if (frames_per_channel == 0) return TETRA_OK;
     hipLaunchKernelGGL(k_track_sync_lists, dim3(n_channels), dim3(kLanes), 0, static_cast<hipStream_t>(hip_stream), d_sb1_type2, type2_stride, d_crc_ok, d_frame_type, d_n_frames, d_chan_first_sync,
                        frames_per_channel, d_cell, d_row_scramb, d_row_time_rx, d_row_time, d_frame_bitnum, d_sb1_labels);

@@ -228,7 +228,7 @@ int tetra_rx_create(const tetra_rx_config_t* cfg, tetra_rx_t** out) {
     if (rc != TETRA_OK) { free_all(h); delete h; return rc; }
     h->F = tetra_bsync_max_frames(h->bs);
     const long long rows = (long long)h->C * h->F;
-    if (rows > 0x7fffffffLL / 512 || h->F > TETRA_LMAC_TRACK_MAX_FRAMES) { free_all(h); delete h; return TETRA_ERR_SIZE; }      // 32-bit row / byte indices downstream
+    if (rows > 0x7fffffffLL / 512) { free_all(h); delete h; return TETRA_ERR_SIZE; }      // 32-bit row / byte indices downstream
     h->rows = (int)rows;
     const size_t n = (size_t)rows;
     bool ok = hipStreamCreateWithFlags(&h->tail, hipStreamNonBlocking) == hipSuccess;

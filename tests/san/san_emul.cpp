@@ -12,6 +12,11 @@ extern "C" int bsync_emul_demux(const uint8_t* frames, int packed, const int32_t
                                 int row_stride, int32_t* valid);
 extern "C" int bsync_emul_demux_compact(const uint8_t* frames, int packed, const int32_t* frame_type, int n, int tpsap, int blk_num,
                                         uint8_t* rows, int row_stride, int32_t* row_frame, int32_t* n_rows);
+// the lower-MAC decoder's lane code (lmac_core.hpp through tests/emul/lmac_emul.cpp): byte rows (both front ends) and straight from packed frames
+extern "C" int lmac_emul_decode_route(int type345, int type2, int type1, int a, const uint8_t* type5, int n_blocks, int in_stride,
+                                      const uint32_t* scramb_init, uint8_t* out, int out_stride, int32_t* crc_ok, int route, int32_t* fast_rows);
+extern "C" int lmac_emul_decode_frames(int tpsap, int blk_num, const uint32_t* frames, const int32_t* frame_type, const int32_t* row_frame,
+                                       int n_rows, const uint32_t* frame_scramb, uint8_t* out, int out_stride, int32_t* crc_ok);
 #define TETRA_HOST_EMUL 1
 #include "../../sdrpp-tetra-demodulator_amd/csrc/constellation_core.hpp"
 
@@ -76,6 +81,39 @@ int main() {
             if (fill != (int)(total % 1024) || blocks != (int)(total / 1024)) return 5;
         }
     }
-    std::printf("san_emul: ok (%lld demultiplexer launches)\n", launches);
+    // the decoder: exact-size rows / frames / outputs; plain bits (packed front end), arbitrary bytes (byte route), frames of every type
+    long long blocks = 0;
+    {
+        const int prm[5][4] = { { 120, 80, 60, 11 }, { 216, 144, 124, 101 }, { 168, 112, 92, 13 }, { 432, 288, 268, 103 }, { 216, 144, 124, 101 } };
+        for (int k = 0; k < 5; k++)
+            for (int route = 0; route < 2; route++)
+                for (int mode = 0; mode < 2; mode++) {
+                    const int n = 37, stride = prm[k][0];
+                    std::vector<uint8_t> rows((size_t)n * stride), out((size_t)n * prm[k][1]);
+                    std::vector<uint32_t> code((size_t)n);
+                    std::vector<int32_t> ok((size_t)n);
+                    for (auto& v : rows) v = mode ? (uint8_t)(lcg(seed) & 0xffu) : (uint8_t)(lcg(seed) & 1u);
+                    for (auto& v : code) v = lcg(seed) * 2654435761u;
+                    int32_t fast = -1;
+                    if (lmac_emul_decode_route(prm[k][0], prm[k][1], prm[k][2], prm[k][3], rows.data(), n, stride, code.data(), out.data(), prm[k][1],
+                                               ok.data(), route, &fast) != 0) return 6;
+                    blocks += n;
+                }
+        const int fk[6][3] = { { 0, 1, 80 }, { 1, 2, 144 }, { 2, 1, 144 }, { 2, 2, 144 }, { 5, 0, 288 }, { 3, 0, 32 } };
+        const int nfr = 200;
+        std::vector<uint32_t> fr((size_t)nfr * 16), code((size_t)nfr);
+        std::vector<int32_t> ft((size_t)nfr), list((size_t)nfr);
+        for (auto& v : fr) v = lcg(seed) * 2654435761u;
+        for (auto& v : code) v = lcg(seed) * 2246822519u;
+        for (int i = 0; i < nfr; i++) { ft[i] = (int32_t)(lcg(seed) % 7u) - 2; list[i] = (int32_t)(lcg(seed) % (unsigned)nfr); }
+        for (int k = 0; k < 6; k++) {
+            std::vector<uint8_t> out((size_t)nfr * fk[k][2]);
+            std::vector<int32_t> ok((size_t)nfr);
+            if (lmac_emul_decode_frames(fk[k][0], fk[k][1], fr.data(), ft.data(), list.data(), nfr, fk[k][0] == 0 ? nullptr : code.data(), out.data(), fk[k][2],
+                                        ok.data()) != 0) return 7;
+            blocks += nfr;
+        }
+    }
+    std::printf("san_emul: ok (%lld demultiplexer launches, %lld decoder blocks)\n", launches, blocks);
     return 0;
 }

@@ -31,12 +31,13 @@ def test_oracles_are_clean_under_asan_and_ubsan():
 
 
 def test_kernel_thread_code_is_clean_under_asan_and_ubsan():
-    """The bit-moving thread-level code of the demultiplexer kernels (csrc/demux_core.hpp) and of the constellation tap
-    (csrc/constellation_core.hpp), host builds, every thread of every launch on exact-size heap buffers."""
+    """The bit-moving thread-level code of the demultiplexer kernels (csrc/demux_core.hpp), of the constellation tap
+    (csrc/constellation_core.hpp) and -- round 6 -- the lower-MAC decoder's lane code (csrc/lmac_core.hpp: byte rows through both front
+    ends, blocks cut straight from packed frames of every burst type), host builds, on exact-size heap buffers."""
     exe = os.path.join(SAN, "san_emul")
     emul = os.path.join(ROOT, "tests", "emul")
-    srcs = [os.path.join(SAN, "san_emul.cpp"), os.path.join(emul, "bsync_emul.cpp")]
-    deps = srcs + [os.path.join(PK, "csrc", f) for f in ("demux_core.hpp", "bsync_core.hpp", "constellation_core.hpp")]
+    srcs = [os.path.join(SAN, "san_emul.cpp"), os.path.join(emul, "bsync_emul.cpp"), os.path.join(emul, "lmac_emul.cpp")]
+    deps = srcs + [os.path.join(PK, "csrc", f) for f in ("demux_core.hpp", "bsync_core.hpp", "constellation_core.hpp", "lmac_core.hpp")]
     if _stale(exe, deps):
         subprocess.run(["g++", "-std=c++17", "-Wall"] + FLAGS + srcs + ["-o", exe], check=True)
     r = subprocess.run([exe], env=ENV, capture_output=True, text=True, timeout=600)
