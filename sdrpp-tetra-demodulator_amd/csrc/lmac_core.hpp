@@ -249,6 +249,9 @@ LM_FN uint32_t pk_bits(Pk a) { return __builtin_bit_cast(uint32_t, a); }
 LM_FN Pk pk_from_bits(uint32_t v) { return __builtin_bit_cast(Pk, v); }
 // v_perm_b32: byte k of the result = byte sel[k] of the eight bytes { hi (7..4), lo (3..0) }
 LM_FN uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// bits of a where keep is set, bits of b elsewhere -- as v_bitop3_b32 (truth table 0xe4), which issues at twice the rate of the
+// v_bfi_b32 the compiler picks for the same expression (profiles/r06/r06_o_int_rate.jsonl)
+LM_FN uint32_t select_bits(uint32_t a, uint32_t b, uint32_t keep) { return __builtin_amdgcn_bitop3_b32(a, b, keep, 0xe4); }
 #else
 struct Pk { int16_t x, y; };
 LM_FN Pk pk_make(int lo, int hi) { return Pk{ (int16_t)lo, (int16_t)hi }; }
@@ -260,6 +263,7 @@ LM_FN Pk pk_hi2(Pk x) { return Pk{ x.y, x.y }; }
 LM_FN Pk pk_swap(Pk x) { return Pk{ x.y, x.x }; }
 LM_FN uint32_t pk_bits(Pk a) { return (uint32_t)(uint16_t)a.x | ((uint32_t)(uint16_t)a.y << 16); }
 LM_FN Pk pk_from_bits(uint32_t v) { return Pk{ (int16_t)(v & 0xffffu), (int16_t)(v >> 16) }; }
+LM_FN uint32_t select_bits(uint32_t a, uint32_t b, uint32_t keep) { return (a & keep) | (b & ~keep); }
 LM_FN uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
     const uint64_t all = ((uint64_t)hi << 32) | lo;
     uint32_t r = 0;
@@ -302,8 +306,8 @@ LM_FN uint32_t decision_word(const Pk De[8], const Pk Do[8]) {
         const uint32_t pe = perm_b32(pk_bits(De[k]), pk_bits(De[k + 4]), 0x05010703u);
         const uint32_t po = perm_b32(pk_bits(Do[k]), pk_bits(Do[k + 4]), 0x05010703u);
         const uint32_t keep_e = 0x01010101u * (0xffu & ~(0xffu >> (2 * k))), keep_o = 0x01010101u * (0xffu & ~(0xffu >> (2 * k + 1)));
-        w = (w & keep_e) | ((pe >> (2 * k)) & ~keep_e);          // bits 7 - 2k and below of every byte from pe (below: overwritten next)
-        w = (w & keep_o) | ((po >> (2 * k + 1)) & ~keep_o);
+        w = select_bits(w, pe >> (2 * k), keep_e);          // bits 7 - 2k and below of every byte from pe (below: overwritten next)
+        w = select_bits(w, po >> (2 * k + 1), keep_o);
     }
     return w;
 }
