@@ -196,6 +196,16 @@ int main(void) {
     /* ABI 6: the constellation tap */
     { float z[2]; int32_t nb; if (tetra_demod_get_constellation(NULL, 0, 1, z, &nb) != TETRA_ERR_ARG) return 24;
       if (TETRA_CONSTELLATION_SYMBOLS != 1024 || TETRA_FLAG_CONSTELLATION != 256) return 25; }
+    /* round 6: frame lists, decoding straight from packed frames, the list tracker, integer captures, the chain handle -- arguments first */
+    { tetra_lmac_frames_t fr = { 0 }; tetra_lmac_job_t job = { 0 };
+      if (tetra_burst_index_device(NULL, 8, 4, NULL, NULL, NULL, NULL, NULL) != TETRA_ERR_ARG) return 26;
+      if (tetra_lmac_decode_frames_device(NULL, &job, 1, NULL) != TETRA_ERR_ARG || tetra_lmac_decode_frames_device(&fr, &job, 9, NULL) != TETRA_ERR_ARG) return 27;
+      if (tetra_lmac_decode_frames_device(&fr, &job, 0, NULL) != TETRA_OK) return 28;
+      job.type = TETRA_TPSAP_T_SCH_F; job.max_rows = 640;
+      if (tetra_lmac_decode_frames_workspace_bytes(&job, 1) != (size_t)10 * 146 * 64 * 4 || tetra_lmac_decode_frames_workspace_bytes(NULL, 1) != 0) return 29;
+      if (tetra_lmac_track_sync_lists_device(NULL, 80, NULL, NULL, NULL, NULL, 1, 4, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != TETRA_ERR_ARG) return 30;
+      if (tetra_chan_process_device_cs16(NULL, NULL, 0, NULL, NULL, NULL) != TETRA_ERR_ARG || tetra_chan_process_device_cs8(NULL, NULL, 0, NULL, NULL, NULL) != TETRA_ERR_ARG) return 31;
+      if (sizeof(tetra_lmac_label_t) != 24 || TETRA_N_LISTS != 4 || TETRA_LMAC_MAX_JOBS != 8) return 32; }
     printf("%d %d %d\\n", (int)cfg.rrc_tap_count, (int)cc.n_channels, tetra_demod_abi_version());
     return 0;
 }
