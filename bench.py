@@ -417,8 +417,11 @@ def receive_chain(args, torch, pkg, device, local_rank, C=CHANNELS_PER_GPU, N=SA
                 by_time[tn | fn << 8 | mn << 16] = sl
             counters, rows_k = {}, {}
             bad = 0
+            t_fetch = 0.0
             for k, nm in names.items():
+                tf = time.perf_counter()
                 blocks, t1 = rx.fetch(k)
+                t_fetch += time.perf_counter() - tf
                 rows_k[k] = len(blocks)
                 good = int((blocks["crc_ok"] != 0).sum())
                 sel = np.nonzero(blocks["channel"] < CHAIN_DISTINCT)[0]
@@ -435,6 +438,10 @@ def receive_chain(args, torch, pkg, device, local_rank, C=CHANNELS_PER_GPU, N=SA
             if bad or cellok != C or locked != C:
                 raise SystemExit("receive chain known-answer check failed: %s" % json.dumps(res["check"]))
             res["rows_per_kind"] = {names[k]: v for k, v in rows_k.items()}
+            # informational, PCIe-inclusive: every block of the call fetched to host memory through tetra_rx_fetch (labels + type-1 bits, one
+            # byte per bit as the reference's upper MAC takes them; pageable numpy buffers, one kind after the other, nothing overlapped)
+            res["host_fetch_all_kinds_ms"] = round(t_fetch * 1e3, 2)
+            res["host_fetch_bytes"] = int(sum(rows_k[k] * (24 + pkg.rx_binding.type1_bits(k)) for k in rows_k))
         rx.close()
     # Rooflines of the one-stream run's stages (round 6 chain: no byte rows between the stages).  Bytes: demodulator 9 B per sample;
     # synchroniser = the bit rows it scans + 64 B per packed frame + 8 B per frame slot; SB1 stage = the frame-list pass (frame types

@@ -101,7 +101,8 @@ int tetra_rx_type1_bits(int kind);
  * order.  Waits for that call's tail (only).
  *   blocks   [capacity] host, may be NULL
  *   type1    [capacity][type1_stride] uint8 host, one bit per byte, tetra_rx_type1_bits(kind) per row, may be NULL;
- *            type1_stride >= that count or TETRA_ERR_SIZE
+ *            type1_stride >= that count or TETRA_ERR_SIZE.  Contiguous rows (type1_stride == the count) are packed on the device and
+ *            come over in ONE copy; any other stride is a strided device-to-host copy, orders of magnitude slower for 10^5 rows
  *   *n_rows  rows available; more than capacity: TETRA_ERR_SIZE and nothing is copied (call again with room for *n_rows)
  * A kind that the configuration does not decode: TETRA_ERR_UNSUPPORTED.  Before the first call / which = 1 before the second: 0 rows.
  */

@@ -272,6 +272,35 @@ def test_gpu_rx_streaming_calls_overlap_and_equal_one_call(pkg, synth):
     rx.close()
 
 
+@pytest.mark.gpu
+def test_gpu_rx_time_major_frames_equal_channel_major(pkg, synth):
+    """The chain behind the channeliser / resampler: the same signals handed over as time-major frames [sample][channel]
+    (TETRA_LAYOUT_TIME_MAJOR, what tetra_chan / tetra_resamp emit) give exactly the blocks, labels and cell states of the
+    channel-major handle."""
+    import torch
+    R = pkg.rx_binding
+    Cn, nslots = 6, 40
+    N = nslots * 510
+    cells, tx, iq = _downlink_batch(synth, Cn, nslots, N, 7100)
+    a = pkg.RxChain(Cn, N)
+    a.process(iq)
+    a.wait()
+    want = _collect(a, R)
+    want_cell = [tuple(getattr(c, f) for f, _ in R.CellState._fields_) for c in a.cells()]
+    a.close()
+    dev = torch.device("cuda", 0)
+    d_tm = torch.from_numpy(np.ascontiguousarray(iq.T)).to(dev)            # [N][C]
+    b = pkg.RxChain(Cn, N, layout=pkg.binding.LAYOUT_TIME_MAJOR)
+    b.process_device(d_tm, N, torch.cuda.current_stream(dev))
+    b.wait()
+    got = _collect(b, R)
+    assert sum(len(v) for v in want.values()) > 100
+    for k in want:
+        assert got[k] == want[k], k
+    assert [tuple(getattr(c, f) for f, _ in R.CellState._fields_) for c in b.cells()] == want_cell
+    b.close()
+
+
 def _collect_kind(rx, R, k):
     blocks, t1 = rx.fetch(k)
     return [(int(b["channel"]), int(b["bitnum"]), int(b["crc_ok"]), int(b["tdma_time_rx"]), int(b["tdma_time"]), t1[j].tobytes())
