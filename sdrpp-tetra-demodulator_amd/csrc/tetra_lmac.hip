@@ -788,7 +788,9 @@ int tetra_lmac_decode_batch(int type, const uint8_t* type5, int n_blocks, int in
         if (krc != TETRA_OK) { rc = krc; break; }
         if (hipDeviceSynchronize() != hipSuccess) break;
         // only the type2_bits columns: the caller's row padding is left alone
-        if (hipMemcpy2D(type2, out_stride, d_out, out_stride, kBlk[type].type2, n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
+        // (rows without padding: one contiguous copy -- a strided device-to-host copy of many narrow rows crawls)
+        if (out_stride == kBlk[type].type2 ? hipMemcpy(type2, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess
+                                           : hipMemcpy2D(type2, out_stride, d_out, out_stride, kBlk[type].type2, n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
         if (hipMemcpy(crc_ok, d_ok, sizeof(int32_t) * n_blocks, hipMemcpyDeviceToHost) != hipSuccess) break;
         rc = TETRA_OK;
     } while (false);
