@@ -92,7 +92,9 @@ int tetra_rx_process(tetra_rx_t* h, const float* iq, int n_samples);
 /* Blocks until everything enqueued has run.  TETRA_ERR_OVERRUN if the demodulator cut a channel off (tetra_demod.h). */
 int tetra_rx_wait(tetra_rx_t* h);
 
-/* Upper bound of the rows a fetch of one kind can return: n_channels x frames per call ((4096 + bits per call) / 510 + 2). */
+/* Upper bound of the rows a fetch of one kind can return: n_channels x frames per call ((4096 + bits per call) / 510 + 2).  Device
+ * memory of a handle: about 5 KB per such row with every kind enabled (results and labels of two calls, the decoder's decision scratch,
+ * frames, the two bit-row buffers): 1.4 GB for 4096 channels x 36000 samples per call. */
 int tetra_rx_max_rows(tetra_rx_t* h);
 /* type-1 bits per block of a kind (60 / 30 / 124 / 124 / 124 / 268); < 0: TETRA_ERR_ARG. */
 int tetra_rx_type1_bits(int kind);
