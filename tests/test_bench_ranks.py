@@ -109,3 +109,26 @@ def test_bench_under_the_driver_s_own_launcher():
     assert d["functional_only"] == (torch.cuda.device_count() < 2)
     # 256 channels per rank from their own seeds at 25 dB: a few true channel errors among millions of bits (bench.py's own bound)
     assert d["check"]["bit_errors"] <= 1e-3 * d["check"]["bits_compared_last_quarter"]
+
+
+def test_chain_leg_known_answer_at_full_size():
+    """The receive chain at BASELINE's size through the one property that does not need the reference beside it: 4096 channels x 36000
+    samples of CODED downlinks (the reference's encoder chain restated in synth.gen_downlink, pinned on the reference's own encoder
+    by tests/test_synth_tx.py) -> tetra_rx -> every one of the ~651 000 blocks of the checked call has a good CRC, every block of
+    the 64 distinct streams carries exactly the type-1 bits sent in the slot its TDMA label names, every channel is locked and reads
+    its cell -- on two streams and on one (`bench.py --chain-only` fails the run otherwise; the counters are asserted here too)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--chain-only"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(d, open(os.path.join(OUT, "bench_chain_only.json"), "w"))
+    ck = d["check"]
+    assert ck["channels"] == 4096 and ck["channels_locked"] == 4096 and ck["cells_read"] == 4096
+    total = 0
+    for nm, c in ck["blocks"].items():
+        assert c["rows"] == c["crc_good"] > 60000 and c["checked_rows"] == c["type1_bits_and_tdma_slot_exact"] > 1000, (nm, c)
+        total += c["rows"]
+    assert total > 600000 and d["rows_per_kind"]["schf"] == ck["blocks"]["schf"]["rows"]
+    assert 3.5 < d["two_streams_ms_per_second"] < d["one_stream_ms_per_second"] * 1.02 < 6.0        # sanity: not a timing claim
+    assert set(d["stages_one_stream"]) == {"demodulator", "burst_sync", "frame_lists_sb1_decode_track", "other_kinds_decode_label"}
