@@ -150,7 +150,7 @@ def index_device(d_frame_type, frames_per_channel, d_lists, d_counts, d_chan_fir
     if d_work is None:
         d_work = torch.empty(N_LISTS * ((n + 255) // 256) + 1, dtype=torch.int32, device=d_frame_type.device)
     vp = C.c_void_p
-    rc = _lib().tetra_burst_index_device(vp(d_frame_type.data_ptr()), n, int(frames_per_channel), vp(d_lists.data_ptr()), vp(d_counts.data_ptr()),
+    rc = _lib().tetra_burst_index_device(vp(d_frame_type.data_ptr()), n, int(frames_per_channel), vp(d_lists.data_ptr()), vp(d_counts.data_ptr()),  # (empty tensors: NULL)
                                          None if d_chan_first is None else vp(d_chan_first.data_ptr()), vp(d_work.data_ptr()), _stream(stream))
     if rc:
         raise TetraDemodError(rc, "tetra_burst_index_device")

@@ -543,10 +543,11 @@ int tetra_burst_demux_compact_packed_device(const uint32_t* d_frames_packed, con
 
 int tetra_burst_index_device(const int32_t* d_frame_type, int n, int frames_per_channel, int32_t* d_lists, int32_t* d_counts,
                              int32_t* d_chan_first, int32_t* d_work, void* hip_stream) {
-    if (!d_frame_type || !d_lists || !d_counts || !d_work || n < 0) return TETRA_ERR_ARG;
-    if (d_chan_first && (frames_per_channel < 1 || n % frames_per_channel)) return TETRA_ERR_ARG;
+    if (!d_counts || n < 0) return TETRA_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    if (n == 0) return hipMemsetAsync(d_counts, 0, sizeof(int32_t) * TETRA_N_LISTS, s) == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;
+    if (n == 0) return hipMemsetAsync(d_counts, 0, sizeof(int32_t) * TETRA_N_LISTS, s) == hipSuccess ? TETRA_OK : TETRA_ERR_HIP;      // (no frames: nothing else is touched)
+    if (!d_frame_type || !d_lists || !d_work) return TETRA_ERR_ARG;
+    if (d_chan_first && (frames_per_channel < 1 || n % frames_per_channel)) return TETRA_ERR_ARG;
     const int nblocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_index_count, dim3(nblocks), dim3(256), 0, s, d_frame_type, n, nblocks, d_work);
     hipLaunchKernelGGL(k_index_scan, dim3(1), dim3(kScanThreads), 0, s, d_work, nblocks, d_counts);

@@ -545,6 +545,23 @@ def test_gpu_decode_frames_all_kinds_in_one_launch(pkg, lref, oracle):
             assert list(lab[j]) == [r // F, r % F, r * 510 + 7, r + 1000, r + 5000, want_ok]
             good += int(want_ok) if tpsap != 3 else 0
     assert good > 150
+    # counts given on the host instead (d_n_rows = NULL: max_rows rows exist), lists without the per-channel positions, an empty call
+    li = 1
+    cnt = want_lists[li].size
+    t2b = torch.full((cnt, 296), 9, dtype=torch.uint8, device=dev)
+    okb = torch.full((cnt,), -3, dtype=torch.int32, device=dev)
+    lb.decode_frames_device(d_fr, d_ft, [dict(type=5, blk_num=0, row_frame=lists[li], n_rows=None, max_rows=cnt, out_stride=296, frame_scramb=d_codes,
+                                              type2=t2b, crc_ok=okb)])
+    torch.cuda.synchronize()
+    assert torch.equal(t2b[:, :288], outs[0][0][:cnt, :288]) and torch.equal(okb, outs[0][1][:cnt])
+    lists2 = torch.full((4, n), -7, dtype=torch.int32, device=dev)
+    counts2 = torch.full((4,), -1, dtype=torch.int32, device=dev)
+    bb.index_device(d_ft, F, lists2, counts2, None)
+    bb.index_device(d_ft[:0], F, torch.empty((4, 1), dtype=torch.int32, device=dev), counts, None)      # n = 0: counts zeroed, nothing launched
+    torch.cuda.synchronize()
+    assert torch.equal(counts2.cpu(), torch.tensor([w.size for w in want_lists], dtype=torch.int32)) and int(counts.abs().sum()) == 0
+    for k in range(4):
+        assert torch.equal(lists2[k, :want_lists[k].size], lists[k, :want_lists[k].size])
     # argument errors: statuses, not launches
     from ctypes import byref
     L = pkg.binding.load_library()
@@ -621,3 +638,23 @@ def test_gpu_track_sync_lists_equals_the_slot_layout_tracker(pkg, lref):
             else:
                 assert (lab[j] == -1).all()              # a SYNC-typed slot past the channel's frame count is not a frame
         assert (lab[sync.size:] == -1).all()
+    # d_n_frames = NULL: every frame slot of every channel counts
+    types = rng.choice(np.array([0, 1, 3, -1], np.int32), n)
+    sync = np.flatnonzero(types == 3)
+    t2c = rng.integers(0, 2, (sync.size, 80), dtype=np.uint8)
+    okc = np.ones(sync.size, np.int32)
+    slot_t2 = np.zeros((n, 80), np.uint8)
+    slot_ok, slot_valid = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    slot_t2[sync], slot_ok[sync], slot_valid[sync] = t2c, okc, 1
+    d = lambda a: torch.from_numpy(a).to(dev)
+    d_ft = d(types)
+    lists = torch.zeros((4, n), dtype=torch.int32, device=dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    chan_first = torch.zeros((4, C_), dtype=torch.int32, device=dev)
+    bb.index_device(d_ft, F, lists, counts, chan_first)
+    oa = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+    ob = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+    lb.track_sync_device(d(slot_t2), 80, d(slot_ok), d(slot_valid), None, C_, F, cell_a, *oa)
+    lb.track_sync_lists_device(d(t2c), 80, d(okc), d_ft, None, chan_first[0], C_, F, cell_b, *ob)
+    torch.cuda.synchronize()
+    assert torch.equal(cell_a, cell_b) and all(torch.equal(a, b) for a, b in zip(oa, ob))
