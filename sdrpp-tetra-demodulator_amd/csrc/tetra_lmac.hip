@@ -161,13 +161,36 @@ __global__ __launch_bounds__(kLanes) void k_lmac_decode(const uint8_t* __restric
     // 1. front end.  Rows of plain bits: each lane packs its own row (8-byte loads), descrambles whole words and leaves the type-4
     //    bits in LDS (cls rows 0..13 as [word][lane]); the workgroup falls back to the byte route if any of its rows holds another
     //    byte value, or if the rows are not 8-byte aligned.
-    bool byte_route = seq_tab == nullptr || (in_stride & 7) || ((uintptr_t)type5 & 7);
+    bool byte_route = seq_tab == nullptr || (in_stride & 7) || ((uintptr_t)type5 & 7) || in_stride > 512;      // (512: the unit -> row map below)
     if (!byte_route) {
-        const U2* row = reinterpret_cast<const U2*>(type5 + (size_t)(blk < n_blocks ? blk : blk0) * in_stride);
-        uint32_t xb[kSeqWords];
-        const uint32_t dirty = pack_row_bits(type345, [&](int i) { return row[i]; }, xb);
+        // The workgroup's rows_here rows are one contiguous run of rows_here * in_stride bytes: read it ONCE, 8 bytes per lane and
+        // 512 contiguous bytes per load instruction, pack each unit's 8 bytes to 8 bits and drop them as one byte into the row's
+        // packed words in LDS (`stage`, 17 words per row); then every lane picks up its own row's words.  (Until late in round 6 every
+        // lane read its own row with strided 8-byte loads: 64 cache lines per instruction, and with a few waves per CU the lines were
+        // evicted before their other 120 bytes were used.)
+        const int units_per_row = in_stride >> 3, total_units = rows_here * units_per_row;
+        const uint32_t inv = ((1u << 20) + (uint32_t)units_per_row - 1u) / (uint32_t)units_per_row;      // exact for u < 64 * 64
+        const U2* base = reinterpret_cast<const U2*>(type5 + (size_t)blk0 * in_stride);
+        uint8_t* sb = reinterpret_cast<uint8_t*>(&stage[0][0]);
+        uint32_t dirty = 0;
+        for (int u = lane; u < total_units; u += kLanes) {
+            const int r = (int)(((uint32_t)u * inv) >> 20), j = u - r * units_per_row;      // row, byte of its packed bits
+            if (8 * j < type345) {
+                const U2 d = base[u];
+                dirty |= (d.x | d.y) & 0xfefefefeu;
+                // type-5 bits 8j .. 8j+7, first bit most significant; byte j of the row's bit string sits in word j / 4 at bits 31 - 8 (j % 4) ..
+                sb[(size_t)r * (4 * (kChunkDwords + 1)) + (j & ~3) + (3 - (j & 3))] = (uint8_t)((pack4(d.x) << 4) | pack4(d.y));
+            }
+        }
         byte_route = __builtin_amdgcn_ballot_w64(dirty != 0) != 0;          // wave-uniform
-        if (!byte_route) descramble_to_lds(type345, code, xb, seq_tab, cls, lane);
+        __syncthreads();
+        if (!byte_route) {
+            uint32_t xb[kSeqWords];
+#pragma unroll
+            for (int w = 0; w < kSeqWords; ++w) xb[w] = 32 * w < type345 ? stage[lane][w] : 0u;
+            if (type345 & 31) xb[type345 >> 5] &= ~(0xffffffffu >> (type345 & 31));      // (bytes behind the row's last bit were never written)
+            descramble_to_lds(type345, code, xb, seq_tab, cls, lane);
+        }
     }
     bool good;
     if (!byte_route) {
