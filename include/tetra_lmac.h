@@ -88,7 +88,8 @@ int tetra_lmac_decode_counted_device(int type, const uint8_t* d_type5, int n_blo
                                      int32_t* d_crc_ok, void* hip_stream);
 /* Rows of plain bits (every byte 0 or 1 -- what this library's demultiplexers write) take a packed route inside the decoder (bytes ->
  * bits, whole words of the scrambling sequence, ~6 x fewer instructions in the front end); a workgroup of 64 rows with any other byte
- * value, or rows that are not 8-byte aligned (d_type5, in_stride), takes the byte route; the results are the same bit for bit.
+ * value, or rows that are not 8-byte aligned (d_type5, in_stride) or further than 512 bytes apart, takes the byte route; the results
+ * are the same bit for bit.
  * tetra_lmac_debug_force_byte_route(1) sends every row through the byte route (process-wide; tests and A/B); returns the old setting. */
 int tetra_lmac_debug_force_byte_route(int on);
 /*

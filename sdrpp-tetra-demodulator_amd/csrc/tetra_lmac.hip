@@ -6,8 +6,8 @@
 //      * from PACKED FRAMES (k_lmac_frames, round 6): the lane reads its frame (four 16-byte loads), cuts the kind's one or two bit
 //        ranges out with funnel shifts and XORs whole words of its scrambling sequence (linear in the code: four rows of a 64 KB
 //        table indexed by the code's bytes);
-//      * from byte rows of plain bits (k_lmac_decode; every byte 0 / 1): the lane reads ITS OWN row with 8-byte loads, packs the
-//        bytes 32 to a register, then the same;
+//      * from byte rows of plain bits (k_lmac_decode; every byte 0 / 1): the workgroup reads its 64 rows as one contiguous run,
+//        8 bytes per lane, packs them to bits through LDS, each lane takes its row's words, then the same;
 //      * from byte rows with any other byte value anywhere in the workgroup's 64 rows (erasures), or rows that are not 8-byte
 //        aligned: the byte route -- rows staged through LDS in coalesced 64-bit chunks, an LFSR step and a three-way classification
 //        (0 / erasure 0xff / 1) per byte, soft classes 2 bits per type-4 bit in LDS;
