@@ -224,7 +224,7 @@ def test_gpu_lmac_packed_route_byte_route_and_mixed_workgroups(pkg, lref):
         si = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
         if t == lref.TPSAP_T_SB1:
             si[:] = lref.SCRAMB_INIT
-        for stride in (n345 + (-n345) % 8, n345 + 4 if (n345 + 4) % 8 else n345 + 12):
+        for stride in (n345 + (-n345) % 8, n345 + 4 if (n345 + 4) % 8 else n345 + 12, 1032):      # aligned (contiguous-run loader), 4-byte aligned and > 512 (byte route)
             rows = rng.integers(0, 2, (n, stride), dtype=np.uint8)
             for b in range(0, n, 3):
                 rows[b, :n345] = lref.lmac_encode(t, rng.integers(0, 2, n1).astype(np.uint8), int(si[b])) ^ (rng.random(n345) < 0.03)
