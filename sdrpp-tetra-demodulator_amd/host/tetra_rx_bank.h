@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "tetra_rx.h"
@@ -73,6 +74,99 @@ public:
 
 private:
     tetra_rx_t* h_ = nullptr;
+    int channels_ = 0;
+};
+
+// The chain over several GPUs of a node, beside PI4DQPSKMultiBank: channels are independent receivers, so GPU g takes the channel
+// range [g C / G, (g + 1) C / G) (the split of shard.py / bench.py --gpus N) and nothing crosses between the GPUs.  tetra_rx_process*
+// only ENQUEUES (every handle has its own streams on its own device), so one host thread drives all shards; blocks come back with
+// their channel numbers in the whole bank's numbering, shard after shard = (channel, frame) order.
+class TetraRxMultiBank {
+public:
+    TetraRxMultiBank() {}
+    TetraRxMultiBank(const TetraRxMultiBank&) = delete;
+    TetraRxMultiBank& operator=(const TetraRxMultiBank&) = delete;
+
+    // cfg.demod.n_channels = ALL channels (>= devices.size()); cfg.demod.device is ignored; one shard per entry of `devices` (an
+    // ordinal may repeat: two shards on one GPU, e.g. for tests on a one-GPU box).
+    int init(const tetra_rx_config_t& cfg, const std::vector<int>& devices) {
+        shards_.clear();
+        channels_ = cfg.demod.n_channels;
+        const int G = (int)devices.size();
+        if (G < 1 || channels_ < G) return TETRA_ERR_ARG;
+        for (int g = 0; g < G; g++) {
+            std::unique_ptr<Shard> s(new Shard());
+            s->first = (int)((long long)g * channels_ / G);
+            s->count = (int)((long long)(g + 1) * channels_ / G) - s->first;
+            tetra_rx_config_t c = cfg;
+            c.demod.n_channels = s->count;
+            c.demod.device = devices[(size_t)g];
+            const int rc = s->bank.init(c);
+            if (rc != TETRA_OK) { shards_.clear(); return rc; }
+            shards_.push_back(std::move(s));
+        }
+        return TETRA_OK;
+    }
+    // Samples already on the GPUs: dIq[s] = device pointer on shard s's device to its [count_s channels x count] samples (in
+    // cfg.demod.layout), streams[s] = a HIP stream of that device (or null).  Enqueues on every shard and returns.
+    int processDevice(int count, const float* const* dIq, void* const* streams) {
+        for (size_t s = 0; s < shards_.size(); s++) {
+            const int rc = shards_[s]->bank.processDevice(count, dIq[s], streams ? streams[s] : nullptr);
+            if (rc != TETRA_OK) return rc;
+        }
+        return TETRA_OK;
+    }
+    // Host samples, channel major [n_channels][count] complex64: every shard copies its rows in and enqueues its chain.
+    int process(int count, const float* iq) {
+        for (auto& s : shards_) {
+            const int rc = s->bank.process(count, iq + (size_t)2 * (size_t)s->first * (size_t)count);
+            if (rc != TETRA_OK) return rc;
+        }
+        return TETRA_OK;
+    }
+    int wait() {
+        int first = TETRA_OK;
+        for (auto& s : shards_) { const int rc = s->bank.wait(); if (first == TETRA_OK) first = rc; }
+        return first;
+    }
+    int reset() {
+        for (auto& s : shards_) { const int rc = s->bank.reset(); if (rc != TETRA_OK) return rc; }
+        return TETRA_OK;
+    }
+    int fetch(int kind, TetraRxBank::Blocks& out, int which = 0) {
+        out.info.clear(); out.type1.clear();
+        TetraRxBank::Blocks part;
+        for (auto& s : shards_) {
+            const int rc = s->bank.fetch(kind, part, which);
+            if (rc != TETRA_OK) return rc;
+            out.bitsPerBlock = part.bitsPerBlock;
+            for (auto& b : part.info) b.channel += s->first;
+            out.info.insert(out.info.end(), part.info.begin(), part.info.end());
+            out.type1.insert(out.type1.end(), part.type1.begin(), part.type1.end());
+        }
+        return TETRA_OK;
+    }
+    int cells(std::vector<tetra_lmac_cell_state_t>& out) {
+        out.clear();
+        std::vector<tetra_lmac_cell_state_t> part;
+        for (auto& s : shards_) {
+            const int rc = s->bank.cells(part);
+            if (rc != TETRA_OK) return rc;
+            out.insert(out.end(), part.begin(), part.end());
+        }
+        return TETRA_OK;
+    }
+    int channels() const { return channels_; }
+    int shards() const { return (int)shards_.size(); }
+    void shardInfo(int shard, int& first, int& count) const { first = shards_[(size_t)shard]->first; count = shards_[(size_t)shard]->count; }
+    TetraRxBank& shard(int s) { return shards_[(size_t)s]->bank; }
+
+private:
+    struct Shard {
+        TetraRxBank bank;
+        int first = 0, count = 0;
+    };
+    std::vector<std::unique_ptr<Shard>> shards_;
     int channels_ = 0;
 };
 

@@ -11,6 +11,7 @@
 #include "tetra_rx_bank.h"
 
 using dsp::demod::TetraRxBank;
+using dsp::demod::TetraRxMultiBank;
 
 static int fail(const char* what, int rc) { std::fprintf(stderr, "san_rx_bank: %s -> %d\n", what, rc); return 1; }
 
@@ -28,10 +29,15 @@ int main(int argc, char** argv) {
         if (bank.fetch(TETRA_RX_KIND_SB1, b) != TETRA_ERR_ARG || bank.fetch(17, b) != TETRA_ERR_ARG) return fail("fetch without a handle", 0);
         if (bank.wait() != TETRA_ERR_ARG || bank.reset() != TETRA_ERR_ARG || bank.process(4, nullptr) != TETRA_ERR_ARG) return fail("calls without a handle", 0);
         if (tetra_rx_type1_bits(TETRA_RX_KIND_SCH_F) != 268 || tetra_rx_type1_bits(-1) != TETRA_ERR_ARG) return fail("type1_bits", 0);
+        TetraRxMultiBank multi;
+        tetra_rx_default_config(&cfg);
+        cfg.demod.n_channels = 1;
+        if (multi.init(cfg, std::vector<int>{ 0, 0 }) != TETRA_ERR_ARG || multi.init(cfg, std::vector<int>()) != TETRA_ERR_ARG) return fail("multi init", 0);
+        if (multi.shards() != 0 || multi.wait() != TETRA_OK) return fail("empty multi bank", 0);
         std::printf("san_rx_bank: ok\n");
         return 0;
     }
-    if (argc != 7) return fail("usage", -1);
+    if (argc != 7 && argc != 8) return fail("usage", -1);
     const int C = std::atoi(argv[2]), N = std::atoi(argv[3]), calls = std::atoi(argv[4]);
     std::vector<float> iq((size_t)2 * C * N);
     std::FILE* in = std::fopen(argv[5], "rb");
@@ -41,13 +47,15 @@ int main(int argc, char** argv) {
     tetra_rx_default_config(&cfg);
     cfg.demod.n_channels = C;
     cfg.demod.max_samples = N;
+    const int n_shards = argc == 8 ? std::atoi(argv[7]) : 0;             // > 0: TetraRxMultiBank with that many shards, all on device 0
     TetraRxBank bank;
-    int rc = bank.init(cfg);
+    TetraRxMultiBank multi;
+    int rc = n_shards ? multi.init(cfg, std::vector<int>((size_t)n_shards, 0)) : bank.init(cfg);
     if (rc != TETRA_OK) return fail("init", rc);
     auto dump = [&](int which) -> int {
         for (int k = 0; k < TETRA_RX_N_KINDS; k++) {
             TetraRxBank::Blocks b;
-            const int r = bank.fetch(k, b, which);
+            const int r = n_shards ? multi.fetch(k, b, which) : bank.fetch(k, b, which);
             if (r != TETRA_OK) return r;
             const int32_t hdr[3] = { k, (int32_t)b.info.size(), b.bitsPerBlock };
             std::fwrite(hdr, sizeof(hdr), 1, out);
@@ -58,17 +66,22 @@ int main(int argc, char** argv) {
     };
     for (int k = 0; k < calls; k++) {
         if (std::fread(iq.data(), sizeof(float), iq.size(), in) != iq.size()) return fail("short input", k);
-        rc = bank.process(N, iq.data());
+        rc = n_shards ? multi.process(N, iq.data()) : bank.process(N, iq.data());
         if (rc != TETRA_OK) return fail("process", rc);
         if (k >= 1 && (rc = dump(1)) != TETRA_OK) return fail("fetch previous", rc);      // call k - 1's blocks while call k runs
     }
     if ((rc = dump(0)) != TETRA_OK) return fail("fetch last", rc);
-    if ((rc = bank.wait()) != TETRA_OK) return fail("wait", rc);
+    if ((rc = n_shards ? multi.wait() : bank.wait()) != TETRA_OK) return fail("wait", rc);
     std::vector<tetra_lmac_cell_state_t> cells;
     std::vector<tetra_bsync_state_t> sync;
-    if ((rc = bank.cells(cells)) != TETRA_OK || (rc = bank.syncStates(sync)) != TETRA_OK) return fail("cells", rc);
+    if (n_shards) {
+        if ((rc = multi.cells(cells)) != TETRA_OK) return fail("cells", rc);
+        int first = -1, count = -1;
+        multi.shardInfo(n_shards - 1, first, count);
+        if (first + count != C || multi.channels() != C || multi.shards() != n_shards) return fail("shardInfo", first + count);
+    } else if ((rc = bank.cells(cells)) != TETRA_OK || (rc = bank.syncStates(sync)) != TETRA_OK) return fail("cells", rc);
     std::fwrite(cells.data(), sizeof(tetra_lmac_cell_state_t), cells.size(), out);
-    if (bank.setParam(TETRA_PARAM_AGC_RATE, 0.02) != TETRA_OK || bank.reset() != TETRA_OK) return fail("setParam / reset", -1);
+    if (n_shards ? multi.reset() != TETRA_OK : (bank.setParam(TETRA_PARAM_AGC_RATE, 0.02) != TETRA_OK || bank.reset() != TETRA_OK)) return fail("setParam / reset", -1);
     std::fclose(in);
     std::fclose(out);
     std::printf("san_rx_bank: ok\n");

@@ -93,8 +93,10 @@ def test_rx_bank_error_paths_are_clean_under_asan_and_ubsan(pkg):
 
 
 @pytest.mark.gpu
-def test_rx_bank_streams_like_rx_chain_under_asan_and_ubsan(pkg, synth, tmp_path):
-    """TetraRxBank fed three blocks of coded downlinks from host memory, fetching the previous call's blocks while the next one runs:
+@pytest.mark.parametrize("shards", [0, 2, 3])
+def test_rx_bank_streams_like_rx_chain_under_asan_and_ubsan(pkg, synth, tmp_path, shards):
+    """TetraRxBank (shards = 0) / TetraRxMultiBank (the bank's channels split into that many channel ranges, each range a handle of its
+    own -- all on device 0 here; on a node one per GPU: the chain shards like the demodulator, no exchange) fed three blocks of coded downlinks from host memory, fetching the previous call's blocks while the next one runs:
     every block of every kind (labels + type-1 bits) and the cell states equal what the Python RxChain returns for the same stream,
     and the sanitizers stay silent (ROCm's own allocations suppressed by library name)."""
     import numpy as np
@@ -108,8 +110,8 @@ def test_rx_bank_streams_like_rx_chain_under_asan_and_ubsan(pkg, synth, tmp_path
         for k in range(calls):
             f.write(np.ascontiguousarray(iq[:, k * N:(k + 1) * N]).astype(np.complex64).tobytes())
     env = dict(ENV, ASAN_OPTIONS="detect_leaks=1:protect_shadow_gap=0")
-    r = subprocess.run([_build_rx_bank(pkg), "gpu", str(Cn), str(N), str(calls), str(blocks_file), str(out_file)], env=env, capture_output=True,
-                       text=True, timeout=180)
+    r = subprocess.run([_build_rx_bank(pkg), "gpu", str(Cn), str(N), str(calls), str(blocks_file), str(out_file)] + ([str(shards)] if shards else []),
+                       env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "san_rx_bank: ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     # the same stream through the Python handle
     rx = pkg.RxChain(Cn, N)
