@@ -476,6 +476,16 @@ def receive_chain(args, torch, pkg, device, local_rank, C=CHANNELS_PER_GPU, N=SA
     return res
 
 
+def informational(leg, *a):
+    """An informational leg of the default line (config 5, the receive chain) must not take the metric line down with it: a leg that
+    fails -- its own known-answer check included -- is reported as {"error": ...} in its place (run alone, --config5 / --chain-only,
+    the same failure ends the run with a non-zero status)."""
+    try:
+        return leg(*a)
+    except (SystemExit, Exception) as e:      # noqa: BLE001 -- SystemExit is what the legs' own checks raise
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command under
     torch.distributed.run (one process per GPU; on a box with fewer GPUs than ranks they share -- functional runs only) and
@@ -817,7 +827,7 @@ def main():
         if not args.no_config5 and world == 1 and C == CHANNELS_PER_GPU:
             dem.close()
             dem = None
-            out["config5"] = wideband_config5(args, torch, pkg, device, local_rank)      # informational, after the timed region
+            out["config5"] = informational(wideband_config5, args, torch, pkg, device, local_rank)      # after the timed region
         if dist is not None:
             out["rccl_world_size"] = dist.get_world_size() if args.backend == "nccl" else None
             out["dist_backend"] = args.backend
@@ -830,7 +840,7 @@ def main():
                 dem.close()
             dem = None
             del iq, bits, nbits
-            out["chain"] = receive_chain(args, torch, pkg, device, local_rank)      # informational, after the timed region
+            out["chain"] = informational(receive_chain, args, torch, pkg, device, local_rank)      # after the timed region
         print(json.dumps(out))
     if dem is not None:
         dem.close()

@@ -81,7 +81,10 @@ def test_default_line_carries_config5_at_the_plugins_rate_and_the_receive_chain(
     known-answer check over >= 256 channels.  (Source-level pins: the line itself needs the GPU; tests/test_bench_ranks.py runs it.)"""
     import inspect
     src = inspect.getsource(bench.main)
-    assert 'out["chain"] = receive_chain(' in src and "args.no_chain" in src and 'out["config5"] = wideband_config5(' in src
+    assert 'out["chain"] = informational(receive_chain, ' in src and "args.no_chain" in src and 'out["config5"] = informational(wideband_config5, ' in src
+    # an informational leg that fails (its own check included) is reported in place, the metric line still comes out
+    assert bench.informational(lambda: (_ for _ in ()).throw(SystemExit("check failed"))) == {"error": "SystemExit: check failed"}
+    assert bench.informational(lambda x: {"ok": x}, 3) == {"ok": 3}
     assert bench.CHECK_CHANNELS >= 256 and "hash_bits(int(seeds[c])" in src
     c5 = inspect.getsource(bench.wideband_config5)
     assert "pkg.Resampler(M, 18, 25, 16" in c5 and '"resampler"' in c5 and "config5_rate" in c5
