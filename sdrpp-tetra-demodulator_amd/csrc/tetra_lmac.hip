@@ -244,6 +244,7 @@ struct DevFrames {
     const uint32_t* time_rx;
     const uint32_t* time;
     int frames_per_channel;
+    int n_frames;
 };
 struct JobTable {
     DevJob job[TETRA_LMAC_MAX_JOBS];
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(kLanes) void k_lmac_frames(const JobTable tab, uint
     }
     if (blk0 >= n_blocks) return;
     const int rows_here = min(kLanes, n_blocks - blk0);
-    const int f = J.row_frame[blk < n_blocks ? blk : blk0];
+    // (a list entry outside [0, n_frames) -- a caller's slip -- reads the nearest frame instead of memory that is not there)
+    const int f = min(max(J.row_frame[blk < n_blocks ? blk : blk0], 0), tab.src.n_frames - 1);
     const uint32_t code = J.frame_scramb ? J.frame_scramb[f] : kScrambInitSb1;
     const int ft = tab.src.frame_type[f];
     uint32_t fw[kFrameWords];
@@ -666,7 +668,8 @@ int tetra_lmac_decode_frames_device(const tetra_lmac_frames_t* src, const tetra_
     if (!src->d_frames || !src->d_frame_type || src->n_frames < 0) return TETRA_ERR_ARG;
     if ((uintptr_t)src->d_frames & 15) return TETRA_ERR_ALIGN;
     JobTable tab = {};
-    tab.src = DevFrames{ src->d_frames, src->d_frame_type, src->d_frame_bitnum, src->d_time_rx, src->d_time, src->frames_per_channel };
+    if (src->n_frames == 0) return TETRA_OK;              // no frames: no row can exist
+    tab.src = DevFrames{ src->d_frames, src->d_frame_type, src->d_frame_bitnum, src->d_time_rx, src->d_time, src->frames_per_channel, src->n_frames };
     long long groups_total = 0, scratch_words = 0;
     int n = 0, max_pairs = 0;
     for (int i = 0; i < n_jobs; ++i) {
